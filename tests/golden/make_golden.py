@@ -1,0 +1,307 @@
+"""Generate golden fixtures by running the REAL reference (read-only at
+/root/reference) in the build container.  Only data (inputs + expected outputs)
+is written; no reference source travels.  Run from anywhere:
+
+    python tests/golden/make_golden.py
+
+Absent third-party modules (tensorboardX, editdistance — plain
+ModuleNotFoundError here, no permission issue) are stubbed before import, as
+SURVEY 8c describes.  Weights/inputs come from tests/golden/synth.py.
+"""
+import copy
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+
+import synth
+
+
+def _stub_modules():
+    tb = types.ModuleType("tensorboardX")
+
+    class SummaryWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def add_text(self, *a, **k):
+            pass
+
+    tb.SummaryWriter = SummaryWriter
+    sys.modules["tensorboardX"] = tb
+    ed = types.ModuleType("editdistance")
+
+    def _eval(a, b):
+        prev = list(range(len(b) + 1))
+        for i, x in enumerate(a, 1):
+            cur = [i]
+            for j, y in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+            prev = cur
+        return prev[-1]
+
+    ed.eval = _eval
+    sys.modules["editdistance"] = ed
+
+
+_stub_modules()
+sys.path.insert(0, "/root/reference")
+import model as ref_model   # noqa: E402
+import utils as ref_utils   # noqa: E402
+
+
+def load_sd(module, arrays):
+    module.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in arrays.items()})
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def build_e2e(cfg, wseed, ldseed):
+    ld = synth.labeldist(cfg["output_dim"], ldseed)
+    m = ref_model.E2E(labeldist=ld, **cfg)
+    load_sd(m, synth.e2e_weights(cfg, wseed))
+    m.train()
+    return m, ld
+
+
+def to_t(xs, ys):
+    return torch.from_numpy(xs), [torch.from_numpy(y) for y in ys]
+
+
+def named_grads(m):
+    return {n: npy(p.grad) for n, p in m.named_parameters()}
+
+
+def gen_tiny_e2e():
+    cfg = synth.TINY
+    m, ld = build_e2e(cfg, 11, 12)
+    xs_np, ilens, ys_np = synth.batch(cfg["input_dim"], cfg["output_dim"], synth.TINY_ILENS,
+                                      synth.TINY_YLENS, 13)
+    xs, ys = to_t(xs_np, ys_np)
+    out = {"labeldist": ld}
+    # ---- encoder intermediates via hooks (model.py:80-81,93)
+    taps = {}
+    hooks = []
+    for i, layer in enumerate(m.encoder.enc2.layers):
+        def _h(mod, inp, res, i=i):
+            padded, _ = torch.nn.utils.rnn.pad_packed_sequence(res[0], batch_first=True)
+            taps["lstm%d" % i] = npy(padded)
+        hooks.append(layer.register_forward_hook(_h))
+    for i, proj in enumerate(m.encoder.enc2.project_layers):
+        def _p(mod, inp, res, i=i):
+            taps["cat%d" % i] = npy(inp[0])
+            taps["proj%d" % i] = npy(torch.relu(res))
+        hooks.append(proj.register_forward_hook(_p))
+    enc_h, enc_lens = m.encoder(xs, ilens)
+    for h in hooks:
+        h.remove()
+    for k, v in taps.items():
+        out["enc_" + k] = v
+    out["enc_h"] = npy(enc_h)
+    out["enc_lens"] = np.asarray(enc_lens)
+    # ---- two attention steps (model.py:139-173)
+    rs = np.random.RandomState(14)
+    z0 = torch.from_numpy(rs.normal(0, 1, (len(ilens), cfg["dec_hidden_dim"])).astype(np.float32))
+    z1 = torch.from_numpy(rs.normal(0, 1, (len(ilens), cfg["dec_hidden_dim"])).astype(np.float32))
+    m.attention.reset()
+    c0, w0 = m.attention(enc_h, enc_lens, z0, None)
+    c1, w1 = m.attention(enc_h, enc_lens, z1, w0)
+    m.attention.reset()
+    out.update(att_z0=npy(z0), att_z1=npy(z1), att_c0=npy(c0), att_w0=npy(w0), att_c1=npy(c1),
+               att_w1=npy(w1))
+    # ---- teacher-forced forward, loss, grads (solver.py:375-383)
+    np.random.seed(5)
+    logits, lp, pred, ws = m(xs, ilens, ys, tf_rate=1.0)
+    loss = -torch.mean(lp)
+    m.zero_grad()
+    loss.backward()
+    out.update(tf_logits=npy(logits), tf_lp=npy(lp), tf_pred=npy(pred), tf_ws=npy(ws),
+               tf_loss=npy(loss), tf_masked_loss=npy(m.mask_and_cal_loss(lp, ys)))
+    for n, g in named_grads(m).items():
+        out["grad/" + n] = g
+    # ---- scheduled sampling tf_rate=0.5 (numpy RNG consumed per step, F7)
+    np.random.seed(7)
+    logits, lp, pred, _ = m(xs, ilens, ys, tf_rate=0.5)
+    out.update(ss_logits=npy(logits), ss_lp=npy(lp), ss_pred=npy(pred))
+    # ---- greedy and smooth free-running decodes (model.py:330-341)
+    logits, lp, pred, ws = m(xs, ilens, ys=None, max_dec_timesteps=5)
+    out.update(gr_logits=npy(logits), gr_lp=npy(lp), gr_pred=npy(pred), gr_ws=npy(ws))
+    logits, lp, pred, _ = m(xs, ilens, ys=None, max_dec_timesteps=5, smooth=True, scaling=3.0,
+                            label_smoothing=False)
+    m.zero_grad()
+    (-lp.mean()).backward()
+    out.update(sm_logits=npy(logits), sm_lp=npy(lp), sm_pred=npy(pred))
+    for n, g in named_grads(m).items():
+        out["smgrad/" + n] = g
+    # ---- eval mode (no label smoothing, F8)
+    m.eval()
+    np.random.seed(5)
+    _, lp_eval, _, _ = m(xs, ilens, ys)
+    out["eval_lp"] = npy(lp_eval)
+    m.train()
+    # ---- 3 optimiser steps (solver.py:152-153,382-385)
+    m2, _ = build_e2e(cfg, 11, 12)
+    opt = torch.optim.Adam(m2.parameters(), lr=5e-4, weight_decay=1e-6, amsgrad=True)
+    for step in range(3):
+        np.random.seed(100 + step)
+        _, lp, _, _ = m2(xs, ilens, ys, tf_rate=1.0)
+        loss = -torch.mean(lp)
+        opt.zero_grad()
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m2.parameters(), max_norm=5)
+        opt.step()
+        out["opt_loss%d" % step] = npy(loss)
+        out["opt_gnorm%d" % step] = npy(gn)
+        if step in (0, 2):
+            for n, p in m2.named_parameters():
+                out["after%d/%s" % (step + 1, n)] = npy(p)
+    # small-clip variant so the clip branch is actually taken
+    m3, _ = build_e2e(cfg, 11, 12)
+    opt = torch.optim.Adam(m3.parameters(), lr=5e-4, weight_decay=1e-6, amsgrad=True)
+    np.random.seed(100)
+    _, lp, _, _ = m3(xs, ilens, ys, tf_rate=1.0)
+    opt.zero_grad()
+    (-torch.mean(lp)).backward()
+    torch.nn.utils.clip_grad_norm_(m3.parameters(), max_norm=0.05)
+    opt.step()
+    for n, p in m3.named_parameters():
+        out["clip/%s" % n] = npy(p)
+    np.savez_compressed(os.path.join(HERE, "tiny_e2e.npz"), **out)
+    print("tiny_e2e: %d arrays, loss %.6f" % (len(out), float(out["tf_loss"])))
+
+
+def build_lm(cfg, wseed, ldseed):
+    ld = synth.labeldist(cfg["output_dim"], ldseed)
+    lm = ref_model.LM(bos=1, eos=2, pad=0, labeldist=ld, **cfg)
+    load_sd(lm, synth.lm_weights(cfg, wseed))
+    lm.train()
+    return lm, ld
+
+
+def gen_tiny_lm():
+    cfg = synth.TINY_LM
+    lm, ld = build_lm(cfg, 31, 32)
+    rs = np.random.RandomState(33)
+    ys_np = [rs.randint(3, cfg["output_dim"], size=(n,)).astype(np.int64) for n in (6, 4, 3)]
+    ys = [torch.from_numpy(y) for y in ys_np]
+    out = {"labeldist": ld}
+    for i, y in enumerate(ys_np):
+        out["ys%d" % i] = y
+    lp, p, pred = lm(ys, discrete_input=True)
+    loss = -lm.mask_and_cal_sum(lp, ys)
+    lm.zero_grad()
+    loss.backward()
+    out.update(d_lp=npy(lp), d_p=npy(p), d_pred=npy(pred), d_loss=npy(loss),
+               d_avg_prob=npy(lm.mask_and_cal_sum(p, ys)))
+    for n, q in lm.named_parameters():
+        out["grad/" + n] = npy(q.grad)
+    lm.eval()
+    lp_e, _, _ = lm(ys, discrete_input=True)
+    out["d_lp_eval"] = npy(lp_e)
+    lm.train()
+    dense = torch.from_numpy(rs.randint(2, cfg["output_dim"], size=(3, 7)).astype(np.int64))
+    lp, p, pred = lm(dense, discrete_input=False)
+    out.update(c_ys=npy(dense), c_lp=npy(lp), c_p=npy(p), c_pred=npy(pred))
+    # one judge optimiser step (solver.py:171-173,288-297)
+    lm2, _ = build_lm(cfg, 31, 32)
+    opt = torch.optim.Adam(lm2.parameters(), lr=2e-4)
+    lp, _, _ = lm2(ys, discrete_input=True)
+    loss = -lm2.mask_and_cal_sum(lp, ys)
+    opt.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(lm2.parameters(), max_norm=5)
+    opt.step()
+    for n, q in lm2.named_parameters():
+        out["after1/" + n] = npy(q)
+    np.savez_compressed(os.path.join(HERE, "tiny_lm.npz"), **out)
+    print("tiny_lm: %d arrays, loss %.6f" % (len(out), float(out["d_loss"])))
+
+
+def gen_tiny_ssl():
+    """Loss assembly of solver.py:465-483 with the tiny model + tiny judge."""
+    cfg = synth.TINY
+    m, _ = build_e2e(cfg, 11, 12)
+    lm, _ = build_lm(synth.TINY_LM, 31, 32)
+    xs_np, ilens, ys_np = synth.batch(cfg["input_dim"], cfg["output_dim"], synth.TINY_ILENS,
+                                      synth.TINY_YLENS, 13)
+    uxs_np, uilens, _ = synth.batch(cfg["input_dim"], cfg["output_dim"], [12, 10, 7], [2, 2, 2], 41)
+    xs, ys = to_t(xs_np, ys_np)
+    uxs = torch.from_numpy(uxs_np)
+    proportion = 0.5
+    _, u_lp, u_pred, _ = m(uxs, uilens, ys=None, sample=False, label_smoothing=False,
+                           max_dec_timesteps=int(uxs.size(1) * proportion), smooth=True, scaling=3)
+    _, lm_p, _ = lm(ys=u_pred, discrete_input=False)
+    mask = (u_pred != 2).float()
+    unsup = -torch.sum(lm_p * u_lp * mask) / torch.sum(mask)
+    np.random.seed(9)
+    _, l_lp, _, _ = m(xs, ilens, ys=ys, tf_rate=1.0, sample=False)
+    sup = -torch.mean(l_lp)
+    loss = sup + 0.5 * unsup
+    m.zero_grad()
+    lm.zero_grad()
+    loss.backward()
+    out = dict(unsup=npy(unsup), sup=npy(sup), loss=npy(loss), u_pred=npy(u_pred), u_lp=npy(u_lp),
+               lm_p=npy(lm_p), unsup_weight=np.float32(0.5), proportion=np.float32(proportion))
+    for n, g in named_grads(m).items():
+        out["grad/" + n] = g
+    np.savez_compressed(os.path.join(HERE, "tiny_ssl.npz"), **out)
+    print("tiny_ssl: sup %.6f unsup %.6f" % (float(sup), float(unsup)))
+
+
+def gen_cfg1():
+    cfg = synth.CFG1
+    m, ld = build_e2e(cfg, 21, 23)
+    xs_np, ilens, ys_np = synth.batch(cfg["input_dim"], cfg["output_dim"], synth.CFG1_ILENS,
+                                      synth.CFG1_YLENS, 22)
+    xs, ys = to_t(xs_np, ys_np)
+    np.random.seed(5)
+    logits, lp, pred, ws = m(xs, ilens, ys, tf_rate=1.0)
+    loss = -torch.mean(lp)
+    m.zero_grad()
+    loss.backward()
+    out = dict(logits=npy(logits), lp=npy(lp), pred=npy(pred), ws=npy(ws), loss=npy(loss))
+    for n, p in m.named_parameters():
+        g = npy(p.grad).ravel()
+        out["gnorm/" + n] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["ghead/" + n] = g[:16].copy()
+    np.savez_compressed(os.path.join(HERE, "cfg1.npz"), **out)
+    print("cfg1: loss %.6f" % float(loss))
+
+
+def gen_text():
+    """utils.py:192-235 helpers on a toy vocabulary."""
+    vocab = {"<PAD>": 0, "<BOS>": 1, "<EOS>": 2, "a": 3, "b": 4, "c": 5, "<space>": 6, "<NOISE>": 7,
+             "'": 8}
+    nls = ["<NOISE>", "<PAD>", "<BOS>", "<EOS>"]
+    preds = [[3, 4, 6, 5, 2, 3, 3], [7, 3, 3, 8, 4], [2, 3, 4], [5, 6, 6, 3, 2, 2]]
+    refs = [[3, 4, 6, 5], [3, 8, 4, 4], [3], [5, 6, 3, 4]]
+    cut = ref_utils.remove_pad_eos(preds, eos=2)
+    hyp = ref_utils.to_sents(cut, vocab, nls)
+    ref = ref_utils.to_sents(refs, vocab, nls)
+    cer = ref_utils.calculate_cer(hyp, ref)
+    mask = ref_utils._seq_mask([3, 1, 4], 5).numpy().tolist()
+    with open(os.path.join(HERE, "text.json"), "w") as f:
+        json.dump(dict(vocab=vocab, non_lang_syms=nls, preds=preds, refs=refs, cut=cut, hyp=hyp,
+                       ref=ref, cer=cer, seq_mask=mask), f, indent=1)
+    print("text: cer %.6f" % cer)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    gen_tiny_e2e()
+    gen_tiny_lm()
+    gen_tiny_ssl()
+    gen_cfg1()
+    gen_text()

@@ -1,0 +1,110 @@
+"""Deterministic synthetic weights / batches from numpy's RandomState (MT19937,
+stream-stable across numpy versions), so large fixtures need not store weights.
+
+Shapes follow the reference constructors (model.py:59-74,115-123,257-263,409-437,
+460-472); values are U(-1/sqrt(fan), 1/sqrt(fan)) like torch's default init but
+drawn from numpy so they can be regenerated anywhere.
+"""
+import numpy as np
+
+TINY = dict(input_dim=8, enc_hidden_dim=16, enc_n_layers=2, subsample=[2, 2], dropout_rate=0.0,
+            dec_hidden_dim=16, att_dim=16, conv_channels=2, conv_kernel_size=3, att_odim=16,
+            embedding_dim=16, output_dim=9, ls_weight=0.05)
+TINY_ILENS = [11, 9, 6]          # odd T exercises the replicate-pad
+TINY_YLENS = [4, 3, 2]
+
+CFG1 = dict(input_dim=80, enc_hidden_dim=128, enc_n_layers=1, subsample=[2], dropout_rate=0.0,
+            dec_hidden_dim=320, att_dim=320, conv_channels=10, conv_kernel_size=100, att_odim=320,
+            embedding_dim=128, output_dim=34, ls_weight=0.05)
+CFG1_ILENS = [200, 180, 150, 120]
+CFG1_YLENS = [25, 22, 18, 15]
+
+TINY_LM = dict(output_dim=9, embedding_dim=16, hidden_dim=16, dropout_rate=0.0, n_layers=2,
+               ls_weight=0.05)
+
+
+def _u(rs, shape, fan):
+    k = 1.0 / np.sqrt(fan)
+    return rs.uniform(-k, k, size=shape).astype(np.float32)
+
+
+def e2e_weights(cfg, seed):
+    """Reference-keyed state dict (incl. the duplicated attention keys, F9)."""
+    rs = np.random.RandomState(seed)
+    H, I = cfg["enc_hidden_dim"], cfg["input_dim"]
+    sd = {}
+    for i in range(cfg["enc_n_layers"]):
+        idim = I if i == 0 else H
+        p = "encoder.enc2.layers.%d." % i
+        for suf in ("", "_reverse"):
+            sd[p + "weight_ih_l0" + suf] = _u(rs, (4 * H, idim), H)
+            sd[p + "weight_hh_l0" + suf] = _u(rs, (4 * H, H), H)
+            sd[p + "bias_ih_l0" + suf] = _u(rs, (4 * H,), H)
+            sd[p + "bias_hh_l0" + suf] = _u(rs, (4 * H,), H)
+    for i in range(cfg["enc_n_layers"]):
+        pd = 4 * H if cfg["subsample"][i] > 1 else 2 * H
+        q = "encoder.enc2.project_layers.%d." % i
+        sd[q + "weight"] = _u(rs, (H, pd), pd)
+        sd[q + "bias"] = _u(rs, (H,), pd)
+    A, D, C, K, O = (cfg["att_dim"], cfg["dec_hidden_dim"], cfg["conv_channels"],
+                     cfg["conv_kernel_size"], cfg["att_odim"])
+    att = {}
+    att["mlp_enc.weight"] = _u(rs, (A, H), H)
+    att["mlp_enc.bias"] = _u(rs, (A,), H)
+    att["mlp_dec.weight"] = _u(rs, (A, D), D)
+    att["mlp_att.weight"] = _u(rs, (A, C), C)
+    att["loc_conv.weight"] = _u(rs, (C, 1, 1, 2 * K + 1), 2 * K + 1)
+    att["gvec.weight"] = _u(rs, (1, A), A)
+    att["mlp_o.weight"] = _u(rs, (O, H), H)
+    att["mlp_o.bias"] = _u(rs, (O,), H)
+    for k, v in att.items():
+        sd["attention." + k] = v
+    E, V = cfg["embedding_dim"], cfg["output_dim"]
+    emb = rs.normal(0, 1, size=(V, E)).astype(np.float32)
+    emb[0] = 0.0                                     # padding_idx row
+    sd["decoder.embedding.weight"] = emb
+    sd["decoder.LSTMCell.weight_ih"] = _u(rs, (4 * D, E + O), D)
+    sd["decoder.LSTMCell.weight_hh"] = _u(rs, (4 * D, D), D)
+    sd["decoder.LSTMCell.bias_ih"] = _u(rs, (4 * D,), D)
+    sd["decoder.LSTMCell.bias_hh"] = _u(rs, (4 * D,), D)
+    sd["decoder.output_layer.weight"] = _u(rs, (V, D + O), D + O)
+    sd["decoder.output_layer.bias"] = _u(rs, (V,), D + O)
+    for k, v in att.items():
+        sd["decoder.attention." + k] = v
+    return sd
+
+
+def lm_weights(cfg, seed):
+    rs = np.random.RandomState(seed)
+    V, E, H = cfg["output_dim"], cfg["embedding_dim"], cfg["hidden_dim"]
+    sd = {}
+    emb = rs.normal(0, 1, size=(V, E)).astype(np.float32)
+    emb[0] = 0.0
+    sd["embedding.weight"] = emb
+    for l in range(cfg["n_layers"]):
+        idim = E if l == 0 else H
+        sd["LSTM.weight_ih_l%d" % l] = _u(rs, (4 * H, idim), H)
+        sd["LSTM.weight_hh_l%d" % l] = _u(rs, (4 * H, H), H)
+        sd["LSTM.bias_ih_l%d" % l] = _u(rs, (4 * H,), H)
+        sd["LSTM.bias_hh_l%d" % l] = _u(rs, (4 * H,), H)
+    sd["output_layer.weight"] = _u(rs, (V, H), H)
+    sd["output_layer.bias"] = _u(rs, (V,), H)
+    return sd
+
+
+def labeldist(V, seed):
+    rs = np.random.RandomState(seed)
+    d = rs.uniform(0.5, 1.5, size=V)
+    d[0] = 0.0
+    d[1] = 0.0
+    return d / d.sum()
+
+
+def batch(input_dim, V, ilens, ylens, seed):
+    """Collate-shaped batch (dataloader.py:6-12): zero-padded xs, descending ilens."""
+    rs = np.random.RandomState(seed)
+    xs = np.zeros((len(ilens), max(ilens), input_dim), dtype=np.float32)
+    for b, l in enumerate(ilens):
+        xs[b, :l] = rs.normal(0, 1, size=(l, input_dim)).astype(np.float32)
+    ys = [rs.randint(3, V, size=(n,)).astype(np.int64) for n in ylens]
+    return xs, list(ilens), ys
