@@ -1,0 +1,224 @@
+/*
+ * asr_hip.h — C ABI of libasr_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for
+ * the seq2seq-ASR training hot path of jjery2243542/semi-supervised-ASR.
+ *
+ * The reference has no FFI: the path sits behind torch modules (model.py) that dispatch
+ * stock operators.  Each entry point below names the reference operator call it replaces
+ * (file:line into the reference) — that is the "interface" a maintainer would bind.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + explicit sizes; contiguous row-major fp32; int32 lengths;
+ *     base pointers 16-byte aligned;
+ *   - the CALLER allocates every buffer (outputs and workspaces); nothing is allocated,
+ *     freed or synchronised inside; work is enqueued on `stream` (a hipStream_t);
+ *   - return 0 on success, a negative ASR_E_* code for a bad argument, or a positive
+ *     hipError_t if a launch failed.  Nothing throws across the ABI;
+ *   - re-entrant; no global mutable state.
+ *
+ * Layout vocabulary:
+ *   time-major      activations are [T][B][...] so one time step is one contiguous slab;
+ *   gate-interleave the 4H gate axis is ordered unit-major: index = unit*4 + gate, gate in
+ *                   (i,f,g,o) (torch order).  Host code permutes W_ih/W_hh/bias
+ *                   rows once per step; a 4-unit slice of all four gates is 16 contiguous
+ *                   floats (64 B).
+ */
+#ifndef ASR_HIP_H
+#define ASR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASR_ABI_VERSION 1
+
+#define ASR_E_ARG    (-1)  /* null pointer / non-positive size */
+#define ASR_E_SHAPE  (-2)  /* size not supported by the kernel (see each function) */
+#define ASR_E_ALIGN  (-3)  /* pointer or leading dimension not 16-byte aligned */
+
+typedef void* asr_stream_t; /* hipStream_t */
+
+int asr_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32; exact-f32 fmaf chain).
+ *   C[M,N] (ldc) = op(A)[M,K] * op(B)[K,N]  (+ bias[N]) (relu) (+ C if accumulate)
+ * Row-major.  transA=0: A is [M][K] (lda>=K); transA=1: A is [K][M] (lda>=M).
+ *             transB=0: B is [K][N] (ldb>=N); transB=1: B is [N][K] (ldb>=K).
+ * batch>1 runs `batch` independent GEMMs with element strides sA,sB,sC.
+ * split_k>1 splits K over grid.z and accumulates with fp32 atomics (C is zero-filled on
+ * the stream first unless accumulate!=0); bias/relu are rejected with split_k>1.
+ * Replaces torch.nn.Linear / mm / bmm on the path: the LSTM input-gate product inside
+ * torch.nn.LSTM (model.py:67-68,80), project_layer (model.py:93-94), mlp_enc
+ * (model.py:144), output_layer (model.py:293) and every autograd mm behind them.
+ * ------------------------------------------------------------------------------------- */
+int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                 const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, const float* bias, int relu, int accumulate,
+                 int batch, int64_t sA, int64_t sB, int64_t sC, int split_k,
+                 asr_stream_t stream);
+
+/* Skinny GEMM for the sequential chains (M = batch rows, tens not thousands):
+ *   C[M,N] (ldc) (+)= A[M,K] (lda) * Bt[N,K]^T (ldb)  (+ bias[N]) (* mask[M,N] from col mask_from)
+ * 16 output columns per workgroup, K split over the 4 waves, 16x16x4 f32 MFMA.
+ * K % 16 == 0, lda/ldb % 4 == 0.  Replaces mlp_dec (model.py:163), output_layer per step
+ * (model.py:293) and the dX products of LSTMCell/mlp_dec backward. */
+int asr_gemm_skinny_f32(int64_t M, int64_t N, int64_t K,
+                        const float* A, int64_t lda, const float* Bt, int64_t ldb,
+                        float* C, int64_t ldc, const float* bias, int accumulate,
+                        const float* mask, int64_t ldmask, int64_t mask_from,
+                        asr_stream_t stream);
+
+/* Column sums: out[N] (+)= sum_m X[m][n]   (bias gradients). */
+int asr_colsum_f32(int64_t M, int64_t N, const float* X, int64_t ldx, float* out,
+                   int accumulate, asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused LSTM sequence, all time steps of one layer, both directions in one call.
+ * Replaces torch.nn.LSTM(bidirectional) on a PackedSequence + pad_packed_sequence
+ * (model.py:79-81) and the 2-layer judge LSTM (model.py:466-467,515-519) — restated as a
+ * masked recurrence on the padded time-major tensor: at t >= lens[b] the
+ * state and the output are 0.
+ *
+ *   gates [T][B][ndir][4H]  in : x_t W_ih^T + b_ih + b_hh, gate-interleaved
+ *                           out: activated gates (i,f,g,o) — saved for backward
+ *   w_hh  [ndir][4H][H]     rows gate-interleaved
+ *   lens  [B] int32 (device)
+ *   y     [T][B][ndir*H]    hidden states; direction d occupies columns [d*H,(d+1)*H)
+ *   c     [T][B][ndir*H]    cell states (saved for backward)
+ * Direction 0 runs t = 0..T-1, direction 1 (if ndir==2) runs t = T-1..0.
+ * One kernel launch per time step covers both directions: workgroup = (4 hidden units x
+ * 4 gates = 16 gate rows) x (<=32 batch rows); h_{t-1} W_hh^T on the 16x16x4 f32 MFMA
+ * with K split over the 4 waves, partials reduced through LDS, then sigmoid/tanh/state
+ * update.  H % 16 == 0.
+ * ------------------------------------------------------------------------------------- */
+int asr_lstm_seq_fwd(int T, int B, int H, int ndir, float* gates, const float* w_hh,
+                     const int32_t* lens, float* y, float* c, asr_stream_t stream);
+
+/* Backward through the same recurrence.
+ *   gates [T][B][ndir][4H]  in : activated gates from the forward; out: dL/d(pre-activation)
+ *                           (= gradient of the x-projection, gate-interleaved)
+ *   w_hhT [ndir][H][4H]     transpose of the gate-interleaved w_hh
+ *   dy    [T][B][ndir*H]    upstream gradient of y
+ *   c     forward cell states;  dcarry [B][ndir*H] zero-initialised scratch (dL/dc carry)
+ * dW_hh is NOT produced here: the caller forms sum_t dG_t^T h_{t-1} with one asr_gemm_f32
+ * (transA=1) over the whole sequence after this call. */
+int asr_lstm_seq_bwd(int T, int B, int H, int ndir, float* gates, const float* w_hhT,
+                     const int32_t* lens, const float* dy, const float* c, float* dcarry,
+                     asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Pyramidal pair-concat (model.py:85-92), time-major:
+ *   in [T][B][C] -> out [ceil(T/2)][B][2C], out[t'] = [in[2t'] | in[2t'+1]]; for odd T the
+ *   missing last frame replicates in[T-1].  Optional elementwise mask (dropout, already
+ *   scaled by 1/(1-p)) of the input shape is applied on the fly.  float4 coalesced.
+ * Backward: din[t] = dout[t/2][.., (t%2)*C ..] (* mask), the replicated frame's gradient
+ * folded into din[T-1].
+ * ------------------------------------------------------------------------------------- */
+int asr_pyramid_concat_fwd(int T, int B, int C, const float* in, const float* mask,
+                           float* out, asr_stream_t stream);
+int asr_pyramid_concat_bwd(int T, int B, int C, const float* dout, const float* mask,
+                           float* din, asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Decoder step = LSTMCell + location-aware attention (Decoder.forward_step model.py:283-294,
+ * AttLoc.forward model.py:139-173).  Per-sequence constants:
+ *   P   [B][Tp][A]   mlp_enc(enc_h)                     (model.py:144)
+ *   Q   [B][Tp][O]   enc_h W_o^T  — mlp_o hoisted out of the step loop by linearity:
+ *                    mlp_o(sum_t w_t h_t) = sum_t w_t (W_o h_t) + b_o   (model.py:171-172)
+ *   X   [L+1][B][KX] step inputs, KX = D + O + E: X[s] = [ z_{s-1} | ctx_{s-1} | emb_s ]
+ *                    (cell_inp of model.py:284 plus the recurrent z); the step writes z_s
+ *                    and ctx_s into X[s+1].
+ *   wcat [4D][KX]    [W_hh | W_ih(ctx cols) | W_ih(emb cols)], rows gate-interleaved
+ *   bcat [4D]        b_ih + b_hh, gate-interleaved
+ * asr_dec_step_fwd(s) enqueues: fused cell (skinny MFMA gate GEMM + activations), mlp_dec
+ * skinny GEMM, attention score kernel (201-tap location conv, tanh energy), softmax +
+ * context kernel.  Softmax runs over ALL Tp frames with temperature `scaling` (SURVEY
+ * F1/F4).  w_prev for s==0 is the caller-provided uniform-over-valid-frames row block.
+ * Saved for backward: gates[s], cstate[s], S[s] (tanh values), fconv[s], ws[s], energies.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int B, Tp, A, D, O, E, C, K; /* K = conv half width, taps = 2K+1 */
+  int L;                        /* number of steps buffers are sized for */
+  float scaling;
+  /* per-sequence inputs */
+  const float* P;     /* [B][Tp][A] */
+  const float* Q;     /* [B][Tp][O] */
+  const float* bo;    /* [O] mlp_o bias */
+  const float* wcat;  /* [4D][KX] */
+  const float* bcat;  /* [4D] */
+  const float* wdec;  /* [A][D]  mlp_dec.weight */
+  const float* convw; /* [C][2K+1] loc_conv.weight */
+  const float* watt;  /* [A][C]  mlp_att.weight */
+  const float* gvec;  /* [A] */
+  const float* w0;    /* [B][Tp] initial attention weights (model.py:151-153) */
+  const float* xmask; /* [L][B][O+E] dropout mask for the (ctx|emb) part of X[s], or NULL */
+  /* state / saved buffers */
+  float* X;       /* [L+1][B][KX] */
+  float* gates;   /* [L][B][4D] */
+  float* cstate;  /* [L][B][D] */
+  float* Dproj;   /* [L][B][A]   mlp_dec(z_s) */
+  float* fconv;   /* [L][B][C][Tp] */
+  float* S;       /* [L][B][Tp][A] */
+  float* energy;  /* [L][B][Tp] */
+  float* ws;      /* [L][B][Tp] attention weights */
+} asr_dec_fwd_t;
+
+int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream);
+int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, asr_stream_t stream);
+
+/* Backward of one decoder step (reverse order s = L-1..0).
+ *   G     [L+1][B][KX]  gradient wrt X; on entry G[s+1][:, 0:D+O] holds every other
+ *                       contribution to d(z_s, ctx_s) (output layer); the step adds its own
+ *                       and accumulates dX[s] into G[s].
+ *   dwext [C][B][Tp]    partial d(w_s) coming from step s+1's location conv (in: consumed,
+ *                       out: overwritten with step s's partials for step s-1).  Zero it
+ *                       before the first (s = L-1) call.
+ *   dws   [L][B][Tp]    optional upstream gradient of the returned attention weights
+ *   dP    [B][Tp][A]    accumulated (+=);  dQw: dQ is formed by the caller as a batched
+ *                       GEMM of ws and dctx after the loop.
+ *   dgates[L][B][4D], dD [L][B][A]  saved per step for the deferred weight-gradient GEMMs
+ *   dgvec_part [B][A], dwatt_part [B][A][C], dconv_part [B][C][2K+1]: per-utterance
+ *                       partial sums accumulated over steps (caller zero-fills, reduces
+ *                       over B afterwards).
+ *   wcatT [KX][4D], wdecT [D][A]: transposes prepared by the caller.
+ */
+typedef struct {
+  asr_dec_fwd_t f;
+  const float* wcatT;
+  const float* wdecT;
+  const float* dws;   /* may be NULL */
+  float* G;
+  float* dwext;
+  float* dwraw;       /* [B][Tp] scratch */
+  float* dfpart;      /* [A/64 tiles][B][C][Tp] scratch */
+  float* dP;
+  float* dgates;
+  float* dD;
+  float* dcell;       /* [B][D] carry of dL/dc, zero-filled by the caller */
+  float* dgvec_part;
+  float* dwatt_part;
+  float* dconv_part;
+} asr_dec_bwd_t;
+
+int asr_dec_step_bwd(const asr_dec_bwd_t* p, int s, asr_stream_t stream);
+int asr_dec_seq_bwd(const asr_dec_bwd_t* p, int s_begin, int s_end, asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser on a flat fp32 buffer (solver.py:152-153,384-385: clip_grad_norm_ + Adam(amsgrad,
+ * weight_decay).step).  asr_sumsq_f32 adds sum(g^2) into the device scalar out[0] (caller zeroes
+ * it); asr_adam_clip_f32 scales g by min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) (skipped when
+ * gnorm_sq is NULL), folds weight_decay*p into g, updates m, v, the AMSGrad max (skipped when vmax
+ * is NULL) and p.  bias_c1 = 1-beta1^t, bias_c2 = 1-beta2^t are passed by the host.
+ * ------------------------------------------------------------------------------------- */
+int asr_sumsq_f32(int64_t n, const float* g, float* out, asr_stream_t stream);
+int asr_adam_clip_f32(int64_t n, float* p, const float* g, float* m, float* v, float* vmax,
+                      const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float bias_c1, float bias_c2,
+                      asr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H */

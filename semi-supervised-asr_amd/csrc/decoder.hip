@@ -1,0 +1,439 @@
+// decoder.hip — decoder time step: LSTMCell + location-aware attention, forward and backward.
+// Replaces Decoder.forward_step (model.py:283-294) and AttLoc.forward (model.py:139-173):
+//   e[b,t] = gvec . tanh(P[b,t,:] + W_dec z_b + W_att (F * w_prev_b)[t,:])
+//   w      = softmax(scaling * e) over ALL Tp frames (unmasked; scaling 2.0, F4)
+//   ctx    = sum_t w[b,t] Q[b,t,:] + b_o,   Q = enc_h W_o^T hoisted out of the loop
+// Kernels (forward):  cell (lstm.hip) -> skinny GEMM W_dec z -> att_score_fwd -> att_softmax_ctx_fwd
+// Kernels (backward): att_dw -> att_score_bwd -> att_conv_bwd -> skinny GEMM (dz += dD W_dec)
+//                     -> cell_bwd pointwise -> skinny GEMM (G[s] += dgates Wcat)
+// All reductions inside a wave use 64-lane shuffles; cross-wave sums go through LDS; cross-workgroup
+// sums are written as partial slabs and added by the consumer kernel of the next launch (no atomics,
+// results are bitwise reproducible run to run).
+#include "common.h"
+
+int asr_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bt, int64_t ldb,
+                      float* C, int64_t ldc, const float* bias, int accumulate, const float* mask, int64_t ldmask,
+                      int64_t mask_from, hipStream_t stream);
+int asr_cell_fwd_launch(int B, int D, int KX, const float* Xs, const float* wcat, const float* bcat,
+                        const float* xmask, int64_t ldmask, float* gates, const float* cprev, float* cout, float* zout,
+                        hipStream_t stream);
+int asr_cell_bwd_launch(int B, int D, int KX, const float* Gnext, const float* gates, const float* cst,
+                        const float* cprev, float* dcell, float* dgates, hipStream_t stream);
+
+namespace {
+
+constexpr int FRAMES_PER_WG = 16;  // 4 waves x 4 frames
+constexpr int CMAX = 16;           // max conv channels held in registers by the backward kernel
+constexpr int ATILE = 64;          // attention-dim columns per workgroup in the backward score kernel
+
+__device__ __forceinline__ float fast_tanh(float x) {
+  // 1 - 2/(1+e^{2x}); saturates correctly at +-inf; abs error ~1e-7
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+}
+
+// ------------------------------------------------------------------ forward: energies
+// grid (ceil(Tp/16), B), 256 threads.  dynamic LDS: wp[Tp+2K] | Fs[C][2K+1] | fs[16][C] | Ut[C][A]
+__global__ __launch_bounds__(256) void att_score_fwd_kernel(int B, int Tp, int A, int C, int K,
+                                                            const float* __restrict__ P,
+                                                            const float* __restrict__ Dp,
+                                                            const float* __restrict__ wprev,
+                                                            const float* __restrict__ convw,
+                                                            const float* __restrict__ watt,
+                                                            const float* __restrict__ gvec, float* __restrict__ S,
+                                                            float* __restrict__ fconv, float* __restrict__ energy) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int taps = 2 * K + 1;
+  float* wp = sm;
+  float* Fs = wp + (Tp + 2 * K);
+  float* fs = Fs + C * taps;
+  float* Ut = fs + FRAMES_PER_WG * C;
+  const int b = blockIdx.y, t0 = blockIdx.x * FRAMES_PER_WG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < Tp + 2 * K; i += 256) {
+    const int fr = i - K;
+    wp[i] = (fr >= 0 && fr < Tp) ? wprev[(int64_t)b * Tp + fr] : 0.f;
+  }
+  for (int i = tid; i < C * taps; i += 256) Fs[i] = convw[i];
+  for (int i = tid; i < A * C; i += 256) {   // watt is [A][C]; LDS image is [C][A]
+    const int a = i / C, ch = i - a * C;
+    Ut[ch * A + a] = watt[i];
+  }
+  __syncthreads();
+  // location conv: 4 lanes per output (frame, channel), taps interleaved over the 4 lanes
+  for (int base = 0; base < FRAMES_PER_WG * C * 4; base += 256) {
+    const int idx = base + tid;
+    float v = 0.f;
+    const int o = idx >> 2, part = idx & 3;
+    const int tl = o / C, ch = o - tl * C;
+    const int t = t0 + tl;
+    if (idx < FRAMES_PER_WG * C * 4 && t < Tp) {
+      const int jlo = K - t > 0 ? K - t : 0;
+      const int jhi = K - t + Tp - 1 < 2 * K ? K - t + Tp - 1 : 2 * K;
+      const float* fr = Fs + ch * taps;
+      for (int j = jlo + part; j <= jhi; j += 4) v += fr[j] * wp[t + j];
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    if (idx < FRAMES_PER_WG * C * 4 && part == 0) {
+      fs[tl * C + ch] = v;
+      if (t < Tp) fconv[((int64_t)b * C + ch) * Tp + t] = v;
+    }
+  }
+  __syncthreads();
+  // energies: wave owns 4 frames, lane strides the attention dim
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tw = t0 + wave * 4;
+  for (int a = lane; a < A; a += 64) {
+    float ucol[CMAX];
+#pragma unroll
+    for (int ch = 0; ch < CMAX; ++ch) ucol[ch] = ch < C ? Ut[ch * A + a] : 0.f;
+    const float dv = Dp[(int64_t)b * A + a];
+    const float gv = gvec[a];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = tw + i;
+      if (t < Tp) {
+        const int64_t off = ((int64_t)b * Tp + t) * A + a;
+        float u = P[off] + dv;
+        const float* f = fs + (wave * 4 + i) * C;
+#pragma unroll
+        for (int ch = 0; ch < CMAX; ++ch)
+          if (ch < C) u += ucol[ch] * f[ch];
+        const float sv = fast_tanh(u);
+        S[off] = sv;
+        part[i] += gv * sv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float e = wave_sum(part[i]);
+    if (lane == 0 && tw + i < Tp) energy[(int64_t)b * Tp + tw + i] = e;
+  }
+}
+
+// ------------------------------------------------------------------ forward: softmax + context
+// grid (ceil(O/256), B), 256 threads; dynamic LDS: ws[Tp] | red[4][256]
+__global__ __launch_bounds__(256) void att_softmax_ctx_fwd_kernel(int B, int Tp, int O, float scaling,
+                                                                  const float* __restrict__ energy,
+                                                                  const float* __restrict__ Q,
+                                                                  const float* __restrict__ bo,
+                                                                  float* __restrict__ wout, float* __restrict__ ctx,
+                                                                  int64_t ldctx) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wsm = sm;
+  float* red = sm + ((Tp + 3) & ~3);
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // every wave computes the softmax statistics redundantly (Tp is ~100): no block-level reduction
+  float mx = -INFINITY;
+  for (int t = lane; t < Tp; t += 64) mx = fmaxf(mx, scaling * energy[(int64_t)b * Tp + t]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int t = lane; t < Tp; t += 64) sum += expf(scaling * energy[(int64_t)b * Tp + t] - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  if (wave == 0) {
+    for (int t = lane; t < Tp; t += 64) {
+      const float w = expf(scaling * energy[(int64_t)b * Tp + t] - mx) * inv;
+      wsm[t] = w;
+      if (blockIdx.x == 0) wout[(int64_t)b * Tp + t] = w;
+    }
+  }
+  __syncthreads();
+  const int o = blockIdx.x * 256 + lane * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (o < O) {
+    const float* q = Q + (int64_t)b * Tp * O + o;
+    for (int t = wave; t < Tp; t += 4) {
+      const float w = wsm[t];
+      const float4 v = *reinterpret_cast<const float4*>(q + (int64_t)t * O);
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+  }
+  *reinterpret_cast<float4*>(red + wave * 256 + lane * 4) = acc;
+  __syncthreads();
+  if (wave == 0 && o < O) {
+    float4 r = *reinterpret_cast<const float4*>(red + lane * 4);
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      const float4 x = *reinterpret_cast<const float4*>(red + w2 * 256 + lane * 4);
+      r.x += x.x; r.y += x.y; r.z += x.z; r.w += x.w;
+    }
+    const float4 bb = *reinterpret_cast<const float4*>(bo + o);
+    r.x += bb.x; r.y += bb.y; r.z += bb.z; r.w += bb.w;
+    *reinterpret_cast<float4*>(ctx + (int64_t)b * ldctx + o) = r;
+  }
+}
+
+// ------------------------------------------------------------------ backward: d(w) before the softmax
+// dwraw[b,t] = Q[b,t,:] . dctx[b,:] + sum_c dwext[c][b][t] (+ dws[b,t]);  grid (ceil(Tp/16), B)
+__global__ __launch_bounds__(256) void att_dw_kernel(int B, int Tp, int O, int C, const float* __restrict__ Q,
+                                                     const float* __restrict__ dctx, int64_t lddctx,
+                                                     const float* __restrict__ dwext,
+                                                     const float* __restrict__ dws, float* __restrict__ dwraw) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tw = blockIdx.x * FRAMES_PER_WG + wave * 4;
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int o = lane * 4; o < O; o += 256) {
+    const float4 g = *reinterpret_cast<const float4*>(dctx + (int64_t)b * lddctx + o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (tw + i < Tp) {
+        const float4 q = *reinterpret_cast<const float4*>(Q + ((int64_t)b * Tp + tw + i) * O + o);
+        part[i] += q.x * g.x + q.y * g.y + q.z * g.z + q.w * g.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v = wave_sum(part[i]);
+    const int t = tw + i;
+    if (lane == 0 && t < Tp) {
+      if (dwext)
+        for (int ch = 0; ch < C; ++ch) v += dwext[((int64_t)ch * B + b) * Tp + t];
+      if (dws) v += dws[(int64_t)b * Tp + t];
+      dwraw[(int64_t)b * Tp + t] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward: scores
+// grid (ceil(A/64), B), 256 threads.  Each workgroup owns 64 attention-dim columns of one utterance for
+// ALL frames, so dD, dgvec, dW_att partials are local; d(conv output) partials go to a slab per tile.
+// dynamic LDS: de[Tp] | wv[Tp] | fsm[C][Tp] | Us[64][C] | du[Tp][65] | red[4][64][2+CMAX]
+__global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A, int C, float scaling,
+                                                            const float* __restrict__ wcur,
+                                                            const float* __restrict__ dwraw,
+                                                            const float* __restrict__ S,
+                                                            const float* __restrict__ fconv,
+                                                            const float* __restrict__ watt,
+                                                            const float* __restrict__ gvec, float* __restrict__ dP,
+                                                            float* __restrict__ dD, float* __restrict__ dgvec_part,
+                                                            float* __restrict__ dwatt_part,
+                                                            float* __restrict__ dfpart) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int TpP = (Tp + 3) & ~3;
+  float* de = sm;
+  float* fsm = de + TpP;
+  float* Us = fsm + C * TpP;
+  float* du = Us + ATILE * C;
+  float* red = du + Tp * 65;
+  const int b = blockIdx.y, tile = blockIdx.x, a0 = tile * ATILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // softmax backward (each wave redundantly reduces the dot product)
+  float dot = 0.f;
+  for (int t = lane; t < Tp; t += 64) dot += wcur[(int64_t)b * Tp + t] * dwraw[(int64_t)b * Tp + t];
+  dot = wave_sum(dot);
+  for (int t = tid; t < Tp; t += 256) {
+    const float w = wcur[(int64_t)b * Tp + t];
+    de[t] = scaling * w * (dwraw[(int64_t)b * Tp + t] - dot);
+  }
+  for (int i = tid; i < C * Tp; i += 256) {
+    const int ch = i / Tp, t = i - ch * Tp;
+    fsm[ch * TpP + t] = fconv[((int64_t)b * C + ch) * Tp + t];
+  }
+  for (int i = tid; i < ATILE * C; i += 256) {
+    const int al = i / C;
+    Us[i] = a0 + al < A ? watt[(int64_t)(a0 + al) * C + (i - al * C)] : 0.f;
+  }
+  __syncthreads();
+  const int a = a0 + lane;
+  const bool live = a < A;
+  const float gv = live ? gvec[a] : 0.f;
+  float dD_acc = 0.f, dg_acc = 0.f, dU_acc[CMAX];
+#pragma unroll
+  for (int ch = 0; ch < CMAX; ++ch) dU_acc[ch] = 0.f;
+  for (int t = wave; t < Tp; t += 4) {
+    float duv = 0.f;
+    if (live) {
+      const int64_t off = ((int64_t)b * Tp + t) * A + a;
+      const float sv = S[off];
+      const float det = de[t];
+      duv = det * gv * (1.f - sv * sv);
+      dP[off] += duv;
+      dD_acc += duv;
+      dg_acc += det * sv;
+#pragma unroll
+      for (int ch = 0; ch < CMAX; ++ch)
+        if (ch < C) dU_acc[ch] += duv * fsm[ch * TpP + t];
+    }
+    du[t * 65 + lane] = duv;
+  }
+  float* myred = red + (wave * 64 + lane) * (2 + CMAX);
+  myred[0] = dD_acc;
+  myred[1] = dg_acc;
+#pragma unroll
+  for (int ch = 0; ch < CMAX; ++ch) myred[2 + ch] = dU_acc[ch];
+  __syncthreads();
+  if (wave == 0 && live) {
+    float tot[2 + CMAX];
+#pragma unroll
+    for (int k = 0; k < 2 + CMAX; ++k) {
+      tot[k] = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) tot[k] += red[(w2 * 64 + lane) * (2 + CMAX) + k];
+    }
+    dD[(int64_t)b * A + a] = tot[0];
+    dgvec_part[(int64_t)b * A + a] += tot[1];
+#pragma unroll
+    for (int ch = 0; ch < CMAX; ++ch)
+      if (ch < C) dwatt_part[((int64_t)b * A + a) * C + ch] += tot[2 + ch];
+  }
+  // d(conv output)[ch][t] restricted to this tile's columns: sum_a U[a][ch] du[t][a]
+  for (int i = tid; i < C * Tp; i += 256) {
+    const int ch = i / Tp, t = i - ch * Tp;
+    float v = 0.f;
+    const float* drow = du + t * 65;
+#pragma unroll 8
+    for (int al = 0; al < ATILE; ++al) v += Us[al * C + ch] * drow[al];
+    dfpart[(((int64_t)tile * B + b) * C + ch) * Tp + t] = v;
+  }
+}
+
+// ------------------------------------------------------------------ backward: location conv
+// grid (C, B), 256 threads.  dynamic LDS: df[Tp] | wp[Tp+2K] | Fs[2K+1]
+__global__ __launch_bounds__(256) void att_conv_bwd_kernel(int B, int Tp, int C, int K, int ntile,
+                                                           const float* __restrict__ dfpart,
+                                                           const float* __restrict__ wprev,
+                                                           const float* __restrict__ convw,
+                                                           float* __restrict__ dwext,
+                                                           float* __restrict__ dconv_part) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int taps = 2 * K + 1;
+  float* df = sm;
+  float* wp = df + ((Tp + 3) & ~3);
+  float* Fs = wp + ((Tp + 2 * K + 3) & ~3);
+  const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  for (int t = tid; t < Tp; t += 256) {
+    float v = 0.f;
+    for (int tl = 0; tl < ntile; ++tl) v += dfpart[(((int64_t)tl * B + b) * C + ch) * Tp + t];
+    df[t] = v;
+  }
+  for (int i = tid; i < Tp + 2 * K; i += 256) {
+    const int fr = i - K;
+    wp[i] = (fr >= 0 && fr < Tp) ? wprev[(int64_t)b * Tp + fr] : 0.f;
+  }
+  for (int i = tid; i < taps; i += 256) Fs[i] = convw[ch * taps + i];
+  __syncthreads();
+  // f[t] = sum_j F[j] wprev[t + j - K]  =>  dwprev[t'] = sum_t F[t' - t + K] df[t]
+  for (int base = 0; base < Tp * 4; base += 256) {
+    const int idx = base + tid;
+    const int tq = idx >> 2, part = idx & 3;
+    float v = 0.f;
+    if (tq < Tp) {
+      const int lo = tq - K > 0 ? tq - K : 0;            // t' - t + K <= 2K
+      const int hi = tq + K < Tp - 1 ? tq + K : Tp - 1;  // t' - t + K >= 0
+      for (int t = lo + part; t <= hi; t += 4) v += Fs[tq - t + K] * df[t];
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    if (tq < Tp && part == 0) dwext[((int64_t)ch * B + b) * Tp + tq] = v;
+  }
+  // dF[j] += sum_t df[t] wprev[t + j - K]
+  for (int j = tid; j < taps; j += 256) {
+    float v = 0.f;
+    for (int t = 0; t < Tp; ++t) v += df[t] * wp[t + j];
+    dconv_part[((int64_t)b * C + ch) * taps + j] += v;
+  }
+}
+
+int check_fwd(const asr_dec_fwd_t* p) {
+  if (!p || !p->P || !p->Q || !p->bo || !p->wcat || !p->bcat || !p->wdec || !p->convw || !p->watt || !p->gvec ||
+      !p->w0 || !p->X || !p->gates || !p->cstate || !p->Dproj || !p->fconv || !p->S || !p->energy || !p->ws)
+    return ASR_E_ARG;
+  if (p->B <= 0 || p->Tp <= 0 || p->L <= 0) return ASR_E_ARG;
+  if (p->D % 16 || p->A % 16 || p->O % 4 || (p->D + p->O + p->E) % 16 || p->C > CMAX || p->C <= 0) return ASR_E_SHAPE;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_fwd(p);
+  if (rc) return rc;
+  if (s < 0 || s >= p->L) return ASR_E_ARG;
+  const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, K = p->K;
+  const int KX = D + O + E;
+  const float* Xs = p->X + (int64_t)s * B * KX;
+  float* Xn = p->X + (int64_t)(s + 1) * B * KX;
+  const float* xm = p->xmask ? p->xmask + (int64_t)s * B * (O + E) : nullptr;
+  rc = asr_cell_fwd_launch(B, D, KX, Xs, p->wcat, p->bcat, xm, O + E, p->gates + (int64_t)s * B * 4 * D,
+                           s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr, p->cstate + (int64_t)s * B * D, Xn,
+                           stream);
+  if (rc) return rc;
+  float* Dp = p->Dproj + (int64_t)s * B * A;
+  rc = asr_skinny_launch(B, A, D, Xn, KX, p->wdec, D, Dp, A, nullptr, 0, nullptr, 0, 0, stream);
+  if (rc) return rc;
+  const float* wprev = s > 0 ? p->ws + (int64_t)(s - 1) * B * Tp : p->w0;
+  const int taps = 2 * K + 1;
+  const size_t lds1 = sizeof(float) * ((size_t)(Tp + 2 * K) + (size_t)C * taps + FRAMES_PER_WG * C + (size_t)C * A);
+  hipLaunchKernelGGL(att_score_fwd_kernel, dim3((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG, B), dim3(256), lds1, stream,
+                     B, Tp, A, C, K, p->P, Dp, wprev, p->convw, p->watt, p->gvec, p->S + (int64_t)s * B * Tp * A,
+                     p->fconv + (int64_t)s * B * C * Tp, p->energy + (int64_t)s * B * Tp);
+  const size_t lds2 = sizeof(float) * ((size_t)((Tp + 3) & ~3) + 4 * 256);
+  hipLaunchKernelGGL(att_softmax_ctx_fwd_kernel, dim3((O + 255) / 256, B), dim3(256), lds2, stream, B, Tp, O,
+                     p->scaling, p->energy + (int64_t)s * B * Tp, p->Q, p->bo, p->ws + (int64_t)s * B * Tp, Xn + D,
+                     (int64_t)KX);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, asr_stream_t stream) {
+  for (int s = s_begin; s < s_end; ++s) {
+    int rc = asr_dec_step_fwd(p, s, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int asr_dec_step_bwd(const asr_dec_bwd_t* q, int s, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!q) return ASR_E_ARG;
+  const asr_dec_fwd_t* p = &q->f;
+  int rc = check_fwd(p);
+  if (rc) return rc;
+  if (!q->wcatT || !q->wdecT || !q->G || !q->dwext || !q->dwraw || !q->dfpart || !q->dP || !q->dgates || !q->dD ||
+      !q->dcell || !q->dgvec_part || !q->dwatt_part || !q->dconv_part)
+    return ASR_E_ARG;
+  if (s < 0 || s >= p->L) return ASR_E_ARG;
+  const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, K = p->K;
+  const int KX = D + O + E, taps = 2 * K + 1;
+  const int ntile = (A + ATILE - 1) / ATILE;
+  float* Gn = q->G + (int64_t)(s + 1) * B * KX;
+  float* Gs = q->G + (int64_t)s * B * KX;
+  const int tgrid = (Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+  hipLaunchKernelGGL(att_dw_kernel, dim3(tgrid, B), dim3(256), 0, stream, B, Tp, O, C, p->Q, Gn + D, (int64_t)KX,
+                     s + 1 < p->L ? q->dwext : nullptr, q->dws ? q->dws + (int64_t)s * B * Tp : nullptr, q->dwraw);
+  const int TpP = (Tp + 3) & ~3;
+  const size_t lds2 = sizeof(float) * ((size_t)TpP + (size_t)C * TpP + ATILE * C + (size_t)Tp * 65 +
+                                       4 * 64 * (2 + CMAX));
+  float* dDs = q->dD + (int64_t)s * B * A;
+  hipLaunchKernelGGL(att_score_bwd_kernel, dim3(ntile, B), dim3(256), lds2, stream, B, Tp, A, C, p->scaling,
+                     p->ws + (int64_t)s * B * Tp, q->dwraw, p->S + (int64_t)s * B * Tp * A,
+                     p->fconv + (int64_t)s * B * C * Tp, p->watt, p->gvec, q->dP, dDs, q->dgvec_part, q->dwatt_part,
+                     q->dfpart);
+  const float* wprev = s > 0 ? p->ws + (int64_t)(s - 1) * B * Tp : p->w0;
+  const size_t lds3 = sizeof(float) * ((size_t)TpP + (size_t)((Tp + 2 * K + 3) & ~3) + taps);
+  hipLaunchKernelGGL(att_conv_bwd_kernel, dim3(C, B), dim3(256), lds3, stream, B, Tp, C, K, ntile, q->dfpart, wprev,
+                     p->convw, q->dwext, q->dconv_part);
+  ASR_CHECK_LAUNCH();
+  // dz_s += dD W_dec
+  rc = asr_skinny_launch(B, D, A, dDs, A, q->wdecT, A, Gn, KX, nullptr, 1, nullptr, 0, 0, stream);
+  if (rc) return rc;
+  float* dg = q->dgates + (int64_t)s * B * 4 * D;
+  rc = asr_cell_bwd_launch(B, D, KX, Gn, p->gates + (int64_t)s * B * 4 * D, p->cstate + (int64_t)s * B * D,
+                           s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr, q->dcell, dg, stream);
+  if (rc) return rc;
+  const float* xm = p->xmask ? p->xmask + (int64_t)s * B * (O + E) : nullptr;
+  rc = asr_skinny_launch(B, KX, 4 * D, dg, 4 * D, q->wcatT, 4 * D, Gs, KX, nullptr, 1, xm, O + E, D, stream);
+  return rc;
+}
+
+extern "C" int asr_dec_seq_bwd(const asr_dec_bwd_t* q, int s_begin, int s_end, asr_stream_t stream) {
+  for (int s = s_end - 1; s >= s_begin; --s) {
+    int rc = asr_dec_step_bwd(q, s, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}

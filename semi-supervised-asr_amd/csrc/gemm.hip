@@ -1,0 +1,306 @@
+// gemm.hip — fp32 GEMMs on the f32-input MFMA of gfx950.
+//   asr_gemm_f32        128x128x32 LDS-tiled, v_mfma_f32_32x32x2_f32, 4 waves x (2x2) 32x32 tiles,
+//                       register-prefetched next K tile, optional split-K with f32 atomics.
+//   asr_gemm_skinny_f32 M = batch rows of a sequential chain; 16 columns per workgroup.
+//   asr_colsum_f32      bias gradients.
+// Replaces the torch mm/addmm/bmm calls behind nn.Linear / nn.LSTM input projections on the
+// reference path (model.py:67-68,80,93-94,144,163,293 and their autograd backward).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+
+// A "stored matrix" view: element (r, c) at p[r*ld + c], valid for r < R, c < Cn.
+struct MatView {
+  const float* p;
+  int64_t ld, R, Cn;
+  bool vec;  // ld % 4 == 0 and base 16B aligned -> float4 loads allowed
+};
+
+__device__ __forceinline__ float4 load4_guard(const MatView& m, int64_t r, int64_t c) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r >= m.R) return v;
+  const float* q = m.p + r * m.ld + c;
+  if (m.vec && c + 3 < m.Cn) return *reinterpret_cast<const float4*>(q);
+  if (c < m.Cn) v.x = q[0];
+  if (c + 1 < m.Cn) v.y = q[1];
+  if (c + 2 < m.Cn) v.z = q[2];
+  if (c + 3 < m.Cn) v.w = q[3];
+  return v;
+}
+
+// LDS image of an operand tile is always [BK][rows(+pad)] (k-major planes, rows contiguous) so
+// that the MFMA fragment read (32 consecutive rows at one k) is a conflict-free ds_read_b32.
+//   KC operand (k contiguous in memory, e.g. A[M][K]):   stride 129, scattered b32 writes
+//   MC operand (row index contiguous, e.g. A stored [K][M]): stride 128, b128 writes
+template <bool KC>
+struct TileCfg {
+  static constexpr int S = KC ? 129 : 128;
+};
+
+// Fetch this thread's 4 float4 pieces of a 128 x 32 operand tile (rows x k) into registers.
+template <bool KC>
+__device__ __forceinline__ void tile_fetch(const MatView& m, int64_t row0, int64_t k0, float4 (&v)[4]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = t + 256 * i;
+    if (KC) {  // stored [rows][K]: 8 float4 per row
+      const int row = f >> 3, kc4 = f & 7;
+      v[i] = load4_guard(m, row0 + row, k0 + 4 * kc4);
+    } else {   // stored [K][rows]: 32 float4 per k
+      const int k = f >> 5, m4 = f & 31;
+      v[i] = load4_guard(m, k0 + k, row0 + 4 * m4);
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void tile_store(float* lds, const float4 (&v)[4]) {
+  constexpr int S = TileCfg<KC>::S;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = t + 256 * i;
+    if (KC) {
+      const int row = f >> 3, kc4 = f & 7;
+      float* d = lds + (4 * kc4) * S + row;
+      d[0] = v[i].x; d[S] = v[i].y; d[2 * S] = v[i].z; d[3 * S] = v[i].w;
+    } else {
+      const int k = f >> 5, m4 = f & 31;
+      *reinterpret_cast<float4*>(lds + k * S + 4 * m4) = v[i];
+    }
+  }
+}
+
+struct GemmArgs {
+  MatView A, B;  // A: KC -> [M][K] else [K][M];  B: KC -> [N][K] else [K][N]
+  float* C;
+  int64_t ldc, M, N, K;
+  const float* bias;
+  int relu, accumulate, split_k;
+  int64_t sA, sB, sC;
+  int tiles_m, tiles_n;
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int SA = TileCfg<AKC>::S, SB = TileCfg<BKC>::S;
+  __shared__ __attribute__((aligned(16))) float smem[BK * SA + BK * SB];
+  float* As = smem;
+  float* Bs = smem + BK * SA;
+
+  // XCD-aware tile order: consecutive tile ids share an A row-panel; the hardware deals
+  // workgroups round-robin over the 8 XCDs, so give each XCD a contiguous chunk of ids.
+  const int ntile = g.tiles_m * g.tiles_n;
+  int tid = blockIdx.x;
+  {
+    const int q = ntile >> 3, rmd = ntile & 7, xcd = tid & 7, idx = tid >> 3;
+    tid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
+  }
+  const int tm = tid / g.tiles_n, tn = tid % g.tiles_n;
+  const int z = blockIdx.y;
+  const int bz = z / g.split_k, kz = z % g.split_k;
+
+  MatView A = g.A, B = g.B;
+  A.p += bz * g.sA;
+  B.p += bz * g.sB;
+  float* C = g.C + bz * g.sC;
+
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t ktiles = (g.K + BK - 1) / BK;
+  const int64_t per = (ktiles + g.split_k - 1) / g.split_k;
+  const int64_t kt_begin = kz * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[4], rb[4];
+  if (kt_begin < kt_end) {
+    tile_fetch<AKC>(A, m0, kt_begin * BK, ra);
+    tile_fetch<BKC>(B, n0, kt_begin * BK, rb);
+  }
+  for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+    tile_store<AKC>(As, ra);
+    tile_store<BKC>(Bs, rb);
+    __syncthreads();
+    if (kt + 1 < kt_end) {
+      tile_fetch<AKC>(A, m0, (kt + 1) * BK, ra);
+      tile_fetch<BKC>(B, n0, (kt + 1) * BK, rb);
+    }
+    const float* ap = As + kh * SA + wm * 64 + l31;
+    const float* bp = Bs + kh * SB + wn * 64 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const float a0 = ap[(2 * kk) * SA], a1 = ap[(2 * kk) * SA + 32];
+      const float b0 = bp[(2 * kk) * SB], b1 = bp[(2 * kk) * SB + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane owns column n, rows (e&3) + 8*(e>>2) + 4*kh of each 32x32 tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= g.N) continue;
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (m >= g.M) continue;
+        float v = acc[i][j][e];
+        float* dst = C + m * g.ldc + n;
+        if (g.split_k > 1) {
+          atomicAdd(dst, v);
+        } else {
+          v += bv;
+          if (g.accumulate) v += *dst;
+          if (g.relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ void zero_rows_kernel(float* C, int64_t ldc, int64_t M, int64_t N, int64_t sC) {
+  float* p = C + blockIdx.z * sC;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M * N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / N, n = i % N;
+    p[m * ldc + n] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void skinny_kernel(int64_t M, int64_t N, int K, const float* A, int64_t lda,
+                                                     const float* Bt, int64_t ldb, float* C, int64_t ldc,
+                                                     const float* bias, int accumulate, const float* mask,
+                                                     int64_t ldmask, int64_t mask_from) {
+  __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
+  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  const int64_t row0 = (int64_t)blockIdx.y * (MT * 16);
+  skinny_partial<MT>(A, lda, row0, M, Bt, ldb, n0, N, K, nullptr, 0, 0, red);
+  __syncthreads();
+  for (int e = threadIdx.x; e < MT * 16 * 16; e += 256) {
+    const int row = e >> 4, col = e & 15;
+    const int64_t m = row0 + row, n = n0 + col;
+    if (m >= M || n >= N) continue;
+    float v = skinny_reduced<MT>(red, row, col);
+    if (bias) v += bias[n];
+    if (mask && n >= mask_from) v *= mask[m * ldmask + (n - mask_from)];
+    float* dst = C + m * ldc + n;
+    if (accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
+__global__ void colsum_kernel(int64_t M, int64_t N, const float* X, int64_t ldx, float* out) {
+  // block = 256 threads = 64 columns x 4 row groups; grid.y strides over 512-row chunks
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + cx;
+  const int64_t mbeg = (int64_t)blockIdx.y * 512;
+  const int64_t mend = mbeg + 512 < M ? mbeg + 512 : M;
+  float s = 0.f;
+  if (n < N)
+    for (int64_t m = mbeg + ry; m < mend; m += 4) s += X[m * ldx + n];
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && n < N) atomicAdd(out + n, (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]));
+}
+
+}  // namespace
+
+extern "C" int asr_abi_version(void) { return ASR_ABI_VERSION; }
+
+extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
+                            int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC, int split_k,
+                            asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return ASR_E_ARG;
+  if (split_k < 1) split_k = 1;
+  if (split_k > 1 && (bias || relu)) return ASR_E_SHAPE;
+  GemmArgs g;
+  const bool akc = !transA, bkc = transB != 0;
+  g.A.p = A; g.A.ld = lda;
+  if (akc) { g.A.R = M; g.A.Cn = K; } else { g.A.R = K; g.A.Cn = M; }
+  g.A.vec = (lda % 4 == 0) && asr_aligned16(A) && (sA % 4 == 0);
+  g.B.p = B; g.B.ld = ldb;
+  if (bkc) { g.B.R = N; g.B.Cn = K; } else { g.B.R = K; g.B.Cn = N; }
+  g.B.vec = (ldb % 4 == 0) && asr_aligned16(B) && (sB % 4 == 0);
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.bias = bias; g.relu = relu; g.accumulate = accumulate; g.split_k = split_k;
+  g.sA = sA; g.sB = sB; g.sC = sC;
+  g.tiles_m = (int)((M + BM - 1) / BM);
+  g.tiles_n = (int)((N + BN - 1) / BN);
+  const int64_t ktiles = (K + BK - 1) / BK;
+  if (split_k > ktiles) { split_k = (int)ktiles; g.split_k = split_k; }
+  if (split_k > 1 && !accumulate) {
+    dim3 zg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
+    hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
+  }
+  dim3 grid(g.tiles_m * g.tiles_n, batch * split_k, 1), block(256);
+  if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+int asr_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bt, int64_t ldb,
+                      float* C, int64_t ldc, const float* bias, int accumulate, const float* mask, int64_t ldmask,
+                      int64_t mask_from, hipStream_t stream) {
+  if (!A || !Bt || !C || M <= 0 || N <= 0 || K <= 0) return ASR_E_ARG;
+  if (K % 16 || lda % 4 || ldb % 4) return ASR_E_SHAPE;
+  if (!asr_aligned16(A) || !asr_aligned16(Bt)) return ASR_E_ALIGN;
+  const unsigned nb = (unsigned)((N + 15) / 16);
+  if (M <= 16) {
+    hipLaunchKernelGGL((skinny_kernel<1>), dim3(nb, 1), dim3(256), 0, stream, M, N, (int)K, A, lda, Bt, ldb, C, ldc,
+                       bias, accumulate, mask, ldmask, mask_from);
+  } else {
+    hipLaunchKernelGGL((skinny_kernel<2>), dim3(nb, (unsigned)((M + 31) / 32)), dim3(256), 0, stream, M, N, (int)K, A,
+                       lda, Bt, ldb, C, ldc, bias, accumulate, mask, ldmask, mask_from);
+  }
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int asr_gemm_skinny_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bt,
+                                   int64_t ldb, float* C, int64_t ldc, const float* bias, int accumulate,
+                                   const float* mask, int64_t ldmask, int64_t mask_from, asr_stream_t stream) {
+  return asr_skinny_launch(M, N, K, A, lda, Bt, ldb, C, ldc, bias, accumulate, mask, ldmask, mask_from,
+                           (hipStream_t)stream);
+}
+
+extern "C" int asr_colsum_f32(int64_t M, int64_t N, const float* X, int64_t ldx, float* out, int accumulate,
+                              asr_stream_t stream) {
+  if (!X || !out || M <= 0 || N <= 0) return ASR_E_ARG;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 511) / 512)), dim3(256), 0,
+                     (hipStream_t)stream, M, N, X, ldx, out);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}

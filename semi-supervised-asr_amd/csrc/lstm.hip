@@ -1,0 +1,223 @@
+// lstm.hip — fused LSTM time-step kernels for gfx950.
+//   encoder / judge recurrence: asr_lstm_seq_fwd / asr_lstm_seq_bwd  (replaces torch.nn.LSTM on a
+//     PackedSequence, model.py:79-81 and 466-467,515-519)
+//   decoder cell: cell_fwd_launch / cell_bwd_launch used by decoder.hip (replaces torch.nn.LSTMCell,
+//     model.py:262,286)
+// One launch per time step; both directions of a layer share the launch (blockIdx.y).  A workgroup owns
+// 4 hidden units x 4 gates (16 gate-interleaved rows of W) x <=32 batch rows in the forward, and 16
+// hidden units in the backward; the recurrent product runs on v_mfma_f32_16x16x4_f32 with K split
+// over the 4 waves and reduced through LDS, followed by the pointwise gate math in the same kernel.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ forward step (encoder/judge)
+template <int MT>
+__global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int H, int ndir, float* __restrict__ gates,
+                                                           const float* __restrict__ w_hh,
+                                                           const int32_t* __restrict__ lens, float* __restrict__ y,
+                                                           float* __restrict__ c, int s) {
+  __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
+  const int j = blockIdx.x, d = blockIdx.y;
+  const int64_t row0 = (int64_t)blockIdx.z * (MT * 16);
+  const int t = d == 0 ? s : T - 1 - s;
+  const int tp = d == 0 ? t - 1 : t + 1;
+  const int64_t ldy = (int64_t)ndir * H;
+  if (s > 0) {
+    skinny_partial<MT>(y + (int64_t)tp * B * ldy + d * H, ldy, row0, B, w_hh + (int64_t)d * 4 * H * H, H,
+                       (int64_t)16 * j, (int64_t)4 * H, H, nullptr, 0, 0, red);
+  }
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < MT * 16 * 4) {
+    const int row = e >> 2, u = e & 3;
+    const int64_t b = row0 + row;
+    if (b < B) {
+      float pre[4] = {0.f, 0.f, 0.f, 0.f};
+      if (s > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = skinny_reduced<MT>(red, row, u * 4 + g);
+      }
+      const int unit = 4 * j + u;
+      float4* gp = reinterpret_cast<float4*>(gates + (((int64_t)t * B + b) * ndir + d) * 4 * H + unit * 4);
+      const float4 gx = *gp;
+      const float gi = asr_sigmoid(pre[0] + gx.x), gf = asr_sigmoid(pre[1] + gx.y);
+      const float gg = tanhf(pre[2] + gx.z), go = asr_sigmoid(pre[3] + gx.w);
+      const int64_t so = ((int64_t)t * B + b) * ldy + d * H + unit;
+      const float cp = s > 0 ? c[((int64_t)tp * B + b) * ldy + d * H + unit] : 0.f;
+      float cn = gf * cp + gi * gg;
+      float hn = go * tanhf(cn);
+      if (t >= lens[b]) { cn = 0.f; hn = 0.f; }
+      *gp = make_float4(gi, gf, gg, go);
+      c[so] = cn;
+      y[so] = hn;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward step (encoder/judge)
+// Workgroup = 16 hidden units of one direction x <=32 batch rows.  Phase 1: dh_rec = dG[t_next] W_hh
+// (K = 4H) for its units; phase 2: pointwise LSTM backward at time t, dG[t] written in place.
+template <int MT>
+__global__ __launch_bounds__(256) void enc_step_bwd_kernel(int T, int B, int H, int ndir, float* __restrict__ gates,
+                                                           const float* __restrict__ w_hhT,
+                                                           const int32_t* __restrict__ lens,
+                                                           const float* __restrict__ dy, const float* __restrict__ c,
+                                                           float* __restrict__ dcarry, int s) {
+  __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
+  const int j = blockIdx.x, d = blockIdx.y;
+  const int64_t row0 = (int64_t)blockIdx.z * (MT * 16);
+  const int t = d == 0 ? T - 1 - s : s;
+  const int tn = d == 0 ? t + 1 : t - 1;   // step handled by the previous launch
+  const int tp = d == 0 ? t - 1 : t + 1;   // forward-time predecessor (owner of c_prev)
+  const bool has_prev = d == 0 ? (t > 0) : (t < T - 1);
+  const int64_t ldy = (int64_t)ndir * H, ldg = (int64_t)ndir * 4 * H;
+  if (s > 0) {
+    skinny_partial<MT>(gates + (int64_t)tn * B * ldg + (int64_t)d * 4 * H, ldg, row0, B,
+                       w_hhT + (int64_t)d * H * 4 * H, (int64_t)4 * H, (int64_t)16 * j, (int64_t)H, 4 * H, nullptr, 0, 0,
+                       red);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < MT * 16 * 16; e += 256) {
+    const int row = e >> 4, u = e & 15;
+    const int64_t b = row0 + row;
+    if (b >= B) continue;
+    const int unit = 16 * j + u;
+    const int64_t so = ((int64_t)t * B + b) * ldy + d * H + unit;
+    float dh = dy[so];
+    if (s > 0) dh += skinny_reduced<MT>(red, row, u);
+    float4* gp = reinterpret_cast<float4*>(gates + ((int64_t)t * B + b) * ldg + (int64_t)d * 4 * H + unit * 4);
+    const float4 a = *gp;  // i f g o
+    const float ct = c[so];
+    const float cp = has_prev ? c[((int64_t)tp * B + b) * ldy + d * H + unit] : 0.f;
+    float* dcp = dcarry + b * ldy + d * H + unit;
+    const float tc = tanhf(ct);
+    const float dc = *dcp + dh * a.w * (1.f - tc * tc);
+    float4 da;
+    da.x = dc * a.z * a.x * (1.f - a.x);
+    da.y = dc * cp * a.y * (1.f - a.y);
+    da.z = dc * a.x * (1.f - a.z * a.z);
+    da.w = dh * tc * a.w * (1.f - a.w);
+    float dcn = dc * a.y;
+    if (t >= lens[b]) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
+    *gp = da;
+    *dcp = dcn;
+  }
+}
+
+// ------------------------------------------------------------------ decoder cell forward
+// gates = [z_prev | ctx_prev | emb] Wcat^T + bcat  (K = KX), then the same pointwise update.
+template <int MT>
+__global__ __launch_bounds__(256) void cell_fwd_kernel(int B, int D, int KX, const float* __restrict__ Xs,
+                                                       const float* __restrict__ wcat,
+                                                       const float* __restrict__ bcat,
+                                                       const float* __restrict__ xmask, int64_t ldmask,
+                                                       float* __restrict__ gates, const float* __restrict__ cprev,
+                                                       float* __restrict__ cout, float* __restrict__ zout) {
+  __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
+  const int j = blockIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.z * (MT * 16);
+  skinny_partial<MT>(Xs, KX, row0, B, wcat, KX, (int64_t)16 * j, (int64_t)4 * D, KX, xmask, ldmask, D, red);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < MT * 16 * 4) {
+    const int row = e >> 2, u = e & 3;
+    const int64_t b = row0 + row;
+    if (b < B) {
+      const int unit = 4 * j + u;
+      const float4 bb = *reinterpret_cast<const float4*>(bcat + unit * 4);
+      const float gi = asr_sigmoid(skinny_reduced<MT>(red, row, u * 4 + 0) + bb.x);
+      const float gf = asr_sigmoid(skinny_reduced<MT>(red, row, u * 4 + 1) + bb.y);
+      const float gg = tanhf(skinny_reduced<MT>(red, row, u * 4 + 2) + bb.z);
+      const float go = asr_sigmoid(skinny_reduced<MT>(red, row, u * 4 + 3) + bb.w);
+      const float cp = cprev ? cprev[b * D + unit] : 0.f;
+      const float cn = gf * cp + gi * gg;
+      *reinterpret_cast<float4*>(gates + (b * 4 * D) + unit * 4) = make_float4(gi, gf, gg, go);
+      cout[b * D + unit] = cn;
+      zout[b * KX + unit] = go * tanhf(cn);
+    }
+  }
+}
+
+// decoder cell backward, pointwise part: dgates from dz (= G[s+1][:,0:D]) and the dc carry
+__global__ void cell_bwd_kernel(int B, int D, int KX, const float* __restrict__ Gnext,
+                                const float* __restrict__ gates, const float* __restrict__ cst,
+                                const float* __restrict__ cprev, float* __restrict__ dcell,
+                                float* __restrict__ dgates) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * D) return;
+  const int b = idx / D, unit = idx % D;
+  const float dh = Gnext[(int64_t)b * KX + unit];
+  const float4 a = *reinterpret_cast<const float4*>(gates + (int64_t)b * 4 * D + unit * 4);
+  const float ct = cst[idx];
+  const float cp = cprev ? cprev[idx] : 0.f;
+  const float tc = tanhf(ct);
+  const float dc = dcell[idx] + dh * a.w * (1.f - tc * tc);
+  float4 da;
+  da.x = dc * a.z * a.x * (1.f - a.x);
+  da.y = dc * cp * a.y * (1.f - a.y);
+  da.z = dc * a.x * (1.f - a.z * a.z);
+  da.w = dh * tc * a.w * (1.f - a.w);
+  *reinterpret_cast<float4*>(dgates + (int64_t)b * 4 * D + unit * 4) = da;
+  dcell[idx] = dc * a.y;
+}
+
+}  // namespace
+
+int asr_cell_fwd_launch(int B, int D, int KX, const float* Xs, const float* wcat, const float* bcat,
+                        const float* xmask, int64_t ldmask, float* gates, const float* cprev, float* cout, float* zout,
+                        hipStream_t stream) {
+  if (D % 16 || KX % 16) return ASR_E_SHAPE;
+  if (B <= 16)
+    hipLaunchKernelGGL((cell_fwd_kernel<1>), dim3(D / 4, 1, 1), dim3(256), 0, stream, B, D, KX, Xs, wcat, bcat, xmask,
+                       ldmask, gates, cprev, cout, zout);
+  else
+    hipLaunchKernelGGL((cell_fwd_kernel<2>), dim3(D / 4, 1, (B + 31) / 32), dim3(256), 0, stream, B, D, KX, Xs, wcat,
+                       bcat, xmask, ldmask, gates, cprev, cout, zout);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+int asr_cell_bwd_launch(int B, int D, int KX, const float* Gnext, const float* gates, const float* cst,
+                        const float* cprev, float* dcell, float* dgates, hipStream_t stream) {
+  hipLaunchKernelGGL(cell_bwd_kernel, dim3((B * D + 255) / 256), dim3(256), 0, stream, B, D, KX, Gnext, gates, cst,
+                     cprev, dcell, dgates);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int asr_lstm_seq_fwd(int T, int B, int H, int ndir, float* gates, const float* w_hh, const int32_t* lens,
+                                float* y, float* c, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!gates || !w_hh || !lens || !y || !c || T <= 0 || B <= 0 || H <= 0) return ASR_E_ARG;
+  if (H % 16 || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
+  if (!asr_aligned16(gates) || !asr_aligned16(w_hh) || !asr_aligned16(y)) return ASR_E_ALIGN;
+  for (int s = 0; s < T; ++s) {
+    if (B <= 16)
+      hipLaunchKernelGGL((enc_step_fwd_kernel<1>), dim3(H / 4, ndir, 1), dim3(256), 0, stream, T, B, H, ndir, gates,
+                         w_hh, lens, y, c, s);
+    else
+      hipLaunchKernelGGL((enc_step_fwd_kernel<2>), dim3(H / 4, ndir, (B + 31) / 32), dim3(256), 0, stream, T, B, H,
+                         ndir, gates, w_hh, lens, y, c, s);
+  }
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int asr_lstm_seq_bwd(int T, int B, int H, int ndir, float* gates, const float* w_hhT, const int32_t* lens,
+                                const float* dy, const float* c, float* dcarry, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!gates || !w_hhT || !lens || !dy || !c || !dcarry || T <= 0 || B <= 0 || H <= 0) return ASR_E_ARG;
+  if (H % 16 || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
+  if (!asr_aligned16(gates) || !asr_aligned16(w_hhT)) return ASR_E_ALIGN;
+  for (int s = 0; s < T; ++s) {
+    if (B <= 16)
+      hipLaunchKernelGGL((enc_step_bwd_kernel<1>), dim3(H / 16, ndir, 1), dim3(256), 0, stream, T, B, H, ndir, gates,
+                         w_hhT, lens, dy, c, dcarry, s);
+    else
+      hipLaunchKernelGGL((enc_step_bwd_kernel<2>), dim3(H / 16, ndir, (B + 31) / 32), dim3(256), 0, stream, T, B, H,
+                         ndir, gates, w_hhT, lens, dy, c, dcarry, s);
+  }
+  ASR_CHECK_LAUNCH();
+  return 0;
+}

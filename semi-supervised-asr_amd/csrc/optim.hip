@@ -1,0 +1,72 @@
+// optim.hip — fused gradient-norm + clip + Adam(amsgrad, L2 weight decay) on a flat fp32 buffer.
+// Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(amsgrad=True).step as called at
+// solver.py:152-153,384-385 (and 171-173,296-297 for the judge, without amsgrad/weight decay).
+// HBM streaming: float4 per lane, grid-stride; the clip coefficient is read from a device scalar so the
+// step needs no host synchronisation.
+#include "common.h"
+
+namespace {
+
+__global__ void sumsq_kernel(int64_t n4, int64_t n, const float* __restrict__ g, float* __restrict__ out) {
+  float s = 0.f;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = g4[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 * 4; i < n; ++i) s += g[i] * g[i];
+  s = wave_sum(s);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float* vmax, float coef, float lr_c1,
+                                         float b1, float b2, float eps, float wd, float rs_c2) {
+  g = g * coef + wd * p;
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  float vv = v;
+  if (vmax) { vv = fmaxf(*vmax, v); *vmax = vv; }
+  p -= lr_c1 * m / (sqrtf(vv) * rs_c2 + eps);
+}
+
+__global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float* __restrict__ vmax, const float* __restrict__ gnorm_sq,
+                            float max_norm, float lr_c1, float b1, float b2, float eps, float wd, float rs_c2) {
+  float coef = 1.f;
+  if (gnorm_sq) {
+    const float nrm = sqrtf(*gnorm_sq);
+    coef = fminf(1.f, max_norm / (nrm + 1e-6f));
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    adam_one(p[i], g[i], m[i], v[i], vmax ? vmax + i : nullptr, coef, lr_c1, b1, b2, eps, wd, rs_c2);
+}
+
+}  // namespace
+
+extern "C" int asr_sumsq_f32(int64_t n, const float* g, float* out, asr_stream_t stream) {
+  if (!g || !out || n <= 0) return ASR_E_ARG;
+  if (!asr_aligned16(g)) return ASR_E_ALIGN;
+  const int64_t n4 = n / 4;
+  int64_t nb = (n4 + 255) / 256;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, (hipStream_t)stream, n4, n, g,
+                     out);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int asr_adam_clip_f32(int64_t n, float* p, const float* g, float* m, float* v, float* vmax,
+                                 const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, float bias_c1, float bias_c2, asr_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0) return ASR_E_ARG;
+  const int64_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, n, p, g,
+                     m, v, vmax, gnorm_sq, max_norm, lr / bias_c1, beta1, beta2, eps, weight_decay,
+                     1.0f / sqrtf(bias_c2));
+  ASR_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,354 @@
+"""MI355X-native seq2seq ASR model behind the reference's class surface.
+
+Same class names, constructor signatures, forward signatures/returns and state_dict keys as
+/root/reference/model.py (pBLSTM 58-98, Encoder 100-112, AttLoc 114-173, Decoder 256-367,
+E2E 408-456, LM 459-573) — but every hot operator is a hand-written gfx950 kernel reached
+through ops.py / hip_backend.py.  Activations are time-major inside the encoder, the decoder
+loop is one fused graph node, and mlp_o is hoisted out of the step loop.
+There is no CPU execution path: tensors must be on the GPU.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import ops
+from utils import cc, pad_list, _seq_mask
+
+
+class _LstmWeights(torch.nn.Module):
+    """Parameter container with torch.nn.LSTM's names / shapes / default init (U(-1/sqrt(H), 1/sqrt(H)))
+    so checkpoints interchange with the reference.  It has no forward of its own."""
+
+    def __init__(self, input_dim, hidden_dim, num_layers=1, bidirectional=False):
+        super().__init__()
+        self.input_size, self.hidden_size = input_dim, hidden_dim
+        self.num_layers, self.bidirectional = num_layers, bidirectional
+        k = 1.0 / math.sqrt(hidden_dim)
+        for layer in range(num_layers):
+            idim = input_dim if layer == 0 else hidden_dim * (2 if bidirectional else 1)
+            for suffix in ([""] + (["_reverse"] if bidirectional else [])):
+                for name, shape in (("weight_ih", (4 * hidden_dim, idim)), ("weight_hh", (4 * hidden_dim, hidden_dim)),
+                                    ("bias_ih", (4 * hidden_dim,)), ("bias_hh", (4 * hidden_dim,))):
+                    p = torch.nn.Parameter(torch.empty(*shape).uniform_(-k, k))
+                    self.register_parameter("%s_l%d%s" % (name, layer, suffix), p)
+
+    def direction_params(self, layer):
+        out = []
+        for suffix in ([""] + (["_reverse"] if self.bidirectional else [])):
+            out += [getattr(self, "%s_l%d%s" % (n, layer, suffix)) for n in
+                    ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        return out
+
+
+class _CellWeights(torch.nn.Module):
+    """torch.nn.LSTMCell-shaped parameter container (weight_ih, weight_hh, bias_ih, bias_hh)."""
+
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        k = 1.0 / math.sqrt(hidden_dim)
+        self.weight_ih = torch.nn.Parameter(torch.empty(4 * hidden_dim, input_dim).uniform_(-k, k))
+        self.weight_hh = torch.nn.Parameter(torch.empty(4 * hidden_dim, hidden_dim).uniform_(-k, k))
+        self.bias_ih = torch.nn.Parameter(torch.empty(4 * hidden_dim).uniform_(-k, k))
+        self.bias_hh = torch.nn.Parameter(torch.empty(4 * hidden_dim).uniform_(-k, k))
+
+
+def _drop_mask(shape, p, device):
+    """Inverted-dropout mask, already scaled by 1/(1-p)."""
+    return torch.bernoulli(torch.full(shape, 1.0 - p, device=device)) / (1.0 - p)
+
+
+def padded_lengths(t_max, n_layers, subsample):
+    """Padded time extent entering each encoder layer (+ the output extent)."""
+    out = [int(t_max)]
+    for i in range(n_layers):
+        out.append((out[-1] + 1) // 2 if subsample[i] > 1 else out[-1])
+    return out
+
+
+class pBLSTM(torch.nn.Module):
+    """Pyramidal BiLSTM stack (model.py:58-98)."""
+
+    def __init__(self, input_dim, hidden_dim, n_layers, subsample, dropout_rate):
+        super(pBLSTM, self).__init__()
+        layers, project_layers = [], []
+        for i in range(n_layers):
+            idim = input_dim if i == 0 else hidden_dim
+            project_dim = hidden_dim * 4 if subsample[i] > 1 else hidden_dim * 2
+            layers.append(_LstmWeights(idim, hidden_dim, num_layers=1, bidirectional=True))
+            project_layers.append(torch.nn.Linear(project_dim, hidden_dim))
+        self.layers = torch.nn.ModuleList(layers)
+        self.project_layers = torch.nn.ModuleList(project_layers)
+        self.dropout_layer = torch.nn.Dropout(p=dropout_rate)
+        self.subsample = subsample
+        self.dropout_rate = dropout_rate
+
+    def forward(self, xpad, ilens, total_length=None):
+        """xpad [B,T,idim] zero padded, ilens descending host ints -> ([B,T',H], list[int]).
+        `total_length` (list from padded_lengths) keeps a data-parallel shard at the global padded
+        extent; default = max(ilens) like pad_packed_sequence (model.py:81)."""
+        dev = xpad.device
+        lens = [int(l) for l in ilens]
+        x = xpad.transpose(0, 1)                                   # time-major
+        drop = self.training and self.dropout_rate > 0
+        for i, (layer, proj) in enumerate(zip(self.layers, self.project_layers)):
+            steps = max(lens) if total_length is None else int(total_length[i])
+            x = x[:steps].contiguous()
+            lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+            y = ops.lstm_layer(x, lens_dev, layer.direction_params(0), 2)      # [T,B,2H]
+            mask = _drop_mask(y.shape, self.dropout_rate, dev) if drop else None
+            sub = self.subsample[i]
+            if sub > 1:
+                y = ops.pyramid_concat(y, mask)                    # [ceil(T/2),B,4H]
+                lens = [(l + 1) // sub for l in lens]
+            elif mask is not None:
+                y = y * mask
+            x = ops.linear(y, proj.weight, proj.bias, relu=True)
+            x = self.dropout_layer(x)
+        return x.transpose(0, 1).contiguous(), [int(l) for l in lens]
+
+
+class Encoder(torch.nn.Module):
+    """model.py:100-112 (pass-through to enc2; the VGG front end is dead code in the reference)."""
+
+    def __init__(self, input_dim, hidden_dim, n_layers, subsample, dropout_rate, in_channel=1):
+        super(Encoder, self).__init__()
+        self.enc2 = pBLSTM(input_dim=input_dim, hidden_dim=hidden_dim, n_layers=n_layers, subsample=subsample,
+                           dropout_rate=dropout_rate)
+
+    def forward(self, x, ilens, total_length=None):
+        return self.enc2(x, ilens, total_length)
+
+
+class AttLoc(torch.nn.Module):
+    """Location-aware attention parameters (model.py:114-137).  The per-step arithmetic of
+    AttLoc.forward (139-173) runs inside the fused decoder sequence (ops.decoder_sequence); this
+    module owns the weights under the reference's names."""
+
+    def __init__(self, encoder_dim, decoder_dim, att_dim, conv_channels, conv_kernel_size, att_odim):
+        super(AttLoc, self).__init__()
+        self.mlp_enc = torch.nn.Linear(encoder_dim, att_dim)
+        self.mlp_dec = torch.nn.Linear(decoder_dim, att_dim, bias=False)
+        self.mlp_att = torch.nn.Linear(conv_channels, att_dim, bias=False)
+        self.loc_conv = torch.nn.Conv2d(1, conv_channels, (1, 2 * conv_kernel_size + 1),
+                                        padding=(0, conv_kernel_size), bias=False)
+        self.gvec = torch.nn.Linear(att_dim, 1, bias=False)
+        self.mlp_o = torch.nn.Linear(encoder_dim, att_odim)
+        self.encoder_dim, self.decoder_dim = encoder_dim, decoder_dim
+        self.att_dim, self.att_odim, self.conv_channels = att_dim, att_odim, conv_channels
+        self.reset()
+
+    def reset(self):
+        self.enc_length = None
+        self.enc_h = None
+        self.pre_compute_enc_h = None
+
+    @staticmethod
+    def initial_weights(enc_len, frames, device):
+        """model.py:151-153: uniform over each utterance's valid frames, 0 on the padding."""
+        w0 = torch.zeros(len(enc_len), frames)
+        for b, l in enumerate(enc_len):
+            w0[b, :l] = 1.0 / l
+        return w0.to(device)
+
+    def forward(self, enc_pad, enc_len, dec_z, att_prev, scaling=2.0):
+        """Single attention step with the reference's signature: returns (mlp_o(context), w).
+        Runs the same kernels as the fused loop (one-step decoder sequence with the cell bypassed is
+        not expressible, so this convenience path composes GEMMs + the step kernels through a
+        1-step sequence whose recurrent input is dec_z)."""
+        raise NotImplementedError(
+            "AttLoc.forward as a stand-alone call is not part of the hot path; use Decoder.forward "
+            "(the fused sequence) — see DESIGN.md 'out of scope'.")
+
+
+class Decoder(torch.nn.Module):
+    """model.py:256-367."""
+
+    def __init__(self, output_dim, embedding_dim, hidden_dim, attention, att_odim, dropout_rate, bos, eos, pad,
+                 ls_weight=0, labeldist=None):
+        super(Decoder, self).__init__()
+        self.bos, self.eos, self.pad = bos, eos, pad
+        self.embedding = torch.nn.Embedding(output_dim, embedding_dim, padding_idx=pad)
+        self.LSTMCell = _CellWeights(embedding_dim + att_odim, hidden_dim)
+        self.output_layer = torch.nn.Linear(hidden_dim + att_odim, output_dim)
+        self.dropout_layer = torch.nn.Dropout(p=dropout_rate)
+        self.attention = attention
+        self.hidden_dim, self.att_odim, self.dropout_rate = hidden_dim, att_odim, dropout_rate
+        self.ls_weight = ls_weight
+        self.labeldist = labeldist
+        if labeldist is not None:
+            # plain attribute, not a buffer -> absent from state_dict
+            self.vlabeldist = cc(torch.from_numpy(np.array(labeldist, dtype=np.float32)))
+
+    def forward(self, enc_pad, enc_len, ys=None, tf_rate=1.0, max_dec_timesteps=500, sample=False, smooth=False,
+                scaling=1.0, label_smoothing=True, olength=None):
+        """-> (logits [B,L,V], ys_log_probs [B,L], prediction [B,L], ws [B,L,T']).
+        `olength` (not in the reference) forces the number of teacher-forced steps so every
+        data-parallel shard decodes the global olength."""
+        dev = enc_pad.device
+        bsz, frames, _ = enc_pad.shape
+        att = self.attention
+        att.reset()
+        have_ys = ys is not None and len(ys) > 0
+        opts = dict(scaling=2.0, smooth=bool(smooth), smooth_scaling=float(scaling), sample=bool(sample),
+                    bos=self.bos)                    # attention temperature is the AttLoc default
+        if ys is not None:
+            bos = ys[0].new_tensor([self.bos])
+            eos = ys[0].new_tensor([self.eos])
+            tok_in = pad_list([torch.cat([bos, y]) for y in ys], self.eos)
+            tok_out = pad_list([torch.cat([y, eos]) for y in ys], self.eos)
+            if olength is not None and olength > tok_out.size(1):
+                extra = olength - tok_out.size(1)
+                tok_in = F.pad(tok_in, (0, extra), value=self.eos)
+                tok_out = F.pad(tok_out, (0, extra), value=self.eos)
+            steps = tok_out.size(1)
+            # one numpy draw per step, also at tf_rate=1 and for step 0 (model.py:328)
+            draws = [np.random.random_sample() <= tf_rate for _ in range(steps)]
+            draws[0] = True
+            opts.update(tokens=tok_in.to(dev), tf_flags=draws)
+        if not have_ys:
+            steps = max_dec_timesteps
+        opts["L"] = steps
+        p = self.dropout_rate
+        if self.training and p > 0:
+            opts["xmask"] = _drop_mask((steps, bsz, self.att_odim + self.embedding.embedding_dim), p, dev)
+        P = ops.linear(enc_pad, att.mlp_enc.weight, att.mlp_enc.bias)
+        Q = ops.linear(enc_pad, att.mlp_o.weight, None)
+        w0 = AttLoc.initial_weights(enc_len, frames, dev)
+        cell = self.LSTMCell
+        logits, ws, pred = ops.decoder_sequence(
+            P, Q, self.embedding.weight, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh,
+            att.mlp_dec.weight, att.loc_conv.weight, att.mlp_att.weight, att.gvec.weight, att.mlp_o.bias,
+            self.output_layer.weight, self.output_layer.bias, w0, opts)
+        logits = logits.transpose(0, 1)
+        prediction = pred.transpose(0, 1)
+        ws = ws.transpose(0, 1)
+        log_probs = F.log_softmax(logits, dim=2)
+        index = tok_out.to(dev) if have_ys else prediction
+        ys_log_probs = torch.gather(log_probs, dim=2, index=index.unsqueeze(2)).squeeze(2)
+        if label_smoothing and self.ls_weight > 0 and self.training:
+            reg = torch.sum(log_probs * self.vlabeldist.to(dev), dim=2)
+            ys_log_probs = (1 - self.ls_weight) * ys_log_probs + self.ls_weight * reg
+        return logits, ys_log_probs, prediction, ws
+
+
+class E2E(torch.nn.Module):
+    """model.py:408-456."""
+
+    def __init__(self, input_dim, enc_hidden_dim, enc_n_layers, subsample, dropout_rate, dec_hidden_dim, att_dim,
+                 conv_channels, conv_kernel_size, att_odim, embedding_dim, output_dim, ls_weight, labeldist,
+                 pad=0, bos=1, eos=2):
+        super(E2E, self).__init__()
+        self.encoder = Encoder(input_dim=input_dim, hidden_dim=enc_hidden_dim, n_layers=enc_n_layers,
+                               subsample=subsample, dropout_rate=dropout_rate)
+        # one AttLoc shared as self.attention and decoder.attention (duplicate state_dict keys)
+        self.attention = AttLoc(encoder_dim=enc_hidden_dim, decoder_dim=dec_hidden_dim, att_dim=att_dim,
+                                conv_channels=conv_channels, conv_kernel_size=conv_kernel_size, att_odim=att_odim)
+        self.decoder = Decoder(output_dim=output_dim, hidden_dim=dec_hidden_dim, embedding_dim=embedding_dim,
+                               attention=self.attention, dropout_rate=dropout_rate, att_odim=att_odim,
+                               ls_weight=ls_weight, labeldist=labeldist, bos=bos, eos=eos, pad=pad)
+
+    def forward(self, data, ilens, ys=None, tf_rate=1.0, max_dec_timesteps=200, sample=False, smooth=False,
+                scaling=1.0, label_smoothing=True, total_length=None, olength=None):
+        enc_h, enc_lens = self.encoder(data, ilens, total_length)
+        return self.decoder(enc_h, enc_lens, ys, tf_rate=tf_rate, max_dec_timesteps=max_dec_timesteps, sample=sample,
+                            smooth=smooth, scaling=scaling, label_smoothing=label_smoothing, olength=olength)
+
+    def mask_and_cal_loss(self, log_probs, ys, mask=None):
+        if mask is None:
+            seq_len = [y.size(0) + 1 for y in ys]              # +1 for <EOS>
+            mask = _seq_mask(seq_len=seq_len, max_len=log_probs.size(1)).to(log_probs.device)
+        else:
+            seq_len = [y.size(0) for y in ys]
+        return -torch.sum(log_probs * mask) / sum(seq_len)
+
+
+class LM(torch.nn.Module):
+    """The judge: 2-layer LSTM language model (model.py:459-573) on the same fused LSTM kernel."""
+
+    def __init__(self, output_dim, embedding_dim, hidden_dim, dropout_rate, n_layers, bos, eos, pad, ls_weight,
+                 labeldist):
+        super(LM, self).__init__()
+        self.bos, self.eos, self.pad = bos, eos, pad
+        self.embedding = torch.nn.Embedding(output_dim, embedding_dim, padding_idx=pad)
+        self.LSTM = _LstmWeights(embedding_dim, hidden_dim, num_layers=n_layers, bidirectional=False)
+        # re-init as utils.weight_init does for nn.LSTM (utils.py:97-103): orthogonal matrices, normal biases
+        for prm in self.LSTM.parameters():
+            if prm.dim() >= 2:
+                torch.nn.init.orthogonal_(prm.data)
+            else:
+                torch.nn.init.normal_(prm.data)
+        self.output_layer = torch.nn.Linear(hidden_dim, output_dim)
+        self.dropout_layer = torch.nn.Dropout(p=dropout_rate)
+        self.hidden_dim, self.output_dim = hidden_dim, output_dim
+        self.dropout_rate, self.n_layers = dropout_rate, n_layers
+        self.ls_weight = ls_weight
+        self.labeldist = labeldist
+        if labeldist is not None:
+            self.vlabeldist = cc(torch.from_numpy(np.array(labeldist, dtype=np.float32)))
+
+    def _run_lstm(self, x_tm, lens_dev, state=None):
+        """x_tm [T,B,E] -> [T,B,H] through all layers; inter-layer dropout like nn.LSTM(dropout=p)."""
+        new_state = []
+        for l in range(self.n_layers):
+            st = None if state is None else state[l]
+            x_tm = ops.lstm_layer(x_tm, lens_dev, self.LSTM.direction_params(l), 1)
+            if l + 1 < self.n_layers and self.training and self.dropout_rate > 0:
+                x_tm = F.dropout(x_tm, self.dropout_rate, True)
+        return x_tm
+
+    def forward(self, ys=None, discrete_input=True):
+        """-> (ys_log_probs, ys_probs, predictions), each [B,L] (model.py:492-532)."""
+        dev = self.embedding.weight.device
+        if discrete_input:
+            bos = ys[0].new_tensor([self.bos])
+            eos = ys[0].new_tensor([self.eos])
+            seq_in = [torch.cat([bos, y, eos, eos, eos, eos]) for y in ys]
+            seq_out = [torch.cat([y, eos, eos, eos, eos, eos]) for y in ys]
+            tok_in = pad_list(seq_in, self.eos).to(dev)
+            tok_out = pad_list(seq_out, self.eos).to(dev)
+            lens = [int(s.size(0)) for s in seq_in]
+        else:
+            first = torch.full((ys.size(0), 1), self.bos, dtype=ys.dtype, device=ys.device)
+            tok_in = torch.cat([first, ys[:, :-1]], dim=1).to(dev)
+            tok_out = ys.to(dev)
+            lens = [tok_in.size(1)] * tok_in.size(0)
+        eys = self.dropout_layer(self.embedding(tok_in))
+        lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+        out = self._run_lstm(eys.transpose(0, 1).contiguous(), lens_dev).transpose(0, 1)
+        out = self.dropout_layer(out)
+        logits = ops.linear(out.contiguous(), self.output_layer.weight, self.output_layer.bias)
+        log_probs = F.log_softmax(logits, dim=2)
+        probs = F.softmax(logits, dim=2)
+        ys_log_probs = torch.gather(log_probs, dim=2, index=tok_out.unsqueeze(2)).squeeze(2)
+        ys_probs = torch.gather(probs, dim=2, index=tok_out.unsqueeze(2)).squeeze(2)
+        if self.ls_weight > 0 and self.training:
+            reg = torch.sum(log_probs * self.vlabeldist.to(dev), dim=2)
+            ys_log_probs = (1 - self.ls_weight) * ys_log_probs + self.ls_weight * reg
+        predictions = torch.argmax(logits, dim=-1)
+        return ys_log_probs, ys_probs, predictions
+
+    def decode(self, n_samples=5, sample=False, max_dec_timesteps=500):
+        """Free-running generation (model.py:544-563).  Diagnostic only (lm_validation): re-runs the
+        prefix through the fused sequence kernel each step instead of carrying state."""
+        dev = self.embedding.weight.device
+        toks = torch.full((n_samples, 1), self.bos, dtype=torch.long, device=dev)
+        preds = []
+        with torch.no_grad():
+            for t in range(max_dec_timesteps):
+                lens_dev = torch.full((n_samples,), toks.size(1), dtype=torch.int32, device=dev)
+                out = self._run_lstm(self.embedding(toks).transpose(0, 1).contiguous(), lens_dev)[-1]
+                logit = ops.linear(out, self.output_layer.weight, self.output_layer.bias)
+                nxt = torch.distributions.Categorical(logits=logit).sample() if sample else logit.argmax(-1)
+                preds.append(nxt)
+                toks = torch.cat([toks, nxt.unsqueeze(1)], dim=1)
+        return torch.stack(preds, dim=1)
+
+    def mask_and_cal_sum(self, log_probs, ys, mask=None):
+        if mask is None:
+            seq_len = [y.size(0) + 1 + 4 for y in ys]
+            mask = _seq_mask(seq_len=seq_len, max_len=log_probs.size(1)).to(log_probs.device)
+        else:
+            seq_len = [y.size(0) for y in ys]
+        return torch.sum(log_probs * mask) / sum(seq_len)

@@ -1,0 +1,359 @@
+"""Training driver with the reference Solver's surface (solver.py:13-565): same constructor, method
+names, config keys, loss formulas and op order (zero_grad -> backward -> [all-reduce] -> clip -> step).
+Differences, all MI355X-first: the optimiser is the fused flat-buffer FlatAdam (one HIP kernel for
+clip+Adam(amsgrad)), gradients of a data-parallel run are exchanged with ONE RCCL all-reduce, and
+under torch.distributed every rank collates the same global batch and keeps its strided shard padded
+to the global extents (parallel.py), which reproduces the single-process numbers exactly.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+import parallel
+from dataloader import get_data_loader
+from dataset import PickleDataset
+from model import E2E, LM, padded_lengths
+from parallel import FlatAdam
+from utils import (Logger, adjust_learning_rate, calculate_cer, cc, infinite_iter, remove_pad_eos, to_gpu,
+                   to_sents)
+
+
+class Solver(object):
+    def __init__(self, config, load_model=False):
+        self.config = config
+        self.rank, self.world, _ = parallel.init_distributed()
+        if self.rank == 0:
+            print(self.config)
+        self.logger = Logger(config["logdir"])
+        self.load_vocab()
+        self.get_data_loaders()
+        self.labeldist = self.get_label_dist(self.train_lab_dataset)
+        self.unlab_labeldist = self.get_label_dist(self.train_unlab_y_dataset)
+        self.proportion = self.calculate_length_proportion()
+        self.build_model(load_model=load_model)
+
+    # ------------------------------------------------------------------ checkpoints (.ckpt/.opt/.judge.*)
+    def save_model(self, model_path):
+        if self.rank == 0:
+            torch.save(self.model.state_dict(), f"{model_path}.ckpt")
+            torch.save(self.gen_opt.state_dict(), f"{model_path}.opt")
+
+    def save_judge(self, model_path):
+        if self.rank == 0:
+            torch.save(self.judge.state_dict(), f"{model_path}.judge.ckpt")
+            torch.save(self.dis_opt.state_dict(), f"{model_path}.judge.opt")
+
+    def load_model(self, model_path, load_optimizer):
+        print(f"Load model from {model_path}.ckpt")
+        self.model.load_state_dict(torch.load(f"{model_path}.ckpt", map_location="cpu"))
+        if load_optimizer:
+            print(f"Load optmizer from {model_path}.opt")
+            self.gen_opt.load_state_dict(torch.load(f"{model_path}.opt", map_location="cpu"))
+
+    def load_judge(self, model_path, load_optimizer):
+        self.judge.load_state_dict(torch.load(f"{model_path}.judge.ckpt", map_location="cpu"))
+        if load_optimizer:
+            self.dis_opt.load_state_dict(torch.load(f"{model_path}.judge.opt", map_location="cpu"))
+
+    # ------------------------------------------------------------------ data
+    def load_vocab(self):
+        with open(self.config["vocab_path"], "rb") as f:
+            self.vocab = pickle.load(f)
+        with open(self.config["non_lang_syms_path"], "rb") as f:
+            self.non_lang_syms = pickle.load(f)
+
+    def get_label_dist(self, dataset):
+        counts = np.zeros(len(self.vocab))
+        for _, tokens in dataset:
+            np.add.at(counts, np.asarray(tokens, dtype=np.int64), 1.0)
+        counts[self.vocab["<EOS>"]] += len(dataset)
+        counts[self.vocab["<PAD>"]] = 0
+        counts[self.vocab["<BOS>"]] = 0
+        return counts / counts.sum()
+
+    def calculate_length_proportion(self):
+        frames = sum(x.shape[0] for x, _ in self.train_lab_dataset)
+        chars = sum(len(y) for _, y in self.train_lab_dataset)
+        return chars / frames
+
+    def _dataset(self, name, config, sort=True):
+        return PickleDataset(os.path.join(self.config["dataset_root_dir"], f"{name}.pkl"), config=config, sort=sort)
+
+    def _loader(self, dataset, batch_size, shuffle, drop_last, **kw):
+        # every rank must draw the SAME global batches: seed the sampler identically
+        gen = torch.Generator()
+        gen.manual_seed(int(self.config.get("data_seed", 0)))
+        return get_data_loader(dataset, batch_size=batch_size, shuffle=shuffle, drop_last=drop_last, generator=gen,
+                               **kw)
+
+    def get_data_loaders(self):
+        cfg = self.config
+        bs, shuffle = cfg["batch_size"] * self.world, cfg["shuffle"]     # batch_size is per GPU
+        self.train_lab_dataset = self._dataset(cfg["labeled_set"], cfg)
+        self.train_lab_loader = self._loader(self.train_lab_dataset, bs, shuffle, False)
+        self.train_unlab_x_dataset = self._dataset(cfg["unlabeled_speech_set"], cfg)
+        self.train_unlab_x_loader = self._loader(self.train_unlab_x_dataset, bs, shuffle, False, speech_only=True)
+        self.train_unlab_y_dataset = self._dataset(cfg["unlabeled_text_set"], cfg)
+        self.train_unlab_y_loader = self._loader(self.train_unlab_y_dataset, bs, shuffle, True, text_only=True)
+        self.dev_dataset = self._dataset(cfg["dev_set"], None)
+        self.dev_loader = self._loader(self.dev_dataset, cfg["batch_size"] // 2, False, False)
+
+    def get_infinite_iter(self):
+        self.lab_iter = infinite_iter(self.train_lab_loader)
+        self.unlab_x_iter = infinite_iter(self.train_unlab_x_loader)
+        self.unlab_y_iter = infinite_iter(self.train_unlab_y_loader)
+
+    # ------------------------------------------------------------------ model + optimisers
+    def build_model(self, load_model=False):
+        cfg = self.config
+        self.model = cc(E2E(
+            input_dim=cfg["input_dim"], enc_hidden_dim=cfg["enc_hidden_dim"], enc_n_layers=cfg["enc_n_layers"],
+            subsample=cfg["subsample"], dropout_rate=cfg["dropout_rate"], dec_hidden_dim=cfg["dec_hidden_dim"],
+            att_dim=cfg["att_dim"], conv_channels=cfg["conv_channels"], conv_kernel_size=cfg["conv_kernel_size"],
+            att_odim=cfg["att_odim"], output_dim=len(self.vocab), embedding_dim=cfg["embedding_dim"],
+            ls_weight=cfg["ls_weight"], labeldist=self.labeldist, pad=self.vocab["<PAD>"], bos=self.vocab["<BOS>"],
+            eos=self.vocab["<EOS>"]))
+        self.gen_opt = FlatAdam(self.model, lr=cfg["learning_rate"], weight_decay=cfg["weight_decay"], amsgrad=True,
+                                max_grad_norm=cfg["max_grad_norm"])
+        if load_model:
+            self.load_model(cfg["load_model_path"], cfg["load_optimizer"])
+        self.judge = cc(LM(
+            output_dim=len(self.vocab), embedding_dim=cfg["dis_embedding_dim"], hidden_dim=cfg["dis_hidden_dim"],
+            dropout_rate=cfg["dis_dropout_rate"], n_layers=cfg["dis_layers"], bos=self.vocab["<BOS>"],
+            eos=self.vocab["<EOS>"], pad=self.vocab["<PAD>"], ls_weight=cfg["ls_weight"],
+            labeldist=self.unlab_labeldist))
+        self.dis_opt = FlatAdam(self.judge, lr=cfg["d_learning_rate"], max_grad_norm=cfg["max_grad_norm"])
+        if self.rank == 0:
+            print(self.model)
+            print(self.judge)
+
+    # ------------------------------------------------------------------ text scoring
+    def ind2sent(self, all_prediction, all_ys):
+        hyp_ids = remove_pad_eos(all_prediction, eos=self.vocab["<EOS>"])
+        hyps = to_sents(hyp_ids, self.vocab, self.non_lang_syms)
+        refs = to_sents(all_ys, self.vocab, self.non_lang_syms)
+        return calculate_cer(hyps, refs), hyps, refs
+
+    def _greedy(self, xs, ilens):
+        with torch.no_grad():
+            _, _, prediction, _ = self.model(xs, ilens, ys=None, max_dec_timesteps=self.config["max_dec_timesteps"])
+        return prediction.cpu().numpy().tolist()
+
+    def validation(self):
+        """Teacher-forced dev loss + greedy CER (solver.py:212-242); greedy pass runs without autograd."""
+        self.model.eval()
+        preds, refs, total = [], [], 0.0
+        for data in self.dev_loader:
+            xs, ilens, ys = to_gpu(data)
+            with torch.no_grad():
+                _, log_probs, _, _ = self.model(xs, ilens, ys=ys)
+                total += self.model.mask_and_cal_loss(log_probs, ys).item()
+            preds += self._greedy(xs, ilens)
+            refs += [y.cpu().numpy().tolist() for y in ys]
+        self.model.train()
+        cer, hyp_sents, ref_sents = self.ind2sent(preds, refs)
+        return total / len(self.dev_loader), cer, hyp_sents, ref_sents
+
+    def lm_validation(self):
+        self.judge.eval()
+        total = 0.0
+        for data in self.dev_loader:
+            _, _, ys = to_gpu(data)
+            ys.sort(key=lambda y: len(y), reverse=True)
+            with torch.no_grad():
+                log_probs, _, _ = self.judge(ys)
+                total += -self.judge.mask_and_cal_sum(log_probs, ys).item()
+        samples = self.judge.decode(n_samples=5, sample=True,
+                                    max_dec_timesteps=int(self.config.get("lm_sample_steps", 100)))
+        sents = to_sents(remove_pad_eos(samples.cpu().numpy(), eos=self.vocab["<EOS>"]), self.vocab,
+                         self.non_lang_syms)
+        self.judge.train()
+        return total / len(self.dev_loader), sents
+
+    def test(self, state_dict=None):
+        if state_dict:
+            self.model.load_state_dict(state_dict)
+        else:
+            self.load_model(self.config["load_model_path"], self.config["load_optimizer"])
+        test_set = self.config["test_set"]
+        loader = get_data_loader(self._dataset(test_set, None, sort=False), batch_size=1, shuffle=False,
+                                 drop_last=False)
+        self.model.eval()
+        preds, refs = [], []
+        for data in loader:
+            xs, ilens, ys = to_gpu(data)
+            preds += self._greedy(xs, ilens)
+            refs += [y.cpu().numpy().tolist() for y in ys]
+        self.model.train()
+        cer, hyp_sents, _ = self.ind2sent(preds, refs)
+        with open(f"{test_set}.txt", "w") as f:
+            f.writelines(f"{p}\n" for p in hyp_sents)
+        print(f"{test_set}: {len(hyp_sents)} utterances, CER={cer:.4f}")
+        return cer
+
+    # ------------------------------------------------------------------ judge (LM) pre-training
+    def judge_train_one_iteration(self, unlab_ys):
+        log_probs, probs, _ = self.judge(ys=unlab_ys, discrete_input=True)
+        loss = -self.judge.mask_and_cal_sum(log_probs, ys=unlab_ys, mask=None)
+        avg_prob = self.judge.mask_and_cal_sum(probs, ys=unlab_ys, mask=None)
+        self.dis_opt.zero_grad()
+        loss.backward()
+        self.dis_opt.step()
+        return {"loss": loss.item(), "avg_prob": avg_prob.item()}
+
+    def judge_pretrain(self):
+        cfg = self.config
+        steps_per_epoch = len(self.train_unlab_y_loader)
+        best = 100
+        base_lr = cfg["d_learning_rate"]
+        path = os.path.join(cfg["model_dir"], cfg["model_name"])
+        print("--------Judge pretraining--------")
+        for epoch in range(cfg["judge_epochs"]):
+            # MultiStepLR(milestones=[dis_change_learning_rate_epoch], gamma) stepped at epoch start (solver.py:308-315)
+            adjust_learning_rate(self.dis_opt, base_lr * (cfg["lr_gamma"] if epoch + 1 >= cfg[
+                "dis_change_learning_rate_epoch"] else 1.0))
+            running = 0.0
+            for it, data in enumerate(self.train_unlab_y_loader):
+                meta = self.judge_train_one_iteration([cc(y) for y in data])
+                running += meta["loss"]
+                print(f"epoch: {epoch}, [{it + 1}/{steps_per_epoch}], loss: {meta['loss']:.3f}, "
+                      f"prob: {meta['avg_prob']:.3f}", end="\r")
+                for key, val in meta.items():
+                    self.logger.scalar_summary(f"{cfg['tag']}/judge_pretrain/{key}", val,
+                                               epoch * steps_per_epoch + it + 1)
+            val_loss, samples = self.lm_validation()
+            print(f"epoch: {epoch}, train_loss={running / steps_per_epoch:.3f}, valid_loss={val_loss:.3f}")
+            for i, s in enumerate(samples):
+                print(f"hyp-{i + 1}: {s}")
+            self.logger.scalar_summary(f"{cfg['tag']}/judge_pretrain/val_loss", val_loss, epoch)
+            self.logger.scalar_summary(f"{cfg['tag']}/judge_pretrain/avg_train_loss", running / steps_per_epoch, epoch)
+            if val_loss < best:
+                best = val_loss
+                self.save_judge(path)
+                print(f"save #{epoch} LM, val_loss={val_loss:.3f}")
+            self.save_judge(f"{path}-{epoch:03d}")
+
+    # ------------------------------------------------------------------ supervised training
+    def _sharded_forward(self, xs, ilens, ys, tf_rate):
+        """Model forward on this rank's strided shard of the (global) batch, padded to the global extents;
+        returns the local loss whose all-reduced gradient equals the single-process one."""
+        if self.world == 1:
+            _, log_probs, _, _ = self.model(xs, ilens, ys, tf_rate=tf_rate, sample=False)
+            return -torch.mean(log_probs)
+        xs_r, ilens_r, ys_r, info = parallel.shard_batch(xs, ilens, ys, self.rank, self.world)
+        cfg = self.config
+        _, log_probs, _, _ = self.model(
+            xs_r, ilens_r, ys_r, tf_rate=tf_rate, sample=False,
+            total_length=padded_lengths(info["t_max"], cfg["enc_n_layers"], cfg["subsample"]),
+            olength=info["olength"])
+        return parallel.local_loss(log_probs, info)
+
+    def sup_train_one_epoch(self, epoch, tf_rate):
+        cfg = self.config
+        steps_per_epoch = len(self.train_lab_loader)
+        running = 0.0
+        for it, data in enumerate(self.train_lab_loader):
+            xs, ilens, ys = to_gpu(data)
+            if cfg["add_gaussian"] and epoch >= cfg["gaussian_epoch"]:
+                noise = np.random.normal(0, cfg["gaussian_std"], tuple(xs.shape)).astype(np.float32)
+                xs = xs + cc(torch.from_numpy(noise))
+            loss = self._sharded_forward(xs, ilens, ys, tf_rate)
+            self.gen_opt.zero_grad()
+            loss.backward()
+            self.gen_opt.step()                      # all-reduce -> clip -> Adam, no host sync
+            value = loss.item() * (self.world if self.world > 1 else 1)   # local losses sum to the global mean
+            running += value
+            if self.rank == 0:
+                print(f"epoch: {epoch}, [{it + 1}/{steps_per_epoch}], loss: {value:.3f}", end="\r")
+            self.logger.scalar_summary(tag=f"{cfg['tag']}/train_loss", value=value,
+                                       step=epoch * steps_per_epoch + it + 1)
+        return running / steps_per_epoch
+
+    def sup_pretrain(self):
+        cfg = self.config
+        self.model.train()
+        best_cer, best_model = 200, None
+        hi, lo, span = cfg["init_tf_rate"], cfg["tf_rate_lowerbound"], cfg["tf_decay_epochs"]
+        path = os.path.join(cfg["model_dir"], cfg["model_name"])
+        print("------supervised pretraining-------")
+        for epoch in range(cfg["epochs"]):
+            tf_rate = hi - (hi - lo) * (epoch / span) if epoch <= span else lo
+            train_loss = self.sup_train_one_epoch(epoch, tf_rate)
+            val_loss, cer, hyps, refs = self.validation()
+            print(f"Epoch: {epoch}, tf_rate={tf_rate:.3f}, train_loss={train_loss:.4f}, "
+                  f"valid_loss={val_loss:.4f}, CER={cer:.4f}")
+            tag = cfg["tag"]
+            self.logger.scalar_summary(f"{tag}/supervised/cer", cer, epoch)
+            self.logger.scalar_summary(f"{tag}/supervised/val_loss", val_loss, epoch)
+            self.logger.scalar_summary(f"{tag}/supervised/avg_train_loss", train_loss, epoch)
+            for i, (p, gt) in enumerate(list(zip(hyps, refs))[:5]):
+                self.logger.text_summary(f"{tag}/supervised/prediction-{i}", p, epoch)
+                self.logger.text_summary(f"{tag}/supervised/ground_truth-{i}", gt, epoch)
+                print(f"hyp-{i + 1}: {p}\nref-{i + 1}: {gt}")
+            if cer < best_cer:
+                best_cer = cer
+                self.save_model(path)
+                best_model = self.model.state_dict()
+                print(f"Save #{epoch} model, val_loss={val_loss:.3f}, CER={cer:.3f}")
+            self.save_model(f"{path}-{epoch:03d}")
+        return best_model, best_cer
+
+    # ------------------------------------------------------------------ semi-supervised training
+    def gen_train_one_iteration(self, lab_xs, lab_ilens, lab_ys, unlab_xs, unlab_ilens):
+        """The LM-judge auxiliary loss (solver.py:460-495): greedy smooth-embedding decode of unlabeled
+        speech WITH grad, judge probabilities of the hypothesis, unsup = -sum(p_LM * log p_model * mask)/sum(mask);
+        loss = sup + unsup_weight * unsup; only the generator is stepped."""
+        cfg = self.config
+        _, u_lp, u_pred, _ = self.model(
+            unlab_xs, unlab_ilens, ys=None, sample=False, label_smoothing=False,
+            max_dec_timesteps=int(unlab_xs.size(1) * self.proportion), smooth=cfg["smooth_embedding"],
+            scaling=cfg["softmax_scaling"])
+        _, lm_probs, _ = self.judge(ys=u_pred, discrete_input=False)
+        mask = (u_pred != self.vocab["<EOS>"]).float()
+        unsup_loss = -torch.sum(lm_probs * u_lp * mask) / torch.sum(mask)
+        _, lab_lp, _, _ = self.model(lab_xs, lab_ilens, ys=lab_ys, tf_rate=1.0, sample=False)
+        sup_loss = -torch.mean(lab_lp)
+        loss = sup_loss + cfg["unsup_weight"] * unsup_loss
+        self.gen_opt.zero_grad()
+        loss.backward()
+        self.gen_opt.step()
+        return {"unsup_loss": unsup_loss.item(), "sup_loss": sup_loss.item(), "loss": loss.item()}
+
+    def ssl_train_one_iteration(self, iteration):
+        lab_data, unlab_data = next(self.lab_iter), next(self.unlab_x_iter)
+        lab_xs, lab_ilens, lab_ys = to_gpu(lab_data)
+        unlab_xs, unlab_ilens = unlab_data
+        meta = self.gen_train_one_iteration(lab_xs, lab_ilens, lab_ys, cc(unlab_xs), unlab_ilens)
+        for key, val in meta.items():
+            self.logger.scalar_summary(f"{self.config['tag']}/ssl_generator/{key}", val, iteration + 1)
+        return meta
+
+    def ssl_train(self):
+        cfg = self.config
+        print("--------SSL training--------")
+        adjust_learning_rate(self.gen_opt, cfg["g_learning_rate"])
+        best_cer, best_model = 2, None
+        total = cfg["ssl_iterations"]
+        path = os.path.join(cfg["model_dir"], cfg["model_name"])
+        if not hasattr(self, "lab_iter"):
+            self.get_infinite_iter()
+        for step in range(total):
+            meta = self.ssl_train_one_iteration(iteration=step)
+            print(f"[{step + 1}/{total}], sup_loss: {meta['sup_loss']:.3f}, unsup_loss: {meta['unsup_loss']:.3f}, "
+                  f"loss: {meta['loss']:.3f}", end="\r")
+            if (step + 1) % cfg["summary_steps"] == 0 or step + 1 == total:
+                val_loss, cer, hyps, refs = self.validation()
+                print(f"Iter: [{step + 1}/{total}], valid_loss={val_loss:.4f}, CER={cer:.4f}")
+                self.logger.scalar_summary(f"{cfg['tag']}/ssl/cer", cer, step + 1)
+                self.logger.scalar_summary(f"{cfg['tag']}/ssl/val_loss", val_loss, step + 1)
+                for i, (p, gt) in enumerate(list(zip(hyps, refs))[:5]):
+                    print(f"hyp-{i + 1}: {p}\nref-{i + 1}: {gt}")
+                if cer < best_cer:
+                    best_cer = cer
+                    self.save_model(path)
+                    self.save_judge(path)
+                    best_model = self.model.state_dict()
+                    print(f"Save #{step} model, val_loss={val_loss:.3f}, CER={cer:.3f}")
+        return best_model, best_cer

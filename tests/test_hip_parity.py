@@ -1,0 +1,350 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed golden
+fixtures.  Tolerance: 1e-3 relative fp32 (BASELINE.json north_star); most checks are much tighter."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+def _gpu():
+    import __graft_entry__ as entry
+    entry.build()
+    assert torch.cuda.is_available()
+    return torch.device("cuda")
+
+
+def _close(got, want, rtol=RTOL, atol=1e-5, what=""):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    scale = max(1e-30, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= atol + rtol * scale, "%s: max abs err %.3e vs scale %.3e" % (what, err, scale)
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
+
+
+# ----------------------------------------------------------------------------------------- GEMMs
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 130, 70), (33, 34, 9), (1000, 96, 513)])
+def test_gemm_variants(ta, tb, M, N, K):
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.t() if ta else A) @ (B.t() if tb else B)
+    out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
+    _close(out, ref, rtol=1e-5, atol=1e-4, what="plain")
+    out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, bias=bias.to(dev), relu=True)
+    _close(out, torch.relu(ref + bias), rtol=1e-5, atol=1e-4, what="bias+relu")
+    out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, split_k=3)
+    _close(out, ref, rtol=1e-5, atol=1e-4, what="split-k")
+    base = torch.randn(M, N, generator=g)
+    out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, out=base.to(dev), accumulate=True)
+    _close(out, ref + base, rtol=1e-5, atol=1e-4, what="accumulate")
+
+
+def test_gemm_strided_views_and_batched():
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(1)
+    big = torch.randn(64, 100, generator=g).to(dev)
+    W = torch.randn(48, 40, generator=g).to(dev)
+    out = torch.zeros(64, 80, device=dev)
+    hb.gemm(big[:, 20:60], W, trans_b=True, out=out[:, 16:64])
+    _close(out[:, 16:64], big[:, 20:60].cpu() @ W.cpu().t(), rtol=1e-5, atol=1e-4)
+    assert float(out[:, :16].abs().max()) == 0.0
+    # batched: C[b] = A[:, b, :]^T B[:, b, :]
+    L, Bn, Tp, Od = 7, 3, 10, 12
+    A = torch.randn(L, Bn, Tp, generator=g).to(dev)
+    Bm = torch.randn(L, Bn, Od, generator=g).to(dev)
+    C = torch.empty(Bn, Tp, Od, device=dev)
+    hb.gemm_batched(A, Bm, C, True, False, Tp, Od, L, Bn * Tp, Bn * Od, Od, Bn, Tp, Od, Tp * Od)
+    _close(C, torch.einsum("lbt,lbo->bto", A.cpu(), Bm.cpu()), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 2048, 512), (3, 9, 32), (20, 34, 1024), (40, 100, 64)])
+def test_gemm_skinny_and_colsum(M, N, K):
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(M + N + K)
+    A, Bt, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    out = hb.gemm_skinny(A.to(dev), Bt.to(dev), bias=bias.to(dev))
+    _close(out, A @ Bt.t() + bias, rtol=1e-5, atol=1e-4)
+    acc = torch.randn(M, N, generator=g)
+    out = hb.gemm_skinny(A.to(dev), Bt.to(dev), out=acc.to(dev), accumulate=True)
+    _close(out, A @ Bt.t() + acc, rtol=1e-5, atol=1e-4)
+    _close(hb.colsum(A.to(dev)), A.sum(0), rtol=1e-5, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------- pyramid
+@pytest.mark.parametrize("T", [10, 11, 1])
+def test_pyramid_concat(T):
+    dev = _gpu()
+    import ops
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, 3, 8, generator=g)
+    mask = (torch.rand(T, 3, 8, generator=g) > 0.3).float() / 0.7
+    for m in (None, mask):
+        xr = x.clone().requires_grad_(True)
+        ref = O.pair_concat((xr if m is None else xr * m).transpose(0, 1)).transpose(0, 1)
+        xg = x.to(dev).requires_grad_(True)
+        got = ops.pyramid_concat(xg, None if m is None else m.to(dev))
+        _close(got, ref, rtol=0, atol=0)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy)
+        got.backward(dy.to(dev))
+        _close(xg.grad, xr.grad, rtol=1e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------- LSTM layer
+@pytest.mark.parametrize("ndir,B,T,I,H,lens", [
+    (2, 3, 9, 8, 16, [9, 7, 4]), (1, 5, 6, 16, 32, [6, 6, 3, 2, 1]), (2, 33, 5, 12, 64, None),
+    (2, 20, 7, 10, 48, None)])
+def test_lstm_layer_fwd_bwd(ndir, B, T, I, H, lens):
+    dev = _gpu()
+    import ops
+    g = torch.Generator().manual_seed(B * 100 + T)
+    if lens is None:
+        lens = sorted([int(v) for v in torch.randint(1, T + 1, (B,), generator=g)], reverse=True)
+        lens[0] = T
+    x = torch.randn(B, T, I, generator=g)
+    k = 1.0 / np.sqrt(H)
+    prm = []
+    for d in range(ndir):
+        prm += [torch.empty(4 * H, I).uniform_(-k, k, generator=g), torch.empty(4 * H, H).uniform_(-k, k, generator=g),
+                torch.empty(4 * H).uniform_(-k, k, generator=g), torch.empty(4 * H).uniform_(-k, k, generator=g)]
+    cp = [p.clone().requires_grad_(True) for p in prm]
+    xc = x.clone().requires_grad_(True)
+    ref = torch.cat([O.lstm_direction(xc, lens, *cp[4 * d:4 * d + 4], reverse=(d == 1)) for d in range(ndir)], 2)
+    gp = [p.to(dev).requires_grad_(True) for p in prm]
+    xg = x.to(dev).requires_grad_(True)
+    got = ops.lstm_layer(xg.transpose(0, 1), torch.tensor(lens, dtype=torch.int32, device=dev), gp, ndir)
+    _close(got.transpose(0, 1), ref, rtol=1e-4, atol=1e-5, what="y")
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    got.backward(dy.transpose(0, 1).contiguous().to(dev))
+    _close(xg.grad, xc.grad, rtol=1e-3, atol=1e-5, what="dx")
+    for i, (a, b) in enumerate(zip(gp, cp)):
+        _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
+
+
+# ----------------------------------------------------------------------------------------- full model
+def _product(cfg, weights, ld, dev):
+    import model as M
+    net = M.E2E(labeldist=ld, **cfg).to(dev)
+    missing = net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    net.train()
+    return net
+
+
+def _grads(net):
+    return {n: p.grad for n, p in net.named_parameters()}
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    dev = _gpu()
+    net = _product(synth.TINY, synth.e2e_weights(synth.TINY, 11), synth.labeldist(9, 12), dev)
+    assert list(net.state_dict().keys()) == list(synth.e2e_weights(synth.TINY, 11).keys())
+    assert len(net.state_dict()) == 43
+
+
+def test_tiny_e2e_teacher_forced(golden_dir):
+    dev = _gpu()
+    g = _load(golden_dir, "tiny_e2e.npz")
+    net = _product(synth.TINY, synth.e2e_weights(synth.TINY, 11), g["labeldist"], dev)
+    xs, ilens, ys = synth.batch(8, 9, synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+    enc_h, enc_lens = net.encoder(xs_d, ilens)
+    assert enc_lens == g["enc_lens"].tolist()
+    _close(enc_h, g["enc_h"], what="enc_h")
+    np.random.seed(5)
+    logits, lp, pred, ws = net(xs_d, ilens, ys_d, tf_rate=1.0)
+    _close(logits, g["tf_logits"], what="logits"); _close(lp, g["tf_lp"], what="lp"); _close(ws, g["tf_ws"], what="ws")
+    assert (pred.cpu().numpy() == g["tf_pred"]).all()
+    loss = -lp.mean()
+    _close(loss, g["tf_loss"], rtol=1e-5, what="loss")
+    _close(net.mask_and_cal_loss(lp, ys_d), g["tf_masked_loss"], rtol=1e-5)
+    net.zero_grad()
+    loss.backward()
+    for n, gr in _grads(net).items():
+        _close(gr, g["grad/" + n], atol=1e-6, what="grad " + n)
+
+
+def test_tiny_e2e_free_running_modes(golden_dir):
+    dev = _gpu()
+    g = _load(golden_dir, "tiny_e2e.npz")
+    net = _product(synth.TINY, synth.e2e_weights(synth.TINY, 11), g["labeldist"], dev)
+    xs, ilens, ys = synth.batch(8, 9, synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+    np.random.seed(7)
+    logits, lp, pred, _ = net(xs_d, ilens, ys_d, tf_rate=0.5)
+    assert (pred.cpu().numpy() == g["ss_pred"]).all()
+    _close(logits, g["ss_logits"], what="ss logits"); _close(lp, g["ss_lp"], what="ss lp")
+    logits, lp, pred, ws = net(xs_d, ilens, ys=None, max_dec_timesteps=5)
+    assert (pred.cpu().numpy() == g["gr_pred"]).all()
+    _close(logits, g["gr_logits"], what="greedy logits"); _close(ws, g["gr_ws"], what="greedy ws")
+    logits, lp, pred, _ = net(xs_d, ilens, ys=None, max_dec_timesteps=5, smooth=True, scaling=3.0,
+                              label_smoothing=False)
+    _close(logits, g["sm_logits"], what="smooth logits"); _close(lp, g["sm_lp"], what="smooth lp")
+    net.zero_grad()
+    (-lp.mean()).backward()
+    for n, gr in _grads(net).items():
+        _close(gr, g["smgrad/" + n], atol=1e-6, what="smooth grad " + n)
+    net.eval()
+    np.random.seed(5)
+    _, lp_eval, _, _ = net(xs_d, ilens, ys_d)
+    _close(lp_eval, g["eval_lp"], what="eval lp")
+
+
+def test_tiny_optimizer_steps(golden_dir):
+    dev = _gpu()
+    from parallel import FlatAdam
+    g = _load(golden_dir, "tiny_e2e.npz")
+    xs, ilens, ys = synth.batch(8, 9, synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+    for clip, prefix, steps in ((5.0, "after", 3), (0.05, "clip", 1)):
+        net = _product(synth.TINY, synth.e2e_weights(synth.TINY, 11), g["labeldist"], dev)
+        opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=clip)
+        for step in range(steps):
+            np.random.seed(100 + step)
+            _, lp, _, _ = net(xs_d, ilens, ys_d, tf_rate=1.0)
+            opt.zero_grad()
+            (-lp.mean()).backward()
+            gsq = opt.step()
+            if prefix == "after":
+                _close(gsq.sqrt(), g["opt_gnorm%d" % step], rtol=1e-3)
+                if step in (0, 2):
+                    for n, p in net.named_parameters():
+                        _close(p, g["after%d/%s" % (step + 1, n)], rtol=1e-4, atol=2e-6, what="after %s" % n)
+            else:
+                for n, p in net.named_parameters():
+                    _close(p, g["clip/" + n], rtol=1e-4, atol=2e-6, what="clip %s" % n)
+
+
+def test_cfg1_against_golden(golden_dir):
+    dev = _gpu()
+    g = _load(golden_dir, "cfg1.npz")
+    net = _product(synth.CFG1, synth.e2e_weights(synth.CFG1, 21), synth.labeldist(34, 23), dev)
+    xs, ilens, ys = synth.batch(80, 34, synth.CFG1_ILENS, synth.CFG1_YLENS, 22)
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+    np.random.seed(5)
+    logits, lp, pred, ws = net(xs_d, ilens, ys_d)
+    _close(logits, g["logits"], what="logits"); _close(lp, g["lp"], what="lp"); _close(ws, g["ws"], what="ws")
+    loss = -lp.mean()
+    _close(loss, g["loss"], rtol=1e-5)
+    net.zero_grad()
+    loss.backward()
+    for n, p in net.named_parameters():
+        flat = p.grad.detach().cpu().numpy().ravel()
+        np.testing.assert_allclose(np.sqrt((flat.astype(np.float64) ** 2).sum()), g["gnorm/" + n], rtol=RTOL)
+        scale = float(np.abs(flat).max())
+        assert np.abs(flat[:16] - g["ghead/" + n]).max() <= RTOL * scale + 1e-7, n
+
+
+def test_lm_against_golden(golden_dir):
+    dev = _gpu()
+    import model as M
+    from parallel import FlatAdam
+    g = _load(golden_dir, "tiny_lm.npz")
+    w = synth.lm_weights(synth.TINY_LM, 31)
+
+    def build():
+        lm = M.LM(bos=1, eos=2, pad=0, labeldist=g["labeldist"], **synth.TINY_LM).to(dev)
+        assert list(lm.state_dict().keys()) == list(w.keys())
+        lm.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+        lm.train()
+        return lm
+
+    lm = build()
+    ys = [torch.from_numpy(g["ys%d" % i]).to(dev) for i in range(3)]
+    lp, p, pred = lm(ys, discrete_input=True)
+    _close(lp, g["d_lp"]); _close(p, g["d_p"])
+    loss = -lm.mask_and_cal_sum(lp, ys)
+    _close(loss, g["d_loss"], rtol=1e-5)
+    _close(lm.mask_and_cal_sum(p, ys), g["d_avg_prob"], rtol=1e-5)
+    lm.zero_grad()
+    loss.backward()
+    for n, q in lm.named_parameters():
+        _close(q.grad, g["grad/" + n], atol=1e-6, what="lm grad " + n)
+    lp, p, pred = lm(torch.from_numpy(g["c_ys"]).to(dev), discrete_input=False)
+    _close(lp, g["c_lp"]); _close(p, g["c_p"])
+    assert (pred.cpu().numpy() == g["c_pred"]).all()
+    lm.eval()
+    lp_e, _, _ = lm(ys, discrete_input=True)
+    _close(lp_e, g["d_lp_eval"])
+    lm2 = build()
+    opt = FlatAdam(lm2, lr=2e-4, max_grad_norm=5.0)
+    lp, _, _ = lm2(ys, discrete_input=True)
+    opt.zero_grad()
+    (-lm2.mask_and_cal_sum(lp, ys)).backward()
+    opt.step()
+    for n, q in lm2.named_parameters():
+        _close(q, g["after1/" + n], rtol=1e-4, atol=2e-6, what="lm after " + n)
+
+
+def test_ssl_loss_against_golden(golden_dir):
+    dev = _gpu()
+    import model as M
+    g = _load(golden_dir, "tiny_ssl.npz")
+    t = _load(golden_dir, "tiny_e2e.npz")
+    net = _product(synth.TINY, synth.e2e_weights(synth.TINY, 11), t["labeldist"], dev)
+    lm = M.LM(bos=1, eos=2, pad=0, labeldist=_load(golden_dir, "tiny_lm.npz")["labeldist"], **synth.TINY_LM).to(dev)
+    lm.load_state_dict({k: torch.from_numpy(v) for k, v in synth.lm_weights(synth.TINY_LM, 31).items()})
+    lm.train()
+    xs, ilens, ys = synth.batch(8, 9, synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    uxs, uilens, _ = synth.batch(8, 9, [12, 10, 7], [2, 2, 2], 41)
+    uxs_d = torch.from_numpy(uxs).to(dev)
+    _, u_lp, u_pred, _ = net(uxs_d, uilens, ys=None, sample=False, label_smoothing=False,
+                             max_dec_timesteps=int(uxs_d.size(1) * float(g["proportion"])), smooth=True, scaling=3)
+    assert (u_pred.cpu().numpy() == g["u_pred"]).all()
+    _, lm_p, _ = lm(ys=u_pred, discrete_input=False)
+    mask = (u_pred != 2).float()
+    unsup = -torch.sum(lm_p * u_lp * mask) / torch.sum(mask)
+    np.random.seed(9)
+    _, l_lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, ys=[torch.from_numpy(y).to(dev) for y in ys], tf_rate=1.0)
+    sup = -l_lp.mean()
+    _close(sup, g["sup"], rtol=1e-5); _close(unsup, g["unsup"], rtol=1e-4)
+    loss = sup + float(g["unsup_weight"]) * unsup
+    net.zero_grad()
+    loss.backward()
+    for n, gr in _grads(net).items():
+        _close(gr, g["grad/" + n], atol=1e-6, what="ssl grad " + n)
+
+
+def test_oracle_parity_random_shapes():
+    """HIP path vs the oracle on a second, larger random configuration (odd T, B not a multiple of 16)."""
+    dev = _gpu()
+    cfg = dict(input_dim=20, enc_hidden_dim=32, enc_n_layers=3, subsample=[2, 2, 1], dropout_rate=0.0,
+               dec_hidden_dim=48, att_dim=32, conv_channels=4, conv_kernel_size=5, att_odim=32, embedding_dim=16,
+               output_dim=12, ls_weight=0.1)
+    ld = synth.labeldist(12, 3)
+    w = synth.e2e_weights(cfg, 77)
+    ilens = [37, 37, 30, 22, 21, 20, 9, 5, 5, 5, 4, 3, 3, 3, 3, 3, 2, 2, 1]
+    xs, ilens, ys = synth.batch(20, 12, ilens, [max(2, l // 6) for l in ilens], 78)
+    net = _product(cfg, w, ld, dev)
+    np.random.seed(1)
+    logits, lp, _, ws = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
+    sd = O.make_leaf_state(w)
+    np.random.seed(1)
+    rl, rlp, _, rws = O.e2e_forward(sd, dict(cfg, labeldist=ld), torch.from_numpy(xs), ilens,
+                                    [torch.from_numpy(y) for y in ys])
+    _close(logits, rl, what="logits"); _close(lp, rlp, what="lp"); _close(ws, rws, what="ws")
+    names = O.unique_param_names(sd)
+    rg = dict(zip(names, torch.autograd.grad(-rlp.mean(), [sd[n] for n in names])))
+    net.zero_grad()
+    (-lp.mean()).backward()
+    for n, gr in _grads(net).items():
+        _close(gr, rg[n], atol=1e-6, what="grad " + n)
