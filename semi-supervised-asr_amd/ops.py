@@ -229,7 +229,7 @@ class _DecoderSeq(torch.autograd.Function):
                     pr = torch.softmax(logits[s - 1] * opts["smooth_scaling"], dim=-1)
                     probs_saved.append(pr)
                     fed[s] = -1
-                    X[s, :, D + O:] = pr @ emb_w
+                    hb.gemm(pr, emb_w, out=X[s][:, D + O:])
                 hb.check(lib.asr_dec_step_fwd(ctypes.byref(fs), s, hb.stream()), "asr_dec_step_fwd")
                 hb.gemm_skinny(X[s + 1][:, :D + O], w_out_c, bias=b_out, out=logits[s])
                 pred[s] = torch.distributions.Categorical(logits=logits[s]).sample() if sample \
@@ -281,12 +281,12 @@ class _DecoderSeq(torch.autograd.Function):
                 if s >= 1:
                     demb = G[s][:, D + O:]
                     pr = probs_saved[s - 1]
-                    demb_w += pr.t() @ demb
-                    dp = demb @ emb_w.t()
-                    dl = k * pr * (dp - (pr * dp).sum(-1, keepdim=True))
-                    hb.gemm_skinny(dl.contiguous(), w_out.t().contiguous(), out=G[s][:, :D + O], accumulate=True)
-                    dw_out += dl.t() @ X[s][:, :D + O]
-                    db_out += dl.sum(0)
+                    hb.gemm(pr, demb, trans_a=True, out=demb_w, accumulate=True, split_k=1)
+                    dp = hb.gemm(demb, emb_w, trans_b=True)
+                    dl = (k * pr * (dp - (pr * dp).sum(-1, keepdim=True))).contiguous()
+                    hb.gemm(dl, w_out, out=G[s][:, :D + O], accumulate=True, split_k=1)
+                    hb.gemm(dl, X[s][:, :D + O], trans_a=True, out=dw_out, accumulate=True, split_k=1)
+                    hb.colsum(dl, out=db_out, accumulate=True)
         # deferred weight gradients: one GEMM each over the whole sequence
         dg2 = wk["dgates"].view(L * B, 4 * D)
         Xin = X[:L]
