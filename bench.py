@@ -1,0 +1,244 @@
+"""bench.py — utterances/sec of a full train step (forward + loss + backward + gradient all-reduce + clip +
+Adam) of the seq2seq ASR hot path on N MI355X GPUs, plus the dominant kernel's roofline fraction and a CPU
+baseline (the oracle port) timed on the host cores of the same box.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] ("cfg-2"): 3x512 pyramidal BiLSTM encoder, 512 LSTM decoder with
+location-aware attention, V=34, batch 32 per GPU, 80-dim x 800-frame synthetic fbank (ragged lengths
+U[0.6T, T], longest pinned to T; label length 0.125 T_i), dropout 0.3 as in config.yaml, fp32.
+Weak scaling: 32 utterances per GPU; at N=8 the global batch is 256 (configs[2]'s shape).  Every rank
+pads its strided shard to the global T_max / olength (exact-parity mode).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "semi-supervised-asr_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+CFG2 = dict(input_dim=80, enc_hidden_dim=512, enc_n_layers=3, subsample=[2, 2, 2], dropout_rate=0.3,
+            dec_hidden_dim=512, att_dim=512, conv_channels=10, conv_kernel_size=100, att_odim=512,
+            embedding_dim=128, output_dim=34, ls_weight=0.05)
+T_FRAMES = 800
+B_PER_GPU = 32
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TF = 157.3
+
+
+def global_batch(n_utt, t_max, seed):
+    """Seeded synthetic batch in collate layout: N(0,1) features, ragged lengths, sorted desc."""
+    rs = np.random.RandomState(seed)
+    lens = sorted([int(v) for v in rs.randint(int(0.6 * t_max), t_max + 1, size=n_utt)], reverse=True)
+    lens[0] = t_max
+    xs = np.zeros((n_utt, t_max, CFG2["input_dim"]), dtype=np.float32)
+    ys = []
+    for b, l in enumerate(lens):
+        xs[b, :l] = rs.normal(0, 1, size=(l, CFG2["input_dim"])).astype(np.float32)
+        ys.append(rs.randint(3, CFG2["output_dim"], size=(max(2, int(0.125 * l)),)).astype(np.int64))
+    ys[0] = rs.randint(3, CFG2["output_dim"], size=(int(0.125 * t_max),)).astype(np.int64)
+    return xs, lens, ys
+
+
+def fwd_flops_per_utt(t_frames, l_plus_1):
+    """SURVEY 8d F_fwd (algorithmic, per utterance)."""
+    c = CFG2
+    H, I = c["enc_hidden_dim"], c["input_dim"]
+    f, t = 0.0, t_frames
+    for layer in range(c["enc_n_layers"]):
+        idim = I if layer == 0 else H
+        f += 2.0 * t * 2 * 4 * H * (idim + H)
+        t2 = (t + 1) // 2 if c["subsample"][layer] > 1 else t
+        f += 2.0 * t2 * (4 * H if c["subsample"][layer] > 1 else 2 * H) * H
+        t = t2
+    tp = t
+    A, D, O, E, V = c["att_dim"], c["dec_hidden_dim"], c["att_odim"], c["embedding_dim"], c["output_dim"]
+    C, K = c["conv_channels"], c["conv_kernel_size"]
+    f += 2.0 * tp * H * A
+    f += l_plus_1 * (2.0 * 4 * D * (E + O + D) + 2 * D * A + 2 * C * (2 * K + 1) * tp + 2 * C * A * tp + 2 * A * tp
+                     + 2 * tp * H + 2 * H * O + 2 * (D + O) * V)
+    return f
+
+
+def usable_cpus():
+    """CPU share of this container: affinity mask, capped by the cgroup quota and by 16 (the GPU box gives one
+    GPU's job 16 cores; os.cpu_count() reports the whole host and oversubscribes badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def note(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU port of the reference path) on a bounded sample of the same workload."""
+    import synth
+    from oracle import asr_oracle as O
+    ncores = usable_cpus()
+    note("cpu baseline on %d threads" % ncores)
+    torch.set_num_threads(ncores)
+    n_s = 2
+    xs, lens, ys = global_batch(B_PER_GPU, T_FRAMES, 1234)
+    xs, lens, ys = xs[:n_s], lens[:n_s], ys[:n_s]
+    cfg = dict(CFG2, labeldist=synth.labeldist(CFG2["output_dim"], 5))
+    sd = O.make_leaf_state(synth.e2e_weights(CFG2, 99))
+    names = O.unique_param_names(sd)
+    opt = O.AdamAmsgrad(names, lr=5e-4, weight_decay=1e-6)
+    xs_t, ys_t = torch.from_numpy(xs), [torch.from_numpy(y) for y in ys]
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        O.sup_train_step(sd, cfg, opt, xs_t, lens, ys_t, max_grad_norm=5.0)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el * (steps + 1) / steps > seconds_budget or steps >= 3:
+            break
+    return dict(value=n_s * steps / el, unit="utterances/sec", cores=ncores, kind="port",
+                sample="%d train step(s) of oracle/asr_oracle.py on the first %d utterances of the cfg-2 batch "
+                       "(T=%d, dropout 0.3), %d torch CPU threads" % (steps, n_s, T_FRAMES, ncores))
+
+
+def kernel_roofline(dev):
+    """Live HIP-event timing of the dominant kernel (the encoder LSTM backward time-step kernel,
+    enc_step_bwd_kernel<1,8,4>) on the layer-0 shape of this workload: every launch of one 800-step sequence
+    is bracketed by events on the launch stream.  Algorithmic flops per launch = the recurrent product
+    dG_t W_hh for both directions: 2 * B * 4H * H * 2 (recurrent term)."""
+    import hip_backend as hb
+    H, B, T = CFG2["enc_hidden_dim"], B_PER_GPU, T_FRAMES
+    g = torch.Generator().manual_seed(3)
+    gates = (torch.rand(T, B, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
+    w = (torch.randn(2, H, 4 * H, generator=g) / np.sqrt(H)).to(dev)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    dy = torch.randn(T, B, 2 * H, generator=g).to(dev)
+    c = torch.randn(T, B, 2 * H, generator=g).to(dev)
+    dcarry = torch.zeros(B, 2 * H, device=dev)
+    stream = torch.cuda.current_stream()
+    keep = gates.clone()
+    for _ in range(2):
+        gates.copy_(keep)
+        dcarry.zero_()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        hb.lstm_seq_bwd(gates, w, lens, dy, c, dcarry)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+    per_launch_s = ms * 1e-3 / T
+    flops = 2.0 * B * 4 * H * H * 2
+    ach = flops / per_launch_s / 1e12
+    return dict(bound="mfma", kernel="enc_step_bwd_kernel<1,8,4>", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                frac=ach / MFMA_F32_PEAK_TF, traffic=None, us_per_launch=per_launch_s * 1e6)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=CFG2["dropout_rate"])
+    args = ap.parse_args()
+
+    import __graft_entry__ as entry
+    entry.build()
+    import parallel
+    import model as M
+    from parallel import FlatAdam
+    import synth
+    import torch.distributed as dist
+
+    rank, world, local = parallel.init_distributed()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = dict(CFG2, dropout_rate=args.dropout)
+    torch.manual_seed(1000 + rank)                     # per-rank dropout streams; weights below are shared
+    net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 5), **cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.e2e_weights(cfg, 99).items()})
+    net = net.to(dev).train()
+    opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0)
+
+    n_global = B_PER_GPU * world
+    xs, lens, ys = global_batch(n_global, T_FRAMES, 1234)
+    xs_r, lens_r, ys_r, info = parallel.shard_batch(xs, lens, ys, rank, world)
+    xs_d = torch.from_numpy(np.ascontiguousarray(xs_r)).to(dev)       # inputs resident in HBM before timing
+    ys_d = [torch.from_numpy(y).to(dev) for y in ys_r]
+    tl = M.padded_lengths(info["t_max"], cfg["enc_n_layers"], cfg["subsample"])
+
+    def step():
+        _, lp, _, _ = net(xs_d, lens_r, ys_d, tf_rate=1.0, total_length=tl, olength=info["olength"])
+        loss = parallel.local_loss(lp, info)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()                                    # one RCCL all-reduce -> clip -> Adam
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        note("warmup")
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if rank == 0:
+        note("timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    final_loss = float(loss.item()) * world
+
+    if rank == 0:
+        ms = el / args.steps * 1e3
+        value = n_global * args.steps / el
+        f_train = 3.0 * sum(fwd_flops_per_utt(info["t_max"], info["olength"]) for _ in range(1))
+        out = {
+            "metric": "utterances/sec (train step)", "value": value, "unit": "utterances/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg-2: 3x512 pBiLSTM enc / 1x512 LSTM dec + location attention, "
+                                   "batch 32 per GPU, 80x800 synthetic fbank (ragged 0.6T..T), V=34, L+1=%d, "
+                                   "dropout %.2f, Adam(amsgrad)+clip 5" % (info["olength"], args.dropout),
+                       "global_batch": n_global, "frames": T_FRAMES, "parallelism": "dp%d" % world,
+                       "pad_mode": "global-exact"},
+            "loss": final_loss,
+            "model_tflops": value * f_train / 1e12,
+        }
+        note("%.1f utt/s, %.2f ms/step; measuring dominant kernel" % (value, ms))
+        out["roofline"] = kernel_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,8 @@ typedef struct {
   const float* xmask; /* [L][B][O+E] dropout mask for the (ctx|emb) part of X[s], or NULL */
   /* state / saved buffers */
   float* X;       /* [L+1][B][KX] */
+  float* Xd;      /* [L+1][B][KX] dropout-masked copy of X (the cell's operand) when xmask != NULL, else NULL;
+                     the caller fills its emb columns, the kernels fill z and ctx*mask */
   float* gates;   /* [L][B][4D] */
   float* cstate;  /* [L][B][D] */
   float* Dproj;   /* [L][B][A]   mlp_dec(z_s) */

@@ -37,18 +37,83 @@ __device__ __forceinline__ float wave_max(float v) {
 //   A operand lane map (16x16x4 f32): a = A[row = lane&15][k-slot = lane>>4]
 //   B operand lane map              : b = B[k-slot = lane>>4][col = lane&15]
 //   C/D: lane holds rows 4*(lane>>4)+i (i=0..3) of column lane&15.
-// Rows >= nrows are clamped on load (caller masks the store).  `amask` (optional) multiplies
-// A elementwise for k >= mask_from (dropout on part of the operand).
+// Rows >= nrows are clamped on load (caller masks the store).
+// The chain is L2-latency bound, so the loop is software pipelined: two statically named register
+// groups of SK_GROUP chunks; group g+1's loads are issued before group g's MFMAs.  Loads are
+// unconditional and nothing touches a loaded value before its MFMA (a branch around a load, or a
+// select right after it, makes hipcc drain vmcnt there and serialises the L2 round trips); the tail
+// group clamps its chunk index and zeroes the B operand at MFMA time.
 // Result lands in LDS red[w][MT*16][17] per wave; caller syncs and sums the 4 waves.
 // ---------------------------------------------------------------------------------------
 #define SK_LDS_STRIDE 17
+#define SK_GROUP 8
+
 template <int MT>
+struct SkinnyRegs {
+  float4 b[SK_GROUP];
+  float4 a[SK_GROUP][MT];
+};
+
+template <int MT, int NW>
+__device__ __forceinline__ void skinny_fetch(SkinnyRegs<MT>& rg, int i0, int nmine, int wave, int q, int cbase,
+                                             const float* __restrict__ brow, const float* __restrict__ A,
+                                             int64_t lda, const int64_t (&arow)[MT]) {
+#pragma unroll
+  for (int u = 0; u < SK_GROUP; ++u) {
+    int i = i0 + u < nmine ? i0 + u : nmine - 1;
+#ifndef ASR_NO_ROTATE
+    i += cbase;                       // per-workgroup rotation of the K traversal (cbase < nmine):
+    i = i < nmine ? i : i - nmine;    // all workgroups share operand A; staggering avoids L2-channel hot spots
+#endif
+    const int k0 = ((wave + NW * i) << 4) + (q << 2);
+#ifdef ASR_ABLATE_NOLOAD
+    rg.b[u] = make_float4(k0 * 1e-9f, 1.f, 2.f, 3.f);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) rg.a[u][m] = make_float4(1.f, k0 * 1e-9f, 2.f, 3.f);
+#else
+    rg.b[u] = *reinterpret_cast<const float4*>(brow + k0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) rg.a[u][m] = *reinterpret_cast<const float4*>(A + arow[m] * lda + k0);
+#endif
+  }
+}
+
+template <int MT, bool FULL>
+__device__ __forceinline__ void skinny_mma(const SkinnyRegs<MT>& rg, int i0, int nmine, f32x4 (&acc)[MT]) {
+#pragma unroll
+  for (int u = 0; u < SK_GROUP; ++u) {
+    float4 b = rg.b[u];
+    if (!FULL && i0 + u >= nmine) b = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef ASR_ABLATE_NOMMA
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc[m][0] += rg.a[u][m].x * b.x + rg.a[u][m].y * b.y + rg.a[u][m].z * b.z + rg.a[u][m].w * b.w; }
+    continue;
+#endif
+    // alternate the accumulators so consecutive MFMAs are independent (40-cycle dependent latency)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(rg.a[u][m].x, b.x, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(rg.a[u][m].y, b.y, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(rg.a[u][m].z, b.z, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(rg.a[u][m].w, b.w, acc[m], 0, 0, 0);
+  }
+}
+
+template <int MT>
+__device__ __forceinline__ void skinny_mma_any(const SkinnyRegs<MT>& rg, int i0, int nmine, f32x4 (&acc)[MT]) {
+  if (i0 + SK_GROUP <= nmine) skinny_mma<MT, true>(rg, i0, nmine, acc);
+  else skinny_mma<MT, false>(rg, i0, nmine, acc);
+}
+
+template <int MT, int NW = 4>
 __device__ __forceinline__ void skinny_partial(const float* __restrict__ A, int64_t lda, int64_t row0,
                                                int64_t nrows, const float* __restrict__ Bt, int64_t ldb,
                                                int64_t bt_row0, int64_t bt_nrows, int K,
-                                               const float* __restrict__ amask,
-                                               int64_t ldmask, int mask_from, float* red /* [4][MT*16][17] */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                               float* red /* [NW][MT*16][17] */) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
   f32x4 acc[MT];
 #pragma unroll
@@ -62,25 +127,17 @@ __device__ __forceinline__ void skinny_partial(const float* __restrict__ A, int6
     arow[m] = rr < nrows ? rr : nrows - 1;
   }
   const int nchunk = K >> 4;
-  for (int cidx = wave; cidx < nchunk; cidx += 4) {
-    const int k0 = (cidx << 4) + (q << 2);
-    const float4 bv = *reinterpret_cast<const float4*>(brow + k0);
-    float4 av[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const float4*>(A + arow[m] * lda + k0);
-    if (amask != nullptr && k0 >= mask_from) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float4 mv = *reinterpret_cast<const float4*>(amask + arow[m] * ldmask + (k0 - mask_from));
-        av[m].x *= mv.x; av[m].y *= mv.y; av[m].z *= mv.z; av[m].w *= mv.w;
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].x, bv.x, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].y, bv.y, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].z, bv.z, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].w, bv.w, acc[m], 0, 0, 0);
+  const int nmine = (nchunk - wave + NW - 1) / NW;   // this wave owns chunks wave, wave+NW, ...
+  const int cbase = nmine > 0 ? (int)((blockIdx.x * 5u + blockIdx.y * 3u + blockIdx.z * 7u) % (unsigned)nmine) : 0;
+  if (nmine > 0) {                              // wave-uniform
+    SkinnyRegs<MT> ra, rb;
+    skinny_fetch<MT, NW>(ra, 0, nmine, wave, q, cbase, brow, A, lda, arow);
+    for (int i0 = 0; i0 < nmine; i0 += 2 * SK_GROUP) {
+      const bool second = i0 + SK_GROUP < nmine;
+      if (second) skinny_fetch<MT, NW>(rb, i0 + SK_GROUP, nmine, wave, q, cbase, brow, A, lda, arow);
+      skinny_mma_any<MT>(ra, i0, nmine, acc);
+      if (i0 + 2 * SK_GROUP < nmine) skinny_fetch<MT, NW>(ra, i0 + 2 * SK_GROUP, nmine, wave, q, cbase, brow, A, lda, arow);
+      if (second) skinny_mma_any<MT>(rb, i0 + SK_GROUP, nmine, acc);
     }
   }
   float* mine = red + wave * (MT * 16 * SK_LDS_STRIDE);
@@ -90,10 +147,12 @@ __device__ __forceinline__ void skinny_partial(const float* __restrict__ A, int6
     for (int i = 0; i < 4; ++i) mine[(m * 16 + q * 4 + i) * SK_LDS_STRIDE + r] = acc[m][i];
 }
 
-// sum of the 4 waves' partials for (row, col) after a __syncthreads()
-template <int MT>
+// sum of the NW waves' partials for (row, col) after a __syncthreads()
+template <int MT, int NW = 4>
 __device__ __forceinline__ float skinny_reduced(const float* red, int row, int col) {
   const int o = row * SK_LDS_STRIDE + col;
   const int st = MT * 16 * SK_LDS_STRIDE;
-  return (red[o] + red[o + st]) + (red[o + 2 * st] + red[o + 3 * st]);
+  float v = (red[o] + red[o + st]) + (red[o + 2 * st] + red[o + 3 * st]);
+  if (NW == 8) v += (red[o + 4 * st] + red[o + 5 * st]) + (red[o + 6 * st] + red[o + 7 * st]);
+  return v;
 }

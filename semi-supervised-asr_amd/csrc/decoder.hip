@@ -14,9 +14,8 @@
 int asr_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bt, int64_t ldb,
                       float* C, int64_t ldc, const float* bias, int accumulate, const float* mask, int64_t ldmask,
                       int64_t mask_from, hipStream_t stream);
-int asr_cell_fwd_launch(int B, int D, int KX, const float* Xs, const float* wcat, const float* bcat,
-                        const float* xmask, int64_t ldmask, float* gates, const float* cprev, float* cout, float* zout,
-                        hipStream_t stream);
+int asr_cell_fwd_launch(int B, int D, int KX, const float* Xs, const float* wcat, const float* bcat, float* gates,
+                        const float* cprev, float* cout, float* zout, float* zout2, hipStream_t stream);
 int asr_cell_bwd_launch(int B, int D, int KX, const float* Gnext, const float* gates, const float* cst,
                         const float* cprev, float* dcell, float* dgates, hipStream_t stream);
 
@@ -119,7 +118,8 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_fwd_kernel(int B, int Tp,
                                                                   const float* __restrict__ Q,
                                                                   const float* __restrict__ bo,
                                                                   float* __restrict__ wout, float* __restrict__ ctx,
-                                                                  int64_t ldctx) {
+                                                                  int64_t ldctx, float* __restrict__ ctxd,
+                                                                  const float* __restrict__ dmask, int64_t ldmask) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wsm = sm;
   float* red = sm + ((Tp + 3) & ~3);
@@ -162,6 +162,11 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_fwd_kernel(int B, int Tp,
     const float4 bb = *reinterpret_cast<const float4*>(bo + o);
     r.x += bb.x; r.y += bb.y; r.z += bb.z; r.w += bb.w;
     *reinterpret_cast<float4*>(ctx + (int64_t)b * ldctx + o) = r;
+    if (ctxd) {   // dropout-masked copy feeding the next step's cell (model.py:284-285)
+      const float4 mk = *reinterpret_cast<const float4*>(dmask + (int64_t)b * ldmask + o);
+      r.x *= mk.x; r.y *= mk.y; r.z *= mk.z; r.w *= mk.w;
+      *reinterpret_cast<float4*>(ctxd + (int64_t)b * ldctx + o) = r;
+    }
   }
 }
 
@@ -357,10 +362,12 @@ extern "C" int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stre
   const int KX = D + O + E;
   const float* Xs = p->X + (int64_t)s * B * KX;
   float* Xn = p->X + (int64_t)(s + 1) * B * KX;
-  const float* xm = p->xmask ? p->xmask + (int64_t)s * B * (O + E) : nullptr;
-  rc = asr_cell_fwd_launch(B, D, KX, Xs, p->wcat, p->bcat, xm, O + E, p->gates + (int64_t)s * B * 4 * D,
-                           s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr, p->cstate + (int64_t)s * B * D, Xn,
-                           stream);
+  const bool drop = p->xmask != nullptr;
+  if (drop && !p->Xd) return ASR_E_ARG;
+  float* Xdn = drop ? p->Xd + (int64_t)(s + 1) * B * KX : nullptr;
+  rc = asr_cell_fwd_launch(B, D, KX, drop ? p->Xd + (int64_t)s * B * KX : Xs, p->wcat, p->bcat,
+                           p->gates + (int64_t)s * B * 4 * D, s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr,
+                           p->cstate + (int64_t)s * B * D, Xn, Xdn, stream);
   if (rc) return rc;
   float* Dp = p->Dproj + (int64_t)s * B * A;
   rc = asr_skinny_launch(B, A, D, Xn, KX, p->wdec, D, Dp, A, nullptr, 0, nullptr, 0, 0, stream);
@@ -374,7 +381,8 @@ extern "C" int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stre
   const size_t lds2 = sizeof(float) * ((size_t)((Tp + 3) & ~3) + 4 * 256);
   hipLaunchKernelGGL(att_softmax_ctx_fwd_kernel, dim3((O + 255) / 256, B), dim3(256), lds2, stream, B, Tp, O,
                      p->scaling, p->energy + (int64_t)s * B * Tp, p->Q, p->bo, p->ws + (int64_t)s * B * Tp, Xn + D,
-                     (int64_t)KX);
+                     (int64_t)KX, (drop && s + 1 < p->L) ? Xdn + D : nullptr,
+                     (drop && s + 1 < p->L) ? p->xmask + (int64_t)(s + 1) * B * (O + E) : nullptr, (int64_t)(O + E));
   ASR_CHECK_LAUNCH();
   return 0;
 }

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(int64_t M, int64_t N, int K
   __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
   const int64_t n0 = (int64_t)blockIdx.x * 16;
   const int64_t row0 = (int64_t)blockIdx.y * (MT * 16);
-  skinny_partial<MT>(A, lda, row0, M, Bt, ldb, n0, N, K, nullptr, 0, 0, red);
+  skinny_partial<MT>(A, lda, row0, M, Bt, ldb, n0, N, K, red);
   __syncthreads();
   for (int e = threadIdx.x; e < MT * 16 * 16; e += 256) {
     const int row = e >> 4, col = e & 15;

@@ -12,6 +12,9 @@
 namespace {
 
 // ------------------------------------------------------------------ forward step (encoder/judge)
+// Workgroup = 4 hidden units x 4 gates (16 gate-interleaved rows of W_hh) x MT*16 batch rows.
+// The pointwise operands (x-projection, c_{t-1}, length) are fetched BEFORE the recurrent product so their
+// HBM/Infinity-Cache miss latency hides under the weight stream + MFMA phase.
 template <int MT>
 __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int H, int ndir, float* __restrict__ gates,
                                                            const float* __restrict__ w_hh,
@@ -23,48 +26,59 @@ __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int H, 
   const int t = d == 0 ? s : T - 1 - s;
   const int tp = d == 0 ? t - 1 : t + 1;
   const int64_t ldy = (int64_t)ndir * H;
+  const int e = threadIdx.x;
+  const int row = e >> 2, u = e & 3;
+  const int64_t b = row0 + row;
+  const bool mine = e < MT * 16 * 4 && b < B;
+  const int unit = 4 * j + u;
+  float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cp = 0.f;
+  int len = 0;
+  float4* gp = nullptr;
+  int64_t so = 0;
+  if (mine) {
+    gp = reinterpret_cast<float4*>(gates + (((int64_t)t * B + b) * ndir + d) * 4 * H + unit * 4);
+    so = ((int64_t)t * B + b) * ldy + d * H + unit;
+    gx = *gp;
+    len = lens[b];
+    if (s > 0) cp = c[((int64_t)tp * B + b) * ldy + d * H + unit];
+  }
   if (s > 0) {
     skinny_partial<MT>(y + (int64_t)tp * B * ldy + d * H, ldy, row0, B, w_hh + (int64_t)d * 4 * H * H, H,
-                       (int64_t)16 * j, (int64_t)4 * H, H, nullptr, 0, 0, red);
+                       (int64_t)16 * j, (int64_t)4 * H, H, red);
   }
   __syncthreads();
-  const int e = threadIdx.x;
-  if (e < MT * 16 * 4) {
-    const int row = e >> 2, u = e & 3;
-    const int64_t b = row0 + row;
-    if (b < B) {
-      float pre[4] = {0.f, 0.f, 0.f, 0.f};
-      if (s > 0) {
+  if (mine) {
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = skinny_reduced<MT>(red, row, u * 4 + g);
-      }
-      const int unit = 4 * j + u;
-      float4* gp = reinterpret_cast<float4*>(gates + (((int64_t)t * B + b) * ndir + d) * 4 * H + unit * 4);
-      const float4 gx = *gp;
-      const float gi = asr_sigmoid(pre[0] + gx.x), gf = asr_sigmoid(pre[1] + gx.y);
-      const float gg = tanhf(pre[2] + gx.z), go = asr_sigmoid(pre[3] + gx.w);
-      const int64_t so = ((int64_t)t * B + b) * ldy + d * H + unit;
-      const float cp = s > 0 ? c[((int64_t)tp * B + b) * ldy + d * H + unit] : 0.f;
-      float cn = gf * cp + gi * gg;
-      float hn = go * tanhf(cn);
-      if (t >= lens[b]) { cn = 0.f; hn = 0.f; }
-      *gp = make_float4(gi, gf, gg, go);
-      c[so] = cn;
-      y[so] = hn;
+      for (int g = 0; g < 4; ++g) pre[g] = skinny_reduced<MT>(red, row, u * 4 + g);
     }
+    const float gi = asr_sigmoid(pre[0] + gx.x), gf = asr_sigmoid(pre[1] + gx.y);
+    const float gg = tanhf(pre[2] + gx.z), go = asr_sigmoid(pre[3] + gx.w);
+    float cn = gf * cp + gi * gg;
+    float hn = go * tanhf(cn);
+    if (t >= len) { cn = 0.f; hn = 0.f; }
+    *gp = make_float4(gi, gf, gg, go);
+    c[so] = cn;
+    y[so] = hn;
   }
 }
 
 // ------------------------------------------------------------------ backward step (encoder/judge)
-// Workgroup = 16 hidden units of one direction x <=32 batch rows.  Phase 1: dh_rec = dG[t_next] W_hh
+// Workgroup = UNITS hidden units of one direction x MT*16 batch rows.  Phase 1: dh_rec = dG[t_next] W_hh
 // (K = 4H) for its units; phase 2: pointwise LSTM backward at time t, dG[t] written in place.
-template <int MT>
-__global__ __launch_bounds__(256) void enc_step_bwd_kernel(int T, int B, int H, int ndir, float* __restrict__ gates,
+// W_hh is re-streamed from Infinity Cache every launch (L2 does not survive the kernel boundary) at the
+// per-CU fabric share, so UNITS is small enough to spread that stream over the whole chip.
+template <int MT, int UNITS, int NW>
+__global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int H, int ndir, float* __restrict__ gates,
                                                            const float* __restrict__ w_hhT,
                                                            const int32_t* __restrict__ lens,
                                                            const float* __restrict__ dy, const float* __restrict__ c,
                                                            float* __restrict__ dcarry, int s) {
-  __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
+  __shared__ float red[NW * MT * 16 * SK_LDS_STRIDE];
+  constexpr int NT = NW * 64;
+  constexpr int NE = (MT * 16 * UNITS + NT - 1) / NT;   // pointwise elements per thread
   const int j = blockIdx.x, d = blockIdx.y;
   const int64_t row0 = (int64_t)blockIdx.z * (MT * 16);
   const int t = d == 0 ? T - 1 - s : s;
@@ -72,36 +86,58 @@ __global__ __launch_bounds__(256) void enc_step_bwd_kernel(int T, int B, int H, 
   const int tp = d == 0 ? t - 1 : t + 1;   // forward-time predecessor (owner of c_prev)
   const bool has_prev = d == 0 ? (t > 0) : (t < T - 1);
   const int64_t ldy = (int64_t)ndir * H, ldg = (int64_t)ndir * 4 * H;
+  // prefetch the pointwise operands
+  float dyv[NE], ctv[NE], cpv[NE], dcv[NE];
+  float4 av[NE];
+  int lenv[NE];
+  bool live[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = threadIdx.x + NT * i;
+    const int row = e / UNITS, u = e % UNITS;
+    const int64_t b = row0 + row;
+    live[i] = e < MT * 16 * UNITS && b < B;
+    dyv[i] = ctv[i] = cpv[i] = dcv[i] = 0.f;
+    av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lenv[i] = 0;
+    if (live[i]) {
+      const int unit = UNITS * j + u;
+      const int64_t so = ((int64_t)t * B + b) * ldy + d * H + unit;
+      dyv[i] = dy[so];
+      av[i] = *reinterpret_cast<const float4*>(gates + ((int64_t)t * B + b) * ldg + (int64_t)d * 4 * H + unit * 4);
+      ctv[i] = c[so];
+      if (has_prev) cpv[i] = c[((int64_t)tp * B + b) * ldy + d * H + unit];
+      dcv[i] = dcarry[b * ldy + d * H + unit];
+      lenv[i] = lens[b];
+    }
+  }
   if (s > 0) {
-    skinny_partial<MT>(gates + (int64_t)tn * B * ldg + (int64_t)d * 4 * H, ldg, row0, B,
-                       w_hhT + (int64_t)d * H * 4 * H, (int64_t)4 * H, (int64_t)16 * j, (int64_t)H, 4 * H, nullptr, 0, 0,
-                       red);
+    skinny_partial<MT, NW>(gates + (int64_t)tn * B * ldg + (int64_t)d * 4 * H, ldg, row0, B,
+                       w_hhT + (int64_t)d * H * 4 * H, (int64_t)4 * H, (int64_t)UNITS * j,
+                       (int64_t)UNITS * (j + 1), 4 * H, red);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < MT * 16 * 16; e += 256) {
-    const int row = e >> 4, u = e & 15;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    if (!live[i]) continue;
+    const int e = threadIdx.x + NT * i;
+    const int row = e / UNITS, u = e % UNITS;
     const int64_t b = row0 + row;
-    if (b >= B) continue;
-    const int unit = 16 * j + u;
-    const int64_t so = ((int64_t)t * B + b) * ldy + d * H + unit;
-    float dh = dy[so];
-    if (s > 0) dh += skinny_reduced<MT>(red, row, u);
-    float4* gp = reinterpret_cast<float4*>(gates + ((int64_t)t * B + b) * ldg + (int64_t)d * 4 * H + unit * 4);
-    const float4 a = *gp;  // i f g o
-    const float ct = c[so];
-    const float cp = has_prev ? c[((int64_t)tp * B + b) * ldy + d * H + unit] : 0.f;
-    float* dcp = dcarry + b * ldy + d * H + unit;
-    const float tc = tanhf(ct);
-    const float dc = *dcp + dh * a.w * (1.f - tc * tc);
+    const int unit = UNITS * j + u;
+    float dh = dyv[i];
+    if (s > 0) dh += skinny_reduced<MT, NW>(red, row, u);
+    const float4 a = av[i];  // i f g o
+    const float tc = tanhf(ctv[i]);
+    const float dc = dcv[i] + dh * a.w * (1.f - tc * tc);
     float4 da;
     da.x = dc * a.z * a.x * (1.f - a.x);
-    da.y = dc * cp * a.y * (1.f - a.y);
+    da.y = dc * cpv[i] * a.y * (1.f - a.y);
     da.z = dc * a.x * (1.f - a.z * a.z);
     da.w = dh * tc * a.w * (1.f - a.w);
     float dcn = dc * a.y;
-    if (t >= lens[b]) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
-    *gp = da;
-    *dcp = dcn;
+    if (t >= lenv[i]) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
+    *reinterpret_cast<float4*>(gates + ((int64_t)t * B + b) * ldg + (int64_t)d * 4 * H + unit * 4) = da;
+    dcarry[b * ldy + d * H + unit] = dcn;
   }
 }
 
@@ -111,13 +147,13 @@ template <int MT>
 __global__ __launch_bounds__(256) void cell_fwd_kernel(int B, int D, int KX, const float* __restrict__ Xs,
                                                        const float* __restrict__ wcat,
                                                        const float* __restrict__ bcat,
-                                                       const float* __restrict__ xmask, int64_t ldmask,
                                                        float* __restrict__ gates, const float* __restrict__ cprev,
-                                                       float* __restrict__ cout, float* __restrict__ zout) {
+                                                       float* __restrict__ cout, float* __restrict__ zout,
+                                                       float* __restrict__ zout2) {
   __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
   const int j = blockIdx.x;
   const int64_t row0 = (int64_t)blockIdx.z * (MT * 16);
-  skinny_partial<MT>(Xs, KX, row0, B, wcat, KX, (int64_t)16 * j, (int64_t)4 * D, KX, xmask, ldmask, D, red);
+  skinny_partial<MT>(Xs, KX, row0, B, wcat, KX, (int64_t)16 * j, (int64_t)4 * D, KX, red);
   __syncthreads();
   const int e = threadIdx.x;
   if (e < MT * 16 * 4) {
@@ -134,7 +170,9 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(int B, int D, int KX, con
       const float cn = gf * cp + gi * gg;
       *reinterpret_cast<float4*>(gates + (b * 4 * D) + unit * 4) = make_float4(gi, gf, gg, go);
       cout[b * D + unit] = cn;
-      zout[b * KX + unit] = go * tanhf(cn);
+      const float zn = go * tanhf(cn);
+      zout[b * KX + unit] = zn;
+      if (zout2) zout2[b * KX + unit] = zn;   // the dropout-masked operand copy shares the recurrent state
     }
   }
 }
@@ -164,16 +202,15 @@ __global__ void cell_bwd_kernel(int B, int D, int KX, const float* __restrict__ 
 
 }  // namespace
 
-int asr_cell_fwd_launch(int B, int D, int KX, const float* Xs, const float* wcat, const float* bcat,
-                        const float* xmask, int64_t ldmask, float* gates, const float* cprev, float* cout, float* zout,
-                        hipStream_t stream) {
+int asr_cell_fwd_launch(int B, int D, int KX, const float* Xs, const float* wcat, const float* bcat, float* gates,
+                        const float* cprev, float* cout, float* zout, float* zout2, hipStream_t stream) {
   if (D % 16 || KX % 16) return ASR_E_SHAPE;
   if (B <= 16)
-    hipLaunchKernelGGL((cell_fwd_kernel<1>), dim3(D / 4, 1, 1), dim3(256), 0, stream, B, D, KX, Xs, wcat, bcat, xmask,
-                       ldmask, gates, cprev, cout, zout);
+    hipLaunchKernelGGL((cell_fwd_kernel<1>), dim3(D / 4, 1, 1), dim3(256), 0, stream, B, D, KX, Xs, wcat, bcat, gates,
+                       cprev, cout, zout, zout2);
   else
     hipLaunchKernelGGL((cell_fwd_kernel<2>), dim3(D / 4, 1, (B + 31) / 32), dim3(256), 0, stream, B, D, KX, Xs, wcat,
-                       bcat, xmask, ldmask, gates, cprev, cout, zout);
+                       bcat, gates, cprev, cout, zout, zout2);
   ASR_CHECK_LAUNCH();
   return 0;
 }
@@ -204,19 +241,26 @@ extern "C" int asr_lstm_seq_fwd(int T, int B, int H, int ndir, float* gates, con
   return 0;
 }
 
+#ifndef ASR_BWD_UNITS
+#define ASR_BWD_UNITS 8
+#endif
+#ifndef ASR_BWD_MT
+#define ASR_BWD_MT 1
+#endif
+#ifndef ASR_BWD_NW
+#define ASR_BWD_NW 4
+#endif
+
 extern "C" int asr_lstm_seq_bwd(int T, int B, int H, int ndir, float* gates, const float* w_hhT, const int32_t* lens,
                                 const float* dy, const float* c, float* dcarry, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hhT || !lens || !dy || !c || !dcarry || T <= 0 || B <= 0 || H <= 0) return ASR_E_ARG;
   if (H % 16 || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
   if (!asr_aligned16(gates) || !asr_aligned16(w_hhT)) return ASR_E_ALIGN;
+  constexpr int U = ASR_BWD_UNITS, MTB = ASR_BWD_MT, NWB = ASR_BWD_NW;
   for (int s = 0; s < T; ++s) {
-    if (B <= 16)
-      hipLaunchKernelGGL((enc_step_bwd_kernel<1>), dim3(H / 16, ndir, 1), dim3(256), 0, stream, T, B, H, ndir, gates,
-                         w_hhT, lens, dy, c, dcarry, s);
-    else
-      hipLaunchKernelGGL((enc_step_bwd_kernel<2>), dim3(H / 16, ndir, (B + 31) / 32), dim3(256), 0, stream, T, B, H,
-                         ndir, gates, w_hhT, lens, dy, c, dcarry, s);
+    hipLaunchKernelGGL((enc_step_bwd_kernel<MTB, U, NWB>), dim3(H / U, ndir, (B + MTB * 16 - 1) / (MTB * 16)), dim3(NWB * 64), 0,
+                       stream, T, B, H, ndir, gates, w_hhT, lens, dy, c, dcarry, s);
   }
   ASR_CHECK_LAUNCH();
   return 0;

@@ -29,7 +29,7 @@ class DecFwd(ctypes.Structure):
     """asr_dec_fwd_t"""
     _fields_ = [(n, c_i) for n in ("B", "Tp", "A", "D", "O", "E", "C", "K", "L")] + [("scaling", c_f)] + \
                [(n, c_p) for n in ("P", "Q", "bo", "wcat", "bcat", "wdec", "convw", "watt", "gvec", "w0", "xmask",
-                                   "X", "gates", "cstate", "Dproj", "fconv", "S", "energy", "ws")]
+                                   "X", "Xd", "gates", "cstate", "Dproj", "fconv", "S", "energy", "ws")]
 
 
 class DecBwd(ctypes.Structure):

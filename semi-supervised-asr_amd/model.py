@@ -105,7 +105,8 @@ class pBLSTM(torch.nn.Module):
             elif mask is not None:
                 y = y * mask
             x = ops.linear(y, proj.weight, proj.bias, relu=True)
-            x = self.dropout_layer(x)
+            if drop:
+                x = x * _drop_mask(x.shape, self.dropout_rate, dev)
         return x.transpose(0, 1).contiguous(), [int(l) for l in lens]
 
 

@@ -184,6 +184,7 @@ class _DecoderSeq(torch.autograd.Function):
         watt_c = watt.contiguous()
         bo_c = bo.contiguous()
         X = torch.zeros(L + 1, B, KX, **f32)
+        Xd = torch.zeros(L + 1, B, KX, **f32) if xmask is not None else None     # dropout-masked operand copy
         buf = dict(
             gates=torch.empty(L, B, 4 * D, **f32), cstate=torch.empty(L, B, D, **f32),
             Dproj=torch.empty(L, B, A, **f32), fconv=torch.empty(L, B, C, Tp, **f32),
@@ -191,7 +192,7 @@ class _DecoderSeq(torch.autograd.Function):
             ws=torch.empty(L, B, Tp, **f32))
         fs = hb.DecFwd(B=B, Tp=Tp, A=A, D=D, O=O, E=E, C=C, K=K, L=L, scaling=float(opts.get("scaling", 2.0)),
                        P=_p(P), Q=_p(Q), bo=_p(bo_c), wcat=_p(wcat), bcat=_p(bcat), wdec=_p(wdec_c),
-                       convw=_p(convw2), watt=_p(watt_c), gvec=_p(gv), w0=_p(w0), xmask=_p(xmask), X=_p(X),
+                       convw=_p(convw2), watt=_p(watt_c), gvec=_p(gv), w0=_p(w0), xmask=_p(xmask), X=_p(X), Xd=_p(Xd),
                        gates=_p(buf["gates"]), cstate=_p(buf["cstate"]), Dproj=_p(buf["Dproj"]),
                        fconv=_p(buf["fconv"]), S=_p(buf["S"]), energy=_p(buf["energy"]), ws=_p(buf["ws"]))
         lib = hb.load()
@@ -206,6 +207,8 @@ class _DecoderSeq(torch.autograd.Function):
         if all_teacher:
             fed.copy_(tokens.t())
             X[:L, :, D + O:] = emb_w[fed]
+            if Xd is not None:
+                Xd[:L, :, D + O:] = X[:L, :, D + O:] * xmask[:, :, O:]
             hb.check(lib.asr_dec_seq_fwd(ctypes.byref(fs), 0, L, hb.stream()), "asr_dec_seq_fwd")
             logits = hb.gemm(X[1:].view(L * B, KX)[:, :D + O], w_out_c, trans_b=True, bias=b_out).view(L, B, V)
             pred = logits.argmax(-1)
@@ -230,13 +233,15 @@ class _DecoderSeq(torch.autograd.Function):
                     probs_saved.append(pr)
                     fed[s] = -1
                     hb.gemm(pr, emb_w, out=X[s][:, D + O:])
+                if Xd is not None:
+                    Xd[s, :, D + O:] = X[s, :, D + O:] * xmask[s, :, O:]
                 hb.check(lib.asr_dec_step_fwd(ctypes.byref(fs), s, hb.stream()), "asr_dec_step_fwd")
                 hb.gemm_skinny(X[s + 1][:, :D + O], w_out_c, bias=b_out, out=logits[s])
                 pred[s] = torch.distributions.Categorical(logits=logits[s]).sample() if sample \
                     else logits[s].argmax(-1)
         ctx.fs = fs
-        ctx.keep = (P, Q, wcat, bcat, wdec_c, convw2, watt_c, gv, bo_c, w0, xmask, X, buf, fed, probs_saved, w_out_c,
-                    emb_w)
+        ctx.keep = (P, Q, wcat, bcat, wdec_c, convw2, watt_c, gv, bo_c, w0, xmask, X, Xd, buf, fed, probs_saved,
+                    w_out_c, emb_w)
         ctx.dims = (B, Tp, A, O, D, E, V, C, K, L, KX)
         ctx.smooth = smooth and tokens is None
         ctx.smooth_scaling = float(opts.get("smooth_scaling", 1.0))
@@ -245,7 +250,8 @@ class _DecoderSeq(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits, dws, _dpred):
-        (P, Q, wcat, bcat, wdec, convw2, watt, gv, bo, w0, xmask, X, buf, fed, probs_saved, w_out, emb_w) = ctx.keep
+        (P, Q, wcat, bcat, wdec, convw2, watt, gv, bo, w0, xmask, X, Xd, buf, fed, probs_saved, w_out,
+         emb_w) = ctx.keep
         B, Tp, A, O, D, E, V, C, K, L, KX = ctx.dims
         dev = P.device
         f32 = dict(device=dev, dtype=torch.float32)
@@ -289,10 +295,7 @@ class _DecoderSeq(torch.autograd.Function):
                     hb.colsum(dl, out=db_out, accumulate=True)
         # deferred weight gradients: one GEMM each over the whole sequence
         dg2 = wk["dgates"].view(L * B, 4 * D)
-        Xin = X[:L]
-        if xmask is not None:
-            Xin = Xin.clone()
-            Xin[:, :, D:] *= xmask
+        Xin = X[:L] if Xd is None else Xd[:L]
         dwcat = hb.gemm(dg2, Xin.view(L * B, KX), trans_a=True)                  # [4D, KX] gate-interleaved rows
         unperm = gate_unperm(D, dev)
         dwcat = dwcat[unperm]

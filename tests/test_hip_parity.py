@@ -348,3 +348,59 @@ def test_oracle_parity_random_shapes():
     (-lp.mean()).backward()
     for n, gr in _grads(net).items():
         _close(gr, rg[n], atol=1e-6, what="grad " + n)
+
+
+def test_dropout_mask_injection(monkeypatch):
+    """Dropout cannot match bitwise across RNGs: inject the SAME masks into the HIP path and the
+    oracle and require forward + gradient parity (covers the fused-mask paths: pyramid kernel, the decoder's
+    masked operand copy, masked dX epilogue)."""
+    dev = _gpu()
+    import model as M
+    import torch.nn.functional as F
+    cfg = dict(input_dim=12, enc_hidden_dim=16, enc_n_layers=2, subsample=[2, 1], dropout_rate=0.4,
+               dec_hidden_dim=32, att_dim=16, conv_channels=3, conv_kernel_size=4, att_odim=16, embedding_dim=16,
+               output_dim=10, ls_weight=0.05)
+    ld = synth.labeldist(10, 3)
+    w = synth.e2e_weights(cfg, 55)
+    ilens = [13, 11, 8, 5]
+    xs, ilens, ys = synth.batch(12, 10, ilens, [3, 2, 2, 2], 56)
+    gen = torch.Generator().manual_seed(9)
+    recorded = []
+
+    def fake_mask(shape, p, device):
+        m = (torch.rand(*shape, generator=gen) >= p).float() / (1.0 - p)
+        recorded.append(m)
+        return m.to(device)
+
+    monkeypatch.setattr(M, "_drop_mask", fake_mask)
+    net = _product(cfg, w, ld, dev)
+    np.random.seed(2)
+    logits, lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
+    net.zero_grad()
+    (-lp.mean()).backward()
+    # replay into the oracle: encoder masks are time-major here / batch-major there; the decoder mask is one
+    # [L,B,O+E] block laid out (ctx|emb) here and a per-step [B,E+O] (emb|ctx) mask there
+    O_, E_ = cfg["att_odim"], cfg["embedding_dim"]
+    queue = [m.transpose(0, 1) for m in recorded[:-1]]
+    xm = recorded[-1]
+    queue += [torch.cat([xm[s][:, O_:], xm[s][:, :O_]], 1) for s in range(xm.shape[0])]
+    assert len(recorded) == 2 * cfg["enc_n_layers"] + 1
+
+    def replay(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0:
+            return x
+        m = queue.pop(0)
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return x * m
+
+    monkeypatch.setattr(O.F, "dropout", replay)
+    sd = O.make_leaf_state(w)
+    np.random.seed(2)
+    rl, rlp, _, _ = O.e2e_forward(sd, dict(cfg, labeldist=ld), torch.from_numpy(xs), ilens,
+                                  [torch.from_numpy(y) for y in ys])
+    assert not queue
+    _close(logits, rl, what="dropout logits"); _close(lp, rlp, what="dropout lp")
+    names = O.unique_param_names(sd)
+    rg = dict(zip(names, torch.autograd.grad(-rlp.mean(), [sd[n] for n in names])))
+    for n, gr in _grads(net).items():
+        _close(gr, rg[n], atol=1e-6, what="dropout grad " + n)
