@@ -130,6 +130,7 @@ def kernel_roofline(dev):
     c = torch.randn(T, B, 2 * H, generator=g).to(dev)
     dcarry = torch.zeros(B, 2 * H, device=dev)
     stream = torch.cuda.current_stream()
+    lib = hb.load()
     keep = gates.clone()
     for _ in range(2):
         gates.copy_(keep)
@@ -137,7 +138,8 @@ def kernel_roofline(dev):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        hb.lstm_seq_bwd(gates, w, lens, dy, c, dcarry)
+        hb.check(lib.asr_lstm_seq_bwd(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c),
+                                      hb.ptr(dcarry), hb.stream()), "asr_lstm_seq_bwd")   # one stream, all rows
         e1.record(stream)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)

@@ -42,6 +42,18 @@ typedef void* asr_stream_t; /* hipStream_t */
 int asr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------
+ * Graph memo for the per-time-step launch chains (asr_lstm_seq_*, asr_dec_seq_*).  The `graphs`
+ * argument of those calls may be NULL (eager launches) or a handle from asr_graphs_create(): the
+ * chain is then stream-captured the second time the same argument tuple is seen and replayed
+ * with one hipGraphLaunch afterwards (kernel arguments are baked, so a different buffer address
+ * is a different key and simply runs eagerly).  One handle per launching host thread; the handle
+ * is the only state and is owned by the caller.
+ * ------------------------------------------------------------------------------------- */
+void* asr_graphs_create(int max_entries);
+void asr_graphs_destroy(void* graphs);
+int asr_graphs_stats(void* graphs, int64_t* hits, int64_t* captures, int64_t* eager);
+
+/* ---------------------------------------------------------------------------------------
  * Dense fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32; exact-f32 fmaf chain).
  *   C[M,N] (ldc) = op(A)[M,K] * op(B)[K,N]  (+ bias[N]) (relu) (+ C if accumulate)
  * Row-major.  transA=0: A is [M][K] (lda>=K); transA=1: A is [K][M] (lda>=M).
@@ -87,14 +99,17 @@ int asr_colsum_f32(int64_t M, int64_t N, const float* X, int64_t ldx, float* out
  *   lens  [B] int32 (device)
  *   y     [T][B][ndir*H]    hidden states; direction d occupies columns [d*H,(d+1)*H)
  *   c     [T][B][ndir*H]    cell states (saved for backward)
+ * B is the batch STRIDE of the buffers, nb <= B the number of rows this call processes: utterances are
+ * independent, so a caller may run disjoint row groups (pointers pre-offset to the group's first row)
+ * concurrently on different streams to overlap the latency-bound chains.
  * Direction 0 runs t = 0..T-1, direction 1 (if ndir==2) runs t = T-1..0.
  * One kernel launch per time step covers both directions: workgroup = (4 hidden units x
  * 4 gates = 16 gate rows) x (<=32 batch rows); h_{t-1} W_hh^T on the 16x16x4 f32 MFMA
  * with K split over the 4 waves, partials reduced through LDS, then sigmoid/tanh/state
  * update.  H % 16 == 0.
  * ------------------------------------------------------------------------------------- */
-int asr_lstm_seq_fwd(int T, int B, int H, int ndir, float* gates, const float* w_hh,
-                     const int32_t* lens, float* y, float* c, asr_stream_t stream);
+int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
+                     const int32_t* lens, float* y, float* c, void* graphs, asr_stream_t stream);
 
 /* Backward through the same recurrence.
  *   gates [T][B][ndir][4H]  in : activated gates from the forward; out: dL/d(pre-activation)
@@ -104,8 +119,8 @@ int asr_lstm_seq_fwd(int T, int B, int H, int ndir, float* gates, const float* w
  *   c     forward cell states;  dcarry [B][ndir*H] zero-initialised scratch (dL/dc carry)
  * dW_hh is NOT produced here: the caller forms sum_t dG_t^T h_{t-1} with one asr_gemm_f32
  * (transA=1) over the whole sequence after this call. */
-int asr_lstm_seq_bwd(int T, int B, int H, int ndir, float* gates, const float* w_hhT,
-                     const int32_t* lens, const float* dy, const float* c, float* dcarry,
+int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
+                     const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
                      asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -139,7 +154,8 @@ int asr_pyramid_concat_bwd(int T, int B, int C, const float* dout, const float* 
  * Saved for backward: gates[s], cstate[s], S[s] (tanh values), fconv[s], ws[s], energies.
  * ------------------------------------------------------------------------------------- */
 typedef struct {
-  int B, Tp, A, D, O, E, C, K; /* K = conv half width, taps = 2K+1 */
+  int B, nb, Tp, A, D, O, E, C, K; /* B = batch stride of every buffer, nb <= B rows processed by this call
+                                       (pointers pre-offset to the group's first row); K = conv half width */
   int L;                        /* number of steps buffers are sized for */
   float scaling;
   /* per-sequence inputs */
@@ -168,7 +184,7 @@ typedef struct {
 } asr_dec_fwd_t;
 
 int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream);
-int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, asr_stream_t stream);
+int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, void* graphs, asr_stream_t stream);
 
 /* Backward of one decoder step (reverse order s = L-1..0).
  *   G     [L+1][B][KX]  gradient wrt X; on entry G[s+1][:, 0:D+O] holds every other
@@ -205,7 +221,7 @@ typedef struct {
 } asr_dec_bwd_t;
 
 int asr_dec_step_bwd(const asr_dec_bwd_t* p, int s, asr_stream_t stream);
-int asr_dec_seq_bwd(const asr_dec_bwd_t* p, int s_begin, int s_end, asr_stream_t stream);
+int asr_dec_seq_bwd(const asr_dec_bwd_t* p, int s_begin, int s_end, void* graphs, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Optimiser on a flat fp32 buffer (solver.py:152-153,384-385: clip_grad_norm_ + Adam(amsgrad,

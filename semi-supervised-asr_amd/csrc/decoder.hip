@@ -10,6 +10,7 @@
 // sums are written as partial slabs and added by the consumer kernel of the next launch (no atomics,
 // results are bitwise reproducible run to run).
 #include "common.h"
+#include "graphs.h"
 
 int asr_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bt, int64_t ldb,
                       float* C, int64_t ldc, const float* bias, int accumulate, const float* mask, int64_t ldmask,
@@ -30,8 +31,59 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
 }
 
+// NOTE on load scheduling (applies to every kernel below): global loads are issued in batches, are never
+// guarded by a branch (indices are clamped instead, invalid lanes get weight 0 / a predicated store) and are
+// hoisted above the LDS staging so that each kernel pays ~one memory round trip.  A guarded load consumed
+// right away costs a full HBM/Infinity-Cache latency per loop iteration (35 us kernels in the first version).
+
 // ------------------------------------------------------------------ forward: energies
 // grid (ceil(Tp/16), B), 256 threads.  dynamic LDS: wp[Tp+2K] | Fs[C][2K+1] | fs[16][C] | Ut[C][A]
+// Each wave owns 4 frames; a lane owns 4 consecutive attention-dim columns of each 256-wide chunk.
+struct ScoreRegs {
+  float4 p[4];   // P[b, frame i, a..a+3]
+  float4 d, g;   // Dproj[b, a..a+3], gvec[a..a+3]
+};
+
+__device__ __forceinline__ void score_load(ScoreRegs& r, const float* __restrict__ P, const float* __restrict__ Dp,
+                                           const float* __restrict__ gvec, int b, int Tp, int A, int tw, int a) {
+  const int ac = a < A ? a : 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = tw + i < Tp ? tw + i : Tp - 1;
+    r.p[i] = *reinterpret_cast<const float4*>(P + ((int64_t)b * Tp + t) * A + ac);
+  }
+  r.d = *reinterpret_cast<const float4*>(Dp + (int64_t)b * A + ac);
+  r.g = *reinterpret_cast<const float4*>(gvec + ac);
+}
+
+__device__ __forceinline__ void score_compute(const ScoreRegs& r, const float* __restrict__ Ut,
+                                              const float* __restrict__ fs4 /* this wave's 4 frames x C */,
+                                              float* __restrict__ S, int b, int Tp, int A, int C, int tw, int a,
+                                              float (&part)[4]) {
+  if (a >= A) return;    // wave-uniform except in the last chunk; no loads below depend on it
+  float4 ucol[CMAX];
+#pragma unroll
+  for (int ch = 0; ch < CMAX; ++ch)
+    ucol[ch] = ch < C ? *reinterpret_cast<const float4*>(Ut + ch * A + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 u = r.p[i];
+    u.x += r.d.x; u.y += r.d.y; u.z += r.d.z; u.w += r.d.w;
+    const float* f = fs4 + i * C;
+#pragma unroll
+    for (int ch = 0; ch < CMAX; ++ch) {
+      if (ch < C) {
+        const float fv = f[ch];
+        u.x += ucol[ch].x * fv; u.y += ucol[ch].y * fv; u.z += ucol[ch].z * fv; u.w += ucol[ch].w * fv;
+      }
+    }
+    float4 sv;
+    sv.x = fast_tanh(u.x); sv.y = fast_tanh(u.y); sv.z = fast_tanh(u.z); sv.w = fast_tanh(u.w);
+    if (tw + i < Tp) *reinterpret_cast<float4*>(S + ((int64_t)b * Tp + tw + i) * A + a) = sv;
+    part[i] += r.g.x * sv.x + r.g.y * sv.y + r.g.z * sv.z + r.g.w * sv.w;
+  }
+}
+
 __global__ __launch_bounds__(256) void att_score_fwd_kernel(int B, int Tp, int A, int C, int K,
                                                             const float* __restrict__ P,
                                                             const float* __restrict__ Dp,
@@ -42,20 +94,27 @@ __global__ __launch_bounds__(256) void att_score_fwd_kernel(int B, int Tp, int A
                                                             float* __restrict__ fconv, float* __restrict__ energy) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int taps = 2 * K + 1;
-  float* wp = sm;
+  float* Ut = sm;                                   // [C][A]  (16-byte aligned: first)
+  float* wp = Ut + C * A;
   float* Fs = wp + (Tp + 2 * K);
   float* fs = Fs + C * taps;
-  float* Ut = fs + FRAMES_PER_WG * C;
   const int b = blockIdx.y, t0 = blockIdx.x * FRAMES_PER_WG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tw = t0 + wave * 4;
+  // prefetch the first two 256-column chunks of this wave's frames (all of A when A <= 512)
+  ScoreRegs r0, r1;
+  score_load(r0, P, Dp, gvec, b, Tp, A, tw, lane * 4);
+  score_load(r1, P, Dp, gvec, b, Tp, A, tw, 256 + lane * 4);
   for (int i = tid; i < Tp + 2 * K; i += 256) {
     const int fr = i - K;
-    wp[i] = (fr >= 0 && fr < Tp) ? wprev[(int64_t)b * Tp + fr] : 0.f;
+    const int frc = fr < 0 ? 0 : (fr >= Tp ? Tp - 1 : fr);
+    const float v = wprev[(int64_t)b * Tp + frc];
+    wp[i] = (fr >= 0 && fr < Tp) ? v : 0.f;
   }
   for (int i = tid; i < C * taps; i += 256) Fs[i] = convw[i];
-  for (int i = tid; i < A * C; i += 256) {   // watt is [A][C]; LDS image is [C][A]
-    const int a = i / C, ch = i - a * C;
-    Ut[ch * A + a] = watt[i];
+  for (int i = tid; i < A * C; i += 256) {   // LDS image [C][A] written in order; watt is [A][C]
+    const int ch = i / A, a = i - ch * A;
+    Ut[i] = watt[a * C + ch];
   }
   __syncthreads();
   // location conv: 4 lanes per output (frame, channel), taps interleaved over the 4 lanes
@@ -79,30 +138,15 @@ __global__ __launch_bounds__(256) void att_score_fwd_kernel(int B, int Tp, int A
     }
   }
   __syncthreads();
-  // energies: wave owns 4 frames, lane strides the attention dim
   float part[4] = {0.f, 0.f, 0.f, 0.f};
-  const int tw = t0 + wave * 4;
-  for (int a = lane; a < A; a += 64) {
-    float ucol[CMAX];
-#pragma unroll
-    for (int ch = 0; ch < CMAX; ++ch) ucol[ch] = ch < C ? Ut[ch * A + a] : 0.f;
-    const float dv = Dp[(int64_t)b * A + a];
-    const float gv = gvec[a];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = tw + i;
-      if (t < Tp) {
-        const int64_t off = ((int64_t)b * Tp + t) * A + a;
-        float u = P[off] + dv;
-        const float* f = fs + (wave * 4 + i) * C;
-#pragma unroll
-        for (int ch = 0; ch < CMAX; ++ch)
-          if (ch < C) u += ucol[ch] * f[ch];
-        const float sv = fast_tanh(u);
-        S[off] = sv;
-        part[i] += gv * sv;
-      }
-    }
+  const float* fs4 = fs + wave * 4 * C;
+  score_compute(r0, Ut, fs4, S, b, Tp, A, C, tw, lane * 4, part);
+  score_compute(r1, Ut, fs4, S, b, Tp, A, C, tw, 256 + lane * 4, part);
+  for (int a0 = 512; a0 < A; a0 += 512) {           // attention dims beyond 512: same code, not prefetched
+    score_load(r0, P, Dp, gvec, b, Tp, A, tw, a0 + lane * 4);
+    score_load(r1, P, Dp, gvec, b, Tp, A, tw, a0 + 256 + lane * 4);
+    score_compute(r0, Ut, fs4, S, b, Tp, A, C, tw, a0 + lane * 4, part);
+    score_compute(r1, Ut, fs4, S, b, Tp, A, C, tw, a0 + 256 + lane * 4, part);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -113,6 +157,25 @@ __global__ __launch_bounds__(256) void att_score_fwd_kernel(int B, int Tp, int A
 
 // ------------------------------------------------------------------ forward: softmax + context
 // grid (ceil(O/256), B), 256 threads; dynamic LDS: ws[Tp] | red[4][256]
+constexpr int CTX_BATCH = 8;
+__device__ __forceinline__ void ctx_load(float4 (&q)[CTX_BATCH], const float* __restrict__ qb, int O, int Tp, int wave,
+                                         int i0) {
+#pragma unroll
+  for (int u = 0; u < CTX_BATCH; ++u) {
+    const int t = wave + 4 * (i0 + u);
+    q[u] = *reinterpret_cast<const float4*>(qb + (int64_t)(t < Tp ? t : Tp - 1) * O);
+  }
+}
+__device__ __forceinline__ void ctx_fma(const float4 (&q)[CTX_BATCH], const float* __restrict__ wsm, int Tp, int wave,
+                                        int i0, float4& acc) {
+#pragma unroll
+  for (int u = 0; u < CTX_BATCH; ++u) {
+    const int t = wave + 4 * (i0 + u);
+    const float w = t < Tp ? wsm[t] : 0.f;
+    acc.x += w * q[u].x; acc.y += w * q[u].y; acc.z += w * q[u].z; acc.w += w * q[u].w;
+  }
+}
+
 __global__ __launch_bounds__(256) void att_softmax_ctx_fwd_kernel(int B, int Tp, int O, float scaling,
                                                                   const float* __restrict__ energy,
                                                                   const float* __restrict__ Q,
@@ -124,31 +187,56 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_fwd_kernel(int B, int Tp,
   float* wsm = sm;
   float* red = sm + ((Tp + 3) & ~3);
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int o = blockIdx.x * 256 + lane * 4;
+  const int oc = o < O ? o : 0;
+  const float* qb = Q + (int64_t)b * Tp * O + oc;
+  const int nmine = (Tp - wave + 3) >> 2;                  // frames wave, wave+4, ...
+  float4 qa[CTX_BATCH], qc[CTX_BATCH];
+  ctx_load(qa, qb, O, Tp, wave, 0);                        // in flight during the softmax
   // every wave computes the softmax statistics redundantly (Tp is ~100): no block-level reduction
+  float ev[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = lane + 64 * k;
+    ev[k] = scaling * energy[(int64_t)b * Tp + (t < Tp ? t : Tp - 1)];
+  }
   float mx = -INFINITY;
-  for (int t = lane; t < Tp; t += 64) mx = fmaxf(mx, scaling * energy[(int64_t)b * Tp + t]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane + 64 * k < Tp) mx = fmaxf(mx, ev[k]);
+  for (int t = lane + 256; t < Tp; t += 64) mx = fmaxf(mx, scaling * energy[(int64_t)b * Tp + t]);
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int t = lane; t < Tp; t += 64) sum += expf(scaling * energy[(int64_t)b * Tp + t] - mx);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane + 64 * k < Tp) sum += expf(ev[k] - mx);
+  for (int t = lane + 256; t < Tp; t += 64) sum += expf(scaling * energy[(int64_t)b * Tp + t] - mx);
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
   if (wave == 0) {
-    for (int t = lane; t < Tp; t += 64) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = lane + 64 * k;
+      if (t < Tp) {
+        const float w = expf(ev[k] - mx) * inv;
+        wsm[t] = w;
+        if (blockIdx.x == 0) wout[(int64_t)b * Tp + t] = w;
+      }
+    }
+    for (int t = lane + 256; t < Tp; t += 64) {
       const float w = expf(scaling * energy[(int64_t)b * Tp + t] - mx) * inv;
       wsm[t] = w;
       if (blockIdx.x == 0) wout[(int64_t)b * Tp + t] = w;
     }
   }
   __syncthreads();
-  const int o = blockIdx.x * 256 + lane * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (o < O) {
-    const float* q = Q + (int64_t)b * Tp * O + o;
-    for (int t = wave; t < Tp; t += 4) {
-      const float w = wsm[t];
-      const float4 v = *reinterpret_cast<const float4*>(q + (int64_t)t * O);
-      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
-    }
+  for (int i0 = 0; i0 < nmine; i0 += 2 * CTX_BATCH) {
+    const bool second = i0 + CTX_BATCH < nmine;
+    if (second) ctx_load(qc, qb, O, Tp, wave, i0 + CTX_BATCH);
+    ctx_fma(qa, wsm, Tp, wave, i0, acc);
+    if (i0 + 2 * CTX_BATCH < nmine) ctx_load(qa, qb, O, Tp, wave, i0 + 2 * CTX_BATCH);
+    if (second) ctx_fma(qc, wsm, Tp, wave, i0 + CTX_BATCH, acc);
   }
   *reinterpret_cast<float4*>(red + wave * 256 + lane * 4) = acc;
   __syncthreads();
@@ -179,33 +267,68 @@ __global__ __launch_bounds__(256) void att_dw_kernel(int B, int Tp, int O, int C
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tw = blockIdx.x * FRAMES_PER_WG + wave * 4;
   float part[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int o = lane * 4; o < O; o += 256) {
-    const float4 g = *reinterpret_cast<const float4*>(dctx + (int64_t)b * lddctx + o);
+  // side terms: lane ch < C fetches channel ch's conv-path partial for each of the 4 frames
+  float ext[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (tw + i < Tp) {
-        const float4 q = *reinterpret_cast<const float4*>(Q + ((int64_t)b * Tp + tw + i) * O + o);
-        part[i] += q.x * g.x + q.y * g.y + q.z * g.z + q.w * g.w;
+  for (int i = 0; i < 4; ++i) {
+    const int t = tw + i < Tp ? tw + i : Tp - 1;
+    float v = 0.f;
+    if (dwext) {
+      const float x = dwext[((int64_t)(lane < C ? lane : 0) * B + b) * Tp + t];
+      v = lane < C ? x : 0.f;
+    }
+    if (dws) {
+      const float x = dws[(int64_t)b * Tp + t];
+      v += lane == 0 ? x : 0.f;
+    }
+    ext[i] = v;
+  }
+  for (int o0 = 0; o0 < O; o0 += 512) {
+    float4 g[2], q[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int o = o0 + 256 * k + lane * 4;
+      const int oc = o < O ? o : 0;
+      g[k] = *reinterpret_cast<const float4*>(dctx + (int64_t)b * lddctx + oc);
+      if (o >= O) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = tw + i < Tp ? tw + i : Tp - 1;
+        q[k][i] = *reinterpret_cast<const float4*>(Q + ((int64_t)b * Tp + t) * O + oc);
       }
     }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        part[i] += q[k][i].x * g[k].x + q[k][i].y * g[k].y + q[k][i].z * g[k].z + q[k][i].w * g[k].w;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float v = wave_sum(part[i]);
-    const int t = tw + i;
-    if (lane == 0 && t < Tp) {
-      if (dwext)
-        for (int ch = 0; ch < C; ++ch) v += dwext[((int64_t)ch * B + b) * Tp + t];
-      if (dws) v += dws[(int64_t)b * Tp + t];
-      dwraw[(int64_t)b * Tp + t] = v;
-    }
+    const float v = wave_sum(part[i] + ext[i]);
+    if (lane == 0 && tw + i < Tp) dwraw[(int64_t)b * Tp + tw + i] = v;
   }
 }
 
 // ------------------------------------------------------------------ backward: scores
 // grid (ceil(A/64), B), 256 threads.  Each workgroup owns 64 attention-dim columns of one utterance for
 // ALL frames, so dD, dgvec, dW_att partials are local; d(conv output) partials go to a slab per tile.
-// dynamic LDS: de[Tp] | wv[Tp] | fsm[C][Tp] | Us[64][C] | du[Tp][65] | red[4][64][2+CMAX]
+// dynamic LDS: de[Tp] | fsm[C][Tp] | Us[64][C] | du[Tp][65] | red[4][64][2+CMAX]
+constexpr int SB_BATCH = 8;
+struct ScoreBwdRegs {
+  float s[SB_BATCH], dp[SB_BATCH];
+};
+__device__ __forceinline__ void sbwd_load(ScoreBwdRegs& r, const float* __restrict__ S, const float* __restrict__ dP,
+                                          int64_t base /* (b*Tp)*A + a */, int A, int Tp, int wave, int i0) {
+#pragma unroll
+  for (int u = 0; u < SB_BATCH; ++u) {
+    const int t = wave + 4 * (i0 + u);
+    const int64_t off = base + (int64_t)(t < Tp ? t : Tp - 1) * A;
+    r.s[u] = S[off];
+    r.dp[u] = dP[off];
+  }
+}
+
 __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A, int C, float scaling,
                                                             const float* __restrict__ wcur,
                                                             const float* __restrict__ dwraw,
@@ -225,13 +348,34 @@ __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A
   float* red = du + Tp * 65;
   const int b = blockIdx.y, tile = blockIdx.x, a0 = tile * ATILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a = a0 + lane;
+  const bool live = a < A;
+  const int64_t base = (int64_t)b * Tp * A + (live ? a : 0);
+  const int nmine = (Tp - wave + 3) >> 2;
+  ScoreBwdRegs ra, rb;
+  sbwd_load(ra, S, dP, base, A, Tp, wave, 0);            // in flight during the staging below
+  const float gv = gvec[live ? a : 0];
   // softmax backward (each wave redundantly reduces the dot product)
+  float wv[4], dv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = lane + 64 * k;
+    const int tc = t < Tp ? t : Tp - 1;
+    wv[k] = wcur[(int64_t)b * Tp + tc];
+    dv[k] = dwraw[(int64_t)b * Tp + tc];
+  }
   float dot = 0.f;
-  for (int t = lane; t < Tp; t += 64) dot += wcur[(int64_t)b * Tp + t] * dwraw[(int64_t)b * Tp + t];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane + 64 * k < Tp) dot += wv[k] * dv[k];
+  for (int t = lane + 256; t < Tp; t += 64) dot += wcur[(int64_t)b * Tp + t] * dwraw[(int64_t)b * Tp + t];
   dot = wave_sum(dot);
-  for (int t = tid; t < Tp; t += 256) {
-    const float w = wcur[(int64_t)b * Tp + t];
-    de[t] = scaling * w * (dwraw[(int64_t)b * Tp + t] - dot);
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane + 64 * k < Tp) de[lane + 64 * k] = scaling * wv[k] * (dv[k] - dot);
+    for (int t = lane + 256; t < Tp; t += 64)
+      de[t] = scaling * wcur[(int64_t)b * Tp + t] * (dwraw[(int64_t)b * Tp + t] - dot);
   }
   for (int i = tid; i < C * Tp; i += 256) {
     const int ch = i / Tp, t = i - ch * Tp;
@@ -239,30 +383,37 @@ __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A
   }
   for (int i = tid; i < ATILE * C; i += 256) {
     const int al = i / C;
-    Us[i] = a0 + al < A ? watt[(int64_t)(a0 + al) * C + (i - al * C)] : 0.f;
+    const float v = watt[(int64_t)(a0 + al < A ? a0 + al : 0) * C + (i - al * C)];
+    Us[i] = a0 + al < A ? v : 0.f;
   }
   __syncthreads();
-  const int a = a0 + lane;
-  const bool live = a < A;
-  const float gv = live ? gvec[a] : 0.f;
   float dD_acc = 0.f, dg_acc = 0.f, dU_acc[CMAX];
 #pragma unroll
   for (int ch = 0; ch < CMAX; ++ch) dU_acc[ch] = 0.f;
-  for (int t = wave; t < Tp; t += 4) {
-    float duv = 0.f;
-    if (live) {
-      const int64_t off = ((int64_t)b * Tp + t) * A + a;
-      const float sv = S[off];
-      const float det = de[t];
-      duv = det * gv * (1.f - sv * sv);
-      dP[off] += duv;
-      dD_acc += duv;
-      dg_acc += det * sv;
+  auto consume = [&](const ScoreBwdRegs& r, int i0) {
 #pragma unroll
-      for (int ch = 0; ch < CMAX; ++ch)
-        if (ch < C) dU_acc[ch] += duv * fsm[ch * TpP + t];
+    for (int u = 0; u < SB_BATCH; ++u) {
+      const int t = wave + 4 * (i0 + u);
+      if (t < Tp) {                                        // wave-uniform
+        const float sv = r.s[u];
+        const float det = de[t];
+        const float duv = live ? det * gv * (1.f - sv * sv) : 0.f;
+        if (live) dP[base + (int64_t)t * A] = r.dp[u] + duv;
+        dD_acc += duv;
+        dg_acc += live ? det * sv : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CMAX; ++ch)
+          if (ch < C) dU_acc[ch] += duv * fsm[ch * TpP + t];
+        du[t * 65 + lane] = duv;
+      }
     }
-    du[t * 65 + lane] = duv;
+  };
+  for (int i0 = 0; i0 < nmine; i0 += 2 * SB_BATCH) {
+    const bool second = i0 + SB_BATCH < nmine;
+    if (second) sbwd_load(rb, S, dP, base, A, Tp, wave, i0 + SB_BATCH);
+    consume(ra, i0);
+    if (i0 + 2 * SB_BATCH < nmine) sbwd_load(ra, S, dP, base, A, Tp, wave, i0 + 2 * SB_BATCH);
+    if (second) consume(rb, i0 + SB_BATCH);
   }
   float* myred = red + (wave * 64 + lane) * (2 + CMAX);
   myred[0] = dD_acc;
@@ -311,14 +462,29 @@ __global__ __launch_bounds__(256) void att_conv_bwd_kernel(int B, int Tp, int C,
   const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   for (int t = tid; t < Tp; t += 256) {
     float v = 0.f;
-    for (int tl = 0; tl < ntile; ++tl) v += dfpart[(((int64_t)tl * B + b) * C + ch) * Tp + t];
+    for (int tl0 = 0; tl0 < ntile; tl0 += 8) {             // 8 tile partials per batch, unconditional loads
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int tl = tl0 + k < ntile ? tl0 + k : ntile - 1;
+        x[k] = dfpart[(((int64_t)tl * B + b) * C + ch) * Tp + t];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += tl0 + k < ntile ? x[k] : 0.f;
+    }
     df[t] = v;
   }
   for (int i = tid; i < Tp + 2 * K; i += 256) {
     const int fr = i - K;
-    wp[i] = (fr >= 0 && fr < Tp) ? wprev[(int64_t)b * Tp + fr] : 0.f;
+    const int frc = fr < 0 ? 0 : (fr >= Tp ? Tp - 1 : fr);
+    const float v = wprev[(int64_t)b * Tp + frc];
+    wp[i] = (fr >= 0 && fr < Tp) ? v : 0.f;
   }
   for (int i = tid; i < taps; i += 256) Fs[i] = convw[ch * taps + i];
+  // accumulate-in-place operand fetched early (one value per tap owned by this thread)
+  float dcv = 0.f;
+  const bool tapmine = tid < taps;
+  if (tapmine) dcv = dconv_part[((int64_t)b * C + ch) * taps + tid];
   __syncthreads();
   // f[t] = sum_j F[j] wprev[t + j - K]  =>  dwprev[t'] = sum_t F[t' - t + K] df[t]
   for (int base = 0; base < Tp * 4; base += 256) {
@@ -335,7 +501,12 @@ __global__ __launch_bounds__(256) void att_conv_bwd_kernel(int B, int Tp, int C,
     if (tq < Tp && part == 0) dwext[((int64_t)ch * B + b) * Tp + tq] = v;
   }
   // dF[j] += sum_t df[t] wprev[t + j - K]
-  for (int j = tid; j < taps; j += 256) {
+  if (tapmine) {
+    float v = 0.f;
+    for (int t = 0; t < Tp; ++t) v += df[t] * wp[t + tid];
+    dconv_part[((int64_t)b * C + ch) * taps + tid] = dcv + v;
+  }
+  for (int j = tid + 256; j < taps; j += 256) {            // taps beyond 256 (K > 127)
     float v = 0.f;
     for (int t = 0; t < Tp; ++t) v += df[t] * wp[t + j];
     dconv_part[((int64_t)b * C + ch) * taps + j] += v;
@@ -346,40 +517,36 @@ int check_fwd(const asr_dec_fwd_t* p) {
   if (!p || !p->P || !p->Q || !p->bo || !p->wcat || !p->bcat || !p->wdec || !p->convw || !p->watt || !p->gvec ||
       !p->w0 || !p->X || !p->gates || !p->cstate || !p->Dproj || !p->fconv || !p->S || !p->energy || !p->ws)
     return ASR_E_ARG;
-  if (p->B <= 0 || p->Tp <= 0 || p->L <= 0) return ASR_E_ARG;
+  if (p->B <= 0 || p->nb <= 0 || p->nb > p->B || p->Tp <= 0 || p->L <= 0) return ASR_E_ARG;
   if (p->D % 16 || p->A % 16 || p->O % 4 || (p->D + p->O + p->E) % 16 || p->C > CMAX || p->C <= 0) return ASR_E_SHAPE;
   return 0;
 }
 
 }  // namespace
 
-extern "C" int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_fwd(p);
-  if (rc) return rc;
-  if (s < 0 || s >= p->L) return ASR_E_ARG;
-  const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, K = p->K;
+static int dec_step_fwd_impl(const asr_dec_fwd_t* p, int s, hipStream_t stream) {
+  const int B = p->B, nb = p->nb, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, K = p->K;
   const int KX = D + O + E;
   const float* Xs = p->X + (int64_t)s * B * KX;
   float* Xn = p->X + (int64_t)(s + 1) * B * KX;
   const bool drop = p->xmask != nullptr;
   if (drop && !p->Xd) return ASR_E_ARG;
   float* Xdn = drop ? p->Xd + (int64_t)(s + 1) * B * KX : nullptr;
-  rc = asr_cell_fwd_launch(B, D, KX, drop ? p->Xd + (int64_t)s * B * KX : Xs, p->wcat, p->bcat,
-                           p->gates + (int64_t)s * B * 4 * D, s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr,
-                           p->cstate + (int64_t)s * B * D, Xn, Xdn, stream);
+  int rc = asr_cell_fwd_launch(nb, D, KX, drop ? p->Xd + (int64_t)s * B * KX : Xs, p->wcat, p->bcat,
+                               p->gates + (int64_t)s * B * 4 * D, s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr,
+                               p->cstate + (int64_t)s * B * D, Xn, Xdn, stream);
   if (rc) return rc;
   float* Dp = p->Dproj + (int64_t)s * B * A;
-  rc = asr_skinny_launch(B, A, D, Xn, KX, p->wdec, D, Dp, A, nullptr, 0, nullptr, 0, 0, stream);
+  rc = asr_skinny_launch(nb, A, D, Xn, KX, p->wdec, D, Dp, A, nullptr, 0, nullptr, 0, 0, stream);
   if (rc) return rc;
   const float* wprev = s > 0 ? p->ws + (int64_t)(s - 1) * B * Tp : p->w0;
   const int taps = 2 * K + 1;
   const size_t lds1 = sizeof(float) * ((size_t)(Tp + 2 * K) + (size_t)C * taps + FRAMES_PER_WG * C + (size_t)C * A);
-  hipLaunchKernelGGL(att_score_fwd_kernel, dim3((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG, B), dim3(256), lds1, stream,
+  hipLaunchKernelGGL(att_score_fwd_kernel, dim3((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG, nb), dim3(256), lds1, stream,
                      B, Tp, A, C, K, p->P, Dp, wprev, p->convw, p->watt, p->gvec, p->S + (int64_t)s * B * Tp * A,
                      p->fconv + (int64_t)s * B * C * Tp, p->energy + (int64_t)s * B * Tp);
   const size_t lds2 = sizeof(float) * ((size_t)((Tp + 3) & ~3) + 4 * 256);
-  hipLaunchKernelGGL(att_softmax_ctx_fwd_kernel, dim3((O + 255) / 256, B), dim3(256), lds2, stream, B, Tp, O,
+  hipLaunchKernelGGL(att_softmax_ctx_fwd_kernel, dim3((O + 255) / 256, nb), dim3(256), lds2, stream, B, Tp, O,
                      p->scaling, p->energy + (int64_t)s * B * Tp, p->Q, p->bo, p->ws + (int64_t)s * B * Tp, Xn + D,
                      (int64_t)KX, (drop && s + 1 < p->L) ? Xdn + D : nullptr,
                      (drop && s + 1 < p->L) ? p->xmask + (int64_t)(s + 1) * B * (O + E) : nullptr, (int64_t)(O + E));
@@ -387,61 +554,92 @@ extern "C" int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stre
   return 0;
 }
 
-extern "C" int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, asr_stream_t stream) {
-  for (int s = s_begin; s < s_end; ++s) {
-    int rc = asr_dec_step_fwd(p, s, stream);
-    if (rc) return rc;
-  }
-  return 0;
+extern "C" int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream_) {
+  int rc = check_fwd(p);
+  if (rc) return rc;
+  if (s < 0 || s >= p->L) return ASR_E_ARG;
+  return dec_step_fwd_impl(p, s, (hipStream_t)stream_);
 }
 
-extern "C" int asr_dec_step_bwd(const asr_dec_bwd_t* q, int s, asr_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!q) return ASR_E_ARG;
-  const asr_dec_fwd_t* p = &q->f;
+extern "C" int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, void* graphs, asr_stream_t stream_) {
   int rc = check_fwd(p);
+  if (rc) return rc;
+  if (s_begin < 0 || s_end > p->L || s_begin > s_end) return ASR_E_ARG;
+  struct { int kind, s0, s1; asr_dec_fwd_t f; } key;
+  memset(&key, 0, sizeof(key));
+  key.kind = 3; key.s0 = s_begin; key.s1 = s_end; key.f = *p;
+  return asr_graph_run((AsrGraphCache*)graphs, &key, sizeof(key), (hipStream_t)stream_, [&](hipStream_t stream) -> int {
+    for (int s = s_begin; s < s_end; ++s) {
+      int r = dec_step_fwd_impl(p, s, stream);
+      if (r) return r;
+    }
+    return 0;
+  });
+}
+
+static int check_bwd(const asr_dec_bwd_t* q) {
+  if (!q) return ASR_E_ARG;
+  int rc = check_fwd(&q->f);
   if (rc) return rc;
   if (!q->wcatT || !q->wdecT || !q->G || !q->dwext || !q->dwraw || !q->dfpart || !q->dP || !q->dgates || !q->dD ||
       !q->dcell || !q->dgvec_part || !q->dwatt_part || !q->dconv_part)
     return ASR_E_ARG;
-  if (s < 0 || s >= p->L) return ASR_E_ARG;
-  const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, K = p->K;
+  return 0;
+}
+
+static int dec_step_bwd_impl(const asr_dec_bwd_t* q, int s, hipStream_t stream) {
+  const asr_dec_fwd_t* p = &q->f;
+  const int B = p->B, nb = p->nb, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, K = p->K;
   const int KX = D + O + E, taps = 2 * K + 1;
   const int ntile = (A + ATILE - 1) / ATILE;
   float* Gn = q->G + (int64_t)(s + 1) * B * KX;
   float* Gs = q->G + (int64_t)s * B * KX;
   const int tgrid = (Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
-  hipLaunchKernelGGL(att_dw_kernel, dim3(tgrid, B), dim3(256), 0, stream, B, Tp, O, C, p->Q, Gn + D, (int64_t)KX,
+  hipLaunchKernelGGL(att_dw_kernel, dim3(tgrid, nb), dim3(256), 0, stream, B, Tp, O, C, p->Q, Gn + D, (int64_t)KX,
                      s + 1 < p->L ? q->dwext : nullptr, q->dws ? q->dws + (int64_t)s * B * Tp : nullptr, q->dwraw);
   const int TpP = (Tp + 3) & ~3;
   const size_t lds2 = sizeof(float) * ((size_t)TpP + (size_t)C * TpP + ATILE * C + (size_t)Tp * 65 +
                                        4 * 64 * (2 + CMAX));
   float* dDs = q->dD + (int64_t)s * B * A;
-  hipLaunchKernelGGL(att_score_bwd_kernel, dim3(ntile, B), dim3(256), lds2, stream, B, Tp, A, C, p->scaling,
+  hipLaunchKernelGGL(att_score_bwd_kernel, dim3(ntile, nb), dim3(256), lds2, stream, B, Tp, A, C, p->scaling,
                      p->ws + (int64_t)s * B * Tp, q->dwraw, p->S + (int64_t)s * B * Tp * A,
                      p->fconv + (int64_t)s * B * C * Tp, p->watt, p->gvec, q->dP, dDs, q->dgvec_part, q->dwatt_part,
                      q->dfpart);
   const float* wprev = s > 0 ? p->ws + (int64_t)(s - 1) * B * Tp : p->w0;
   const size_t lds3 = sizeof(float) * ((size_t)TpP + (size_t)((Tp + 2 * K + 3) & ~3) + taps);
-  hipLaunchKernelGGL(att_conv_bwd_kernel, dim3(C, B), dim3(256), lds3, stream, B, Tp, C, K, ntile, q->dfpart, wprev,
+  hipLaunchKernelGGL(att_conv_bwd_kernel, dim3(C, nb), dim3(256), lds3, stream, B, Tp, C, K, ntile, q->dfpart, wprev,
                      p->convw, q->dwext, q->dconv_part);
   ASR_CHECK_LAUNCH();
   // dz_s += dD W_dec
-  rc = asr_skinny_launch(B, D, A, dDs, A, q->wdecT, A, Gn, KX, nullptr, 1, nullptr, 0, 0, stream);
+  int rc = asr_skinny_launch(nb, D, A, dDs, A, q->wdecT, A, Gn, KX, nullptr, 1, nullptr, 0, 0, stream);
   if (rc) return rc;
   float* dg = q->dgates + (int64_t)s * B * 4 * D;
-  rc = asr_cell_bwd_launch(B, D, KX, Gn, p->gates + (int64_t)s * B * 4 * D, p->cstate + (int64_t)s * B * D,
+  rc = asr_cell_bwd_launch(nb, D, KX, Gn, p->gates + (int64_t)s * B * 4 * D, p->cstate + (int64_t)s * B * D,
                            s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr, q->dcell, dg, stream);
   if (rc) return rc;
   const float* xm = p->xmask ? p->xmask + (int64_t)s * B * (O + E) : nullptr;
-  rc = asr_skinny_launch(B, KX, 4 * D, dg, 4 * D, q->wcatT, 4 * D, Gs, KX, nullptr, 1, xm, O + E, D, stream);
-  return rc;
+  return asr_skinny_launch(nb, KX, 4 * D, dg, 4 * D, q->wcatT, 4 * D, Gs, KX, nullptr, 1, xm, O + E, D, stream);
 }
 
-extern "C" int asr_dec_seq_bwd(const asr_dec_bwd_t* q, int s_begin, int s_end, asr_stream_t stream) {
-  for (int s = s_end - 1; s >= s_begin; --s) {
-    int rc = asr_dec_step_bwd(q, s, stream);
-    if (rc) return rc;
-  }
-  return 0;
+extern "C" int asr_dec_step_bwd(const asr_dec_bwd_t* q, int s, asr_stream_t stream_) {
+  int rc = check_bwd(q);
+  if (rc) return rc;
+  if (s < 0 || s >= q->f.L) return ASR_E_ARG;
+  return dec_step_bwd_impl(q, s, (hipStream_t)stream_);
+}
+
+extern "C" int asr_dec_seq_bwd(const asr_dec_bwd_t* q, int s_begin, int s_end, void* graphs, asr_stream_t stream_) {
+  int rc = check_bwd(q);
+  if (rc) return rc;
+  if (s_begin < 0 || s_end > q->f.L || s_begin > s_end) return ASR_E_ARG;
+  struct { int kind, s0, s1; asr_dec_bwd_t b; } key;
+  memset(&key, 0, sizeof(key));
+  key.kind = 4; key.s0 = s_begin; key.s1 = s_end; key.b = *q;
+  return asr_graph_run((AsrGraphCache*)graphs, &key, sizeof(key), (hipStream_t)stream_, [&](hipStream_t stream) -> int {
+    for (int s = s_end - 1; s >= s_begin; --s) {
+      int r = dec_step_bwd_impl(q, s, stream);
+      if (r) return r;
+    }
+    return 0;
+  });
 }

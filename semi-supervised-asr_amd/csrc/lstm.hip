@@ -8,6 +8,7 @@
 // hidden units in the backward; the recurrent product runs on v_mfma_f32_16x16x4_f32 with K split
 // over the 4 waves and reduced through LDS, followed by the pointwise gate math in the same kernel.
 #include "common.h"
+#include "graphs.h"
 
 namespace {
 
@@ -16,7 +17,8 @@ namespace {
 // The pointwise operands (x-projection, c_{t-1}, length) are fetched BEFORE the recurrent product so their
 // HBM/Infinity-Cache miss latency hides under the weight stream + MFMA phase.
 template <int MT>
-__global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int H, int ndir, float* __restrict__ gates,
+__global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int nb, int H, int ndir,
+                                                           float* __restrict__ gates,
                                                            const float* __restrict__ w_hh,
                                                            const int32_t* __restrict__ lens, float* __restrict__ y,
                                                            float* __restrict__ c, int s) {
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int H, 
   const int e = threadIdx.x;
   const int row = e >> 2, u = e & 3;
   const int64_t b = row0 + row;
-  const bool mine = e < MT * 16 * 4 && b < B;
+  const bool mine = e < MT * 16 * 4 && b < nb;
   const int unit = 4 * j + u;
   float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
   float cp = 0.f;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int H, 
     if (s > 0) cp = c[((int64_t)tp * B + b) * ldy + d * H + unit];
   }
   if (s > 0) {
-    skinny_partial<MT>(y + (int64_t)tp * B * ldy + d * H, ldy, row0, B, w_hh + (int64_t)d * 4 * H * H, H,
+    skinny_partial<MT>(y + (int64_t)tp * B * ldy + d * H, ldy, row0, nb, w_hh + (int64_t)d * 4 * H * H, H,
                        (int64_t)16 * j, (int64_t)4 * H, H, red);
   }
   __syncthreads();
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int H, 
 // W_hh is re-streamed from Infinity Cache every launch (L2 does not survive the kernel boundary) at the
 // per-CU fabric share, so UNITS is small enough to spread that stream over the whole chip.
 template <int MT, int UNITS, int NW>
-__global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int H, int ndir, float* __restrict__ gates,
+__global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int nb, int H, int ndir,
+                                                           float* __restrict__ gates,
                                                            const float* __restrict__ w_hhT,
                                                            const int32_t* __restrict__ lens,
                                                            const float* __restrict__ dy, const float* __restrict__ c,
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int
     const int e = threadIdx.x + NT * i;
     const int row = e / UNITS, u = e % UNITS;
     const int64_t b = row0 + row;
-    live[i] = e < MT * 16 * UNITS && b < B;
+    live[i] = e < MT * 16 * UNITS && b < nb;
     dyv[i] = ctv[i] = cpv[i] = dcv[i] = 0.f;
     av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     lenv[i] = 0;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int
     }
   }
   if (s > 0) {
-    skinny_partial<MT, NW>(gates + (int64_t)tn * B * ldg + (int64_t)d * 4 * H, ldg, row0, B,
+    skinny_partial<MT, NW>(gates + (int64_t)tn * B * ldg + (int64_t)d * 4 * H, ldg, row0, nb,
                        w_hhT + (int64_t)d * H * 4 * H, (int64_t)4 * H, (int64_t)UNITS * j,
                        (int64_t)UNITS * (j + 1), 4 * H, red);
   }
@@ -223,22 +226,26 @@ int asr_cell_bwd_launch(int B, int D, int KX, const float* Gnext, const float* g
   return 0;
 }
 
-extern "C" int asr_lstm_seq_fwd(int T, int B, int H, int ndir, float* gates, const float* w_hh, const int32_t* lens,
-                                float* y, float* c, asr_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!gates || !w_hh || !lens || !y || !c || T <= 0 || B <= 0 || H <= 0) return ASR_E_ARG;
+extern "C" int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
+                                const int32_t* lens, float* y, float* c, void* graphs, asr_stream_t stream_) {
+  hipStream_t stream0 = (hipStream_t)stream_;
+  if (!gates || !w_hh || !lens || !y || !c || T <= 0 || B <= 0 || H <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
   if (H % 16 || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
   if (!asr_aligned16(gates) || !asr_aligned16(w_hh) || !asr_aligned16(y)) return ASR_E_ALIGN;
-  for (int s = 0; s < T; ++s) {
-    if (B <= 16)
-      hipLaunchKernelGGL((enc_step_fwd_kernel<1>), dim3(H / 4, ndir, 1), dim3(256), 0, stream, T, B, H, ndir, gates,
-                         w_hh, lens, y, c, s);
-    else
-      hipLaunchKernelGGL((enc_step_fwd_kernel<2>), dim3(H / 4, ndir, (B + 31) / 32), dim3(256), 0, stream, T, B, H,
-                         ndir, gates, w_hh, lens, y, c, s);
-  }
-  ASR_CHECK_LAUNCH();
-  return 0;
+  struct { int kind, T, B, nb, H, ndir; const void *a, *b, *c, *d, *e; } key = {1, T, B, nb, H, ndir, gates, w_hh,
+                                                                             lens, y, c};
+  return asr_graph_run((AsrGraphCache*)graphs, &key, sizeof(key), stream0, [&](hipStream_t stream) -> int {
+    for (int s = 0; s < T; ++s) {
+      if (nb <= 16)
+        hipLaunchKernelGGL((enc_step_fwd_kernel<1>), dim3(H / 4, ndir, 1), dim3(256), 0, stream, T, B, nb, H, ndir,
+                           gates, w_hh, lens, y, c, s);
+      else
+        hipLaunchKernelGGL((enc_step_fwd_kernel<2>), dim3(H / 4, ndir, (nb + 31) / 32), dim3(256), 0, stream, T, B, nb,
+                           H, ndir, gates, w_hh, lens, y, c, s);
+    }
+    ASR_CHECK_LAUNCH();
+    return 0;
+  });
 }
 
 #ifndef ASR_BWD_UNITS
@@ -251,17 +258,46 @@ extern "C" int asr_lstm_seq_fwd(int T, int B, int H, int ndir, float* gates, con
 #define ASR_BWD_NW 4
 #endif
 
-extern "C" int asr_lstm_seq_bwd(int T, int B, int H, int ndir, float* gates, const float* w_hhT, const int32_t* lens,
-                                const float* dy, const float* c, float* dcarry, asr_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!gates || !w_hhT || !lens || !dy || !c || !dcarry || T <= 0 || B <= 0 || H <= 0) return ASR_E_ARG;
+extern "C" int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
+                                const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
+                                asr_stream_t stream_) {
+  hipStream_t stream0 = (hipStream_t)stream_;
+  if (!gates || !w_hhT || !lens || !dy || !c || !dcarry || T <= 0 || B <= 0 || H <= 0 || nb <= 0 || nb > B)
+    return ASR_E_ARG;
   if (H % 16 || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
   if (!asr_aligned16(gates) || !asr_aligned16(w_hhT)) return ASR_E_ALIGN;
   constexpr int U = ASR_BWD_UNITS, MTB = ASR_BWD_MT, NWB = ASR_BWD_NW;
-  for (int s = 0; s < T; ++s) {
-    hipLaunchKernelGGL((enc_step_bwd_kernel<MTB, U, NWB>), dim3(H / U, ndir, (B + MTB * 16 - 1) / (MTB * 16)), dim3(NWB * 64), 0,
-                       stream, T, B, H, ndir, gates, w_hhT, lens, dy, c, dcarry, s);
-  }
-  ASR_CHECK_LAUNCH();
+  struct { int kind, T, B, nb, H, ndir; const void *a, *b, *c, *d, *e, *f; } key = {2, T, B, nb, H, ndir, gates, w_hhT,
+                                                                                 lens, dy, c, dcarry};
+  return asr_graph_run((AsrGraphCache*)graphs, &key, sizeof(key), stream0, [&](hipStream_t stream) -> int {
+    for (int s = 0; s < T; ++s) {
+      hipLaunchKernelGGL((enc_step_bwd_kernel<MTB, U, NWB>), dim3(H / U, ndir, (nb + MTB * 16 - 1) / (MTB * 16)),
+                         dim3(NWB * 64), 0, stream, T, B, nb, H, ndir, gates, w_hhT, lens, dy, c, dcarry, s);
+    }
+    ASR_CHECK_LAUNCH();
+    return 0;
+  });
+}
+
+extern "C" void* asr_graphs_create(int max_entries) {
+  AsrGraphCache* gc = new AsrGraphCache();
+  if (max_entries > 0) gc->max_entries = (size_t)max_entries;
+  return gc;
+}
+
+extern "C" void asr_graphs_destroy(void* graphs) {
+  AsrGraphCache* gc = (AsrGraphCache*)graphs;
+  if (!gc) return;
+  for (auto& e : gc->entries)
+    if (e.exec) hipGraphExecDestroy(e.exec);
+  delete gc;
+}
+
+extern "C" int asr_graphs_stats(void* graphs, int64_t* hits, int64_t* captures, int64_t* eager) {
+  AsrGraphCache* gc = (AsrGraphCache*)graphs;
+  if (!gc) return ASR_E_ARG;
+  if (hits) *hits = (int64_t)gc->hits;
+  if (captures) *captures = (int64_t)gc->captures;
+  if (eager) *eager = (int64_t)gc->eager;
   return 0;
 }

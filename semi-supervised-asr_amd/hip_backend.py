@@ -17,7 +17,7 @@ EXPORTS = (
     "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_bwd", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_dec_step_fwd", "asr_dec_seq_fwd", "asr_dec_step_bwd", "asr_dec_seq_bwd",
-    "asr_adam_clip_f32", "asr_sumsq_f32",
+    "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
 
 _lib = None
@@ -27,7 +27,7 @@ c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_vo
 
 class DecFwd(ctypes.Structure):
     """asr_dec_fwd_t"""
-    _fields_ = [(n, c_i) for n in ("B", "Tp", "A", "D", "O", "E", "C", "K", "L")] + [("scaling", c_f)] + \
+    _fields_ = [(n, c_i) for n in ("B", "nb", "Tp", "A", "D", "O", "E", "C", "K", "L")] + [("scaling", c_f)] + \
                [(n, c_p) for n in ("P", "Q", "bo", "wcat", "bcat", "wdec", "convw", "watt", "gvec", "w0", "xmask",
                                    "X", "Xd", "gates", "cstate", "Dproj", "fconv", "S", "energy", "ws")]
 
@@ -51,19 +51,24 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     for name in EXPORTS:
         getattr(lib, name).restype = c_i
+    lib.asr_graphs_create.restype = c_p
+    lib.asr_graphs_create.argtypes = [c_i]
+    lib.asr_graphs_destroy.restype = None
+    lib.asr_graphs_destroy.argtypes = [c_p]
+    lib.asr_graphs_stats.argtypes = [c_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
     lib.asr_gemm_f32.argtypes = [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_i,
                                  c_i, c_i64, c_i64, c_i64, c_i, c_p]
     lib.asr_gemm_skinny_f32.argtypes = [c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p,
                                         c_i64, c_i64, c_p]
     lib.asr_colsum_f32.argtypes = [c_i64, c_i64, c_p, c_i64, c_p, c_i, c_p]
-    lib.asr_lstm_seq_fwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]
-    lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_fwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_dec_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
-    lib.asr_dec_seq_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_i, c_p]
+    lib.asr_dec_seq_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_i, c_p, c_p]
     lib.asr_dec_step_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_p]
-    lib.asr_dec_seq_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_i, c_p]
+    lib.asr_dec_seq_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_i, c_p, c_p]
     lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                       c_f, c_p]
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]
@@ -155,16 +160,135 @@ def colsum(X, out=None, accumulate=False):
     return out
 
 
-def lstm_seq_fwd(gates, w_hh, lens, y, c):
+# ---------------------------------------------------------------------------------------------------
+# Utterance-group concurrency: the recurrent chains are latency-bound (one small kernel per time step), and
+# utterances are independent, so disjoint row groups run on separate HIP streams and overlap each other's
+# launch-boundary / memory latency.  Each group's launch loop runs in its own host thread (ctypes drops the
+# GIL inside the C call), so the host enqueue rate scales with the number of groups as well.
+# Measured on MI355X: graph-replayed kernels run ~0.8 us slower each than eager launches and
+# two concurrent row groups disturb each other (per-kernel cache maintenance), so the defaults are one group and
+# eager launches; graphs pay off only when the host cannot keep up (bench.py picks the faster mode in warm-up).
+GROUPS = int(os.environ.get("ASR_ROW_GROUPS", "1"))
+USE_GRAPHS = os.environ.get("ASR_GRAPHS", "0") != "0"
+_side_streams = {}
+_pool = None
+_graph_handles = {}
+
+
+def graphs_for(group_index):
+    """hipGraph memo handle of a row group (one per launching thread; see include/asr_hip.h)."""
+    if not USE_GRAPHS:
+        return None
+    key = (torch.cuda.current_device(), group_index)
+    h = _graph_handles.get(key)
+    if h is None:
+        h = c_p(load().asr_graphs_create(96))
+        _graph_handles[key] = h
+    return h
+
+
+def graph_stats():
+    out = {}
+    for key, h in _graph_handles.items():
+        a, b, c = c_i64(0), c_i64(0), c_i64(0)
+        load().asr_graphs_stats(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        out[key] = dict(hits=a.value, captures=b.value, eager=c.value)
+    return out
+
+
+def row_groups(B):
+    """Split B rows into <= GROUPS contiguous groups whose sizes are multiples of 16 where possible."""
+    g = max(1, min(GROUPS, B // 16))
+    if g <= 1:
+        return [(0, B)]
+    per = ((B + g - 1) // g + 15) // 16 * 16
+    out, b0 = [], 0
+    while b0 < B:
+        out.append((b0, min(per, B - b0)))
+        b0 += per
+    return out
+
+
+def run_grouped(groups, fn):
+    """fn(group_index, (b0, nb), stream_ptr) for every group.  Every group runs on its own non-default HIP stream
+    (stream capture for the graph memo is illegal on the legacy default stream), forked from and joined back
+    into the current stream.  With several groups the launch loops run concurrently on a thread pool."""
+    global _pool
+    if len(groups) == 1 and not USE_GRAPHS:
+        fn(0, groups[0], stream())          # plain in-order launches on the current stream (fastest on the GPU side)
+        return
+    main = torch.cuda.current_stream()
+    dev = main.device
+    side = _side_streams.setdefault(dev, [])
+    while len(side) < len(groups):
+        side.append(torch.cuda.Stream(device=dev))
+    used = side[: len(groups)]
+    for st in used:
+        st.wait_stream(main)
+    if len(groups) == 1:
+        fn(0, groups[0], c_p(used[0].cuda_stream))
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        if _pool is None:
+            _pool = ThreadPoolExecutor(max_workers=8)
+        futs = [_pool.submit(fn, gi, groups[gi], c_p(used[gi].cuda_stream)) for gi in range(1, len(groups))]
+        fn(0, groups[0], c_p(used[0].cuda_stream))
+        for f in futs:
+            f.result()
+    for st in used:
+        main.wait_stream(st)
+
+
+_pinned_ring = {}
+
+
+def to_device_i32(values, device):
+    """Host ints -> int32 device tensor without blocking the host: staged through a small ring of pinned buffers
+    and copied with non_blocking=True (a pageable-memory copy would stall the host until the stream drains)."""
+    import numpy as np
+    arr = np.asarray(values, dtype=np.int32)
+    key = (str(device), arr.size)
+    ring = _pinned_ring.setdefault(key, dict(bufs=[torch.empty(arr.size, dtype=torch.int32).pin_memory()
+                                                   for _ in range(8)], i=0))
+    buf = ring["bufs"][ring["i"] % 8]
+    ring["i"] += 1
+    buf.copy_(torch.from_numpy(arr.reshape(-1)))
+    return buf.to(device, non_blocking=True).view(arr.shape)
+
+
+def _off(t, elems):
+    return c_p(_dev(t).data_ptr() + 4 * int(elems))
+
+
+def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
     T, B, ndir, H4 = gates.shape
-    check(load().asr_lstm_seq_fwd(T, B, H4 // 4, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(y), ptr(c), stream()),
-          "asr_lstm_seq_fwd")
+    H = H4 // 4
+    lib = load()
+    groups = row_groups(B)
+    gh = [graphs_for(i) if use_graphs else None for i in range(len(groups))]     # created on the calling thread
+
+    def one(gi, grp, st):
+        b0, nb = grp
+        check(lib.asr_lstm_seq_fwd(T, B, nb, H, ndir, _off(gates, b0 * ndir * H4), ptr(w_hh), _off(lens, b0),
+                                   _off(y, b0 * ndir * H), _off(c, b0 * ndir * H), gh[gi], st), "asr_lstm_seq_fwd")
+
+    run_grouped(groups, one)
 
 
 def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry):
     T, B, ndir, H4 = gates.shape
-    check(load().asr_lstm_seq_bwd(T, B, H4 // 4, ndir, ptr(gates), ptr(w_hhT), ptr(lens), ptr(dy), ptr(c),
-                                  ptr(dcarry), stream()), "asr_lstm_seq_bwd")
+    H = H4 // 4
+    lib = load()
+    groups = row_groups(B)
+    gh = [graphs_for(i) for i in range(len(groups))]
+
+    def one(gi, grp, st):
+        b0, nb = grp
+        check(lib.asr_lstm_seq_bwd(T, B, nb, H, ndir, _off(gates, b0 * ndir * H4), ptr(w_hhT), _off(lens, b0),
+                                   _off(dy, b0 * ndir * H), _off(c, b0 * ndir * H), _off(dcarry, b0 * ndir * H), gh[gi],
+                                   st), "asr_lstm_seq_bwd")
+
+    run_grouped(groups, one)
 
 
 def pyramid_fwd(x, mask, out):

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 import ops
+from hip_backend import to_device_i32 as hb_to_device
 from utils import cc, pad_list, _seq_mask
 
 
@@ -90,12 +91,18 @@ class pBLSTM(torch.nn.Module):
         extent; default = max(ilens) like pad_packed_sequence (model.py:81)."""
         dev = xpad.device
         lens = [int(l) for l in ilens]
+        # lengths entering every layer are known on the host up front: one non-blocking upload for all layers
+        per_layer = [lens]
+        for i in range(len(self.layers)):
+            sub = self.subsample[i]
+            per_layer.append([(l + 1) // sub for l in per_layer[-1]] if sub > 1 else per_layer[-1])
+        lens_all = hb_to_device(per_layer, dev)                    # [n_layers+1, B] int32
         x = xpad.transpose(0, 1)                                   # time-major
         drop = self.training and self.dropout_rate > 0
         for i, (layer, proj) in enumerate(zip(self.layers, self.project_layers)):
             steps = max(lens) if total_length is None else int(total_length[i])
             x = x[:steps].contiguous()
-            lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+            lens_dev = lens_all[i]
             y = ops.lstm_layer(x, lens_dev, layer.direction_params(0), 2)      # [T,B,2H]
             mask = _drop_mask(y.shape, self.dropout_rate, dev) if drop else None
             sub = self.subsample[i]
@@ -107,6 +114,7 @@ class pBLSTM(torch.nn.Module):
             x = ops.linear(y, proj.weight, proj.bias, relu=True)
             if drop:
                 x = x * _drop_mask(x.shape, self.dropout_rate, dev)
+        self.last_lens_dev = lens_all[-1]                          # device copy of the output lengths
         return x.transpose(0, 1).contiguous(), [int(l) for l in lens]
 
 
@@ -147,11 +155,11 @@ class AttLoc(torch.nn.Module):
 
     @staticmethod
     def initial_weights(enc_len, frames, device):
-        """model.py:151-153: uniform over each utterance's valid frames, 0 on the padding."""
-        w0 = torch.zeros(len(enc_len), frames)
-        for b, l in enumerate(enc_len):
-            w0[b, :l] = 1.0 / l
-        return w0.to(device)
+        """model.py:151-153: uniform over each utterance's valid frames, 0 on the padding.  Built on the device
+        from a non-blocking upload of the lengths (no host stall in the middle of the step)."""
+        lens = hb_to_device(enc_len, device).to(torch.float32).unsqueeze(1)
+        grid = torch.arange(frames, device=device, dtype=torch.float32).unsqueeze(0)
+        return (grid < lens).to(torch.float32) / lens
 
     def forward(self, enc_pad, enc_len, dec_z, att_prev, scaling=2.0):
         """Single attention step with the reference's signature: returns (mlp_o(context), w).
@@ -316,7 +324,7 @@ class LM(torch.nn.Module):
             tok_out = ys.to(dev)
             lens = [tok_in.size(1)] * tok_in.size(0)
         eys = self.dropout_layer(self.embedding(tok_in))
-        lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+        lens_dev = hb_to_device(lens, dev)
         out = self._run_lstm(eys.transpose(0, 1).contiguous(), lens_dev).transpose(0, 1)
         out = self.dropout_layer(out)
         logits = ops.linear(out.contiguous(), self.output_layer.weight, self.output_layer.bias)

@@ -8,6 +8,14 @@ recurrence, decoder loop) never bounce through Python/autograd per time step:
     pyramid_concat    pair-concat (+dropout mask)                 -> asr_pyramid_concat_*
     decoder_sequence  all decoder steps incl. attention           -> asr_dec_* (+ GEMMs)
 
+Workspaces.  The per-time-step launch chains are replayed as HIP graphs whose kernel arguments are baked
+(see csrc/graphs.h), so the chain buffers must keep their addresses from step to step.  Each chain op
+therefore leases a preallocated, shape-keyed workspace from a pool for the span forward -> end of backward
+(`_Lease`); a second concurrent user of the same shape (e.g. the two model passes of the SSL step) simply gets
+another instance.  With autograd disabled (validation / greedy decoding) plain fresh tensors are used.
+Outputs that alias a workspace (`y`) are only valid until that op's backward has run — the model consumes
+them immediately; double backward / retain_graph through these ops is not supported.
+
 GPU only; see hip_backend for the no-fallback rule.
 """
 import ctypes
@@ -24,6 +32,33 @@ def gate_perm(H, device):
 
 def gate_unperm(H, device):
     return torch.arange(4 * H, device=device).view(H, 4).t().reshape(-1)
+
+
+# -------------------------------------------------------------------------------------- workspace pool
+class _Lease(object):
+    """Exclusive use of one workspace (a dict of tensors) until release() / garbage collection."""
+
+    def __init__(self, free_list, ws):
+        self._free, self.ws = free_list, ws
+
+    def release(self):
+        if self.ws is not None:
+            self._free.append(self.ws)
+            self.ws = None
+
+    __del__ = release
+
+
+class _Pool(object):
+    def __init__(self):
+        self.free = {}
+
+    def acquire(self, key, factory):
+        lst = self.free.setdefault(key, [])
+        return _Lease(lst, lst.pop() if lst else factory())
+
+
+_POOL = _Pool()
 
 
 # --------------------------------------------------------------------------------------
@@ -58,12 +93,23 @@ def linear(x, weight, bias=None, relu=False):
 
 
 # --------------------------------------------------------------------------------------
+def _lstm_workspace(T, B, H, ndir, dev, with_bwd):
+    f32 = dict(device=dev, dtype=torch.float32)
+    ws = dict(gates=torch.empty(T, B, ndir, 4 * H, **f32), y=torch.empty(T, B, ndir * H, **f32),
+              c=torch.empty(T, B, ndir * H, **f32), w_hh=torch.empty(ndir, 4 * H, H, **f32),
+              lens=torch.empty(B, dtype=torch.int32, device=dev))
+    if with_bwd:
+        ws.update(w_hhT=torch.empty(ndir, H, 4 * H, **f32), dy=torch.empty(T, B, ndir * H, **f32),
+                  dcarry=torch.empty(B, ndir * H, **f32))
+    return ws
+
+
 class _LstmLayer(torch.autograd.Function):
     """One (bi)directional LSTM layer over a padded time-major batch (model.py:79-81).
     params: for each direction w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H] (torch layout)."""
 
     @staticmethod
-    def forward(ctx, x, lens, ndir, *params):
+    def forward(ctx, x, lens, ndir, pooled, *params):
         T, B, I = x.shape
         H = params[1].shape[1]
         dev = x.device
@@ -71,25 +117,36 @@ class _LstmLayer(torch.autograd.Function):
         x2 = x.reshape(T * B, I)
         w_ih = torch.cat([params[4 * d][perm] for d in range(ndir)], 0)                       # [ndir*4H, I]
         bias = torch.cat([(params[4 * d + 2] + params[4 * d + 3])[perm] for d in range(ndir)], 0)
-        w_hh = torch.stack([params[4 * d + 1][perm] for d in range(ndir)], 0).contiguous()     # [ndir,4H,H]
-        gates = hb.gemm(x2, w_ih, trans_b=True, bias=bias).view(T, B, ndir, 4 * H)
-        y = torch.empty(T, B, ndir * H, device=dev, dtype=torch.float32)
-        c = torch.empty(T, B, ndir * H, device=dev, dtype=torch.float32)
-        hb.lstm_seq_fwd(gates, w_hh, lens, y, c)
-        ctx.save_for_backward(x2, w_ih, w_hh, gates, y, c, lens)
+        if pooled:
+            lease = _POOL.acquire(("lstm", dev.index, T, B, H, ndir),
+                                  lambda: _lstm_workspace(T, B, H, ndir, dev, True))
+            ws = lease.ws
+        else:
+            lease, ws = None, _lstm_workspace(T, B, H, ndir, dev, False)
+        for d in range(ndir):
+            ws["w_hh"][d].copy_(params[4 * d + 1][perm])
+        ws["lens"].copy_(lens)
+        hb.gemm(x2, w_ih, trans_b=True, bias=bias, out=ws["gates"].view(T * B, ndir * 4 * H))
+        hb.lstm_seq_fwd(ws["gates"], ws["w_hh"], ws["lens"], ws["y"], ws["c"], use_graphs=pooled)
+        ctx.save_for_backward(x2, w_ih)
+        ctx.lease = lease
         ctx.dims = (T, B, I, H, ndir)
-        ctx.mark_non_differentiable(lens)
-        return y
+        return ws["y"].detach()      # fresh tensor object aliasing the workspace (no stale autograd metadata)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w_ih, w_hh, gates, y, c, lens = ctx.saved_tensors
+        x2, w_ih = ctx.saved_tensors
         T, B, I, H, ndir = ctx.dims
+        lease = ctx.lease
+        assert lease is not None and lease.ws is not None, "lstm_layer backward needs the leased workspace " \
+            "(autograd was off in forward, or backward ran twice)"
+        ws = lease.ws
         dev = dy.device
-        dy = dy.contiguous()
-        w_hhT = w_hh.transpose(1, 2).contiguous()
-        dcarry = torch.zeros(B, ndir * H, device=dev, dtype=torch.float32)
-        hb.lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry)        # gates now holds dG (in place)
+        ws["dy"].copy_(dy)
+        ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2))
+        ws["dcarry"].zero_()
+        gates, y = ws["gates"], ws["y"]
+        hb.lstm_seq_bwd(gates, ws["w_hhT"], ws["lens"], ws["dy"], ws["c"], ws["dcarry"])    # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = hb.gemm(dG, x2, trans_a=True)                     # [ndir*4H, I]
@@ -110,12 +167,14 @@ class _LstmLayer(torch.autograd.Function):
                 dw_hh = torch.zeros(4 * H, H, device=dev)
             dbd = db[d * 4 * H:(d + 1) * 4 * H][unperm]
             grads += [dw_ih[d * 4 * H:(d + 1) * 4 * H][unperm], dw_hh[unperm], dbd, dbd]
-        return (dx, None, None) + tuple(grads)
+        lease.release()
+        return (dx, None, None, None) + tuple(grads)
 
 
 def lstm_layer(x, lens, params, ndir):
     """x [T,B,I] time-major contiguous, lens int32 device [B] -> y [T,B,ndir*H]."""
-    return _LstmLayer.apply(x.contiguous(), lens, ndir, *params)
+    pooled = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    return _LstmLayer.apply(x.contiguous(), lens, ndir, pooled, *params)
 
 
 # --------------------------------------------------------------------------------------
@@ -143,8 +202,57 @@ def pyramid_concat(x, mask=None):
 
 
 # --------------------------------------------------------------------------------------
-def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+def _p(t, off=0):
+    """device pointer of tensor t advanced by `off` float elements (None stays NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * int(off))
+
+
+def _dec_fwd_struct(d, b0, nb):
+    """asr_dec_fwd_t for rows [b0, b0+nb) of the decoder buffers in dict d (pointers pre-offset, B = stride)."""
+    Tp, A, D, O, E, C, KX = d["Tp"], d["A"], d["D"], d["O"], d["E"], d["C"], d["KX"]
+    return hb.DecFwd(
+        B=d["B"], nb=nb, Tp=Tp, A=A, D=D, O=O, E=E, C=C, K=d["K"], L=d["L"], scaling=d["scaling"],
+        P=_p(d["P"], b0 * Tp * A), Q=_p(d["Q"], b0 * Tp * O), bo=_p(d["bo"]), wcat=_p(d["wcat"]), bcat=_p(d["bcat"]),
+        wdec=_p(d["wdec"]), convw=_p(d["convw"]), watt=_p(d["watt"]), gvec=_p(d["gvec"]), w0=_p(d["w0"], b0 * Tp),
+        xmask=_p(d["xmask"], b0 * (O + E)), X=_p(d["X"], b0 * KX), Xd=_p(d["Xd"], b0 * KX),
+        gates=_p(d["gates"], b0 * 4 * D), cstate=_p(d["cstate"], b0 * D), Dproj=_p(d["Dproj"], b0 * A),
+        fconv=_p(d["fconv"], b0 * C * Tp), S=_p(d["S"], b0 * Tp * A), energy=_p(d["energy"], b0 * Tp),
+        ws=_p(d["ws"], b0 * Tp))
+
+
+def _dec_bwd_struct(d, w, b0, nb):
+    Tp, A, D, C, KX = d["Tp"], d["A"], d["D"], d["C"], d["KX"]
+    taps = 2 * d["K"] + 1
+    return hb.DecBwd(
+        f=_dec_fwd_struct(d, b0, nb), wcatT=_p(w["wcatT"]), wdecT=_p(w["wdecT"]), dws=_p(w["dws"], b0 * Tp),
+        G=_p(w["G"], b0 * KX), dwext=_p(w["dwext"], b0 * Tp), dwraw=_p(w["dwraw"], b0 * Tp),
+        dfpart=_p(w["dfpart"], b0 * C * Tp), dP=_p(w["dP"], b0 * Tp * A), dgates=_p(w["dgates"], b0 * 4 * D),
+        dD=_p(w["dD"], b0 * A), dcell=_p(w["dcell"], b0 * D), dgvec_part=_p(w["dgvec_part"], b0 * A),
+        dwatt_part=_p(w["dwatt_part"], b0 * A * C), dconv_part=_p(w["dconv_part"], b0 * C * taps))
+
+
+def _dec_workspace(B, Tp, A, D, O, E, C, K, L, drop, dev, with_bwd):
+    f32 = dict(device=dev, dtype=torch.float32)
+    KX = D + O + E
+    ws = dict(
+        P=torch.empty(B, Tp, A, **f32), Q=torch.empty(B, Tp, O, **f32), wcat=torch.empty(4 * D, KX, **f32),
+        bcat=torch.empty(4 * D, **f32), convw=torch.empty(C, 2 * K + 1, **f32), gvec=torch.empty(A, **f32),
+        w0=torch.empty(B, Tp, **f32), X=torch.empty(L + 1, B, KX, **f32),
+        Xd=torch.empty(L + 1, B, KX, **f32) if drop else None,
+        xmask=torch.empty(L, B, O + E, **f32) if drop else None,
+        gates=torch.empty(L, B, 4 * D, **f32), cstate=torch.empty(L, B, D, **f32), Dproj=torch.empty(L, B, A, **f32),
+        fconv=torch.empty(L, B, C, Tp, **f32), S=torch.empty(L, B, Tp, A, **f32), energy=torch.empty(L, B, Tp, **f32),
+        ws=torch.empty(L, B, Tp, **f32))
+    if with_bwd:
+        ntile = (A + 63) // 64
+        ws.update(
+            wcatT=torch.empty(KX, 4 * D, **f32), wdecT=torch.empty(D, A, **f32), G=torch.empty(L + 1, B, KX, **f32),
+            dwext=torch.empty(C, B, Tp, **f32), dwraw=torch.empty(B, Tp, **f32),
+            dfpart=torch.empty(ntile, B, C, Tp, **f32), dP=torch.empty(B, Tp, A, **f32),
+            dgates=torch.empty(L, B, 4 * D, **f32), dD=torch.empty(L, B, A, **f32), dcell=torch.empty(B, D, **f32),
+            dgvec_part=torch.empty(B, A, **f32), dwatt_part=torch.empty(B, A, C, **f32),
+            dconv_part=torch.empty(B, C, 2 * K + 1, **f32), dws=torch.empty(L, B, Tp, **f32))
+    return ws
 
 
 class _DecoderSeq(torch.autograd.Function):
@@ -154,7 +262,7 @@ class _DecoderSeq(torch.autograd.Function):
              b_ih, b_hh, wdec [A,D], convw [C,1,1,2K+1], watt [A,C], gvec [1,A], bo [O], w_out [V,D+O],
              b_out [V], w0 [B,Tp]
     opts   : dict(L, tokens [B,L] long or None, tf_flags list[bool] or None, smooth, smooth_scaling,
-                  sample, scaling (attention temperature), xmask [L,B,O+E] or None)
+                  sample, scaling (attention temperature), xmask [L,B,O+E] or None, pooled)
     returns: logits [L,B,V], ws [L,B,Tp], prediction [L,B] (long)
     """
 
@@ -171,48 +279,59 @@ class _DecoderSeq(torch.autograd.Function):
         L = int(opts["L"])
         KX = D + O + E
         f32 = dict(device=dev, dtype=torch.float32)
+        xmask_in = opts.get("xmask")
+        drop = xmask_in is not None
+        pooled = bool(opts.get("pooled", False))
+        if pooled:
+            lease = _POOL.acquire(("dec", dev.index, B, Tp, A, D, O, E, C, K, L, drop),
+                                  lambda: _dec_workspace(B, Tp, A, D, O, E, C, K, L, drop, dev, True))
+            ws = lease.ws
+        else:
+            lease, ws = None, _dec_workspace(B, Tp, A, D, O, E, C, K, L, drop, dev, False)
         perm = gate_perm(D, dev)
-        wcat = torch.cat([w_hh, w_ih[:, E:E + O], w_ih[:, :E]], 1)[perm].contiguous()      # [4D, KX]
-        bcat = (b_ih + b_hh)[perm].contiguous()
-        convw2 = convw.reshape(C, 2 * K + 1).contiguous()
-        gv = gvec.reshape(A).contiguous()
-        xmask = opts.get("xmask")
-        P = P.contiguous()
-        Q = Q.contiguous()
-        w0 = w0.contiguous()
-        wdec_c = wdec.contiguous()
-        watt_c = watt.contiguous()
-        bo_c = bo.contiguous()
-        X = torch.zeros(L + 1, B, KX, **f32)
-        Xd = torch.zeros(L + 1, B, KX, **f32) if xmask is not None else None     # dropout-masked operand copy
-        buf = dict(
-            gates=torch.empty(L, B, 4 * D, **f32), cstate=torch.empty(L, B, D, **f32),
-            Dproj=torch.empty(L, B, A, **f32), fconv=torch.empty(L, B, C, Tp, **f32),
-            S=torch.empty(L, B, Tp, A, **f32), energy=torch.empty(L, B, Tp, **f32),
-            ws=torch.empty(L, B, Tp, **f32))
-        fs = hb.DecFwd(B=B, Tp=Tp, A=A, D=D, O=O, E=E, C=C, K=K, L=L, scaling=float(opts.get("scaling", 2.0)),
-                       P=_p(P), Q=_p(Q), bo=_p(bo_c), wcat=_p(wcat), bcat=_p(bcat), wdec=_p(wdec_c),
-                       convw=_p(convw2), watt=_p(watt_c), gvec=_p(gv), w0=_p(w0), xmask=_p(xmask), X=_p(X), Xd=_p(Xd),
-                       gates=_p(buf["gates"]), cstate=_p(buf["cstate"]), Dproj=_p(buf["Dproj"]),
-                       fconv=_p(buf["fconv"]), S=_p(buf["S"]), energy=_p(buf["energy"]), ws=_p(buf["ws"]))
+        ws["wcat"].copy_(torch.cat([w_hh, w_ih[:, E:E + O], w_ih[:, :E]], 1)[perm])          # [4D, KX]
+        ws["bcat"].copy_((b_ih + b_hh)[perm])
+        ws["convw"].copy_(convw.reshape(C, 2 * K + 1))
+        ws["gvec"].copy_(gvec.reshape(A))
+        ws["P"].copy_(P)
+        ws["Q"].copy_(Q)
+        ws["w0"].copy_(w0)
+        if drop:
+            ws["xmask"].copy_(xmask_in)
+        X, Xd, xmask = ws["X"], ws["Xd"], ws["xmask"]
+        X.zero_()
+        if drop:
+            Xd.zero_()
+        wdec_c, watt_c, bo_c, w_out_c = wdec.contiguous(), watt.contiguous(), bo.contiguous(), w_out.contiguous()
+        d = dict(B=B, Tp=Tp, A=A, D=D, O=O, E=E, C=C, K=K, L=L, KX=KX, scaling=float(opts.get("scaling", 2.0)),
+                 bo=bo_c, wdec=wdec_c, watt=watt_c)
+        d.update({k: ws[k] for k in ("P", "Q", "wcat", "bcat", "convw", "gvec", "w0", "xmask", "X", "Xd", "gates",
+                                     "cstate", "Dproj", "fconv", "S", "energy", "ws")})
         lib = hb.load()
         tokens = opts.get("tokens")
         tf_flags = opts.get("tf_flags")
         smooth = bool(opts.get("smooth", False))
         sample = bool(opts.get("sample", False))
         all_teacher = tokens is not None and (tf_flags is None or all(tf_flags)) and not sample
-        w_out_c = w_out.contiguous()
         fed = torch.zeros(L, B, dtype=torch.long, device=dev)       # token whose embedding fed step s (-1: smooth)
         probs_saved = []
         if all_teacher:
             fed.copy_(tokens.t())
             X[:L, :, D + O:] = emb_w[fed]
-            if Xd is not None:
+            if drop:
                 Xd[:L, :, D + O:] = X[:L, :, D + O:] * xmask[:, :, O:]
-            hb.check(lib.asr_dec_seq_fwd(ctypes.byref(fs), 0, L, hb.stream()), "asr_dec_seq_fwd")
+            groups = hb.row_groups(B)
+            gh = [hb.graphs_for(i) if pooled else None for i in range(len(groups))]
+
+            def run(gi, grp, st):
+                fg = _dec_fwd_struct(d, grp[0], grp[1])
+                hb.check(lib.asr_dec_seq_fwd(ctypes.byref(fg), 0, L, gh[gi], st), "asr_dec_seq_fwd")
+
+            hb.run_grouped(groups, run)
             logits = hb.gemm(X[1:].view(L * B, KX)[:, :D + O], w_out_c, trans_b=True, bias=b_out).view(L, B, V)
             pred = logits.argmax(-1)
         else:
+            fs = _dec_fwd_struct(d, 0, B)
             logits = torch.empty(L, B, V, **f32)
             pred = torch.empty(L, B, dtype=torch.long, device=dev)
             for s in range(L):
@@ -233,54 +352,61 @@ class _DecoderSeq(torch.autograd.Function):
                     probs_saved.append(pr)
                     fed[s] = -1
                     hb.gemm(pr, emb_w, out=X[s][:, D + O:])
-                if Xd is not None:
+                if drop:
                     Xd[s, :, D + O:] = X[s, :, D + O:] * xmask[s, :, O:]
                 hb.check(lib.asr_dec_step_fwd(ctypes.byref(fs), s, hb.stream()), "asr_dec_step_fwd")
                 hb.gemm_skinny(X[s + 1][:, :D + O], w_out_c, bias=b_out, out=logits[s])
                 pred[s] = torch.distributions.Categorical(logits=logits[s]).sample() if sample \
                     else logits[s].argmax(-1)
-        ctx.fs = fs
-        ctx.keep = (P, Q, wcat, bcat, wdec_c, convw2, watt_c, gv, bo_c, w0, xmask, X, Xd, buf, fed, probs_saved,
-                    w_out_c, emb_w)
+        ctx.d = d
+        ctx.lease = lease
+        ctx.keep = (wdec_c, watt_c, bo_c, fed, probs_saved, w_out_c, emb_w)
         ctx.dims = (B, Tp, A, O, D, E, V, C, K, L, KX)
         ctx.smooth = smooth and tokens is None
         ctx.smooth_scaling = float(opts.get("smooth_scaling", 1.0))
         ctx.mark_non_differentiable(pred)
-        return logits, buf["ws"], pred
+        return logits, ws["ws"].clone(), pred
 
     @staticmethod
     def backward(ctx, dlogits, dws, _dpred):
-        (P, Q, wcat, bcat, wdec, convw2, watt, gv, bo, w0, xmask, X, Xd, buf, fed, probs_saved, w_out,
-         emb_w) = ctx.keep
+        wdec, watt, bo, fed, probs_saved, w_out, emb_w = ctx.keep
         B, Tp, A, O, D, E, V, C, K, L, KX = ctx.dims
-        dev = P.device
-        f32 = dict(device=dev, dtype=torch.float32)
+        lease, d = ctx.lease, ctx.d
+        assert lease is not None and lease.ws is not None, "decoder_sequence backward needs the leased workspace"
+        wk = lease.ws
+        X, Xd = wk["X"], wk["Xd"]
+        dev = X.device
         lib = hb.load()
         dlog2 = dlogits.contiguous().view(L * B, V)
-        G = torch.zeros(L + 1, B, KX, **f32)
+        G = wk["G"]
+        G.zero_()
+        for k in ("dwext", "dP", "dcell", "dgvec_part", "dwatt_part", "dconv_part"):
+            wk[k].zero_()
+        wk["wcatT"].copy_(wk["wcat"].t())
+        wk["wdecT"].copy_(wdec.t())
         XO = X[1:].view(L * B, KX)[:, :D + O]
         hb.gemm(dlog2, w_out, out=G[1:].view(L * B, KX)[:, :D + O])
         dw_out = hb.gemm(dlog2, XO, trans_a=True)
         db_out = hb.colsum(dlog2)
-        ntile = (A + 63) // 64
-        wk = dict(
-            wcatT=wcat.t().contiguous(), wdecT=wdec.t().contiguous(), dwext=torch.zeros(C, B, Tp, **f32),
-            dwraw=torch.empty(B, Tp, **f32), dfpart=torch.empty(ntile, B, C, Tp, **f32),
-            dP=torch.zeros(B, Tp, A, **f32), dgates=torch.empty(L, B, 4 * D, **f32), dD=torch.empty(L, B, A, **f32),
-            dcell=torch.zeros(B, D, **f32), dgvec_part=torch.zeros(B, A, **f32),
-            dwatt_part=torch.zeros(B, A, C, **f32), dconv_part=torch.zeros(B, C, 2 * K + 1, **f32))
-        dws_c = dws.contiguous() if dws is not None else None
-        bs = hb.DecBwd(f=ctx.fs, wcatT=_p(wk["wcatT"]), wdecT=_p(wk["wdecT"]), dws=_p(dws_c), G=_p(G),
-                       dwext=_p(wk["dwext"]), dwraw=_p(wk["dwraw"]), dfpart=_p(wk["dfpart"]), dP=_p(wk["dP"]),
-                       dgates=_p(wk["dgates"]), dD=_p(wk["dD"]), dcell=_p(wk["dcell"]),
-                       dgvec_part=_p(wk["dgvec_part"]), dwatt_part=_p(wk["dwatt_part"]),
-                       dconv_part=_p(wk["dconv_part"]))
+        w = dict(wk)
+        if dws is not None:
+            wk["dws"].copy_(dws)
+        else:
+            w["dws"] = None
         demb_w = torch.zeros_like(emb_w)
         if not ctx.smooth:
-            hb.check(lib.asr_dec_seq_bwd(ctypes.byref(bs), 0, L, hb.stream()), "asr_dec_seq_bwd")
+            groups = hb.row_groups(B)
+            gh = [hb.graphs_for(i) for i in range(len(groups))]
+
+            def run(gi, grp, st):
+                bg = _dec_bwd_struct(d, w, grp[0], grp[1])
+                hb.check(lib.asr_dec_seq_bwd(ctypes.byref(bg), 0, L, gh[gi], st), "asr_dec_seq_bwd")
+
+            hb.run_grouped(groups, run)
         else:
             # smooth-embedding feedback (model.py:341): emb_s = softmax(logit_{s-1}*k) @ E couples step s to
             # the logits of step s-1, so the extra gradient is injected between the per-step kernels.
+            bs = _dec_bwd_struct(d, w, 0, B)
             k = ctx.smooth_scaling
             for s in range(L - 1, -1, -1):
                 hb.check(lib.asr_dec_step_bwd(ctypes.byref(bs), s, hb.stream()), "asr_dec_step_bwd")
@@ -296,7 +422,7 @@ class _DecoderSeq(torch.autograd.Function):
         # deferred weight gradients: one GEMM each over the whole sequence
         dg2 = wk["dgates"].view(L * B, 4 * D)
         Xin = X[:L] if Xd is None else Xd[:L]
-        dwcat = hb.gemm(dg2, Xin.view(L * B, KX), trans_a=True)                  # [4D, KX] gate-interleaved rows
+        dwcat = hb.gemm(dg2, Xin.reshape(L * B, KX), trans_a=True)               # [4D, KX] gate-interleaved rows
         unperm = gate_unperm(D, dev)
         dwcat = dwcat[unperm]
         dw_hh = dwcat[:, :D].contiguous()
@@ -307,21 +433,25 @@ class _DecoderSeq(torch.autograd.Function):
         dwatt = wk["dwatt_part"].sum(0)
         dconvw = wk["dconv_part"].sum(0).view(C, 1, 1, 2 * K + 1)
         # dQ[b] = ws[:, b, :]^T dctx[:, b, :]   (batched over utterances)
-        dQ = torch.empty(B, Tp, O, **f32)
+        dQ = torch.empty(B, Tp, O, device=dev, dtype=torch.float32)
         dctx_base = G[1:]                               # [L, B, KX], ctx grad at columns D:D+O
-        hb.gemm_batched(buf["ws"], dctx_base[:, :, D:], dQ, True, False, Tp, O, L, B * Tp, B * KX, O, B, Tp, KX,
+        hb.gemm_batched(wk["ws"], dctx_base[:, :, D:], dQ, True, False, Tp, O, L, B * Tp, B * KX, O, B, Tp, KX,
                         Tp * O)
         dbo = hb.colsum(dctx_base.view(L * B, KX)[:, D:D + O])
         # embedding gradient for token-fed steps
         demb_all = G[:L, :, D + O:]
-        tokfed = fed >= 0
-        if bool(tokfed.all()):
+        if not probs_saved:          # every step was fed a token (decided on the host: no device sync here)
             demb_w.index_add_(0, fed.view(-1), demb_all.reshape(L * B, E))
         else:
+            tokfed = fed >= 0
             demb_w.index_add_(0, fed[tokfed], demb_all[tokfed])
-        return (wk["dP"], dQ, demb_w, dw_ih, dw_hh, dbias, dbias, dwdec, dconvw, dwatt, dgvec, dbo, dw_out, db_out,
+        dP = wk["dP"].clone()
+        lease.release()
+        return (dP, dQ, demb_w, dw_ih, dw_hh, dbias, dbias, dwdec, dconvw, dwatt, dgvec, dbo, dw_out, db_out,
                 None, None)
 
 
 def decoder_sequence(P, Q, emb_w, w_ih, w_hh, b_ih, b_hh, wdec, convw, watt, gvec, bo, w_out, b_out, w0, opts):
+    opts = dict(opts)
+    opts["pooled"] = torch.is_grad_enabled() and (P.requires_grad or w_hh.requires_grad)
     return _DecoderSeq.apply(P, Q, emb_w, w_ih, w_hh, b_ih, b_hh, wdec, convw, watt, gvec, bo, w_out, b_out, w0, opts)

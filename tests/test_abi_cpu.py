@@ -16,7 +16,7 @@ def test_build_and_exports():
     import hip_backend as hb
     lib = hb.load()
     header = open(os.path.join(ROOT, "include", "asr_hip.h")).read()
-    declared = set(re.findall(r"^int\s+(asr_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void\*?)\s+(asr_\w+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(hb.EXPORTS), (declared ^ set(hb.EXPORTS))
     for name in declared:

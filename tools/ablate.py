@@ -19,7 +19,7 @@ def timeit(fn):
 for rnd in range(3):
     for v,l in libs.items():
         gates=gates0.clone(); dcarry.zero_()
-        tb=timeit(lambda: l.asr_lstm_seq_bwd(T,B,H,2,P(gates),P(w),P(lens),P(dy),P(c),P(dcarry),st))
+        tb=timeit(lambda: l.asr_lstm_seq_bwd(T,B,B,H,2,P(gates),P(w),P(lens),P(dy),P(c),P(dcarry),st))
         gates=gates0.clone()
-        tf=timeit(lambda: l.asr_lstm_seq_fwd(T,B,H,2,P(gates),P(wf),P(lens),P(y),P(c2),st))
+        tf=timeit(lambda: l.asr_lstm_seq_fwd(T,B,B,H,2,P(gates),P(wf),P(lens),P(y),P(c2),st))
         print(rnd, v, 'bwd us/step %.2f  fwd us/step %.2f'%(tb,tf), flush=True)
