@@ -139,7 +139,7 @@ def kernel_roofline(dev):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         hb.check(lib.asr_lstm_seq_bwd(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c),
-                                      hb.ptr(dcarry), hb.stream()), "asr_lstm_seq_bwd")   # one stream, all rows
+                                      hb.ptr(dcarry), None, hb.stream()), "asr_lstm_seq_bwd")   # eager, one stream
         e1.record(stream)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)

@@ -167,6 +167,7 @@ typedef struct {
   const float* wdec;  /* [A][D]  mlp_dec.weight */
   const float* convw; /* [C][2K+1] loc_conv.weight */
   const float* watt;  /* [A][C]  mlp_att.weight */
+  const float* wattT; /* [C][A]  its transpose (prepared by the caller once per sequence) */
   const float* gvec;  /* [A] */
   const float* w0;    /* [B][Tp] initial attention weights (model.py:151-153) */
   const float* xmask; /* [L][B][O+E] dropout mask for the (ctx|emb) part of X[s], or NULL */

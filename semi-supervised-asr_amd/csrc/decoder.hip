@@ -36,19 +36,59 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // hoisted above the LDS staging so that each kernel pays ~one memory round trip.  A guarded load consumed
 // right away costs a full HBM/Infinity-Cache latency per loop iteration (35 us kernels in the first version).
 
+// Copy n floats global -> LDS with all of a thread's loads of a batch issued before any store (one memory round
+// trip per PER*256 elements instead of one per element).
+template <int PER, int NT = 256>
+__device__ __forceinline__ void stage_copy(float* __restrict__ lds, const float* __restrict__ g, int n) {
+  for (int base = 0; base < n; base += NT * PER) {
+    float v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = base + k * NT + (int)threadIdx.x;
+      v[k] = g[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = base + k * NT + (int)threadIdx.x;
+      if (i < n) lds[i] = v[k];
+    }
+  }
+}
+
+// previous attention weights of utterance b with a zero halo of K frames on both sides
+__device__ __forceinline__ void stage_wprev(float* __restrict__ wp, const float* __restrict__ wrow, int Tp, int K) {
+  const int n = Tp + 2 * K;
+  for (int base = 0; base < n; base += 512) {
+    float v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int fr = base + k * 256 + (int)threadIdx.x - K;
+      v[k] = wrow[fr < 0 ? 0 : (fr >= Tp ? Tp - 1 : fr)];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = base + k * 256 + (int)threadIdx.x;
+      if (i < n) wp[i] = (i - K >= 0 && i - K < Tp) ? v[k] : 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ forward: energies
 // grid (ceil(Tp/16), B), 256 threads.  dynamic LDS: wp[Tp+2K] | Fs[C][2K+1] | fs[16][C] | Ut[C][A]
 // Each wave owns 4 frames; a lane owns 4 consecutive attention-dim columns of each 256-wide chunk.
+constexpr int SC_WAVES = 8;                          // waves per workgroup of the score kernels
+constexpr int SC_FPW = FRAMES_PER_WG / SC_WAVES;     // frames per wave (2)
+constexpr int SC_NT = SC_WAVES * 64;
 struct ScoreRegs {
-  float4 p[4];   // P[b, frame i, a..a+3]
-  float4 d, g;   // Dproj[b, a..a+3], gvec[a..a+3]
+  float4 p[SC_FPW];   // P[b, frame i, a..a+3]
+  float4 d, g;        // Dproj[b, a..a+3], gvec[a..a+3]
 };
 
 __device__ __forceinline__ void score_load(ScoreRegs& r, const float* __restrict__ P, const float* __restrict__ Dp,
                                            const float* __restrict__ gvec, int b, int Tp, int A, int tw, int a) {
   const int ac = a < A ? a : 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < SC_FPW; ++i) {
     const int t = tw + i < Tp ? tw + i : Tp - 1;
     r.p[i] = *reinterpret_cast<const float4*>(P + ((int64_t)b * Tp + t) * A + ac);
   }
@@ -57,16 +97,16 @@ __device__ __forceinline__ void score_load(ScoreRegs& r, const float* __restrict
 }
 
 __device__ __forceinline__ void score_compute(const ScoreRegs& r, const float* __restrict__ Ut,
-                                              const float* __restrict__ fs4 /* this wave's 4 frames x C */,
+                                              const float* __restrict__ fs4 /* this wave's frames x C */,
                                               float* __restrict__ S, int b, int Tp, int A, int C, int tw, int a,
-                                              float (&part)[4]) {
+                                              float (&part)[SC_FPW]) {
   if (a >= A) return;    // wave-uniform except in the last chunk; no loads below depend on it
   float4 ucol[CMAX];
 #pragma unroll
   for (int ch = 0; ch < CMAX; ++ch)
     ucol[ch] = ch < C ? *reinterpret_cast<const float4*>(Ut + ch * A + a) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < SC_FPW; ++i) {
     float4 u = r.p[i];
     u.x += r.d.x; u.y += r.d.y; u.z += r.d.z; u.w += r.d.w;
     const float* f = fs4 + i * C;
@@ -79,69 +119,98 @@ __device__ __forceinline__ void score_compute(const ScoreRegs& r, const float* _
     }
     float4 sv;
     sv.x = fast_tanh(u.x); sv.y = fast_tanh(u.y); sv.z = fast_tanh(u.z); sv.w = fast_tanh(u.w);
+#if !(defined(ASR_ABL) && (ASR_ABL & 8))
     if (tw + i < Tp) *reinterpret_cast<float4*>(S + ((int64_t)b * Tp + tw + i) * A + a) = sv;
+#endif
     part[i] += r.g.x * sv.x + r.g.y * sv.y + r.g.z * sv.z + r.g.w * sv.w;
   }
 }
 
-__global__ __launch_bounds__(256) void att_score_fwd_kernel(int B, int Tp, int A, int C, int K,
+__global__ __launch_bounds__(SC_NT) void att_score_fwd_kernel(int B, int Tp, int A, int C, int K,
                                                             const float* __restrict__ P,
                                                             const float* __restrict__ Dp,
                                                             const float* __restrict__ wprev,
                                                             const float* __restrict__ convw,
-                                                            const float* __restrict__ watt,
+                                                            const float* __restrict__ wattT /* [C][A] */,
                                                             const float* __restrict__ gvec, float* __restrict__ S,
                                                             float* __restrict__ fconv, float* __restrict__ energy) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int taps = 2 * K + 1;
   float* Ut = sm;                                   // [C][A]  (16-byte aligned: first)
   float* wp = Ut + C * A;
-  float* Fs = wp + (Tp + 2 * K);
-  float* fs = Fs + C * taps;
+  float* Fs = wp + (FRAMES_PER_WG * ((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG) + 2 * K + 4);
+  float* fs = Fs + 16 * ((taps + 3) & ~3);
+  float* cred = fs + FRAMES_PER_WG * C;               // [SC_WAVES][16][17] conv partial tiles
   const int b = blockIdx.y, t0 = blockIdx.x * FRAMES_PER_WG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tw = t0 + wave * 4;
+  const int tw = t0 + wave * SC_FPW;
   // prefetch the first two 256-column chunks of this wave's frames (all of A when A <= 512)
   ScoreRegs r0, r1;
   score_load(r0, P, Dp, gvec, b, Tp, A, tw, lane * 4);
   score_load(r1, P, Dp, gvec, b, Tp, A, tw, 256 + lane * 4);
-  for (int i = tid; i < Tp + 2 * K; i += 256) {
+  // wp: previous weights with a zero halo, long enough for the last (partial) frame tile; Fs: [16][taps4] with
+  // zero rows/taps beyond C / 2K+1 so the conv is a plain 16 x 16 x taps4 product
+  const int taps4 = (taps + 3) & ~3;
+  const int wlen = FRAMES_PER_WG * ((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG) + 2 * K + 4;
+  for (int base = 0; base < wlen; base += SC_NT) {
+    const int i = base + tid;
     const int fr = i - K;
-    const int frc = fr < 0 ? 0 : (fr >= Tp ? Tp - 1 : fr);
-    const float v = wprev[(int64_t)b * Tp + frc];
-    wp[i] = (fr >= 0 && fr < Tp) ? v : 0.f;
+    const float v = wprev[(int64_t)b * Tp + (fr < 0 ? 0 : (fr >= Tp ? Tp - 1 : fr))];
+    if (i < wlen) wp[i] = (fr >= 0 && fr < Tp) ? v : 0.f;
   }
-  for (int i = tid; i < C * taps; i += 256) Fs[i] = convw[i];
-  for (int i = tid; i < A * C; i += 256) {   // LDS image [C][A] written in order; watt is [A][C]
-    const int ch = i / A, a = i - ch * A;
-    Ut[i] = watt[a * C + ch];
+  for (int base = 0; base < 16 * taps4; base += SC_NT * 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + k * SC_NT + tid;
+      const int ch = i / taps4, j = i - ch * taps4;
+      v[k] = convw[(ch < C && j < taps) ? ch * taps + j : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + k * SC_NT + tid;
+      const int ch = i / taps4, j = i - ch * taps4;
+      if (i < 16 * taps4) Fs[i] = (ch < C && j < taps) ? v[k] : 0.f;
+    }
+  }
+#if !(defined(ASR_ABL) && (ASR_ABL & 1))
+  stage_copy<10, SC_NT>(Ut, wattT, A * C);
+#endif
+  __syncthreads();
+  // location conv f[tl][ch] = sum_j F[ch][j] wp[t0+tl+j] as a Toeplitz product on the f32 MFMA, K (taps) split
+  // over the waves: A[row=tl][k=j] = wp[t0+tl+j], B[k=j][col=ch] = F[ch][j]; D: lane holds rows 4*(lane>>4)+i of
+  // column lane&15.  Partial tiles are summed through LDS (cred).
+  {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, q = lane >> 4;
+    const float* ap = wp + t0 + r + q;
+    const float* bp = Fs + r * taps4 + q;
+    for (int j = 4 * wave; j < taps4; j += 4 * SC_WAVES) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[j], bp[j], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cred[(wave * 16 + 4 * q + i) * 17 + r] = acc[i];
   }
   __syncthreads();
-  // location conv: 4 lanes per output (frame, channel), taps interleaved over the 4 lanes
-  for (int base = 0; base < FRAMES_PER_WG * C * 4; base += 256) {
-    const int idx = base + tid;
+  if (tid < FRAMES_PER_WG * 16) {
+    const int tl = tid >> 4, ch = tid & 15;
     float v = 0.f;
-    const int o = idx >> 2, part = idx & 3;
-    const int tl = o / C, ch = o - tl * C;
-    const int t = t0 + tl;
-    if (idx < FRAMES_PER_WG * C * 4 && t < Tp) {
-      const int jlo = K - t > 0 ? K - t : 0;
-      const int jhi = K - t + Tp - 1 < 2 * K ? K - t + Tp - 1 : 2 * K;
-      const float* fr = Fs + ch * taps;
-      for (int j = jlo + part; j <= jhi; j += 4) v += fr[j] * wp[t + j];
-    }
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    if (idx < FRAMES_PER_WG * C * 4 && part == 0) {
+#pragma unroll
+    for (int w2 = 0; w2 < SC_WAVES; ++w2) v += cred[(w2 * 16 + tl) * 17 + ch];
+    if (ch < C) {
       fs[tl * C + ch] = v;
-      if (t < Tp) fconv[((int64_t)b * C + ch) * Tp + t] = v;
+      if (t0 + tl < Tp) fconv[((int64_t)b * C + ch) * Tp + t0 + tl] = v;
     }
   }
   __syncthreads();
-  float part[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* fs4 = fs + wave * 4 * C;
+  float part[SC_FPW];
+#pragma unroll
+  for (int i = 0; i < SC_FPW; ++i) part[i] = 0.f;
+  const float* fs4 = fs + wave * SC_FPW * C;
+#if defined(ASR_ABL) && (ASR_ABL & 4)
+  part[0] = r0.p[0].x + r1.p[3].w + r0.d.x + r1.g.y;
+#else
   score_compute(r0, Ut, fs4, S, b, Tp, A, C, tw, lane * 4, part);
   score_compute(r1, Ut, fs4, S, b, Tp, A, C, tw, 256 + lane * 4, part);
+#endif
   for (int a0 = 512; a0 < A; a0 += 512) {           // attention dims beyond 512: same code, not prefetched
     score_load(r0, P, Dp, gvec, b, Tp, A, tw, a0 + lane * 4);
     score_load(r1, P, Dp, gvec, b, Tp, A, tw, a0 + 256 + lane * 4);
@@ -149,7 +218,7 @@ __global__ __launch_bounds__(256) void att_score_fwd_kernel(int B, int Tp, int A
     score_compute(r1, Ut, fs4, S, b, Tp, A, C, tw, a0 + 256 + lane * 4, part);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < SC_FPW; ++i) {
     const float e = wave_sum(part[i]);
     if (lane == 0 && tw + i < Tp) energy[(int64_t)b * Tp + tw + i] = e;
   }
@@ -322,14 +391,14 @@ __device__ __forceinline__ void sbwd_load(ScoreBwdRegs& r, const float* __restri
                                           int64_t base /* (b*Tp)*A + a */, int A, int Tp, int wave, int i0) {
 #pragma unroll
   for (int u = 0; u < SB_BATCH; ++u) {
-    const int t = wave + 4 * (i0 + u);
+    const int t = wave + SC_WAVES * (i0 + u);
     const int64_t off = base + (int64_t)(t < Tp ? t : Tp - 1) * A;
     r.s[u] = S[off];
     r.dp[u] = dP[off];
   }
 }
 
-__global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A, int C, float scaling,
+__global__ __launch_bounds__(SC_NT) void att_score_bwd_kernel(int B, int Tp, int A, int C, float scaling,
                                                             const float* __restrict__ wcur,
                                                             const float* __restrict__ dwraw,
                                                             const float* __restrict__ S,
@@ -351,7 +420,7 @@ __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A
   const int a = a0 + lane;
   const bool live = a < A;
   const int64_t base = (int64_t)b * Tp * A + (live ? a : 0);
-  const int nmine = (Tp - wave + 3) >> 2;
+  const int nmine = (Tp - wave + SC_WAVES - 1) / SC_WAVES;
   ScoreBwdRegs ra, rb;
   sbwd_load(ra, S, dP, base, A, Tp, wave, 0);            // in flight during the staging below
   const float gv = gvec[live ? a : 0];
@@ -377,14 +446,11 @@ __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A
     for (int t = lane + 256; t < Tp; t += 64)
       de[t] = scaling * wcur[(int64_t)b * Tp + t] * (dwraw[(int64_t)b * Tp + t] - dot);
   }
-  for (int i = tid; i < C * Tp; i += 256) {
-    const int ch = i / Tp, t = i - ch * Tp;
-    fsm[ch * TpP + t] = fconv[((int64_t)b * C + ch) * Tp + t];
-  }
-  for (int i = tid; i < ATILE * C; i += 256) {
-    const int al = i / C;
-    const float v = watt[(int64_t)(a0 + al < A ? a0 + al : 0) * C + (i - al * C)];
-    Us[i] = a0 + al < A ? v : 0.f;
+  stage_copy<2, SC_NT>(fsm, fconv + (int64_t)b * C * Tp, C * Tp);                     // [C][Tp], unpadded
+  {
+    const int nval = (A - a0 < ATILE ? A - a0 : ATILE) * C;                    // rows of watt inside this tile
+    stage_copy<2, SC_NT>(Us, watt + (int64_t)a0 * C, nval);
+    for (int i = nval + tid; i < ATILE * C; i += SC_NT) Us[i] = 0.f;
   }
   __syncthreads();
   float dD_acc = 0.f, dg_acc = 0.f, dU_acc[CMAX];
@@ -393,7 +459,7 @@ __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A
   auto consume = [&](const ScoreBwdRegs& r, int i0) {
 #pragma unroll
     for (int u = 0; u < SB_BATCH; ++u) {
-      const int t = wave + 4 * (i0 + u);
+      const int t = wave + SC_WAVES * (i0 + u);
       if (t < Tp) {                                        // wave-uniform
         const float sv = r.s[u];
         const float det = de[t];
@@ -403,7 +469,7 @@ __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A
         dg_acc += live ? det * sv : 0.f;
 #pragma unroll
         for (int ch = 0; ch < CMAX; ++ch)
-          if (ch < C) dU_acc[ch] += duv * fsm[ch * TpP + t];
+          if (ch < C) dU_acc[ch] += duv * fsm[ch * Tp + t];
         du[t * 65 + lane] = duv;
       }
     }
@@ -427,7 +493,7 @@ __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A
     for (int k = 0; k < 2 + CMAX; ++k) {
       tot[k] = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) tot[k] += red[(w2 * 64 + lane) * (2 + CMAX) + k];
+      for (int w2 = 0; w2 < SC_WAVES; ++w2) tot[k] += red[(w2 * 64 + lane) * (2 + CMAX) + k];
     }
     dD[(int64_t)b * A + a] = tot[0];
     dgvec_part[(int64_t)b * A + a] += tot[1];
@@ -435,14 +501,28 @@ __global__ __launch_bounds__(256) void att_score_bwd_kernel(int B, int Tp, int A
     for (int ch = 0; ch < CMAX; ++ch)
       if (ch < C) dwatt_part[((int64_t)b * A + a) * C + ch] += tot[2 + ch];
   }
-  // d(conv output)[ch][t] restricted to this tile's columns: sum_a U[a][ch] du[t][a]
-  for (int i = tid; i < C * Tp; i += 256) {
-    const int ch = i / Tp, t = i - ch * Tp;
-    float v = 0.f;
-    const float* drow = du + t * 65;
-#pragma unroll 8
-    for (int al = 0; al < ATILE; ++al) v += Us[al * C + ch] * drow[al];
-    dfpart[(((int64_t)tile * B + b) * C + ch) * Tp + t] = v;
+  // d(conv output)[ch][t] restricted to this tile's columns: sum_a U[a][ch] du[t][a].  Four outputs per
+  // thread advance together so the LDS reads of one step are independent (the loop is LDS-latency bound).
+  for (int base = 0; base < C * Tp; base += 4 * SC_NT) {
+    int chk[4], tk[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + k * SC_NT + tid;
+      const int ic = i < C * Tp ? i : C * Tp - 1;
+      chk[k] = ic / Tp;
+      tk[k] = ic - chk[k] * Tp;
+    }
+#pragma unroll 4
+    for (int al = 0; al < ATILE; ++al) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += Us[al * C + chk[k]] * du[tk[k] * 65 + al];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + k * SC_NT + tid;
+      if (i < C * Tp) dfpart[(((int64_t)tile * B + b) * C + chk[k]) * Tp + tk[k]] = acc[k];
+    }
   }
 }
 
@@ -474,13 +554,8 @@ __global__ __launch_bounds__(256) void att_conv_bwd_kernel(int B, int Tp, int C,
     }
     df[t] = v;
   }
-  for (int i = tid; i < Tp + 2 * K; i += 256) {
-    const int fr = i - K;
-    const int frc = fr < 0 ? 0 : (fr >= Tp ? Tp - 1 : fr);
-    const float v = wprev[(int64_t)b * Tp + frc];
-    wp[i] = (fr >= 0 && fr < Tp) ? v : 0.f;
-  }
-  for (int i = tid; i < taps; i += 256) Fs[i] = convw[ch * taps + i];
+  stage_wprev(wp, wprev + (int64_t)b * Tp, Tp, K);
+  stage_copy<1>(Fs, convw + ch * taps, taps);
   // accumulate-in-place operand fetched early (one value per tap owned by this thread)
   float dcv = 0.f;
   const bool tapmine = tid < taps;
@@ -494,7 +569,16 @@ __global__ __launch_bounds__(256) void att_conv_bwd_kernel(int B, int Tp, int C,
     if (tq < Tp) {
       const int lo = tq - K > 0 ? tq - K : 0;            // t' - t + K <= 2K
       const int hi = tq + K < Tp - 1 ? tq + K : Tp - 1;  // t' - t + K >= 0
-      for (int t = lo + part; t <= hi; t += 4) v += Fs[tq - t + K] * df[t];
+      float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+      int t = lo + part;
+      for (; t + 12 <= hi; t += 16) {
+        v += Fs[tq - t + K] * df[t];
+        v1 += Fs[tq - t - 4 + K] * df[t + 4];
+        v2 += Fs[tq - t - 8 + K] * df[t + 8];
+        v3 += Fs[tq - t - 12 + K] * df[t + 12];
+      }
+      for (; t <= hi; t += 4) v += Fs[tq - t + K] * df[t];
+      v += (v1 + v2) + v3;
     }
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
@@ -502,9 +586,16 @@ __global__ __launch_bounds__(256) void att_conv_bwd_kernel(int B, int Tp, int C,
   }
   // dF[j] += sum_t df[t] wprev[t + j - K]
   if (tapmine) {
-    float v = 0.f;
-    for (int t = 0; t < Tp; ++t) v += df[t] * wp[t + tid];
-    dconv_part[((int64_t)b * C + ch) * taps + tid] = dcv + v;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int t = 0;
+    for (; t + 3 < Tp; t += 4) {
+      v0 += df[t] * wp[t + tid];
+      v1 += df[t + 1] * wp[t + 1 + tid];
+      v2 += df[t + 2] * wp[t + 2 + tid];
+      v3 += df[t + 3] * wp[t + 3 + tid];
+    }
+    for (; t < Tp; ++t) v0 += df[t] * wp[t + tid];
+    dconv_part[((int64_t)b * C + ch) * taps + tid] = dcv + ((v0 + v1) + (v2 + v3));
   }
   for (int j = tid + 256; j < taps; j += 256) {            // taps beyond 256 (K > 127)
     float v = 0.f;
@@ -514,7 +605,7 @@ __global__ __launch_bounds__(256) void att_conv_bwd_kernel(int B, int Tp, int C,
 }
 
 int check_fwd(const asr_dec_fwd_t* p) {
-  if (!p || !p->P || !p->Q || !p->bo || !p->wcat || !p->bcat || !p->wdec || !p->convw || !p->watt || !p->gvec ||
+  if (!p || !p->P || !p->Q || !p->bo || !p->wcat || !p->bcat || !p->wdec || !p->convw || !p->watt || !p->wattT || !p->gvec ||
       !p->w0 || !p->X || !p->gates || !p->cstate || !p->Dproj || !p->fconv || !p->S || !p->energy || !p->ws)
     return ASR_E_ARG;
   if (p->B <= 0 || p->nb <= 0 || p->nb > p->B || p->Tp <= 0 || p->L <= 0) return ASR_E_ARG;
@@ -532,20 +623,32 @@ static int dec_step_fwd_impl(const asr_dec_fwd_t* p, int s, hipStream_t stream) 
   const bool drop = p->xmask != nullptr;
   if (drop && !p->Xd) return ASR_E_ARG;
   float* Xdn = drop ? p->Xd + (int64_t)(s + 1) * B * KX : nullptr;
-  int rc = asr_cell_fwd_launch(nb, D, KX, drop ? p->Xd + (int64_t)s * B * KX : Xs, p->wcat, p->bcat,
+  int rc = 0;
+#ifdef ASR_ONLY
+  const int only = ASR_ONLY;
+#else
+  const int only = 0;
+#endif
+  if (only == 0 || only == 1)
+  rc = asr_cell_fwd_launch(nb, D, KX, drop ? p->Xd + (int64_t)s * B * KX : Xs, p->wcat, p->bcat,
                                p->gates + (int64_t)s * B * 4 * D, s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr,
                                p->cstate + (int64_t)s * B * D, Xn, Xdn, stream);
   if (rc) return rc;
   float* Dp = p->Dproj + (int64_t)s * B * A;
+  if (only == 0 || only == 2)
   rc = asr_skinny_launch(nb, A, D, Xn, KX, p->wdec, D, Dp, A, nullptr, 0, nullptr, 0, 0, stream);
   if (rc) return rc;
   const float* wprev = s > 0 ? p->ws + (int64_t)(s - 1) * B * Tp : p->w0;
   const int taps = 2 * K + 1;
-  const size_t lds1 = sizeof(float) * ((size_t)(Tp + 2 * K) + (size_t)C * taps + FRAMES_PER_WG * C + (size_t)C * A);
-  hipLaunchKernelGGL(att_score_fwd_kernel, dim3((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG, nb), dim3(256), lds1, stream,
-                     B, Tp, A, C, K, p->P, Dp, wprev, p->convw, p->watt, p->gvec, p->S + (int64_t)s * B * Tp * A,
+  const size_t lds1 = sizeof(float) * ((size_t)(FRAMES_PER_WG * ((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG) + 2 * K + 4) +
+                                       (size_t)16 * ((taps + 3) & ~3) + FRAMES_PER_WG * C + (size_t)C * A +
+                                       (size_t)SC_WAVES * 16 * 17);
+  if (only == 0 || only == 3)
+  hipLaunchKernelGGL(att_score_fwd_kernel, dim3((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG, nb), dim3(SC_NT), lds1, stream,
+                     B, Tp, A, C, K, p->P, Dp, wprev, p->convw, p->wattT, p->gvec, p->S + (int64_t)s * B * Tp * A,
                      p->fconv + (int64_t)s * B * C * Tp, p->energy + (int64_t)s * B * Tp);
   const size_t lds2 = sizeof(float) * ((size_t)((Tp + 3) & ~3) + 4 * 256);
+  if (only == 0 || only == 4)
   hipLaunchKernelGGL(att_softmax_ctx_fwd_kernel, dim3((O + 255) / 256, nb), dim3(256), lds2, stream, B, Tp, O,
                      p->scaling, p->energy + (int64_t)s * B * Tp, p->Q, p->bo, p->ws + (int64_t)s * B * Tp, Xn + D,
                      (int64_t)KX, (drop && s + 1 < p->L) ? Xdn + D : nullptr,
@@ -599,9 +702,9 @@ static int dec_step_bwd_impl(const asr_dec_bwd_t* q, int s, hipStream_t stream) 
                      s + 1 < p->L ? q->dwext : nullptr, q->dws ? q->dws + (int64_t)s * B * Tp : nullptr, q->dwraw);
   const int TpP = (Tp + 3) & ~3;
   const size_t lds2 = sizeof(float) * ((size_t)TpP + (size_t)C * TpP + ATILE * C + (size_t)Tp * 65 +
-                                       4 * 64 * (2 + CMAX));
+                                       SC_WAVES * 64 * (2 + CMAX));
   float* dDs = q->dD + (int64_t)s * B * A;
-  hipLaunchKernelGGL(att_score_bwd_kernel, dim3(ntile, nb), dim3(256), lds2, stream, B, Tp, A, C, p->scaling,
+  hipLaunchKernelGGL(att_score_bwd_kernel, dim3(ntile, nb), dim3(SC_NT), lds2, stream, B, Tp, A, C, p->scaling,
                      p->ws + (int64_t)s * B * Tp, q->dwraw, p->S + (int64_t)s * B * Tp * A,
                      p->fconv + (int64_t)s * B * C * Tp, p->watt, p->gvec, q->dP, dDs, q->dgvec_part, q->dwatt_part,
                      q->dfpart);

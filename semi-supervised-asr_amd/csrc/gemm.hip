@@ -193,22 +193,40 @@ template <int MT>
 __global__ __launch_bounds__(256) void skinny_kernel(int64_t M, int64_t N, int K, const float* A, int64_t lda,
                                                      const float* Bt, int64_t ldb, float* C, int64_t ldc,
                                                      const float* bias, int accumulate, const float* mask,
-                                                     int64_t ldmask, int64_t mask_from) {
+                                                     int64_t ldmask, int64_t mask_from, int ksplit) {
   __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
   const int64_t n0 = (int64_t)blockIdx.x * 16;
   const int64_t row0 = (int64_t)blockIdx.y * (MT * 16);
+  // ksplit > 1 (only with accumulate): grid.z slices K, partial products are added with f32 atomics
+  const int kper = K / ksplit;
+  A += (int64_t)blockIdx.z * kper;
+  Bt += (int64_t)blockIdx.z * kper;
+  K = kper;
+  // epilogue operands (bias, dropout mask, accumulate-into value) are fetched before the product
+  constexpr int NE = MT;                      // MT*256 outputs / 256 threads
+  float bv[NE], mv[NE], cv[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int row = e >> 4, col = e & 15;
+    const int64_t m = row0 + row, n = n0 + col;
+    const bool ok = m < M && n < N;
+    const int64_t mc = ok ? m : 0, nc = ok ? n : 0;
+    bv[i] = bias ? bias[nc] : 0.f;
+    mv[i] = (mask && nc >= mask_from) ? mask[mc * ldmask + (nc - mask_from)] : 1.f;
+    cv[i] = (accumulate && ksplit == 1) ? C[mc * ldc + nc] : 0.f;
+  }
   skinny_partial<MT>(A, lda, row0, M, Bt, ldb, n0, N, K, red);
   __syncthreads();
-  for (int e = threadIdx.x; e < MT * 16 * 16; e += 256) {
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = threadIdx.x + 256 * i;
     const int row = e >> 4, col = e & 15;
     const int64_t m = row0 + row, n = n0 + col;
     if (m >= M || n >= N) continue;
-    float v = skinny_reduced<MT>(red, row, col);
-    if (bias) v += bias[n];
-    if (mask && n >= mask_from) v *= mask[m * ldmask + (n - mask_from)];
-    float* dst = C + m * ldc + n;
-    if (accumulate) v += *dst;
-    *dst = v;
+    const float v = (skinny_reduced<MT>(red, row, col) + bv[i]) * mv[i];
+    if (ksplit > 1) atomicAdd(C + m * ldc + n, v);
+    else C[m * ldc + n] = v + cv[i];
   }
 }
 
@@ -274,12 +292,19 @@ int asr_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
   if (K % 16 || lda % 4 || ldb % 4) return ASR_E_SHAPE;
   if (!asr_aligned16(A) || !asr_aligned16(Bt)) return ASR_E_ALIGN;
   const unsigned nb = (unsigned)((N + 15) / 16);
-  if (M <= 16) {
-    hipLaunchKernelGGL((skinny_kernel<1>), dim3(nb, 1), dim3(256), 0, stream, M, N, (int)K, A, lda, Bt, ldb, C, ldc,
-                       bias, accumulate, mask, ldmask, mask_from);
+  // long-K accumulate products (the decoder's dX = dgates Wcat, K = 4D) are split over K: the consumer is a later
+  // launch, so partial sums can simply be added atomically into C
+  int ksplit = 1;
+  if (accumulate && !bias && K >= 1024 && K % 64 == 0) {
+    ksplit = (int)(K / 512);
+    while ((K / 16) % ksplit) --ksplit;
+  }
+  if (M <= 32) {   // 16-row workgroups (MT = 1) also for 17..32 rows: more workgroups, fewer bytes each
+    hipLaunchKernelGGL((skinny_kernel<1>), dim3(nb, (unsigned)((M + 15) / 16), ksplit), dim3(256), 0, stream, M, N,
+                       (int)K, A, lda, Bt, ldb, C, ldc, bias, accumulate, mask, ldmask, mask_from, ksplit);
   } else {
-    hipLaunchKernelGGL((skinny_kernel<2>), dim3(nb, (unsigned)((M + 31) / 32)), dim3(256), 0, stream, M, N, (int)K, A,
-                       lda, Bt, ldb, C, ldc, bias, accumulate, mask, ldmask, mask_from);
+    hipLaunchKernelGGL((skinny_kernel<2>), dim3(nb, (unsigned)((M + 31) / 32), ksplit), dim3(256), 0, stream, M, N,
+                       (int)K, A, lda, Bt, ldb, C, ldc, bias, accumulate, mask, ldmask, mask_from, ksplit);
   }
   ASR_CHECK_LAUNCH();
   return 0;

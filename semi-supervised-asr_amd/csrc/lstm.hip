@@ -156,20 +156,29 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(int B, int D, int KX, con
   __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
   const int j = blockIdx.x;
   const int64_t row0 = (int64_t)blockIdx.z * (MT * 16);
+  const int e = threadIdx.x;
+  // epilogue operands first: their latency hides under the gate product
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cp = 0.f;
+  {
+    const int row = e >> 2, u = e & 3;
+    const int64_t b = row0 + row;
+    if (e < MT * 16 * 4 && b < B) {
+      bb = *reinterpret_cast<const float4*>(bcat + (4 * j + u) * 4);
+      if (cprev) cp = cprev[b * D + 4 * j + u];
+    }
+  }
   skinny_partial<MT>(Xs, KX, row0, B, wcat, KX, (int64_t)16 * j, (int64_t)4 * D, KX, red);
   __syncthreads();
-  const int e = threadIdx.x;
   if (e < MT * 16 * 4) {
     const int row = e >> 2, u = e & 3;
     const int64_t b = row0 + row;
     if (b < B) {
       const int unit = 4 * j + u;
-      const float4 bb = *reinterpret_cast<const float4*>(bcat + unit * 4);
       const float gi = asr_sigmoid(skinny_reduced<MT>(red, row, u * 4 + 0) + bb.x);
       const float gf = asr_sigmoid(skinny_reduced<MT>(red, row, u * 4 + 1) + bb.y);
       const float gg = tanhf(skinny_reduced<MT>(red, row, u * 4 + 2) + bb.z);
       const float go = asr_sigmoid(skinny_reduced<MT>(red, row, u * 4 + 3) + bb.w);
-      const float cp = cprev ? cprev[b * D + unit] : 0.f;
       const float cn = gf * cp + gi * gg;
       *reinterpret_cast<float4*>(gates + (b * 4 * D) + unit * 4) = make_float4(gi, gf, gg, go);
       cout[b * D + unit] = cn;
@@ -208,8 +217,8 @@ __global__ void cell_bwd_kernel(int B, int D, int KX, const float* __restrict__ 
 int asr_cell_fwd_launch(int B, int D, int KX, const float* Xs, const float* wcat, const float* bcat, float* gates,
                         const float* cprev, float* cout, float* zout, float* zout2, hipStream_t stream) {
   if (D % 16 || KX % 16) return ASR_E_SHAPE;
-  if (B <= 16)
-    hipLaunchKernelGGL((cell_fwd_kernel<1>), dim3(D / 4, 1, 1), dim3(256), 0, stream, B, D, KX, Xs, wcat, bcat, gates,
+  if (B <= 32)   // 16-row workgroups: twice the workgroups, half the shared-operand bytes each
+    hipLaunchKernelGGL((cell_fwd_kernel<1>), dim3(D / 4, 1, (B + 15) / 16), dim3(256), 0, stream, B, D, KX, Xs, wcat, bcat, gates,
                        cprev, cout, zout, zout2);
   else
     hipLaunchKernelGGL((cell_fwd_kernel<2>), dim3(D / 4, 1, (B + 31) / 32), dim3(256), 0, stream, B, D, KX, Xs, wcat,

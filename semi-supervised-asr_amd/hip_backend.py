@@ -28,7 +28,7 @@ c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_vo
 class DecFwd(ctypes.Structure):
     """asr_dec_fwd_t"""
     _fields_ = [(n, c_i) for n in ("B", "nb", "Tp", "A", "D", "O", "E", "C", "K", "L")] + [("scaling", c_f)] + \
-               [(n, c_p) for n in ("P", "Q", "bo", "wcat", "bcat", "wdec", "convw", "watt", "gvec", "w0", "xmask",
+               [(n, c_p) for n in ("P", "Q", "bo", "wcat", "bcat", "wdec", "convw", "watt", "wattT", "gvec", "w0", "xmask",
                                    "X", "Xd", "gates", "cstate", "Dproj", "fconv", "S", "energy", "ws")]
 
 

@@ -213,7 +213,7 @@ def _dec_fwd_struct(d, b0, nb):
     return hb.DecFwd(
         B=d["B"], nb=nb, Tp=Tp, A=A, D=D, O=O, E=E, C=C, K=d["K"], L=d["L"], scaling=d["scaling"],
         P=_p(d["P"], b0 * Tp * A), Q=_p(d["Q"], b0 * Tp * O), bo=_p(d["bo"]), wcat=_p(d["wcat"]), bcat=_p(d["bcat"]),
-        wdec=_p(d["wdec"]), convw=_p(d["convw"]), watt=_p(d["watt"]), gvec=_p(d["gvec"]), w0=_p(d["w0"], b0 * Tp),
+        wdec=_p(d["wdec"]), convw=_p(d["convw"]), watt=_p(d["watt"]), wattT=_p(d["wattT"]), gvec=_p(d["gvec"]), w0=_p(d["w0"], b0 * Tp),
         xmask=_p(d["xmask"], b0 * (O + E)), X=_p(d["X"], b0 * KX), Xd=_p(d["Xd"], b0 * KX),
         gates=_p(d["gates"], b0 * 4 * D), cstate=_p(d["cstate"], b0 * D), Dproj=_p(d["Dproj"], b0 * A),
         fconv=_p(d["fconv"], b0 * C * Tp), S=_p(d["S"], b0 * Tp * A), energy=_p(d["energy"], b0 * Tp),
@@ -237,6 +237,7 @@ def _dec_workspace(B, Tp, A, D, O, E, C, K, L, drop, dev, with_bwd):
     ws = dict(
         P=torch.empty(B, Tp, A, **f32), Q=torch.empty(B, Tp, O, **f32), wcat=torch.empty(4 * D, KX, **f32),
         bcat=torch.empty(4 * D, **f32), convw=torch.empty(C, 2 * K + 1, **f32), gvec=torch.empty(A, **f32),
+        wattT=torch.empty(C, A, **f32),
         w0=torch.empty(B, Tp, **f32), X=torch.empty(L + 1, B, KX, **f32),
         Xd=torch.empty(L + 1, B, KX, **f32) if drop else None,
         xmask=torch.empty(L, B, O + E, **f32) if drop else None,
@@ -293,6 +294,7 @@ class _DecoderSeq(torch.autograd.Function):
         ws["bcat"].copy_((b_ih + b_hh)[perm])
         ws["convw"].copy_(convw.reshape(C, 2 * K + 1))
         ws["gvec"].copy_(gvec.reshape(A))
+        ws["wattT"].copy_(watt.t())
         ws["P"].copy_(P)
         ws["Q"].copy_(Q)
         ws["w0"].copy_(w0)
@@ -305,7 +307,7 @@ class _DecoderSeq(torch.autograd.Function):
         wdec_c, watt_c, bo_c, w_out_c = wdec.contiguous(), watt.contiguous(), bo.contiguous(), w_out.contiguous()
         d = dict(B=B, Tp=Tp, A=A, D=D, O=O, E=E, C=C, K=K, L=L, KX=KX, scaling=float(opts.get("scaling", 2.0)),
                  bo=bo_c, wdec=wdec_c, watt=watt_c)
-        d.update({k: ws[k] for k in ("P", "Q", "wcat", "bcat", "convw", "gvec", "w0", "xmask", "X", "Xd", "gates",
+        d.update({k: ws[k] for k in ("P", "Q", "wcat", "bcat", "convw", "gvec", "wattT", "w0", "xmask", "X", "Xd", "gates",
                                      "cstate", "Dproj", "fconv", "S", "energy", "ws")})
         lib = hb.load()
         tokens = opts.get("tokens")
