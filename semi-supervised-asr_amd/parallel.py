@@ -170,8 +170,9 @@ def init_distributed():
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if torch.cuda.is_available():
+        local = local % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one card
         torch.cuda.set_device(local)
-        backend = "nccl"            # RCCL on ROCm
+        backend = os.environ.get("ASR_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
     else:
         backend = "gloo"
     if not dist.is_initialized():

@@ -404,3 +404,37 @@ def test_dropout_mask_injection(monkeypatch):
     rg = dict(zip(names, torch.autograd.grad(-rlp.mean(), [sd[n] for n in names])))
     for n, gr in _grads(net).items():
         _close(gr, rg[n], atol=1e-6, what="dropout grad " + n)
+
+
+def test_sharded_equals_full_batch_on_gpu():
+    """Exact-parity sharding on the HIP path: two strided shards padded to the global T_max / olength, local loss
+    -sum/(B_global*olength); summed gradients == single-process gradients."""
+    dev = _gpu()
+    import model as M
+    import parallel
+    cfg = dict(synth.TINY)
+    ld = synth.labeldist(9, 12)
+    w = synth.e2e_weights(cfg, 11)
+    ilens, ylens = [11, 10, 9, 6, 5, 3], [4, 2, 3, 2, 3, 2]
+    xs, ilens, ys = synth.batch(8, 9, ilens, ylens, 13)
+    net = _product(cfg, w, ld, dev)
+    np.random.seed(4)
+    _, lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
+    net.zero_grad()
+    (-lp.mean()).backward()
+    full = {n: p.grad.clone() for n, p in net.named_parameters()}
+    full_loss = float(-lp.mean())
+    net.zero_grad()
+    tot = 0.0
+    for rank in range(2):
+        xs_r, il_r, ys_r, info = parallel.shard_batch(xs, ilens, ys, rank, 2)
+        tl = M.padded_lengths(info["t_max"], cfg["enc_n_layers"], cfg["subsample"])
+        np.random.seed(4)
+        _, lp_r, _, _ = net(torch.from_numpy(np.ascontiguousarray(xs_r)).to(dev), il_r,
+                            [torch.from_numpy(y).to(dev) for y in ys_r], total_length=tl, olength=info["olength"])
+        loss_r = parallel.local_loss(lp_r, info)
+        loss_r.backward()                       # accumulates into .grad
+        tot += float(loss_r)
+    assert abs(tot - full_loss) < 1e-5 * abs(full_loss)
+    for n, p in net.named_parameters():
+        _close(p.grad, full[n], rtol=1e-4, atol=1e-6, what="sharded grad " + n)

@@ -1,0 +1,75 @@
+"""End-to-end run of the reference-surface Solver on synthetic pickles (GPU): supervised epoch + validation CER,
+judge pre-training epoch, semi-supervised iterations, test(), checkpoint round trip."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _vocab():
+    syms = ["<PAD>", "<BOS>", "<EOS>"] + [chr(ord("a") + i) for i in range(8)] + ["<space>", "<NOISE>"]
+    return {s: i for i, s in enumerate(syms)}
+
+
+def _write_data(root, vocab):
+    from dataset import synthetic_utterances
+    for name, n, seed in (("train", 12, 1), ("dev", 6, 2), ("eval", 3, 3)):
+        data = synthetic_utterances(n, 16, len(vocab), 40, seed)
+        with open(os.path.join(root, name + ".pkl"), "wb") as f:
+            pickle.dump(data, f)
+    with open(os.path.join(root, "vocab_dict.pkl"), "wb") as f:
+        pickle.dump(vocab, f)
+    with open(os.path.join(root, "non_lang_syms.pkl"), "wb") as f:
+        pickle.dump(["<NOISE>", "<PAD>", "<BOS>", "<EOS>"], f)
+
+
+def _config(root):
+    import yaml
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(here, "semi-supervised-asr_amd", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(logdir=os.path.join(root, "log"), model_dir=root, model_name="m", load_model_path=os.path.join(root, "m"),
+               load_judge_path=os.path.join(root, "m"), dataset_root_dir=root,
+               vocab_path=os.path.join(root, "vocab_dict.pkl"),
+               non_lang_syms_path=os.path.join(root, "non_lang_syms.pkl"), labeled_set="train",
+               unlabeled_speech_set="train", unlabeled_text_set="train", dev_set="dev", test_set="eval",
+               min_feature_length=4, max_dec_timesteps=8, batch_size=4, input_dim=16, enc_hidden_dim=16,
+               enc_n_layers=2, subsample=[2, 2], dec_hidden_dim=16, att_dim=16, att_odim=16, conv_channels=2,
+               conv_kernel_size=3, embedding_dim=16, dis_hidden_dim=16, dis_embedding_dim=16, epochs=1, judge_epochs=1,
+               ssl_iterations=2, summary_steps=2, lm_sample_steps=5)
+    return cfg
+
+
+def test_solver_end_to_end(tmp_path, monkeypatch):
+    import __graft_entry__ as entry
+    entry.build()
+    assert torch.cuda.is_available()
+    from solver import Solver
+    root = str(tmp_path)
+    vocab = _vocab()
+    _write_data(root, vocab)
+    monkeypatch.chdir(root)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    solver = Solver(_config(root))
+    assert abs(solver.labeldist.sum() - 1.0) < 1e-9 and solver.labeldist[vocab["<PAD>"]] == 0
+    w_before = solver.model.decoder.output_layer.weight.detach().clone()
+    best, cer = solver.sup_pretrain()
+    assert np.isfinite(cer) and best is not None
+    assert not torch.equal(w_before, solver.model.decoder.output_layer.weight.detach())
+    assert os.path.exists(os.path.join(root, "m.ckpt")) and os.path.exists(os.path.join(root, "m.opt"))
+    solver.judge_pretrain()
+    assert os.path.exists(os.path.join(root, "m.judge.ckpt"))
+    solver.ssl_train()
+    cer = solver.test(state_dict=solver.model.state_dict())
+    assert np.isfinite(cer) and os.path.exists(os.path.join(root, "eval.txt"))
+    # checkpoint round trip incl. optimiser state in torch.optim.Adam's schema
+    solver2 = Solver(_config(root), load_model=True)
+    for (n1, p1), (n2, p2) in zip(solver.model.state_dict().items(), solver2.model.state_dict().items()):
+        assert n1 == n2
+    sd = solver.gen_opt.state_dict()
+    assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
