@@ -146,8 +146,14 @@ def kernel_roofline(dev):
     per_launch_s = ms * 1e-3 / T
     flops = 2.0 * B * 4 * H * H * 2
     ach = flops / per_launch_s / 1e12
+    traffic = None          # fabric-side bytes per launch from the committed PMC passes (profiles/r01_pmc_lstm_step.json)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_lstm_step.json")) as f:
+            traffic = float(json.load(f)["enc_step_bwd"]["hbm_side_bytes_per_launch"])
+    except Exception:
+        pass
     return dict(bound="mfma", kernel="enc_step_bwd_kernel<1,8,4>", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                frac=ach / MFMA_F32_PEAK_TF, traffic=None, us_per_launch=per_launch_s * 1e6)
+                frac=ach / MFMA_F32_PEAK_TF, traffic=traffic, us_per_launch=per_launch_s * 1e6)
 
 
 def main():
