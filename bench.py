@@ -209,6 +209,30 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # launch-mode autotune (untimed): eager launches on the current stream vs hipGraph replay of the per-step chains.
+    # Replay costs ~0.8 us more per kernel on the GPU but frees the host; which wins depends on the host CPU.
+    import hip_backend as hb
+    mode_ms = {}
+    if os.environ.get("ASR_GRAPHS") is None:
+        for mode in (False, True):
+            hb.USE_GRAPHS = mode
+            for _ in range(3 if mode else 1):       # replay needs: first sighting, capture, then steady state
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step()
+            fence()
+            mode_ms["graphs" if mode else "eager"] = (time.perf_counter() - t0) / 2 * 1e3
+        use = mode_ms["graphs"] < 0.97 * mode_ms["eager"]
+        if world > 1:                               # all ranks must agree
+            flag = torch.tensor([1.0 if use else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use = bool(flag.item() > 0.5)
+        hb.USE_GRAPHS = use
+        step()
+        fence()
+    launch_mode = "hipgraph-replay" if hb.USE_GRAPHS else "eager"
     if rank == 0:
         note("timing %d steps" % args.steps)
     t0 = time.perf_counter()
@@ -234,7 +258,7 @@ def main():
                                    "batch 32 per GPU, 80x800 synthetic fbank (ragged 0.6T..T), V=34, L+1=%d, "
                                    "dropout %.2f, Adam(amsgrad)+clip 5" % (info["olength"], args.dropout),
                        "global_batch": n_global, "frames": T_FRAMES, "parallelism": "dp%d" % world,
-                       "pad_mode": "global-exact"},
+                       "pad_mode": "global-exact", "launch_mode": launch_mode, "launch_mode_probe_ms": mode_ms},
             "loss": final_loss,
             "model_tflops": value * f_train / 1e12,
         }
