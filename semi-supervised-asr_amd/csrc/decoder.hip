@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void att_dw_kernel(int B, int Tp, int O, int C
 // grid (ceil(A/64), B), 256 threads.  Each workgroup owns 64 attention-dim columns of one utterance for
 // ALL frames, so dD, dgvec, dW_att partials are local; d(conv output) partials go to a slab per tile.
 // dynamic LDS: de[Tp] | fsm[C][Tp] | Us[64][C] | du[Tp][65] | red[4][64][2+CMAX]
-constexpr int SB_BATCH = 8;
+constexpr int SB_BATCH = 16;   // frames per wave fetched in one batch (Tp <= 128 -> a single memory round trip)
 struct ScoreBwdRegs {
   float s[SB_BATCH], dp[SB_BATCH];
 };
@@ -398,6 +398,12 @@ __device__ __forceinline__ void sbwd_load(ScoreBwdRegs& r, const float* __restri
   }
 }
 
+// grid (ceil(A/64), B), 512 threads (8 waves; frames dealt round-robin to the waves).  Each workgroup owns 64
+// attention-dim columns of one utterance for ALL frames, so dD, dgvec, dW_att are local; d(conv output) partials
+// go to a slab per tile.  The two contractions over the du tile run on the f32 MFMA:
+//   dW_att[a][ch] = sum_t du[t][a] f[ch][t]          (M = 64 columns, N = 16 channels, K = Tp)
+//   df[ch][t]     = sum_a U[a][ch]  du[t][a]          (M = Tp frames,  N = 16 channels, K = 64)
+// dynamic LDS: de[TpP] | fsm[16][TpK] | Us[64][16] | du[TpM][65] | red[8][64][2] | ured[2][64][17]
 __global__ __launch_bounds__(SC_NT) void att_score_bwd_kernel(int B, int Tp, int A, int C, float scaling,
                                                             const float* __restrict__ wcur,
                                                             const float* __restrict__ dwraw,
@@ -409,19 +415,21 @@ __global__ __launch_bounds__(SC_NT) void att_score_bwd_kernel(int B, int Tp, int
                                                             float* __restrict__ dwatt_part,
                                                             float* __restrict__ dfpart) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int TpP = (Tp + 3) & ~3;
+  const int TpP = (Tp + 3) & ~3;          // padded lengths: K of the dW_att product (multiple of 4)
+  const int TpM = (Tp + 15) & ~15;        // M of the df product (multiple of 16)
   float* de = sm;
-  float* fsm = de + TpP;
-  float* Us = fsm + C * TpP;
-  float* du = Us + ATILE * C;
-  float* red = du + Tp * 65;
+  float* fsm = de + TpP;                  // [16][TpP], zero beyond C / Tp
+  float* Us = fsm + 16 * TpP;             // [64][16], zero beyond A / C
+  float* du = Us + ATILE * 16;            // [TpM][65], zero rows beyond Tp
+  float* red = du + TpM * 65;             // [8][64][2]
+  float* ured = red + SC_WAVES * 64 * 2;  // [2][64][17]
   const int b = blockIdx.y, tile = blockIdx.x, a0 = tile * ATILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int a = a0 + lane;
   const bool live = a < A;
   const int64_t base = (int64_t)b * Tp * A + (live ? a : 0);
   const int nmine = (Tp - wave + SC_WAVES - 1) / SC_WAVES;
-  ScoreBwdRegs ra, rb;
+  ScoreBwdRegs ra;
   sbwd_load(ra, S, dP, base, A, Tp, wave, 0);            // in flight during the staging below
   const float gv = gvec[live ? a : 0];
   // softmax backward (each wave redundantly reduces the dot product)
@@ -446,16 +454,40 @@ __global__ __launch_bounds__(SC_NT) void att_score_bwd_kernel(int B, int Tp, int
     for (int t = lane + 256; t < Tp; t += 64)
       de[t] = scaling * wcur[(int64_t)b * Tp + t] * (dwraw[(int64_t)b * Tp + t] - dot);
   }
-  stage_copy<2, SC_NT>(fsm, fconv + (int64_t)b * C * Tp, C * Tp);                     // [C][Tp], unpadded
-  {
-    const int nval = (A - a0 < ATILE ? A - a0 : ATILE) * C;                    // rows of watt inside this tile
-    stage_copy<2, SC_NT>(Us, watt + (int64_t)a0 * C, nval);
-    for (int i = nval + tid; i < ATILE * C; i += SC_NT) Us[i] = 0.f;
-  }
-  __syncthreads();
-  float dD_acc = 0.f, dg_acc = 0.f, dU_acc[CMAX];
+  // fsm[ch][t] (zero padded), Us[al][ch] (zero padded), zero rows of du beyond Tp
+  for (int base2 = 0; base2 < 16 * TpP; base2 += SC_NT * 4) {
+    float v[4];
 #pragma unroll
-  for (int ch = 0; ch < CMAX; ++ch) dU_acc[ch] = 0.f;
+    for (int k = 0; k < 4; ++k) {
+      const int i = base2 + k * SC_NT + tid;
+      const int ch = i / TpP, t = i - ch * TpP;
+      v[k] = fconv[((int64_t)b * C + (ch < C ? ch : 0)) * Tp + (t < Tp ? t : 0)];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base2 + k * SC_NT + tid;
+      const int ch = i / TpP, t = i - ch * TpP;
+      if (i < 16 * TpP) fsm[i] = (ch < C && t < Tp) ? v[k] : 0.f;
+    }
+  }
+  {
+    float v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = k * SC_NT + tid;               // ATILE*16 = 1024 = 2 * SC_NT
+      const int al = i >> 4, ch = i & 15;
+      v[k] = watt[(int64_t)(a0 + al < A ? a0 + al : 0) * C + (ch < C ? ch : 0)];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = k * SC_NT + tid;
+      const int al = i >> 4, ch = i & 15;
+      Us[i] = (a0 + al < A && ch < C) ? v[k] : 0.f;
+    }
+  }
+  for (int i = Tp * 65 + tid; i < TpM * 65; i += SC_NT) du[i] = 0.f;
+  __syncthreads();
+  float dD_acc = 0.f, dg_acc = 0.f;
   auto consume = [&](const ScoreBwdRegs& r, int i0) {
 #pragma unroll
     for (int u = 0; u < SB_BATCH; ++u) {
@@ -467,62 +499,63 @@ __global__ __launch_bounds__(SC_NT) void att_score_bwd_kernel(int B, int Tp, int
         if (live) dP[base + (int64_t)t * A] = r.dp[u] + duv;
         dD_acc += duv;
         dg_acc += live ? det * sv : 0.f;
-#pragma unroll
-        for (int ch = 0; ch < CMAX; ++ch)
-          if (ch < C) dU_acc[ch] += duv * fsm[ch * Tp + t];
         du[t * 65 + lane] = duv;
       }
     }
   };
-  for (int i0 = 0; i0 < nmine; i0 += 2 * SB_BATCH) {
-    const bool second = i0 + SB_BATCH < nmine;
-    if (second) sbwd_load(rb, S, dP, base, A, Tp, wave, i0 + SB_BATCH);
+  consume(ra, 0);
+  for (int i0 = SB_BATCH; i0 < nmine; i0 += SB_BATCH) {   // only for Tp > 128
+    sbwd_load(ra, S, dP, base, A, Tp, wave, i0);
     consume(ra, i0);
-    if (i0 + 2 * SB_BATCH < nmine) sbwd_load(ra, S, dP, base, A, Tp, wave, i0 + 2 * SB_BATCH);
-    if (second) consume(rb, i0 + SB_BATCH);
   }
-  float* myred = red + (wave * 64 + lane) * (2 + CMAX);
-  myred[0] = dD_acc;
-  myred[1] = dg_acc;
-#pragma unroll
-  for (int ch = 0; ch < CMAX; ++ch) myred[2 + ch] = dU_acc[ch];
+  red[(wave * 64 + lane) * 2] = dD_acc;
+  red[(wave * 64 + lane) * 2 + 1] = dg_acc;
   __syncthreads();
   if (wave == 0 && live) {
-    float tot[2 + CMAX];
+    float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2 + CMAX; ++k) {
-      tot[k] = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < SC_WAVES; ++w2) tot[k] += red[(w2 * 64 + lane) * (2 + CMAX) + k];
+    for (int w2 = 0; w2 < SC_WAVES; ++w2) {
+      t0 += red[(w2 * 64 + lane) * 2];
+      t1 += red[(w2 * 64 + lane) * 2 + 1];
     }
-    dD[(int64_t)b * A + a] = tot[0];
-    dgvec_part[(int64_t)b * A + a] += tot[1];
-#pragma unroll
-    for (int ch = 0; ch < CMAX; ++ch)
-      if (ch < C) dwatt_part[((int64_t)b * A + a) * C + ch] += tot[2 + ch];
+    dD[(int64_t)b * A + a] = t0;
+    dgvec_part[(int64_t)b * A + a] += t1;
   }
-  // d(conv output)[ch][t] restricted to this tile's columns: sum_a U[a][ch] du[t][a].  Four outputs per
-  // thread advance together so the LDS reads of one step are independent (the loop is LDS-latency bound).
-  for (int base = 0; base < C * Tp; base += 4 * SC_NT) {
-    int chk[4], tk[4];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = base + k * SC_NT + tid;
-      const int ic = i < C * Tp ? i : C * Tp - 1;
-      chk[k] = ic / Tp;
-      tk[k] = ic - chk[k] * Tp;
+  const int r = lane & 15, q = lane >> 4;
+  // dW_att tile: wave -> (M tile m = wave&3, K half kh = wave>>2); A[row=a][k=t] = du[t][a], B[k=t][col=ch] = fsm[ch][t]
+  {
+    const int m = wave & 3, kh = wave >> 2;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int khalf = ((TpP >> 2) + 1) >> 1;                 // k-steps per half
+    const int s0 = kh * khalf, s1 = (s0 + khalf) < (TpP >> 2) ? (s0 + khalf) : (TpP >> 2);
+    for (int st = s0; st < s1; ++st) {
+      const int t = 4 * st + q;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(du[t * 65 + 16 * m + r], fsm[r * TpP + t], acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ured[(kh * 64 + 16 * m + 4 * q + i) * 17 + r] = acc[i];
+  }
+  // df tiles: M tile = 16 frames, K = 64 columns; A[row=t][k=al] = du[t][al], B[k=al][col=ch] = Us[al][ch]
+  for (int mt = wave; mt < (TpM >> 4); mt += SC_WAVES) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int al = 0; al < ATILE; ++al) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] += Us[al * C + chk[k]] * du[tk[k] * 65 + al];
+    for (int st = 0; st < ATILE / 4; ++st) {
+      const int al = 4 * st + q;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(du[(16 * mt + r) * 65 + al], Us[al * 16 + r], acc, 0, 0, 0);
     }
+    if (r < C) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = base + k * SC_NT + tid;
-      if (i < C * Tp) dfpart[(((int64_t)tile * B + b) * C + chk[k]) * Tp + tk[k]] = acc[k];
+      for (int i = 0; i < 4; ++i) {
+        const int t = 16 * mt + 4 * q + i;
+        if (t < Tp) dfpart[(((int64_t)tile * B + b) * C + r) * Tp + t] = acc[i];
+      }
     }
+  }
+  __syncthreads();
+  for (int i = tid; i < ATILE * C; i += SC_NT) {
+    const int al = i / C, ch = i - al * C;
+    if (a0 + al < A)
+      dwatt_part[((int64_t)b * A + a0 + al) * C + ch] += ured[al * 17 + ch] + ured[(64 + al) * 17 + ch];
   }
 }
 
@@ -698,29 +731,42 @@ static int dec_step_bwd_impl(const asr_dec_bwd_t* q, int s, hipStream_t stream) 
   float* Gn = q->G + (int64_t)(s + 1) * B * KX;
   float* Gs = q->G + (int64_t)s * B * KX;
   const int tgrid = (Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+#ifdef ASR_ONLYB
+  const int onlyb = ASR_ONLYB;
+#else
+  const int onlyb = 0;
+#endif
+  if (onlyb == 0 || onlyb == 1)
   hipLaunchKernelGGL(att_dw_kernel, dim3(tgrid, nb), dim3(256), 0, stream, B, Tp, O, C, p->Q, Gn + D, (int64_t)KX,
                      s + 1 < p->L ? q->dwext : nullptr, q->dws ? q->dws + (int64_t)s * B * Tp : nullptr, q->dwraw);
   const int TpP = (Tp + 3) & ~3;
-  const size_t lds2 = sizeof(float) * ((size_t)TpP + (size_t)C * TpP + ATILE * C + (size_t)Tp * 65 +
-                                       SC_WAVES * 64 * (2 + CMAX));
+  const int TpM = (Tp + 15) & ~15;
+  const size_t lds2 = sizeof(float) * ((size_t)TpP + (size_t)16 * TpP + ATILE * 16 + (size_t)TpM * 65 +
+                                       SC_WAVES * 64 * 2 + 2 * 64 * 17);
   float* dDs = q->dD + (int64_t)s * B * A;
+  if (onlyb == 0 || onlyb == 2)
   hipLaunchKernelGGL(att_score_bwd_kernel, dim3(ntile, nb), dim3(SC_NT), lds2, stream, B, Tp, A, C, p->scaling,
                      p->ws + (int64_t)s * B * Tp, q->dwraw, p->S + (int64_t)s * B * Tp * A,
                      p->fconv + (int64_t)s * B * C * Tp, p->watt, p->gvec, q->dP, dDs, q->dgvec_part, q->dwatt_part,
                      q->dfpart);
   const float* wprev = s > 0 ? p->ws + (int64_t)(s - 1) * B * Tp : p->w0;
   const size_t lds3 = sizeof(float) * ((size_t)TpP + (size_t)((Tp + 2 * K + 3) & ~3) + taps);
+  if (onlyb == 0 || onlyb == 3)
   hipLaunchKernelGGL(att_conv_bwd_kernel, dim3(C, nb), dim3(256), lds3, stream, B, Tp, C, K, ntile, q->dfpart, wprev,
                      p->convw, q->dwext, q->dconv_part);
   ASR_CHECK_LAUNCH();
   // dz_s += dD W_dec
-  int rc = asr_skinny_launch(nb, D, A, dDs, A, q->wdecT, A, Gn, KX, nullptr, 1, nullptr, 0, 0, stream);
+  int rc = 0;
+  if (onlyb == 0 || onlyb == 4)
+  rc = asr_skinny_launch(nb, D, A, dDs, A, q->wdecT, A, Gn, KX, nullptr, 1, nullptr, 0, 0, stream);
   if (rc) return rc;
   float* dg = q->dgates + (int64_t)s * B * 4 * D;
+  if (onlyb == 0 || onlyb == 5)
   rc = asr_cell_bwd_launch(nb, D, KX, Gn, p->gates + (int64_t)s * B * 4 * D, p->cstate + (int64_t)s * B * D,
                            s > 0 ? p->cstate + (int64_t)(s - 1) * B * D : nullptr, q->dcell, dg, stream);
   if (rc) return rc;
   const float* xm = p->xmask ? p->xmask + (int64_t)s * B * (O + E) : nullptr;
+  if (!(onlyb == 0 || onlyb == 6)) return 0;
   return asr_skinny_launch(nb, KX, 4 * D, dg, 4 * D, q->wcatT, 4 * D, Gs, KX, nullptr, 1, xm, O + E, D, stream);
 }
 

@@ -24,3 +24,22 @@ for path in sorted(glob.glob(ROOT+'/scratchlibs/lib_*.so')):
         assert rc==0, rc
         best=min(best,e0.elapsed_time(e1)*1e3/L)
     print('%-20s %.2f us/launch'%(os.path.basename(path),best),flush=True)
+
+# ---- backward kernels (libs named lib_b*)
+wsb=ops._dec_workspace(B,Tp,A,D,O,E,C,K,L,False,dev,True)
+for k,v in wsb.items():
+    if v is not None: v.normal_(0,0.1)
+wk=dict(wsb); wk['dws']=None
+d2=dict(d); d2.update({k: wsb[k] for k in ("P","Q","wcat","bcat","convw","gvec","wattT","w0","xmask","X","Xd","gates","cstate","Dproj","fconv","S","energy","ws")})
+d2['ws'].copy_(torch.softmax(torch.randn(L,B,Tp,device=dev),-1))
+bs=ops._dec_bwd_struct(d2,wk,0,B)
+for path in sorted(glob.glob(ROOT+'/scratchlibs/libb_*.so')):
+    l=ctypes.CDLL(path); l.asr_dec_seq_bwd.restype=ctypes.c_int
+    l.asr_dec_seq_bwd.argtypes=[ctypes.POINTER(hb.DecBwd),ctypes.c_int,ctypes.c_int,ctypes.c_void_p,ctypes.c_void_p]
+    best=1e9
+    for r in range(3):
+        torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+        e0.record(); rc=l.asr_dec_seq_bwd(ctypes.byref(bs),0,L,None,st); e1.record(); torch.cuda.synchronize()
+        assert rc==0, rc
+        best=min(best,e0.elapsed_time(e1)*1e3/L)
+    print('%-20s %.2f us/launch'%(os.path.basename(path),best),flush=True)
