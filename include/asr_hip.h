@@ -185,6 +185,9 @@ typedef struct {
 } asr_dec_fwd_t;
 
 int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream);
+/* attention part of step s only (AttLoc.forward model.py:139-173): z is read from X[s+1][:,0:D]; writes
+ * mlp_o(context) to X[s+1][:,D:D+O] and the weights to ws[s] */
+int asr_att_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream);
 int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, void* graphs, asr_stream_t stream);
 
 /* Backward of one decoder step (reverse order s = L-1..0).

@@ -697,6 +697,36 @@ extern "C" int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stre
   return dec_step_fwd_impl(p, s, (hipStream_t)stream_);
 }
 
+// Attention part of step s only (AttLoc.forward, model.py:139-173): the caller has placed the decoder state z in
+// X[s+1][:, 0:D]; runs mlp_dec -> energies -> softmax + context, leaving mlp_o(context) in X[s+1][:, D:D+O] and the
+// weights in ws[s].
+extern "C" int asr_att_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_fwd(p);
+  if (rc) return rc;
+  if (s < 0 || s >= p->L) return ASR_E_ARG;
+  const int B = p->B, nb = p->nb, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, K = p->K;
+  const int KX = D + O + E;
+  float* Xn = p->X + (int64_t)(s + 1) * B * KX;
+  float* Dp = p->Dproj + (int64_t)s * B * A;
+  rc = asr_skinny_launch(nb, A, D, Xn, KX, p->wdec, D, Dp, A, nullptr, 0, nullptr, 0, 0, stream);
+  if (rc) return rc;
+  const float* wprev = s > 0 ? p->ws + (int64_t)(s - 1) * B * Tp : p->w0;
+  const int taps = 2 * K + 1;
+  const size_t lds1 = sizeof(float) * ((size_t)(FRAMES_PER_WG * ((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG) + 2 * K + 4) +
+                                       (size_t)16 * ((taps + 3) & ~3) + FRAMES_PER_WG * C + (size_t)C * A +
+                                       (size_t)SC_WAVES * 16 * 17);
+  hipLaunchKernelGGL(att_score_fwd_kernel, dim3((Tp + FRAMES_PER_WG - 1) / FRAMES_PER_WG, nb), dim3(SC_NT), lds1, stream,
+                     B, Tp, A, C, K, p->P, Dp, wprev, p->convw, p->wattT, p->gvec, p->S + (int64_t)s * B * Tp * A,
+                     p->fconv + (int64_t)s * B * C * Tp, p->energy + (int64_t)s * B * Tp);
+  const size_t lds2 = sizeof(float) * ((size_t)((Tp + 3) & ~3) + 4 * 256);
+  hipLaunchKernelGGL(att_softmax_ctx_fwd_kernel, dim3((O + 255) / 256, nb), dim3(256), lds2, stream, B, Tp, O,
+                     p->scaling, p->energy + (int64_t)s * B * Tp, p->Q, p->bo, p->ws + (int64_t)s * B * Tp, Xn + D,
+                     (int64_t)KX, nullptr, nullptr, (int64_t)0);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, void* graphs, asr_stream_t stream_) {
   int rc = check_fwd(p);
   if (rc) return rc;

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_bwd", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
-    "asr_dec_step_fwd", "asr_dec_seq_fwd", "asr_dec_step_bwd", "asr_dec_seq_bwd",
+    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_step_bwd", "asr_dec_seq_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
 
@@ -66,6 +66,7 @@ def load():
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_dec_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
+    lib.asr_att_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_dec_seq_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_i, c_p, c_p]
     lib.asr_dec_step_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_p]
     lib.asr_dec_seq_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_i, c_p, c_p]

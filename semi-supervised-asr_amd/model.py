@@ -162,13 +162,23 @@ class AttLoc(torch.nn.Module):
         return (grid < lens).to(torch.float32) / lens
 
     def forward(self, enc_pad, enc_len, dec_z, att_prev, scaling=2.0):
-        """Single attention step with the reference's signature: returns (mlp_o(context), w).
-        Runs the same kernels as the fused loop (one-step decoder sequence with the cell bypassed is
-        not expressible, so this convenience path composes GEMMs + the step kernels through a
-        1-step sequence whose recurrent input is dec_z)."""
-        raise NotImplementedError(
-            "AttLoc.forward as a stand-alone call is not part of the hot path; use Decoder.forward "
-            "(the fused sequence) — see DESIGN.md 'out of scope'.")
+        """Single attention step with the reference's signature (model.py:139-173): returns (mlp_o(context), w).
+        Caches mlp_enc(enc_h) and enc_h W_o^T until reset(), like the reference caches pre_compute_enc_h.
+        Forward only: training differentiates through the fused decoder sequence instead."""
+        bsz, frames, _ = enc_pad.shape
+        if self.pre_compute_enc_h is None:
+            self.enc_h = enc_pad
+            self.enc_length = frames
+            with torch.no_grad():
+                self.pre_compute_enc_h = ops.linear(enc_pad, self.mlp_enc.weight, self.mlp_enc.bias)
+                self._q = ops.linear(enc_pad, self.mlp_o.weight, None)
+        if dec_z is None:
+            dec_z = enc_pad.new_zeros(bsz, self.decoder_dim)
+        if att_prev is None:
+            att_prev = AttLoc.initial_weights(enc_len, frames, enc_pad.device)
+        return ops.attention_step(enc_pad, self.pre_compute_enc_h, self._q, self.mlp_dec.weight, self.loc_conv.weight,
+                                  self.mlp_att.weight, self.gvec.weight, self.mlp_o.bias,
+                                  dec_z.view(bsz, self.decoder_dim), att_prev, scaling)
 
 
 class Decoder(torch.nn.Module):

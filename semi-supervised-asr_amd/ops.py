@@ -457,3 +457,27 @@ def decoder_sequence(P, Q, emb_w, w_ih, w_hh, b_ih, b_hh, wdec, convw, watt, gve
     opts = dict(opts)
     opts["pooled"] = torch.is_grad_enabled() and (P.requires_grad or w_hh.requires_grad)
     return _DecoderSeq.apply(P, Q, emb_w, w_ih, w_hh, b_ih, b_hh, wdec, convw, watt, gvec, bo, w_out, b_out, w0, opts)
+
+
+def attention_step(enc_pad, P, Q, wdec, convw, watt, gvec, bo, dec_z, att_prev, scaling):
+    """One stand-alone location-aware attention step (AttLoc.forward, model.py:139-173) on the same kernels as the
+    fused loop; forward only (the training path differentiates through decoder_sequence).
+    Returns (mlp_o(context) [B,O], w [B,T'])."""
+    dev = P.device
+    B, Tp, A = P.shape
+    O, D, C = Q.shape[2], wdec.shape[1], convw.shape[0]
+    K = (convw.shape[-1] - 1) // 2
+    E = 16                                                   # dummy embedding width (unused columns of X)
+    ws = _dec_workspace(B, Tp, A, D, O, E, C, K, 1, False, dev, False)
+    with torch.no_grad():
+        ws["P"].copy_(P); ws["Q"].copy_(Q); ws["w0"].copy_(att_prev)
+        ws["convw"].copy_(convw.reshape(C, 2 * K + 1)); ws["gvec"].copy_(gvec.reshape(A)); ws["wattT"].copy_(watt.t())
+        ws["wcat"].zero_(); ws["bcat"].zero_(); ws["X"].zero_()
+        ws["X"][1, :, :D] = dec_z
+        d = dict(B=B, Tp=Tp, A=A, D=D, O=O, E=E, C=C, K=K, L=1, KX=D + O + E, scaling=float(scaling),
+                 bo=bo.contiguous(), wdec=wdec.contiguous(), watt=watt.contiguous())
+        d.update({k: ws[k] for k in ("P", "Q", "wcat", "bcat", "convw", "gvec", "wattT", "w0", "xmask", "X", "Xd",
+                                     "gates", "cstate", "Dproj", "fconv", "S", "energy", "ws")})
+        fs = _dec_fwd_struct(d, 0, B)
+        hb.check(hb.load().asr_att_step_fwd(ctypes.byref(fs), 0, hb.stream()), "asr_att_step_fwd")
+        return ws["X"][1, :, D:D + O].clone(), ws["ws"][0].clone()

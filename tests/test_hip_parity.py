@@ -438,3 +438,43 @@ def test_sharded_equals_full_batch_on_gpu():
     assert abs(tot - full_loss) < 1e-5 * abs(full_loss)
     for n, p in net.named_parameters():
         _close(p.grad, full[n], rtol=1e-4, atol=1e-6, what="sharded grad " + n)
+
+
+def test_attloc_forward_standalone(golden_dir):
+    """AttLoc.forward with the reference's signature against the two golden attention steps."""
+    dev = _gpu()
+    g = _load(golden_dir, "tiny_e2e.npz")
+    net = _product(synth.TINY, synth.e2e_weights(synth.TINY, 11), g["labeldist"], dev)
+    enc_h = torch.from_numpy(g["enc_h"]).to(dev)
+    lens = g["enc_lens"].tolist()
+    net.attention.reset()
+    c0, w0 = net.attention(enc_h, lens, torch.from_numpy(g["att_z0"]).to(dev), None)
+    c1, w1 = net.attention(enc_h, lens, torch.from_numpy(g["att_z1"]).to(dev), w0)
+    net.attention.reset()
+    _close(c0, g["att_c0"], what="c0"); _close(w0, g["att_w0"], what="w0")
+    _close(c1, g["att_c1"], what="c1"); _close(w1, g["att_w1"], what="w1")
+
+
+@pytest.mark.parametrize("B,T", [(1, 7), (2, 1), (5, 2)])
+def test_edge_shapes(B, T):
+    """Single utterance, single frame, two frames: model vs oracle (forward + gradients)."""
+    dev = _gpu()
+    cfg = dict(synth.TINY)
+    ld = synth.labeldist(9, 12)
+    w = synth.e2e_weights(cfg, 11)
+    ilens = sorted([max(1, T - i) for i in range(B)], reverse=True)
+    xs, ilens, ys = synth.batch(8, 9, ilens, [2] * B, 90 + B)
+    net = _product(cfg, w, ld, dev)
+    np.random.seed(3)
+    logits, lp, _, ws = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
+    sd = O.make_leaf_state(w)
+    np.random.seed(3)
+    rl, rlp, _, rws = O.e2e_forward(sd, dict(cfg, labeldist=ld), torch.from_numpy(xs), ilens,
+                                    [torch.from_numpy(y) for y in ys])
+    _close(logits, rl, what="logits"); _close(lp, rlp, what="lp"); _close(ws, rws, what="ws")
+    names = O.unique_param_names(sd)
+    rg = dict(zip(names, torch.autograd.grad(-rlp.mean(), [sd[n] for n in names])))
+    net.zero_grad()
+    (-lp.mean()).backward()
+    for n, gr in _grads(net).items():
+        _close(gr, rg[n], atol=1e-6, what="grad " + n)
