@@ -111,6 +111,16 @@ int asr_colsum_f32(int64_t M, int64_t N, const float* X, int64_t ldx, float* out
 int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
                      const int32_t* lens, float* y, float* c, void* graphs, asr_stream_t stream);
 
+/* Persistent fast path of asr_lstm_seq_fwd (same arguments and results; csrc/lstm_persist.hip): ONE launch runs
+ * all T steps, each XCD owns a (direction, 8-row) group, W_hh stays in registers, h_t is exchanged inside the XCD
+ * with tagged 8-byte granules.  Applies when H == 512 and nb <= 8 * (8 / ndir); otherwise returns ASR_E_SHAPE and
+ * the caller uses asr_lstm_seq_fwd.  xch (>= 512 KB) and ctrl (>= 64 B) are caller-allocated scratch; after the
+ * stream has drained ctrl[8] != 0 means the kernel aborted (bounded spin expired / unexpected placement) and
+ * poisoned y with NaN. */
+int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
+                             const int32_t* lens, float* y, float* c, void* xch, void* ctrl,
+                             asr_stream_t stream);
+
 /* Backward through the same recurrence.
  *   gates [T][B][ndir][4H]  in : activated gates from the forward; out: dL/d(pre-activation)
  *                           (= gradient of the x-projection, gate-interleaved)
@@ -122,6 +132,11 @@ int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const 
 int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                      const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
                      asr_stream_t stream);
+/* Persistent fast path of asr_lstm_seq_bwd (same conditions / abort convention as asr_lstm_seq_fwd_persist;
+ * xch >= 1 MB).  The exchanged copy of dG carries a 1-bit tag in each mantissa LSB; the in-place dG is exact. */
+int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
+                             const int32_t* lens, const float* dy, const float* c, void* xch, void* ctrl,
+                             asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pyramidal pair-concat (model.py:85-92), time-major:

@@ -1,0 +1,433 @@
+// lstm_persist.hip — persistent, XCD-local LSTM sequence kernels (fast path for H = 512, <= 8 rows per XCD).
+//
+// Why: with one launch per time step every step pays a kernel boundary (~1.7 us) plus a cold start — L2 does not
+// survive the boundary, so the 8 MB of recurrent weights are re-streamed from Infinity Cache 1 400 times per
+// direction and pass.  Here ONE launch runs the whole sequence:
+//   * the 8 XCDs each take one (direction, 8-batch-row group); the XCD's 32 CUs each own 16 hidden units
+//     (64 gate-interleaved rows of W_hh) and keep that 128 KB slice in REGISTERS for all T steps
+//     (8 waves x 64 VGPRs: wave w holds the K range [64w, 64w+64));
+//   * per step only h_t of the group (8 rows x 512 units = 16 KB) is exchanged, inside the XCD, as 8-byte
+//     {tag = step+1, value} granules written and read with relaxed agent-scope atomics (sc1: the store is
+//     write-through, the load bypasses L1).  The data is the flag: no fences, no separate counters, and
+//     correctness does not depend on which CU/XCD a workgroup landed on — only the speed does;
+//   * the gate product runs on v_mfma_f32_4x4x1_16b_f32: its 16 blocks are this CU's 16 units, A = the 4 gates
+//     of a unit (one W register per k), B = 4 batch rows of h; K accumulates over instructions, so the 4 gate
+//     pre-activations of a (unit, row) land in one lane and the pointwise update needs no shuffles.  The 8
+//     waves' K-partials are summed through LDS.
+// Roles come from HW_REG_XCC_ID + a per-XCC ticket.  Every spin is bounded; on a timeout or an unexpected
+// placement the kernel raises an abort word, poisons its outputs with NaN and drains — the host falls back to
+// the per-step kernels.  1 workgroup per CU is enforced by the LDS request, so 256 workgroups are co-resident.
+#include "common.h"
+
+namespace {
+
+constexpr int PH = 512;          // hidden size supported by this path
+constexpr int PW = 8;            // waves per workgroup
+constexpr int PNT = PW * 64;     // 512 threads
+constexpr int PKW = PH / PW;     // K columns per wave (64)
+constexpr int PUC = PH / 32;     // hidden units per CU (16) = MFMA blocks
+constexpr int PRG = 8;           // batch rows per XCD group
+constexpr unsigned SPIN_LIMIT = 400000u;
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+struct PersistArgs {
+  int T, B, nb, ndir;
+  float* gates;         // [T][B][ndir][4H]
+  const float* w;       // fwd: w_hh [ndir][4H][H];  bwd: w_hhT [ndir][H][4H]
+  const int32_t* lens;
+  float* y;             // fwd: out y;  bwd: unused
+  float* c;             // [T][B][ndir*H]
+  const float* dy;      // bwd
+  u64* xch;             // fwd: [2][8][PRG][H] granules;  bwd: [2][8][PRG][4H]
+  unsigned* ctrl;       // [0..7] tickets per XCC, [8] abort, [9] error code
+};
+
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; }
+
+__device__ __forceinline__ u64 granule_load(const u64* p) {
+  return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Producer and consumers of a group sit on the SAME XCD by construction (the group id is the XCC id), so the
+// granule store may stay in that XCD's L2 (plain store; the L1 is write-through) instead of being written through
+// to the memory side (sc1), which would make every consumer poll a fabric round trip.  Consumers bypass their L1.
+__device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
+#ifdef ASR_GRANULE_SC1
+  __hip_atomic_store((gu64*)p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  __hip_atomic_store((gu64*)p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ __forceinline__ unsigned flag_load(const unsigned* p) {
+  return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_store(unsigned* p, unsigned v) {
+  __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// role of this workgroup: (group g in 0..7, slice in 0..31); slice < 0 = no role
+__device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g, int& slice) {
+  if (threadIdx.x == 0) {
+    const unsigned x = xcc_id() & 7u;
+    const unsigned tk = atomicAdd(ctrl + x, 1u);
+    lds_role[0] = (int)x;
+    lds_role[1] = tk < 32u ? (int)tk : -1;
+    if (tk >= 32u) { flag_store(ctrl + 9, 2u); flag_store(ctrl + 8, 1u); }   // unexpected placement
+  }
+  __syncthreads();
+  g = lds_role[0];
+  slice = lds_role[1];
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
+  // this wave's K range of h_{t-1}; rows padded by 4 floats so the 4 rows a ds_read_b128 touches (the MFMA blocks
+  // broadcast) fall on different bank slots
+  __shared__ __attribute__((aligned(16))) float hs[PW][PRG][PKW + 4];
+  __shared__ float part[2][PW][64][9];                                    // K-partials, double buffered (36 KB)
+  __shared__ int role[2];
+  extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int g, slice;
+  take_role(a.ctrl, role, g, slice);
+  if (slice < 0) return;
+  const int T = a.T, B = a.B, ndir = a.ndir;
+  const int d = ndir == 2 ? (g & 1) : 0;
+  const int rowgroup = ndir == 2 ? (g >> 1) : g;
+  const int r0 = rowgroup * PRG;
+  if (r0 >= a.nb) return;                      // this group has no rows (nobody waits for it)
+  const int64_t ldy = (int64_t)ndir * PH;
+  // recurrent weights of this CU -> registers: lane owns gate-interleaved row 64*slice+lane, wave owns 64 k's
+  float wreg[PKW];
+  {
+    const float* wr = a.w + ((int64_t)d * 4 * PH + 64 * slice + lane) * PH + wave * PKW;
+#pragma unroll
+    for (int k4 = 0; k4 < PKW / 4; ++k4) {
+      const float4 v = *reinterpret_cast<const float4*>(wr + 4 * k4);
+      wreg[4 * k4] = v.x; wreg[4 * k4 + 1] = v.y; wreg[4 * k4 + 2] = v.z; wreg[4 * k4 + 3] = v.w;
+    }
+  }
+  // pointwise ownership: thread (pu, pj) for tid < 128 -> unit 16*slice+pu, row r0+pj
+  const int pu = tid >> 3, pj = tid & 7;
+  const bool pw_thread = tid < PUC * PRG;
+  const int prow = r0 + pj;
+  const bool prow_ok = pw_thread && prow < a.nb;
+  const int punit = PUC * slice + pu;
+  const int plen = prow_ok ? a.lens[prow] : 0;
+  float c_prev = 0.f;
+  u64* xch_g = a.xch + (int64_t)g * PRG * PH;          // + parity * 8*PRG*PH
+  const int64_t par_stride = (int64_t)8 * PRG * PH;
+  bool aborted = false;
+  // x-projection of the NEXT step is fetched one step ahead: vmcnt retires in order, so an HBM first-touch load
+  // issued just before the poll would hold back this wave's poll loads for ~2 us every step
+  float4 gx_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (prow_ok) {
+    const int t0 = d == 0 ? 0 : T - 1;
+    gx_next = *reinterpret_cast<const float4*>(a.gates + (((int64_t)t0 * B + prow) * ndir + d) * 4 * PH + punit * 4);
+  }
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? s : T - 1 - s;
+    const float4 gx = gx_next;
+    float4* gp = nullptr;
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      // gather this wave's K range of h_{t-1}: 8 rows x 64 units of granules tagged s
+      const u64* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKW + lane;
+      u64 gr[PRG];
+      unsigned spins = 0;
+      while (true) {
+        gr[PRG - 1] = granule_load(src + (int64_t)(PRG - 1) * PH);          // sentinel row first (see backward)
+        if (__all((unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
+#pragma unroll
+          for (int rr = 0; rr < PRG - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
+          bool ok = true;
+#pragma unroll
+          for (int rr = 0; rr < PRG - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
+          if (__all(ok)) break;
+        }
+        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
+          aborted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int rr = 0; rr < PRG; ++rr) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
+      if (prow_ok && s + 1 < T) {     // next step's x-projection, in flight during MFMA / reduce / pointwise / hand-off
+        const int tn1 = d == 0 ? s + 1 : T - 2 - s;
+        gx_next = *reinterpret_cast<const float4*>(a.gates + (((int64_t)tn1 * B + prow) * ndir + d) * 4 * PH + punit * 4);
+      }
+      // (wave-private LDS region: program order within the wave is enough)
+      const int j = lane & 3;
+#pragma unroll
+      for (int k4 = 0; k4 < PKW / 4; ++k4) {
+        const float4 b0 = *reinterpret_cast<const float4*>(&hs[wave][j][4 * k4]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&hs[wave][4 + j][4 * k4]);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b1.w, acc1, 0, 0, 0);
+      }
+    }
+    if (s == 0 && prow_ok && T > 1) {
+      const int tn1 = d == 0 ? 1 : T - 2;
+      gx_next = *reinterpret_cast<const float4*>(a.gates + (((int64_t)tn1 * B + prow) * ndir + d) * 4 * PH + punit * 4);
+    }
+    float* pp = &part[s & 1][wave][lane][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; pp[4 + i] = acc1[i]; }
+    __syncthreads();
+    if (pw_thread) {
+      // lane holding (unit pu, row pj): 4*pu + (pj&3); registers 4*(pj>>2) + gate
+      float pre[4] = {gx.x, gx.y, gx.z, gx.w};
+      const int pl = 4 * pu + (pj & 3), pr = 4 * (pj >> 2);
+#pragma unroll
+      for (int w2 = 0; w2 < PW; ++w2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[i] += part[s & 1][w2][pl][pr + i];
+      const float gi = asr_sigmoid(pre[0]), gf = asr_sigmoid(pre[1]);
+      const float gg = tanhf(pre[2]), go = asr_sigmoid(pre[3]);
+      float cn = gf * c_prev + gi * gg;
+      float hn = go * tanhf(cn);
+      if (t >= plen) { cn = 0.f; hn = 0.f; }
+      if (aborted || flag_load(a.ctrl + 8) != 0u) hn = __builtin_nanf("");
+      c_prev = cn;
+      if (prow_ok) {
+        *gp = make_float4(gi, gf, gg, go);
+        const int64_t so = ((int64_t)t * B + prow) * ldy + d * PH + punit;
+        a.c[so] = cn;
+        a.y[so] = hn;
+      }
+      granule_store(xch_g + (s & 1) * par_stride + (int64_t)pj * PH + punit, (unsigned)(s + 1), hn);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------- backward
+// dh_rec = dG_{t_next} W_hh for this CU's 16 units, then the pointwise LSTM backward at time t (dG_t written in
+// place over the saved gates AND published to the group).  The exchange here is 4x larger than in the forward
+// (8 rows x 4H), so it uses bare fp32 words whose mantissa LSB is the validity tag: a slot is rewritten every
+// second step and the expected bit flips with every rewrite (the buffer starts zeroed = invalid), so a consumer
+// can tell new from stale per word; tearing between words is harmless.  Cost: <= 1 ulp on the exchanged copy
+// (the in-place dG used by the weight-gradient GEMMs is untouched).  Float4 traffic both ways.
+// MFMA blocks: 16 = 4 unit-groups x 4 k-subs; A[blk][i] = W_hhT[unit 4ug+i][k], B[blk][j] = dG[row j][k],
+// k = 256*wave + 64*ks + q.  The 4 k-sub partials and the 8 waves' partials are summed by the pointwise thread.
+constexpr int PKB = 4 * PH / PW;   // gate columns per wave in the backward (256)
+
+__device__ __forceinline__ float tag_word(float v, unsigned bit) {
+  return __uint_as_float((__float_as_uint(v) & ~1u) | bit);
+}
+
+__global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
+  // this wave's K range of dG as [row][k-sub][64 + 4]: the 16 distinct (k-sub, row) addresses of one ds_read_b128
+  // differ by 68*ks + 272*row floats = 16 distinct 16-B bank slots (unpadded they are all 256-B multiples: 16-way)
+  __shared__ __attribute__((aligned(16))) float hs[PW][PRG][4 * 68];
+  __shared__ float part[2][PW][64][9];                                    // partial dh_rec, double buffered (36 KB)
+  __shared__ int role[2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int g, slice;
+  take_role(a.ctrl, role, g, slice);
+  if (slice < 0) return;
+  const int T = a.T, B = a.B, ndir = a.ndir;
+  const int d = ndir == 2 ? (g & 1) : 0;
+  const int rowgroup = ndir == 2 ? (g >> 1) : g;
+  const int r0 = rowgroup * PRG;
+  if (r0 >= a.nb) return;
+  const int64_t ldy = (int64_t)ndir * PH, ldg = (int64_t)ndir * 4 * PH;
+  // W_hhT slice -> registers: lane (ug = lane>>4, ks = (lane>>2)&3, i = lane&3) holds unit 16*slice+4ug+i,
+  // k = 256*wave + 64*ks + q, q = 0..63
+  const int ug = lane >> 4, ks = (lane >> 2) & 3, li = lane & 3;
+  float wreg[64];
+  {
+    const float* wr = a.w + ((int64_t)d * PH + PUC * slice + 4 * ug + li) * (4 * PH) + wave * PKB + 64 * ks;
+#pragma unroll
+    for (int q4 = 0; q4 < 16; ++q4) {
+      const float4 v = *reinterpret_cast<const float4*>(wr + 4 * q4);
+      wreg[4 * q4] = v.x; wreg[4 * q4 + 1] = v.y; wreg[4 * q4 + 2] = v.z; wreg[4 * q4 + 3] = v.w;
+    }
+  }
+  const int pu = tid >> 3, pj = tid & 7;
+  const bool pw_thread = tid < PUC * PRG;
+  const int prow = r0 + pj;
+  const bool prow_ok = pw_thread && prow < a.nb;
+  const int punit = PUC * slice + pu;
+  const int plen = prow_ok ? a.lens[prow] : 0;
+  float dcarry = 0.f;
+  float* xch_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * PRG * 4 * PH;   // + parity * 8*PRG*4H
+  const int64_t par_stride = (int64_t)8 * PRG * 4 * PH;
+  bool aborted = false;
+  // pointwise operands are fetched one step ahead (see the forward kernel)
+  float n_dy = 0.f, n_ct = 0.f, n_cp = 0.f;
+  float4 n_av = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch_step = [&](int sn) {
+    const int tt = d == 0 ? T - 1 - sn : sn;
+    const int ttp = d == 0 ? tt - 1 : tt + 1;
+    const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
+    const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
+    n_dy = a.dy[so];
+    n_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    n_ct = a.c[so];
+    n_cp = hp ? a.c[((int64_t)ttp * B + prow) * ldy + d * PH + punit] : 0.f;
+  };
+  if (prow_ok) fetch_step(0);
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? T - 1 - s : s;
+    const float dyv = n_dy, ct = n_ct, cp = n_cp;
+    const float4 av = n_av;
+    float4* gp = nullptr;
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;      // tag bit of the data written at step s-1
+      const float* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKB + 4 * lane;
+      float4 gr[PRG];
+      unsigned spins = 0;
+      auto load_row = [&](int rr) {
+        // L1-bypassing 16-byte read as two 8-byte agent-scope atomics
+        const u64 lo = granule_load(reinterpret_cast<const u64*>(src + (int64_t)rr * 4 * PH));
+        const u64 hi = granule_load(reinterpret_cast<const u64*>(src + (int64_t)rr * 4 * PH) + 1);
+        gr[rr].x = __uint_as_float((unsigned)lo); gr[rr].y = __uint_as_float((unsigned)(lo >> 32));
+        gr[rr].z = __uint_as_float((unsigned)hi); gr[rr].w = __uint_as_float((unsigned)(hi >> 32));
+      };
+      auto row_bits = [&](int rr) -> unsigned {
+        const unsigned m = (__float_as_uint(gr[rr].x) & 1u) | ((__float_as_uint(gr[rr].y) & 1u) << 1) |
+                           ((__float_as_uint(gr[rr].z) & 1u) << 2) | ((__float_as_uint(gr[rr].w) & 1u) << 3);
+        return want ? m : (~m & 0xFu);
+      };
+      while (true) {
+        // cheap sentinel poll: the last row of this wave's K range (1 KB, touches all 4 producer CUs); a failed
+        // poll of the whole 64 KB per CU would saturate the XCD's L2 and delay the producers themselves
+        load_row(PRG - 1);
+        bool ok = row_bits(PRG - 1) == 0xFu;
+        if (__all(ok)) {
+#pragma unroll
+          for (int rr = 0; rr < PRG - 1; ++rr) load_row(rr);
+          unsigned bits = 0xFu;
+#pragma unroll
+          for (int rr = 0; rr < PRG - 1; ++rr) bits &= row_bits(rr);
+          if (__all(bits == 0xFu)) break;
+        }
+        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
+          aborted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int rr = 0; rr < PRG; ++rr)
+        *reinterpret_cast<float4*>(&hs[wave][rr][68 * (lane >> 4) + 4 * (lane & 15)]) = gr[rr];
+      if (prow_ok && s + 1 < T) fetch_step(s + 1);
+      const float* h0 = &hs[wave][li][68 * ks];
+      const float* h1 = &hs[wave][4 + li][68 * ks];
+#pragma unroll
+      for (int q4 = 0; q4 < 16; ++q4) {
+        const float4 b0 = *reinterpret_cast<const float4*>(h0 + 4 * q4);
+        const float4 b1 = *reinterpret_cast<const float4*>(h1 + 4 * q4);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b1.w, acc1, 0, 0, 0);
+      }
+    }
+    if (s == 0 && prow_ok && T > 1) fetch_step(1);
+    float* pp = &part[s & 1][wave][lane][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; pp[4 + i] = acc1[i]; }
+    __syncthreads();
+    if (pw_thread) {
+      // dh_rec[unit pu][row pj]: lanes 16*(pu>>2) + 4*ks + (pj&3), register 4*(pj>>2) + (pu&3), all ks, all waves
+      float dh = dyv;
+      const int pl = 16 * (pu >> 2) + (pj & 3), pr = 4 * (pj >> 2) + (pu & 3);
+#pragma unroll
+      for (int w2 = 0; w2 < PW; ++w2)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) dh += part[s & 1][w2][pl + 4 * k2][pr];
+      const float tc = tanhf(ct);
+      const float dc = dcarry + dh * av.w * (1.f - tc * tc);
+      float4 da;
+      da.x = dc * av.z * av.x * (1.f - av.x);
+      da.y = dc * cp * av.y * (1.f - av.y);
+      da.z = dc * av.x * (1.f - av.z * av.z);
+      da.w = dh * tc * av.w * (1.f - av.w);
+      float dcn = dc * av.y;
+      if (t >= plen) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
+      if (aborted || flag_load(a.ctrl + 8) != 0u) da.x = __builtin_nanf("");
+      dcarry = dcn;
+      if (prow_ok) *gp = da;
+      const unsigned bit = (((unsigned)s >> 1) & 1u) ^ 1u;
+      float4 tg;
+      tg.x = tag_word(da.x, bit); tg.y = tag_word(da.y, bit); tg.z = tag_word(da.z, bit); tg.w = tag_word(da.w, bit);
+      float* dst = xch_g + (s & 1) * par_stride + (int64_t)pj * 4 * PH + punit * 4;
+      // two 8-byte workgroup-scope (plain, L2-resident) stores; every word carries its own tag
+      __hip_atomic_store((gu64*)dst, ((u64)__float_as_uint(tg.y) << 32) | __float_as_uint(tg.x), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store((gu64*)dst + 1, ((u64)__float_as_uint(tg.w) << 32) | __float_as_uint(tg.z), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+}  // namespace
+
+// Returns ASR_E_SHAPE when the fast path does not apply (caller falls back to asr_lstm_seq_fwd).
+// xch: >= 2*8*8*512 u64 (512 KB), ctrl: >= 16 u32; both are zeroed here on the stream.
+extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
+                                        const int32_t* lens, float* y, float* c, void* xch, void* ctrl,
+                                        asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
+  if (H != PH || (ndir != 1 && ndir != 2) || nb > PRG * (8 / ndir)) return ASR_E_SHAPE;
+  hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(xch, 0, (size_t)2 * 8 * PRG * PH * sizeof(u64), stream);
+  if (e != hipSuccess) return (int)e;
+  PersistArgs a;
+  a.T = T; a.B = B; a.nb = nb; a.ndir = ndir; a.gates = gates; a.w = w_hh; a.lens = lens; a.y = y; a.c = c;
+  a.dy = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
+  const size_t pad = 44 * 1024;     // static 52 KB + 44 KB > 80 KB -> at most one workgroup per CU
+  static bool attr_set = false;     // idempotent attribute, harmless to race
+  if (!attr_set) {
+    e = hipFuncSetAttribute((const void*)lstm_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm_persist_fwd_kernel, dim3(256), dim3(PNT), pad, stream, a);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+// Persistent fast path of asr_lstm_seq_bwd (same arguments and results except that no dcarry scratch is needed).
+// xch: >= 2*8*8*2048 floats (1 MB), ctrl: >= 16 u32.
+extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
+                                        const int32_t* lens, const float* dy, const float* c, void* xch, void* ctrl,
+                                        asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!gates || !w_hhT || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
+  if (H != PH || (ndir != 1 && ndir != 2) || nb > PRG * (8 / ndir)) return ASR_E_SHAPE;
+  hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(xch, 0, (size_t)2 * 8 * PRG * 4 * PH * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  PersistArgs a;
+  a.T = T; a.B = B; a.nb = nb; a.ndir = ndir; a.gates = gates; a.w = w_hhT; a.lens = lens; a.y = nullptr;
+  a.c = const_cast<float*>(c); a.dy = dy; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
+  hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(256), dim3(PNT), 0, stream, a);   // 100 KB static LDS: 1 WG per CU
+  ASR_CHECK_LAUNCH();
+  return 0;
+}

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 EXPORTS = (
     "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
-    "asr_lstm_seq_fwd", "asr_lstm_seq_bwd", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
+    "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_step_bwd", "asr_dec_seq_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
@@ -62,6 +62,8 @@ def load():
                                         c_i64, c_i64, c_p]
     lib.asr_colsum_f32.argtypes = [c_i64, c_i64, c_p, c_i64, c_p, c_i, c_p]
     lib.asr_lstm_seq_fwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_fwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -261,10 +263,37 @@ def _off(t, elems):
     return c_p(_dev(t).data_ptr() + 4 * int(elems))
 
 
+USE_PERSIST = os.environ.get("ASR_PERSIST", "1") != "0"
+_persist_scratch = {}
+
+
+def persist_scratch(device):
+    """(xch, ctrl) scratch of the persistent LSTM kernels, one pair per device (calls are stream-ordered)."""
+    key = str(device)
+    if key not in _persist_scratch:
+        _persist_scratch[key] = (torch.zeros(2 * 8 * 8 * 2048, dtype=torch.int64, device=device),
+                                 torch.zeros(16, dtype=torch.int32, device=device))
+    return _persist_scratch[key]
+
+
+def persist_aborted(device):
+    """True if the last persistent launch on `device` aborted (synchronises; for tests / end-of-step checks)."""
+    key = str(device)
+    return key in _persist_scratch and int(_persist_scratch[key][1][8].item()) != 0
+
+
 def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
     T, B, ndir, H4 = gates.shape
     H = H4 // 4
     lib = load()
+    if USE_PERSIST:
+        xch, ctrl = persist_scratch(gates.device)
+        rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(y), ptr(c),
+                                          c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
+        if rc == 0:
+            return
+        if rc != -2:                      # anything but ASR_E_SHAPE is an error
+            check(rc, "asr_lstm_seq_fwd_persist")
     groups = row_groups(B)
     gh = [graphs_for(i) if use_graphs else None for i in range(len(groups))]     # created on the calling thread
 
@@ -280,6 +309,14 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry):
     T, B, ndir, H4 = gates.shape
     H = H4 // 4
     lib = load()
+    if USE_PERSIST:
+        xch, ctrl = persist_scratch(gates.device)
+        rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hhT), ptr(lens), ptr(dy), ptr(c),
+                                          c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
+        if rc == 0:
+            return
+        if rc != -2:
+            check(rc, "asr_lstm_seq_bwd_persist")
     groups = row_groups(B)
     gh = [graphs_for(i) for i in range(len(groups))]
 

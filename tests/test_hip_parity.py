@@ -478,3 +478,38 @@ def test_edge_shapes(B, T):
     (-lp.mean()).backward()
     for n, gr in _grads(net).items():
         _close(gr, rg[n], atol=1e-6, what="grad " + n)
+
+
+@pytest.mark.parametrize("ndir,B,T,lens", [(2, 32, 9, None), (2, 20, 6, None), (1, 40, 5, None), (2, 3, 4, [4, 2, 1])])
+def test_lstm_persistent_path_h512(ndir, B, T, lens):
+    """H = 512 takes the persistent XCD-local kernel (forward); parity vs the oracle incl. ragged lengths, and the
+    kernel must not have aborted."""
+    dev = _gpu()
+    import ops
+    import hip_backend as hb
+    assert hb.USE_PERSIST
+    H, I = 512, 24
+    g = torch.Generator().manual_seed(B * 10 + T)
+    if lens is None:
+        lens = sorted([int(v) for v in torch.randint(1, T + 1, (B,), generator=g)], reverse=True)
+        lens[0] = T
+    x = torch.randn(B, T, I, generator=g)
+    k = 1.0 / np.sqrt(H)
+    prm = []
+    for d in range(ndir):
+        prm += [torch.empty(4 * H, I).uniform_(-k, k, generator=g), torch.empty(4 * H, H).uniform_(-k, k, generator=g),
+                torch.empty(4 * H).uniform_(-k, k, generator=g), torch.empty(4 * H).uniform_(-k, k, generator=g)]
+    cp = [p.clone().requires_grad_(True) for p in prm]
+    xc = x.clone().requires_grad_(True)
+    ref = torch.cat([O.lstm_direction(xc, lens, *cp[4 * d:4 * d + 4], reverse=(d == 1)) for d in range(ndir)], 2)
+    gp = [p.to(dev).requires_grad_(True) for p in prm]
+    xg = x.to(dev).requires_grad_(True)
+    got = ops.lstm_layer(xg.transpose(0, 1), torch.tensor(lens, dtype=torch.int32, device=dev), gp, ndir)
+    assert not hb.persist_aborted(dev)
+    _close(got.transpose(0, 1), ref, rtol=1e-4, atol=1e-5, what="y (persistent)")
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    got.backward(dy.transpose(0, 1).contiguous().to(dev))
+    _close(xg.grad, xc.grad, rtol=1e-3, atol=1e-5, what="dx")
+    for i, (a, b) in enumerate(zip(gp, cp)):
+        _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
