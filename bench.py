@@ -115,45 +115,88 @@ def cpu_baseline(seconds_budget=25.0):
                        "(T=%d, dropout 0.3), %d torch CPU threads" % (steps, n_s, T_FRAMES, ncores))
 
 
+def tn_gemm_shapes():
+    """The weight-gradient (transA) GEMM launches of ONE cfg-2 train step: (M, N, K, batch)."""
+    c = CFG2
+    H, I, B = c["enc_hidden_dim"], c["input_dim"], B_PER_GPU
+    D, O, E, A, V = c["dec_hidden_dim"], c["att_odim"], c["embedding_dim"], c["att_dim"], c["output_dim"]
+    shapes, t = [], T_FRAMES
+    for layer in range(c["enc_n_layers"]):
+        idim = I if layer == 0 else H
+        shapes.append((8 * H, idim, t * B, 1))                       # dW_ih (both directions)
+        shapes += [(4 * H, H, (t - 1) * B, 1)] * 2                   # dW_hh per direction
+        t2 = (t + 1) // 2
+        shapes.append((H, 4 * H, t2 * B, 1))                         # dW of the pyramid projection
+        t = t2
+    L = int(0.125 * T_FRAMES) + 1
+    shapes += [(A, H, t * B, 1), (O, H, t * B, 1)]                   # mlp_enc, mlp_o (hoisted)
+    shapes += [(V, D + O, L * B, 1), (4 * D, D + O + E, L * B, 1), (A, D, L * B, 1)]   # output layer, cell, mlp_dec
+    shapes.append((t, O, L, B))                                      # dQ, batched over utterances
+    return shapes
+
+
 def kernel_roofline(dev):
-    """Live HIP-event timing of the dominant kernel (the encoder LSTM backward time-step kernel,
-    enc_step_bwd_kernel<1,8,4>) on the layer-0 shape of this workload: every launch of one 800-step sequence
-    is bracketed by events on the launch stream.  Algorithmic flops per launch = the recurrent product
-    dG_t W_hh for both directions: 2 * B * 4H * H * 2 (recurrent term)."""
+    """Dominant kernel by total time (profiles/r01_bench_kernel_stats_v3.csv): gemm_f32_kernel<false,false>, the
+    transA f32-MFMA GEMM that forms every weight gradient.  All of one train step's launches of it are replayed on
+    synthetic operands and timed live with HIP events on the launch stream; `achieved` = algorithmic flops of those
+    launches / their total time, so the average launch duration is directly comparable with rocprofv3's average for
+    that kernel name.  The persistent LSTM kernels (next by time) are timed as well and reported in `also`."""
     import hip_backend as hb
-    H, B, T = CFG2["enc_hidden_dim"], B_PER_GPU, T_FRAMES
-    g = torch.Generator().manual_seed(3)
-    gates = (torch.rand(T, B, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
-    w = (torch.randn(2, H, 4 * H, generator=g) / np.sqrt(H)).to(dev)
-    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
-    dy = torch.randn(T, B, 2 * H, generator=g).to(dev)
-    c = torch.randn(T, B, 2 * H, generator=g).to(dev)
-    dcarry = torch.zeros(B, 2 * H, device=dev)
-    stream = torch.cuda.current_stream()
     lib = hb.load()
-    keep = gates.clone()
-    for _ in range(2):
-        gates.copy_(keep)
-        dcarry.zero_()
+    stream = torch.cuda.current_stream()
+    shapes = tn_gemm_shapes()
+    bufs = []
+    for (M, N, K, batch) in shapes:
+        bufs.append((torch.randn(batch * K, M, device=dev) if batch == 1 else torch.randn(K, batch, M, device=dev),
+                     torch.randn(batch * K, N, device=dev) if batch == 1 else torch.randn(K, batch, N, device=dev),
+                     torch.empty(batch * M, N, device=dev)))
+
+    def run_all():
+        for (M, N, K, batch), (a_, b_, o_) in zip(shapes, bufs):
+            if batch == 1:
+                hb.gemm(a_, b_, trans_a=True, out=o_)
+            else:
+                hb.gemm_batched(a_, b_, o_, True, False, M, N, K, batch * M, batch * N, N, batch, M, N, M * N)
+
+    run_all()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record(stream)
+    for _ in range(reps):
+        run_all()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    total_s = e0.elapsed_time(e1) * 1e-3 / reps
+    flops = sum(2.0 * M * N * K * batch for (M, N, K, batch) in shapes)
+    ach = flops / total_s / 1e12
+    out = dict(bound="mfma", kernel="gemm_f32_kernel<false,false> (transA weight-gradient GEMMs of one step)",
+               achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TF, traffic=None,
+               launches_per_step=len(shapes), us_per_launch=total_s / len(shapes) * 1e6)
+    # secondary: the persistent LSTM sequence kernels on the layer-0 shape (latency-bound chains)
+    try:
+        H, B, T = CFG2["enc_hidden_dim"], B_PER_GPU, T_FRAMES
+        g = torch.Generator().manual_seed(3)
+        gates = (torch.rand(T, B, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
+        w = (torch.randn(2, H, 4 * H, generator=g) / np.sqrt(H)).to(dev)
+        lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        dy = torch.randn(T, B, 2 * H, generator=g).to(dev)
+        c = torch.randn(T, B, 2 * H, generator=g).to(dev)
+        xch, ctrl = hb.persist_scratch(dev)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        hb.check(lib.asr_lstm_seq_bwd(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c),
-                                      hb.ptr(dcarry), None, hb.stream()), "asr_lstm_seq_bwd")   # eager, one stream
+        hb.check(lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy),
+                                              hb.ptr(c), hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()),
+                                              hb.stream()), "asr_lstm_seq_bwd_persist")
         e1.record(stream)
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-    per_launch_s = ms * 1e-3 / T
-    flops = 2.0 * B * 4 * H * H * 2
-    ach = flops / per_launch_s / 1e12
-    traffic = None          # fabric-side bytes per launch from the committed PMC passes (profiles/r01_pmc_lstm_step.json)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_lstm_step.json")) as f:
-            traffic = float(json.load(f)["enc_step_bwd"]["hbm_side_bytes_per_launch"])
-    except Exception:
-        pass
-    return dict(bound="mfma", kernel="enc_step_bwd_kernel<1,8,4>", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                frac=ach / MFMA_F32_PEAK_TF, traffic=traffic, us_per_launch=per_launch_s * 1e6)
+        us_step = e0.elapsed_time(e1) * 1e3 / T
+        out["also"] = dict(kernel="lstm_persist_bwd_kernel", us_per_time_step=us_step,
+                           tflops=2.0 * B * 4 * H * H * 2 / (us_step * 1e-6) / 1e12,
+                           aborted=bool(hb.persist_aborted(dev)))
+    except Exception as exc:    # the fast path is optional
+        out["also"] = dict(error=str(exc))
+    return out
 
 
 def main():
