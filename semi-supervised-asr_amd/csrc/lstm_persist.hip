@@ -21,11 +21,10 @@
 
 namespace {
 
-constexpr int PH = 512;          // hidden size supported by this path
+// Hidden sizes: H % 32 == 0 and H <= 512 (a CU's H/32 units must fit the 16 MFMA blocks; instantiated for 128,
+// 256, 320, 512).  Blocks / lanes beyond a smaller H idle.
 constexpr int PW = 8;            // waves per workgroup
 constexpr int PNT = PW * 64;     // 512 threads
-constexpr int PKW = PH / PW;     // K columns per wave (64)
-constexpr int PUC = PH / 32;     // hidden units per CU (16) = MFMA blocks
 constexpr int PRG = 8;           // batch rows per XCD group
 constexpr unsigned SPIN_LIMIT = 400000u;
 
@@ -83,7 +82,10 @@ __device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g,
 }
 
 // ---------------------------------------------------------------------------------------------------- forward
+template <int PH>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
+  constexpr int PKW = PH / PW;     // K columns per wave
+  constexpr int PUC = PH / 32;     // hidden units per CU (<= 16 MFMA blocks)
   // this wave's K range of h_{t-1}; rows padded by 4 floats so the 4 rows a ds_read_b128 touches (the MFMA blocks
   // broadcast) fall on different bank slots
   __shared__ __attribute__((aligned(16))) float hs[PW][PRG][PKW + 4];
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   // recurrent weights of this CU -> registers: lane owns gate-interleaved row 64*slice+lane, wave owns 64 k's
   float wreg[PKW];
   {
-    const float* wr = a.w + ((int64_t)d * 4 * PH + 64 * slice + lane) * PH + wave * PKW;
+    const int wrow = lane < 4 * PUC ? lane : 0;       // lanes beyond this CU's 4*PUC gate rows idle (results unused)
+    const float* wr = a.w + ((int64_t)d * 4 * PH + 4 * PUC * slice + wrow) * PH + wave * PKW;
 #pragma unroll
     for (int k4 = 0; k4 < PKW / 4; ++k4) {
       const float4 v = *reinterpret_cast<const float4*>(wr + 4 * k4);
@@ -137,18 +140,19 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       // gather this wave's K range of h_{t-1}: 8 rows x 64 units of granules tagged s
-      const u64* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKW + lane;
+      const u64* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKW + (lane < PKW ? lane : 0);
+      const bool gl = lane < PKW;                       // lanes beyond the wave's K range re-read column 0
       u64 gr[PRG];
       unsigned spins = 0;
       while (true) {
         gr[PRG - 1] = granule_load(src + (int64_t)(PRG - 1) * PH);          // sentinel row first (see backward)
-        if (__all((unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
+        if (__all(!gl || (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
           bool ok = true;
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
-          if (__all(ok)) break;
+          if (__all(!gl || ok)) break;
         }
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
           if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
@@ -158,7 +162,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
-      for (int rr = 0; rr < PRG; ++rr) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
+      for (int rr = 0; rr < PRG; ++rr)
+        if (gl) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
       if (prow_ok && s + 1 < T) {     // next step's x-projection, in flight during MFMA / reduce / pointwise / hand-off
         const int tn1 = d == 0 ? s + 1 : T - 2 - s;
         gx_next = *reinterpret_cast<const float4*>(a.gates + (((int64_t)tn1 * B + prow) * ndir + d) * 4 * PH + punit * 4);
@@ -222,16 +227,19 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
 // (the in-place dG used by the weight-gradient GEMMs is untouched).  Float4 traffic both ways.
 // MFMA blocks: 16 = 4 unit-groups x 4 k-subs; A[blk][i] = W_hhT[unit 4ug+i][k], B[blk][j] = dG[row j][k],
 // k = 256*wave + 64*ks + q.  The 4 k-sub partials and the 8 waves' partials are summed by the pointwise thread.
-constexpr int PKB = 4 * PH / PW;   // gate columns per wave in the backward (256)
-
 __device__ __forceinline__ float tag_word(float v, unsigned bit) {
   return __uint_as_float((__float_as_uint(v) & ~1u) | bit);
 }
 
+template <int PH>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
+  constexpr int PUC = PH / 32;       // hidden units per CU
+  constexpr int PKB = 4 * PH / PW;   // gate columns per wave
+  constexpr int PQ = PKB / 4;        // k's per (wave, k-sub)
+  constexpr int PQS = PQ + 4;        // padded LDS stride of a k-sub chunk
   // this wave's K range of dG as [row][k-sub][64 + 4]: the 16 distinct (k-sub, row) addresses of one ds_read_b128
   // differ by 68*ks + 272*row floats = 16 distinct 16-B bank slots (unpadded they are all 256-B multiples: 16-way)
-  __shared__ __attribute__((aligned(16))) float hs[PW][PRG][4 * 68];
+  __shared__ __attribute__((aligned(16))) float hs[PW][PRG][4 * PQS];
   __shared__ float part[2][PW][64][9];                                    // partial dh_rec, double buffered (36 KB)
   __shared__ int role[2];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -248,11 +256,12 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   // W_hhT slice -> registers: lane (ug = lane>>4, ks = (lane>>2)&3, i = lane&3) holds unit 16*slice+4ug+i,
   // k = 256*wave + 64*ks + q, q = 0..63
   const int ug = lane >> 4, ks = (lane >> 2) & 3, li = lane & 3;
-  float wreg[64];
+  float wreg[PQ];
   {
-    const float* wr = a.w + ((int64_t)d * PH + PUC * slice + 4 * ug + li) * (4 * PH) + wave * PKB + 64 * ks;
+    const int wu = 4 * ug + li < PUC ? 4 * ug + li : 0;     // unit groups beyond PUC idle
+    const float* wr = a.w + ((int64_t)d * PH + PUC * slice + wu) * (4 * PH) + wave * PKB + PQ * ks;
 #pragma unroll
-    for (int q4 = 0; q4 < 16; ++q4) {
+    for (int q4 = 0; q4 < PQ / 4; ++q4) {
       const float4 v = *reinterpret_cast<const float4*>(wr + 4 * q4);
       wreg[4 * q4] = v.x; wreg[4 * q4 + 1] = v.y; wreg[4 * q4 + 2] = v.z; wreg[4 * q4 + 3] = v.w;
     }
@@ -290,7 +299,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;      // tag bit of the data written at step s-1
-      const float* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKB + 4 * lane;
+      const bool gl = 4 * lane < PKB;                   // lanes beyond the wave's K range re-read column 0
+      const float* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKB + (gl ? 4 * lane : 0);
       float4 gr[PRG];
       unsigned spins = 0;
       auto load_row = [&](int rr) {
@@ -309,14 +319,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
         // cheap sentinel poll: the last row of this wave's K range (1 KB, touches all 4 producer CUs); a failed
         // poll of the whole 64 KB per CU would saturate the XCD's L2 and delay the producers themselves
         load_row(PRG - 1);
-        bool ok = row_bits(PRG - 1) == 0xFu;
+        bool ok = !gl || row_bits(PRG - 1) == 0xFu;
         if (__all(ok)) {
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) load_row(rr);
           unsigned bits = 0xFu;
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) bits &= row_bits(rr);
-          if (__all(bits == 0xFu)) break;
+          if (__all(!gl || bits == 0xFu)) break;
         }
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
           if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
@@ -327,12 +337,12 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       }
 #pragma unroll
       for (int rr = 0; rr < PRG; ++rr)
-        *reinterpret_cast<float4*>(&hs[wave][rr][68 * (lane >> 4) + 4 * (lane & 15)]) = gr[rr];
+        if (gl) *reinterpret_cast<float4*>(&hs[wave][rr][PQS * ((4 * lane) / PQ) + (4 * lane) % PQ]) = gr[rr];
       if (prow_ok && s + 1 < T) fetch_step(s + 1);
-      const float* h0 = &hs[wave][li][68 * ks];
-      const float* h1 = &hs[wave][4 + li][68 * ks];
+      const float* h0 = &hs[wave][li][PQS * ks];
+      const float* h1 = &hs[wave][4 + li][PQS * ks];
 #pragma unroll
-      for (int q4 = 0; q4 < 16; ++q4) {
+      for (int q4 = 0; q4 < PQ / 4; ++q4) {
         const float4 b0 = *reinterpret_cast<const float4*>(h0 + 4 * q4);
         const float4 b1 = *reinterpret_cast<const float4*>(h1 + 4 * q4);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b0.x, acc0, 0, 0, 0);
@@ -385,49 +395,86 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
 
 }  // namespace
 
-// Returns ASR_E_SHAPE when the fast path does not apply (caller falls back to asr_lstm_seq_fwd).
-// xch: >= 2*8*8*512 u64 (512 KB), ctrl: >= 16 u32; both are zeroed here on the stream.
+namespace {
+
+template <int PH>
+int launch_fwd(const PersistArgs& a, hipStream_t stream) {
+  const size_t stat = sizeof(float) * ((size_t)PW * PRG * (PH / PW + 4) + 2 * PW * 64 * 9) + 64;
+  const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_kernel<PH>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((lstm_persist_fwd_kernel<PH>), dim3(256), dim3(PNT), pad, stream, a);
+  return 0;
+}
+
+template <int PH>
+int launch_bwd(const PersistArgs& a, hipStream_t stream) {
+  const size_t stat = sizeof(float) * ((size_t)PW * PRG * 4 * (PH / 2 / 4 + 4) + 2 * PW * 64 * 9) + 64;
+  const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel<PH>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((lstm_persist_bwd_kernel<PH>), dim3(256), dim3(PNT), pad, stream, a);
+  return 0;
+}
+
+bool persist_supported(int H) { return H == 128 || H == 256 || H == 320 || H == 512; }
+
+}  // namespace
+
+// Returns ASR_E_SHAPE when the fast path does not apply (caller falls back to asr_lstm_seq_fwd).  Batches larger
+// than 8 * (8 / ndir) rows run as consecutive launches over row blocks (rows are independent).
+// xch: >= 1 MB, ctrl: >= 64 B; both are zeroed here on the stream before every launch.
 extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
                                         const int32_t* lens, float* y, float* c, void* xch, void* ctrl,
                                         asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
-  if (H != PH || (ndir != 1 && ndir != 2) || nb > PRG * (8 / ndir)) return ASR_E_SHAPE;
-  hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(xch, 0, (size_t)2 * 8 * PRG * PH * sizeof(u64), stream);
-  if (e != hipSuccess) return (int)e;
-  PersistArgs a;
-  a.T = T; a.B = B; a.nb = nb; a.ndir = ndir; a.gates = gates; a.w = w_hh; a.lens = lens; a.y = y; a.c = c;
-  a.dy = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
-  const size_t pad = 44 * 1024;     // static 52 KB + 44 KB > 80 KB -> at most one workgroup per CU
-  static bool attr_set = false;     // idempotent attribute, harmless to race
-  if (!attr_set) {
-    e = hipFuncSetAttribute((const void*)lstm_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  if (!persist_supported(H) || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
+  const int rows_per_launch = PRG * (8 / ndir);
+  if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;          // large batches: the per-step kernels are the better fit
+  for (int rb = 0; rb < nb; rb += rows_per_launch) {
+    hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    e = hipMemsetAsync(xch, 0, (size_t)2 * 8 * PRG * H * sizeof(u64), stream);
+    if (e != hipSuccess) return (int)e;
+    PersistArgs a;
+    a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
+    a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
+    a.y = y + (int64_t)rb * ndir * H; a.c = c + (int64_t)rb * ndir * H;
+    a.dy = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
+    int rc = H == 512 ? launch_fwd<512>(a, stream) : H == 320 ? launch_fwd<320>(a, stream)
+           : H == 256 ? launch_fwd<256>(a, stream) : launch_fwd<128>(a, stream);
+    if (rc) return rc;
   }
-  hipLaunchKernelGGL(lstm_persist_fwd_kernel, dim3(256), dim3(PNT), pad, stream, a);
   ASR_CHECK_LAUNCH();
   return 0;
 }
 
 // Persistent fast path of asr_lstm_seq_bwd (same arguments and results except that no dcarry scratch is needed).
-// xch: >= 2*8*8*2048 floats (1 MB), ctrl: >= 16 u32.
 extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                                         const int32_t* lens, const float* dy, const float* c, void* xch, void* ctrl,
                                         asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hhT || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
-  if (H != PH || (ndir != 1 && ndir != 2) || nb > PRG * (8 / ndir)) return ASR_E_SHAPE;
-  hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(xch, 0, (size_t)2 * 8 * PRG * 4 * PH * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  PersistArgs a;
-  a.T = T; a.B = B; a.nb = nb; a.ndir = ndir; a.gates = gates; a.w = w_hhT; a.lens = lens; a.y = nullptr;
-  a.c = const_cast<float*>(c); a.dy = dy; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
-  hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(256), dim3(PNT), 0, stream, a);   // 100 KB static LDS: 1 WG per CU
+  if (!persist_supported(H) || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
+  const int rows_per_launch = PRG * (8 / ndir);
+  if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;
+  for (int rb = 0; rb < nb; rb += rows_per_launch) {
+    hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(xch, 0, (size_t)2 * 8 * PRG * 4 * H * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    PersistArgs a;
+    a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
+    a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hhT; a.lens = lens + rb; a.y = nullptr;
+    a.c = const_cast<float*>(c) + (int64_t)rb * ndir * H; a.dy = dy + (int64_t)rb * ndir * H;
+    a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
+    int rc = H == 512 ? launch_bwd<512>(a, stream) : H == 320 ? launch_bwd<320>(a, stream)
+           : H == 256 ? launch_bwd<256>(a, stream) : launch_bwd<128>(a, stream);
+    if (rc) return rc;
+  }
   ASR_CHECK_LAUNCH();
   return 0;
 }

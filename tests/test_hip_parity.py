@@ -480,15 +480,17 @@ def test_edge_shapes(B, T):
         _close(gr, rg[n], atol=1e-6, what="grad " + n)
 
 
-@pytest.mark.parametrize("ndir,B,T,lens", [(2, 32, 9, None), (2, 20, 6, None), (1, 40, 5, None), (2, 3, 4, [4, 2, 1])])
-def test_lstm_persistent_path_h512(ndir, B, T, lens):
-    """H = 512 takes the persistent XCD-local kernel (forward); parity vs the oracle incl. ragged lengths, and the
-    kernel must not have aborted."""
+@pytest.mark.parametrize("ndir,B,T,lens,H", [(2, 32, 9, None, 512), (2, 20, 6, None, 512), (1, 40, 5, None, 512),
+                                              (2, 3, 4, [4, 2, 1], 512), (2, 48, 5, None, 320), (2, 7, 6, None, 128),
+                                              (1, 70, 4, None, 256)])
+def test_lstm_persistent_path(ndir, B, T, lens, H):
+    """H in {128,256,320,512} takes the persistent XCD-local kernels (forward and backward); parity vs the oracle
+    incl. ragged lengths and batches spanning several row blocks; the kernels must not have aborted."""
     dev = _gpu()
     import ops
     import hip_backend as hb
     assert hb.USE_PERSIST
-    H, I = 512, 24
+    I = 24
     g = torch.Generator().manual_seed(B * 10 + T)
     if lens is None:
         lens = sorted([int(v) for v in torch.randint(1, T + 1, (B,), generator=g)], reverse=True)
