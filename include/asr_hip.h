@@ -133,10 +133,13 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
                      const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
                      asr_stream_t stream);
 /* Persistent fast path of asr_lstm_seq_bwd (same conditions / abort convention as asr_lstm_seq_fwd_persist;
- * xch >= 1 MB).  The exchanged copy of dG carries a 1-bit tag in each mantissa LSB; the in-place dG is exact. */
+ * xch >= 1 MB).  The exchanged copy of dG carries a 1-bit tag in each mantissa LSB; the in-place dG is exact.
+ * If y (forward hidden states) and dw_hh ([ndir][4H][H], gate-interleaved, zero-filled or holding a running sum)
+ * are given, the recurrent weight gradient sum_t dG_t^T h_{t-1} is accumulated into dw_hh inside the kernel
+ * (fp32 atomics across the row groups) and the caller skips that GEMM. */
 int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
-                             const int32_t* lens, const float* dy, const float* c, void* xch, void* ctrl,
-                             asr_stream_t stream);
+                             const int32_t* lens, const float* dy, const float* c, const float* y,
+                             float* dw_hh, void* xch, void* ctrl, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pyramidal pair-concat (model.py:85-92), time-major:

@@ -40,6 +40,8 @@ struct PersistArgs {
   float* y;             // fwd: out y;  bwd: unused
   float* c;             // [T][B][ndir*H]
   const float* dy;      // bwd
+  const float* yfwd;    // bwd: forward hidden states [T][B][ndir*H] (partner of dG in dW_hh), or NULL
+  float* dw;            // bwd: dW_hh [ndir][4H][H] gate-interleaved, accumulated with atomics, or NULL
   u64* xch;             // fwd: [2][8][PRG][H] granules;  bwd: [2][8][PRG][4H]
   unsigned* ctrl;       // [0..7] tickets per XCC, [8] abort, [9] error code
 };
@@ -241,8 +243,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   // differ by 68*ks + 272*row floats = 16 distinct 16-B bank slots (unpadded they are all 256-B multiples: 16-way)
   __shared__ __attribute__((aligned(16))) float hs[PW][PRG][4 * PQS];
   __shared__ float part[2][PW][64][9];                                    // partial dh_rec, double buffered (36 KB)
+  __shared__ float ysl[2][PRG][16];                                       // this CU's slice of h at the current time
   __shared__ int role[2];
+  constexpr int NKQ = (PKB + 63) / 64;                                    // 64-column chunks of the wave's K range
   const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 2 * PRG * 16) (&ysl[0][0][0])[tid] = 0.f;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int g, slice;
   take_role(a.ctrl, role, g, slice);
@@ -277,8 +282,15 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   const int64_t par_stride = (int64_t)8 * PRG * 4 * PH;
   bool aborted = false;
   // pointwise operands are fetched one step ahead (see the forward kernel)
-  float n_dy = 0.f, n_ct = 0.f, n_cp = 0.f;
+  float n_dy = 0.f, n_ct = 0.f, n_cp = 0.f, n_y = 0.f;
   float4 n_av = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool fuse_dw = a.dw != nullptr && a.yfwd != nullptr;
+  // dW_hh accumulators: [64-column chunk][unit group] 4x4 blocks, kept in registers for the whole sequence
+  f32x4 dwacc[NKQ][4];
+#pragma unroll
+  for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) dwacc[kq][u4] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto fetch_step = [&](int sn) {
     const int tt = d == 0 ? T - 1 - sn : sn;
     const int ttp = d == 0 ? tt - 1 : tt + 1;
@@ -288,6 +300,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     n_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
     n_ct = a.c[so];
     n_cp = hp ? a.c[((int64_t)ttp * B + prow) * ldy + d * PH + punit] : 0.f;
+    if (fuse_dw) n_y = a.yfwd[so];
   };
   if (prow_ok) fetch_step(0);
   for (int s = 0; s < T; ++s) {
@@ -296,6 +309,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     const float4 av = n_av;
     float4* gp = nullptr;
     if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (fuse_dw && pw_thread) ysl[s & 1][pj][pu] = prow_ok ? n_y : 0.f;     // h_t of this CU's units (read after the barrier)
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;      // tag bit of the data written at step s-1
@@ -390,6 +404,43 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       __hip_atomic_store((gu64*)dst + 1, ((u64)__float_as_uint(tg.w) << 32) | __float_as_uint(tg.z), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    // Fused recurrent weight gradient: dW_hh[k][u] += sum_rows dG_{t_next}[row][k] * h_t[row][u].  The gathered dG
+    // tile is still in this wave's LDS region and h_t is the partner of dG_{t_next} in both directions.  Placed
+    // after the publish so that it fills the wait for the next hand-off.  Blocks = 16 groups of 4 gate columns,
+    // A = dG (4 columns), B = h (4 units), K = one batch row per instruction.
+    if (fuse_dw && s > 0) {
+      const int kb4 = lane;                      // column within the 64-column chunk (= 4*block + i)
+      const int jj = lane & 3;
+#pragma unroll
+      for (int rr = 0; rr < PRG; ++rr) {
+        float bv[4];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) bv[u4] = ysl[s & 1][rr][4 * u4 + jj];
+#pragma unroll
+        for (int kq = 0; kq < NKQ; ++kq) {
+          const int cidx = 64 * kq + kb4;
+          const float av2 = cidx < PKB ? hs[wave][rr][PQS * (cidx / PQ) + cidx % PQ] : 0.f;
+#pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4)
+            dwacc[kq][u4] = __builtin_amdgcn_mfma_f32_4x4x1f32(av2, bv[u4], dwacc[kq][u4], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (fuse_dw) {
+    // D[i][j] of block kb: gate column 64*kq + 4*kb + i of this wave's range, unit 4*u4 + j of this CU; the 4 row
+    // groups (XCDs) of a direction add into the same dW_hh
+    const int kb = lane >> 2, jj = lane & 3;
+#pragma unroll
+    for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cidx = 64 * kq + 4 * kb + i, un = 4 * u4 + jj;
+          if (cidx < PKB && un < PUC)
+            atomicAdd(a.dw + ((int64_t)d * 4 * PH + wave * PKB + cidx) * PH + PUC * slice + un, dwacc[kq][u4][i]);
+        }
   }
 }
 
@@ -443,7 +494,7 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
     a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
     a.y = y + (int64_t)rb * ndir * H; a.c = c + (int64_t)rb * ndir * H;
-    a.dy = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
+    a.dy = nullptr; a.yfwd = nullptr; a.dw = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
     int rc = H == 512 ? launch_fwd<512>(a, stream) : H == 320 ? launch_fwd<320>(a, stream)
            : H == 256 ? launch_fwd<256>(a, stream) : launch_fwd<128>(a, stream);
     if (rc) return rc;
@@ -454,8 +505,8 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
 
 // Persistent fast path of asr_lstm_seq_bwd (same arguments and results except that no dcarry scratch is needed).
 extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
-                                        const int32_t* lens, const float* dy, const float* c, void* xch, void* ctrl,
-                                        asr_stream_t stream_) {
+                                        const int32_t* lens, const float* dy, const float* c, const float* y,
+                                        float* dw_hh, void* xch, void* ctrl, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hhT || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
   if (!persist_supported(H) || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
@@ -470,6 +521,7 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
     a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hhT; a.lens = lens + rb; a.y = nullptr;
     a.c = const_cast<float*>(c) + (int64_t)rb * ndir * H; a.dy = dy + (int64_t)rb * ndir * H;
+    a.yfwd = (y && dw_hh) ? y + (int64_t)rb * ndir * H : nullptr; a.dw = (y && dw_hh) ? dw_hh : nullptr;
     a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
     int rc = H == 512 ? launch_bwd<512>(a, stream) : H == 320 ? launch_bwd<320>(a, stream)
            : H == 256 ? launch_bwd<256>(a, stream) : launch_bwd<128>(a, stream);

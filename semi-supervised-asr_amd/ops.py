@@ -100,7 +100,7 @@ def _lstm_workspace(T, B, H, ndir, dev, with_bwd):
               lens=torch.empty(B, dtype=torch.int32, device=dev))
     if with_bwd:
         ws.update(w_hhT=torch.empty(ndir, H, 4 * H, **f32), dy=torch.empty(T, B, ndir * H, **f32),
-                  dcarry=torch.empty(B, ndir * H, **f32))
+                  dcarry=torch.empty(B, ndir * H, **f32), dw_hh=torch.empty(ndir, 4 * H, H, **f32))
     return ws
 
 
@@ -146,7 +146,9 @@ class _LstmLayer(torch.autograd.Function):
         ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2))
         ws["dcarry"].zero_()
         gates, y = ws["gates"], ws["y"]
-        hb.lstm_seq_bwd(gates, ws["w_hhT"], ws["lens"], ws["dy"], ws["c"], ws["dcarry"])    # gates <- dG in place
+        ws["dw_hh"].zero_()
+        fused_dw = hb.lstm_seq_bwd(gates, ws["w_hhT"], ws["lens"], ws["dy"], ws["c"], ws["dcarry"], y=y,
+                                   dw_hh=ws["dw_hh"])                                     # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = hb.gemm(dG, x2, trans_a=True)                     # [ndir*4H, I]
@@ -155,7 +157,9 @@ class _LstmLayer(torch.autograd.Function):
         unperm = gate_unperm(H, dev)
         grads = []
         for d in range(ndir):
-            if T > 1:
+            if fused_dw:       # accumulated inside the persistent kernel
+                dw_hh = ws["dw_hh"][d]
+            elif T > 1:
                 if d == 0:     # h_{t-1} = y[t-1]
                     a = dG[B:, d * 4 * H:(d + 1) * 4 * H]
                     hprev = y2[:(T - 1) * B, d * H:(d + 1) * H]

@@ -1,20 +1,30 @@
-"""Runs only the dominant kernel chain (LSTM backward step kernel, layer-0 shape) so that a rocprofv3 --pmc pass
-stays short:  rocprofv3 --pmc FETCH_SIZE -- python3 tools/pmc_probe.py   (and again with WRITE_SIZE)."""
+"""Runs only the persistent LSTM sequence kernels (cfg-2 layer-0 shape, T=800, B=32, H=512, both directions, with
+the fused dW_hh) so that a rocprofv3 --pmc pass stays short:
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/pmc_probe.py
+and again with WRITE_SIZE (the two counters do not fit one pass).  `python3 tools/pmc_probe.py step` runs the
+per-time-step fallback kernels instead."""
 import sys, os
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0]=[ROOT, ROOT+'/semi-supervised-asr_amd']
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/semi-supervised-asr_amd']
 import torch, numpy as np, hip_backend as hb
-dev=torch.device('cuda'); lib=hb.load()
-H,B,T=512,32,int(sys.argv[1]) if len(sys.argv)>1 else 64
-g=torch.Generator().manual_seed(3)
-gates=(torch.rand(T,B,2,4*H,generator=g)*0.8+0.1).to(dev)
-w=(torch.randn(2,H,4*H,generator=g)/np.sqrt(H)).to(dev); wf=(torch.randn(2,4*H,H,generator=g)/np.sqrt(H)).to(dev)
-lens=torch.full((B,),T,dtype=torch.int32,device=dev)
-dy=torch.randn(T,B,2*H,generator=g).to(dev); c=torch.randn(T,B,2*H,generator=g).to(dev)
-y=torch.empty(T,B,2*H,device=dev); c2=torch.empty(T,B,2*H,device=dev)
-dcarry=torch.zeros(B,2*H,device=dev)
-g2=gates.clone()
-hb.check(lib.asr_lstm_seq_fwd(T,B,B,H,2,hb.ptr(g2),hb.ptr(wf),hb.ptr(lens),hb.ptr(y),hb.ptr(c2),None,hb.stream()),'fwd')
-hb.check(lib.asr_lstm_seq_bwd(T,B,B,H,2,hb.ptr(gates),hb.ptr(w),hb.ptr(lens),hb.ptr(dy),hb.ptr(c),hb.ptr(dcarry),None,hb.stream()),'bwd')
+mode = sys.argv[1] if len(sys.argv) > 1 else 'persist'
+dev = torch.device('cuda'); lib = hb.load()
+H, B, T = 512, 32, int(sys.argv[2]) if len(sys.argv) > 2 else 800
+g = torch.Generator().manual_seed(3)
+gates = (torch.rand(T, B, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
+w = (torch.randn(2, H, 4 * H, generator=g) / np.sqrt(H)).to(dev); wf = (torch.randn(2, 4 * H, H, generator=g) / np.sqrt(H)).to(dev)
+lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+dy = (torch.randn(T, B, 2 * H, generator=g) * 0.01).to(dev); c = torch.randn(T, B, 2 * H, generator=g).to(dev)
+y = torch.empty(T, B, 2 * H, device=dev); c2 = torch.empty(T, B, 2 * H, device=dev)
+dcarry = torch.zeros(B, 2 * H, device=dev); dw = torch.zeros(2, 4 * H, H, device=dev)
+g2 = gates.clone()
+if mode == 'persist':
+    xch, ctrl = hb.persist_scratch(dev)
+    x_, c_ = hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr())
+    hb.check(lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, hb.ptr(g2), hb.ptr(wf), hb.ptr(lens), hb.ptr(y), hb.ptr(c2), x_, c_, hb.stream()), 'fwd')
+    hb.check(lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c), hb.ptr(y), hb.ptr(dw), x_, c_, hb.stream()), 'bwd')
+else:
+    hb.check(lib.asr_lstm_seq_fwd(T, B, B, H, 2, hb.ptr(g2), hb.ptr(wf), hb.ptr(lens), hb.ptr(y), hb.ptr(c2), None, hb.stream()), 'fwd')
+    hb.check(lib.asr_lstm_seq_bwd(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c), hb.ptr(dcarry), None, hb.stream()), 'bwd')
 torch.cuda.synchronize()
-print('done')
+print('done', 'aborted' if mode == 'persist' and hb.persist_aborted(dev) else '')
