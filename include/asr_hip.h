@@ -207,6 +207,13 @@ int asr_dec_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream);
  * mlp_o(context) to X[s+1][:,D:D+O] and the weights to ws[s] */
 int asr_att_step_fwd(const asr_dec_fwd_t* p, int s, asr_stream_t stream);
 int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, void* graphs, asr_stream_t stream);
+/* Persistent fast path of asr_dec_seq_fwd(p, 0, L): all L teacher-forced steps in one launch per 32 rows (each XCD
+ * owns 4 utterances; W_cat, W_dec and the P slice stay in registers, exchanges stay in the XCD's L2).  Same results
+ * except that Dproj is not written.  Returns ASR_E_SHAPE (-2) when it does not apply ((D,A,O,E) other than
+ * (512,512,512,128) / (320,320,320,128), Tp > 128, C > 16, K > 100, not an 8 x 32-CU device): use asr_dec_seq_fwd.
+ * xch >= 2 MB and ctrl >= 64 B are caller-allocated scratch (shared with the LSTM fast path); abort convention as
+ * asr_lstm_seq_fwd_persist. */
+int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream);
 
 /* Backward of one decoder step (reverse order s = L-1..0).
  *   G     [L+1][B][KX]  gradient wrt X; on entry G[s+1][:, 0:D+O] holds every other

@@ -17,7 +17,7 @@
 // Roles come from HW_REG_XCC_ID + a per-XCC ticket.  Every spin is bounded; on a timeout or an unexpected
 // placement the kernel raises an abort word, poisons its outputs with NaN and drains — the host falls back to
 // the per-step kernels.  1 workgroup per CU is enforced by the LDS request, so 256 workgroups are co-resident.
-#include "common.h"
+#include "persist.h"
 
 namespace {
 
@@ -26,11 +26,6 @@ namespace {
 constexpr int PW = 8;            // waves per workgroup
 constexpr int PNT = PW * 64;     // 512 threads
 constexpr int PRG = 8;           // batch rows per XCD group
-constexpr unsigned SPIN_LIMIT = 400000u;
-
-typedef unsigned long long u64;
-typedef __attribute__((address_space(1))) u64 gu64;
-typedef __attribute__((address_space(1))) unsigned gu32;
 
 struct PersistArgs {
   int T, B, nb, ndir;
@@ -45,43 +40,6 @@ struct PersistArgs {
   u64* xch;             // fwd: [2][8][PRG][H] granules;  bwd: [2][8][PRG][4H]
   unsigned* ctrl;       // [0..7] tickets per XCC, [8] abort, [9] error code
 };
-
-__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; }
-
-__device__ __forceinline__ u64 granule_load(const u64* p) {
-  return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Producer and consumers of a group sit on the SAME XCD by construction (the group id is the XCC id), so the
-// granule store may stay in that XCD's L2 (plain store; the L1 is write-through) instead of being written through
-// to the memory side (sc1), which would make every consumer poll a fabric round trip.  Consumers bypass their L1.
-__device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
-#ifdef ASR_GRANULE_SC1
-  __hip_atomic_store((gu64*)p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  __hip_atomic_store((gu64*)p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-__device__ __forceinline__ unsigned flag_load(const unsigned* p) {
-  return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void flag_store(unsigned* p, unsigned v) {
-  __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// role of this workgroup: (group g in 0..7, slice in 0..31); slice < 0 = no role
-__device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g, int& slice) {
-  if (threadIdx.x == 0) {
-    const unsigned x = xcc_id() & 7u;
-    const unsigned tk = atomicAdd(ctrl + x, 1u);
-    lds_role[0] = (int)x;
-    lds_role[1] = tk < 32u ? (int)tk : -1;
-    if (tk >= 32u) { flag_store(ctrl + 9, 2u); flag_store(ctrl + 8, 1u); }   // unexpected placement
-  }
-  __syncthreads();
-  g = lds_role[0];
-  slice = lds_role[1];
-}
 
 // ---------------------------------------------------------------------------------------------------- forward
 template <int PH>
@@ -229,10 +187,6 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
 // (the in-place dG used by the weight-gradient GEMMs is untouched).  Float4 traffic both ways.
 // MFMA blocks: 16 = 4 unit-groups x 4 k-subs; A[blk][i] = W_hhT[unit 4ug+i][k], B[blk][j] = dG[row j][k],
 // k = 256*wave + 64*ks + q.  The 4 k-sub partials and the 8 waves' partials are summed by the pointwise thread.
-__device__ __forceinline__ float tag_word(float v, unsigned bit) {
-  return __uint_as_float((__float_as_uint(v) & ~1u) | bit);
-}
-
 template <int PH>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   constexpr int PUC = PH / 32;       // hidden units per CU
@@ -474,6 +428,19 @@ bool persist_supported(int H) { return H == 128 || H == 256 || H == 320 || H == 
 
 }  // namespace
 
+// The role assignment needs 8 XCDs x 32 CUs, one workgroup per CU (MI355X); anything else takes the per-step path.
+bool asr_persist_device_ok() {
+  static int cached = -1;
+  if (cached < 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return false;
+    cached = cus == 256 ? 1 : 0;
+  }
+  return cached == 1;
+}
+
 // Returns ASR_E_SHAPE when the fast path does not apply (caller falls back to asr_lstm_seq_fwd).  Batches larger
 // than 8 * (8 / ndir) rows run as consecutive launches over row blocks (rows are independent).
 // xch: >= 1 MB, ctrl: >= 64 B; both are zeroed here on the stream before every launch.
@@ -482,7 +449,7 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
                                         asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
-  if (!persist_supported(H) || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
+  if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   const int rows_per_launch = PRG * (8 / ndir);
   if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;          // large batches: the per-step kernels are the better fit
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
@@ -509,7 +476,7 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
                                         float* dw_hh, void* xch, void* ctrl, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hhT || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
-  if (!persist_supported(H) || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
+  if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   const int rows_per_launch = PRG * (8 / ndir);
   if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;
   for (int rb = 0; rb < nb; rb += rows_per_launch) {

@@ -1,0 +1,96 @@
+// persist.h — shared pieces of the persistent, XCD-local sequence kernels (lstm_persist.hip, dec_persist.hip):
+// role assignment from HW_REG_XCC_ID, the L2-resident exchange primitives and the bounded poll.
+//
+// Exchange protocol.  Producer and consumers of a group sit on the SAME XCD by construction (the group id is the
+// XCC id), so a producer's store may stay in that XCD's L2 (plain workgroup-scope store; the L1 is write-through)
+// and consumers read with agent-scope (sc1) loads that bypass their stale L1.  The data is the flag: either an
+// 8-byte {tag, value} granule, or a bare fp32 word whose mantissa LSB is a validity bit that flips each time the
+// slot is rewritten (buffers start zeroed = invalid).  No fences, no counters.  Every spin is bounded; a timeout
+// raises the abort word ctrl[8] (reason in ctrl[9]) and every other poll loop drains.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+constexpr unsigned SPIN_LIMIT = 400000u;
+
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; }
+
+__device__ __forceinline__ u64 granule_load(const u64* p) {
+  return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(u64* p, unsigned tag, float v) {
+  __hip_atomic_store((gu64*)p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned flag_load(const unsigned* p) {
+  return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_store(unsigned* p, unsigned v) {
+  __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LSB-tagged fp32 words
+__device__ __forceinline__ float tag_word(float v, unsigned bit) {
+  return __uint_as_float((__float_as_uint(v) & ~1u) | bit);
+}
+__device__ __forceinline__ unsigned tag_bit_of_step(int s) { return (((unsigned)s >> 1) & 1u) ^ 1u; }
+__device__ __forceinline__ void word_store(float* p, float v, unsigned bit) {
+  __hip_atomic_store((gu32*)p, (__float_as_uint(v) & ~1u) | bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// role of this workgroup: (group g in 0..7 = XCC id, slice in 0..31 = arrival ticket); slice < 0 = no role
+__device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g, int& slice) {
+  if (threadIdx.x == 0) {
+    const unsigned x = xcc_id() & 7u;
+    const unsigned tk = atomicAdd(ctrl + x, 1u);
+    lds_role[0] = (int)x;
+    lds_role[1] = tk < 32u ? (int)tk : -1;
+    if (tk >= 32u) { flag_store(ctrl + 9, 2u); flag_store(ctrl + 8, 1u); }   // unexpected placement
+  }
+  __syncthreads();
+  g = lds_role[0];
+  slice = lds_role[1];
+}
+
+// Poll N 8-byte slots, each holding two LSB-tagged fp32 words, until every word carries tag bit `want`.  The last
+// slot is the sentinel: the other N-1 are only fetched once it is valid (a failed poll of everything would
+// saturate the XCD's L2 and delay the producers themselves).  Lanes without work point at any slot that becomes
+// valid in the same hand-off.  Returns with `aborted` set (values undefined) on a timeout or a raised abort word.
+template <int N>
+__device__ __forceinline__ void poll_pairs(const u64* const (&p)[N], unsigned want, u64 (&v)[N], unsigned* ctrl,
+                                           bool& aborted, unsigned code) {
+  const u64 m = 0x0000000100000001ull;
+  const u64 expect = want ? m : 0ull;
+  if (aborted) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = 0ull;
+    return;
+  }
+  unsigned spins = 0;
+  while (true) {
+    v[N - 1] = granule_load(p[N - 1]);
+    if (__all((v[N - 1] & m) == expect)) {
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < N - 1; ++i) v[i] = granule_load(p[i]);
+#pragma unroll
+      for (int i = 0; i < N - 1; ++i) ok = ok && ((v[i] & m) == expect);
+      if (__all(ok)) return;
+    }
+    if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(ctrl + 8) != 0u)) {
+      if ((threadIdx.x & 63) == 0) { flag_store(ctrl + 9, code); flag_store(ctrl + 8, 1u); }
+      aborted = true;
+      return;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ float pair_lo(u64 v) { return __uint_as_float((unsigned)v); }
+__device__ __forceinline__ float pair_hi(u64 v) { return __uint_as_float((unsigned)(v >> 32)); }
+
+}  // namespace

@@ -327,13 +327,24 @@ class _DecoderSeq(torch.autograd.Function):
             if drop:
                 Xd[:L, :, D + O:] = X[:L, :, D + O:] * xmask[:, :, O:]
             groups = hb.row_groups(B)
-            gh = [hb.graphs_for(i) if pooled else None for i in range(len(groups))]
+            done = False
+            if hb.USE_PERSIST_DEC and len(groups) == 1:          # one launch for the whole sequence
+                fg = _dec_fwd_struct(d, 0, B)
+                xch, ctrl = hb.persist_scratch(dev)
+                rc = lib.asr_dec_seq_fwd_persist(ctypes.byref(fg), ctypes.c_void_p(xch.data_ptr()),
+                                                 ctypes.c_void_p(ctrl.data_ptr()), hb.stream())
+                if rc == 0:
+                    done = True
+                elif rc != -2:                                  # -2: shape/device not covered by the fast path
+                    hb.check(rc, "asr_dec_seq_fwd_persist")
+            if not done:
+                gh = [hb.graphs_for(i) if pooled else None for i in range(len(groups))]
 
-            def run(gi, grp, st):
-                fg = _dec_fwd_struct(d, grp[0], grp[1])
-                hb.check(lib.asr_dec_seq_fwd(ctypes.byref(fg), 0, L, gh[gi], st), "asr_dec_seq_fwd")
+                def run(gi, grp, st):
+                    fg = _dec_fwd_struct(d, grp[0], grp[1])
+                    hb.check(lib.asr_dec_seq_fwd(ctypes.byref(fg), 0, L, gh[gi], st), "asr_dec_seq_fwd")
 
-            hb.run_grouped(groups, run)
+                hb.run_grouped(groups, run)
             logits = hb.gemm(X[1:].view(L * B, KX)[:, :D + O], w_out_c, trans_b=True, bias=b_out).view(L, B, V)
             pred = logits.argmax(-1)
         else:

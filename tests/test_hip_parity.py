@@ -515,3 +515,64 @@ def test_lstm_persistent_path(ndir, B, T, lens, H):
     _close(xg.grad, xc.grad, rtol=1e-3, atol=1e-5, what="dx")
     for i, (a, b) in enumerate(zip(gp, cp)):
         _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,B,Tp,L,drop", [(512, 32, 100, 6, True), (512, 7, 37, 4, False), (320, 32, 100, 5, True),
+                                             (512, 40, 100, 3, False), (512, 32, 128, 3, True), (320, 5, 9, 4, False)])
+def test_decoder_persistent_path(dim, B, Tp, L, drop):
+    """The persistent XCD-local decoder forward kernel (one launch for the whole teacher-forced sequence) against the
+    per-step kernels on the same inputs: outputs and every gradient (the backward consumes the buffers it saved).
+    The tiny/cfg-1 end-to-end tests hold the per-step kernels to the oracle; cfg-2 end to end covers this path."""
+    dev = _gpu()
+    import ops
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(13 + B + Tp)
+    D = A = O = dim
+    E, C, K, V = 128, 10, 100, 34
+    sc0 = 1.0 / np.sqrt(D)
+
+    def rnd(*sh, sc=1.0):
+        return (torch.randn(*sh, generator=g) * sc).to(dev)
+
+    base = dict(P=rnd(B, Tp, A, sc=0.5), Q=rnd(B, Tp, O, sc=0.5), emb_w=rnd(V, E, sc=0.5),
+                w_ih=rnd(4 * D, E + O, sc=sc0), w_hh=rnd(4 * D, D, sc=sc0), b_ih=rnd(4 * D, sc=sc0),
+                b_hh=rnd(4 * D, sc=sc0), wdec=rnd(A, D, sc=sc0), convw=rnd(C, 1, 1, 2 * K + 1, sc=0.1),
+                watt=rnd(A, C, sc=0.3), gvec=rnd(1, A, sc=sc0), bo=rnd(O, sc=sc0), w_out=rnd(V, D + O, sc=sc0),
+                b_out=rnd(V, sc=sc0))
+    lens = torch.randint(max(1, Tp // 2), Tp + 1, (B,), generator=g)
+    w0 = torch.zeros(B, Tp)
+    for b in range(B):
+        w0[b, :lens[b]] = 1.0 / float(lens[b])
+    w0 = w0.to(dev)
+    tokens = torch.randint(0, V, (B, L), generator=g).to(dev)
+    xmask = ((torch.rand(L, B, O + E, generator=g) > 0.3).float() / 0.7).to(dev) if drop else None
+    dlog = rnd(L, B, V)
+    dws = rnd(L, B, Tp, sc=0.1)
+    names = list(base.keys())
+
+    def run(persist):
+        old = hb.USE_PERSIST_DEC
+        hb.USE_PERSIST_DEC = persist
+        try:
+            par = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            opts = dict(L=L, tokens=tokens, tf_flags=None, smooth=False, sample=False, scaling=2.0, xmask=xmask, bos=1)
+            logits, ws, _pred = ops.decoder_sequence(par["P"], par["Q"], par["emb_w"], par["w_ih"], par["w_hh"],
+                                                     par["b_ih"], par["b_hh"], par["wdec"], par["convw"], par["watt"],
+                                                     par["gvec"], par["bo"], par["w_out"], par["b_out"], w0, opts)
+            ((logits * dlog).sum() + (ws * dws).sum()).backward()
+            torch.cuda.synchronize()
+            return logits.detach(), ws.detach(), {k: par[k].grad.detach() for k in names}
+        finally:
+            hb.USE_PERSIST_DEC = old
+
+    lr, wr, gr = run(False)
+    lp, wpp, gp = run(True)
+    assert not hb.persist_aborted(dev)
+    assert torch.isfinite(lp).all()
+    _close(lp, lr, rtol=2e-4, atol=2e-5, what="logits (persistent decoder)")
+    _close(wpp, wr, rtol=2e-4, atol=2e-5, what="attention weights (persistent decoder)")
+    for k in names:
+        scale = float(gr[k].abs().max()) + 1e-12
+        err = float((gp[k] - gr[k]).abs().max()) / scale
+        assert err < 2e-4, (k, err)
