@@ -22,6 +22,13 @@
 // the same buffers as the per-step path, so asr_dec_seq_bwd runs unchanged on the result.
 #include "persist.h"
 
+#ifndef ASR_DP_ABL
+#define ASR_DP_ABL 0
+#endif
+#ifndef ASR_DP_FULL
+#define ASR_DP_FULL false
+#endif
+
 namespace {
 
 constexpr int DP_NT = 512;          // 8 waves
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         const int row = (2 * id) / OO, o = 2 * id - row * OO;
         p[i] = reinterpret_cast<const u64*>(cx + ((2 * id < 4 * OO) ? row * 512 + o : 0));
       }
-      poll_pairs<NC>(p, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 11u);
+      poll_pairs<NC, ASR_DP_FULL>(p, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 11u);
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int id = tid_ + DP_NT * i;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* xr = xs + (lane_ & 3) * XS + wave * KXW;
 #pragma unroll
-      for (int k4 = 0; k4 < KXW / 4; ++k4) {
+      for (int k4 = 0; k4 < ((ASR_DP_ABL & 2) ? 1 : KXW / 4); ++k4) {
         const float4 b = *reinterpret_cast<const float4*>(xr + 4 * k4);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b.y, acc, 0, 0, 0);
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       float zn = go * tanhf(cn);
       if (aborted || flag_load(a.ctrl + 8) != 0u) zn = __builtin_nanf("");
       c_prev = cn;
-      if (pb_ok_) {
+      if (pb_ok_ && !(ASR_DP_ABL & 32)) {
         *reinterpret_cast<float4*>(a.gates + ((int64_t)s * B + pb_) * 4 * DD + punit_ * 4) = make_float4(gi, gf, gg, go);
         a.cstate[((int64_t)s * B + pb_) * DD + punit_] = cn;
         a.X[((int64_t)(s + 1) * B + pb_) * KX + punit_] = zn;
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       const int r = lane_ & 15, q = lane_ >> 4;
       const float* ap = wp + aq * DP_FPC + r + q;
       const float* bp = Fs + r * DP_TAPS4 + q;
-      for (int j = 4 * wave; j < taps4; j += 32) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[j], bp[j], acc, 0, 0, 0);
+      for (int j = 4 * wave; j < ((ASR_DP_ABL & 8) ? 4 : taps4); j += 32) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[j], bp[j], acc, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) cred[(wave * 16 + 4 * q + i) * 17 + r] = acc[i];
     }
@@ -307,23 +314,40 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         word_store(xg + DX_F + ((par * 4 + ar) * 16 + ch) * DP_TPM + t, v, bit);
       }
     }
-    // ------------------------------------------------------------ (4) z_s (exchange) -> W_dec z_s for AU columns
+    // ------------------------------------------------------------ (4)+(5) z_s and f_s (exchange) -> W_dec z_s for AU columns
     {
+      // one poll for both: z_s pairs over [4][DD/2] and the conv features f_s (published ~2 us ago) as pairs
+      // id = tid + 512 i over [4 rows][C][TpP/2]; small-integer divisions via exact float reciprocals
       const float* zx = xg + DX_Z + par * 4 * 512;
-      const u64* p[NZ];
-      u64 v[NZ];
+      const float* fx = xg + DX_F + par * 4 * 16 * DP_TPM;
+      const int hp = TpP >> 1;
+      const float rhp = 1.0f / (float)hp, rC = 1.0f / (float)C;
+      int foff[4];
+      const u64* p[NZ + 4];
+      u64 v[NZ + 4];
 #pragma unroll
-      for (int i = 0; i < NZ; ++i) {
+      for (int i = 0; i < 4; ++i) {
         const int id = tid_ + DP_NT * i;
-        const int row = (2 * id) / DD, d = 2 * id - row * DD;
-        p[i] = reinterpret_cast<const u64*>(zx + ((2 * id < 4 * DD) ? row * 512 + d : 0));
+        const int rc = (int)(((float)id + 0.5f) * rhp), t2 = id - rc * hp;
+        const int row = (int)(((float)rc + 0.5f) * rC), c = rc - row * C;
+        foff[i] = rc < 4 * C ? (row * 16 + c) * DP_TPM + 2 * t2 : -1;
+        p[i] = reinterpret_cast<const u64*>(fx + (foff[i] < 0 ? 0 : foff[i]));
       }
-      poll_pairs<NZ>(p, bit, v, a.ctrl, aborted, 12u);
 #pragma unroll
       for (int i = 0; i < NZ; ++i) {
         const int id = tid_ + DP_NT * i;
         const int row = (2 * id) / DD, d = 2 * id - row * DD;
-        if (2 * id < 4 * DD) { xs[row * XS + d] = pair_lo(v[i]); xs[row * XS + d + 1] = pair_hi(v[i]); }
+        p[4 + i] = reinterpret_cast<const u64*>(zx + ((2 * id < 4 * DD) ? row * 512 + d : 0));
+      }
+      poll_pairs<NZ + 4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 12u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (foff[i] >= 0) { fs[foff[i]] = pair_lo(v[i]); fs[foff[i] + 1] = pair_hi(v[i]); }
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) {
+        const int id = tid_ + DP_NT * i;
+        const int row = (2 * id) / DD, d = 2 * id - row * DD;
+        if (2 * id < 4 * DD) { xs[row * XS + d] = pair_lo(v[4 + i]); xs[row * XS + d + 1] = pair_hi(v[4 + i]); }
       }
     }
     __syncthreads();
@@ -347,27 +371,6 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         for (int ks = 0; ks < 4; ++ks) v += part[(w2 * 64 + 4 * (4 * ks + ag) + row) * 5 + ii];
       dps[row * 16 + al] = v;
     }
-    // ------------------------------------------------------------ (5) conv features of all rows (exchange)
-    {
-      // 8-byte pairs id = tid_ + 512 i over [4 rows][C][TpP/2]
-      const float* fx = xg + DX_F + par * 4 * 16 * DP_TPM;
-      const int hp = TpP >> 1;
-      int foff[4];
-      const u64* p[4];
-      u64 v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int id = tid_ + DP_NT * i;
-        const int rc = id / hp, t2 = id - rc * hp;
-        const int row = rc / C, c = rc - row * C;
-        foff[i] = rc < 4 * C ? (row * 16 + c) * DP_TPM + 2 * t2 : -1;
-        p[i] = reinterpret_cast<const u64*>(fx + (foff[i] < 0 ? 0 : foff[i]));
-      }
-      poll_pairs<4>(p, bit, v, a.ctrl, aborted, 13u);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (foff[i] >= 0) { fs[foff[i]] = pair_lo(v[i]); fs[foff[i] + 1] = pair_hi(v[i]); }
-    }
     __syncthreads();
     // ------------------------------------------------------------ (6) energies: partial sums over this CU's columns
     {
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int tile = wave + 8 * it;
-        if (4 * tile < TpP) {                        // wave-uniform
+        if (4 * tile < TpP && !(ASR_DP_ABL & 4)) {                        // wave-uniform
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
           const float* fa = fs + ((m & 3) * 16 + sq_) * DP_TPM + 4 * tile + (m >> 2);
 #pragma unroll
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
           for (int i = 0; i < 4; ++i) {
             const float sv = dp_tanh(acc[i] + Ps[(tile * 4 + i) * 64 + lane_] + dps[i * 16 + a_l_]);
             const int b = r0 + i;
-            if (sc_ok_ && b < nb && t < Tp) a.S[(((int64_t)s * B + b) * Tp + t) * AA + acol_] = sv;
+            if (sc_ok_ && b < nb && t < Tp && !(ASR_DP_ABL & 16)) a.S[(((int64_t)s * B + b) * Tp + t) * AA + acol_] = sv;
             float pe = sc_ok_ ? gv * sv : 0.f;
             pe += __shfl_xor(pe, 1, 64);
             pe += __shfl_xor(pe, 2, 64);
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         p[i] = reinterpret_cast<const u64*>(ex + (4 * wave + i) * 4 * DP_TPM + (ok ? 2 * t2 : 0));
-      poll_pairs<4>(p, bit, v, a.ctrl, aborted, 14u);
+      poll_pairs<4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 14u);
       float e0 = 0.f, e1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { e0 += pair_lo(v[i]); e1 += pair_hi(v[i]); }

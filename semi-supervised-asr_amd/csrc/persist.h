@@ -60,8 +60,9 @@ __device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g,
 // Poll N 8-byte slots, each holding two LSB-tagged fp32 words, until every word carries tag bit `want`.  The last
 // slot is the sentinel: the other N-1 are only fetched once it is valid (a failed poll of everything would
 // saturate the XCD's L2 and delay the producers themselves).  Lanes without work point at any slot that becomes
-// valid in the same hand-off.  Returns with `aborted` set (values undefined) on a timeout or a raised abort word.
-template <int N>
+// valid in the same hand-off.  FULL = fetch all N slots on every attempt (one L2 round trip less when the data is
+// already there; only for small N).  Returns with `aborted` set (values undefined) on a timeout or a raised abort word.
+template <int N, bool FULL = false>
 __device__ __forceinline__ void poll_pairs(const u64* const (&p)[N], unsigned want, u64 (&v)[N], unsigned* ctrl,
                                            bool& aborted, unsigned code) {
   const u64 m = 0x0000000100000001ull;
@@ -73,15 +74,27 @@ __device__ __forceinline__ void poll_pairs(const u64* const (&p)[N], unsigned wa
   }
   unsigned spins = 0;
   while (true) {
-    v[N - 1] = granule_load(p[N - 1]);
-    if (__all((v[N - 1] & m) == expect)) {
+    if (FULL) {
       bool ok = true;
 #pragma unroll
-      for (int i = 0; i < N - 1; ++i) v[i] = granule_load(p[i]);
+      for (int i = 0; i < N; ++i) v[i] = granule_load(p[i]);
 #pragma unroll
-      for (int i = 0; i < N - 1; ++i) ok = ok && ((v[i] & m) == expect);
+      for (int i = 0; i < N; ++i) ok = ok && ((v[i] & m) == expect);
       if (__all(ok)) return;
+    } else {
+      v[N - 1] = granule_load(p[N - 1]);
+      if (__all((v[N - 1] & m) == expect)) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) v[i] = granule_load(p[i]);
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) ok = ok && ((v[i] & m) == expect);
+        if (__all(ok)) return;
+      }
     }
+#ifdef ASR_NO_POLL   /* measurement only: never wait (results are garbage) */
+    return;
+#endif
     if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(ctrl + 8) != 0u)) {
       if ((threadIdx.x & 63) == 0) { flag_store(ctrl + 9, code); flag_store(ctrl + 8, 1u); }
       aborted = true;
