@@ -154,6 +154,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 
   // epilogue: lane owns column n, rows (e&3) + 8*(e>>2) + 4*kh of each 32x32 tile
+  if (m0 + BM <= g.M && n0 + BN <= g.N) {
+    // interior tile: no bounds checks, 32-bit row offsets from one base pointer per 32x32 tile (the generic path
+    // below costs ~30 VALU instructions per element, which is visible for short K)
+    const unsigned ldc = (unsigned)g.ldc;
+    const bool split = g.split_k > 1, accum = g.accumulate != 0, relu = g.relu != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 32 + l31;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* base = C + (m0 + wm * 64 + i * 32 + 4 * kh) * g.ldc + n;
+        if (split) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) atomicAdd(base + (unsigned)((e & 3) + 8 * (e >> 2)) * ldc, acc[i][j][e]);
+        } else if (accum) {
+          float old[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) old[e] = base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv + old[e];
+            if (relu) v = fmaxf(v, 0.f);
+            base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int64_t n = n0 + wn * 64 + j * 32 + l31;

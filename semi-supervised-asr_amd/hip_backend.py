@@ -110,10 +110,14 @@ def _rowmajor(t):
 
 
 def auto_split_k(M, N, K, batch=1):
+    """Split-K factor for GEMMs without an epilogue (partials are added with f32 atomics).  Measured on MI355X
+    (tools/gemm_split_sweep.py): with K >= 2048 the 128x128 tiling leaves the 256 CUs unevenly loaded unless there
+    are several workgroups per CU, and ~6 K-slices is the sweet spot from 100 to 400 output tiles."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    if tiles >= 192 or K < 1024:
+    if K < 2048 or tiles >= 1024:
         return 1
-    return int(max(1, min(32, 512 // tiles, K // 256)))
+    want = 6 if tiles >= 100 else (8 if tiles >= 48 else 16)
+    return int(max(1, min(want, K // 256)))
 
 
 def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, split_k=None):
