@@ -251,6 +251,12 @@ typedef struct {
 
 int asr_dec_step_bwd(const asr_dec_bwd_t* p, int s, asr_stream_t stream);
 int asr_dec_seq_bwd(const asr_dec_bwd_t* p, int s_begin, int s_end, void* graphs, asr_stream_t stream);
+/* Persistent fast path of asr_dec_seq_bwd(p, 0, L) (same applicability rule and scratch convention as
+ * asr_dec_seq_fwd_persist; the sequence must have been teacher-forced).  mbuf: caller-allocated scratch
+ * [L][B][C][Tp].  Results as the per-step path in G[:, :, D:], dgates, dD, dP; dgvec_part / dwatt_part / dconv_part
+ * receive the same totals over rows (placed in other rows: reduce over B as usual); dwext, dwraw, dfpart and dcell
+ * are not used.  The embedding part of dX is formed by one batched GEMM after the recurrence. */
+int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* p, float* mbuf, void* xch, void* ctrl, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Optimiser on a flat fp32 buffer (solver.py:152-153,384-385: clip_grad_norm_ + Adam(amsgrad,

@@ -495,6 +495,646 @@ int launch_dec_fwd(const DecPersistArgs& a, hipStream_t stream) {
   return 0;
 }
 
+
+// ======================================================================================================= backward
+// Persistent backward of the same sequence (reverse order s = L-1 .. 0), same XCD-local organisation:
+//   (a) CU (row r, part q) reads the TOTAL d(ctx_s) of its row from the exchange and forms dw_raw for its 16 frames
+//       (Q slice of those frames in LDS) + the location-conv path kept from the previous iteration;      -> XW
+//   (c) every CU reads dw_raw of the 4 rows (400 words), softmax backward -> de;
+//   (d) score backward for this CU's A/32 attention columns x 4 rows x all frames: du = de g (1 - S^2);
+//       dP accumulates in LDS for the whole sequence, dD = sum_t du                                       -> XD
+//       dgvec / dW_att accumulate in registers (dW_att on the 16x16x4 MFMA);
+//   (e) d(conv features) of the CU's row WITHOUT a cross-CU reduction: df[c][t] = de[t] (UG[c] - M[c][t]) with
+//       M[c][t] = sum_a U[a][c] g[a] S[t][a]^2 precomputed by att_m_kernel from forward data; conv backward gives
+//       the dw path of the next iteration (local) and dconv (registers);
+//   (f) dz_s = G_out + dX_z(previous iteration, local) + dD W_dec for the CU's D/32 units, LSTM cell backward,
+//       dgates -> global (deferred weight gradients) and                                                   -> XG
+//   (g) dX = dgates W_cat for the CU's z and ctx columns (W_cat^T slice in registers, 4x4x1 MFMA); the z part
+//       stays in the CU, the (masked) ctx part + G_out is the total d(ctx_{s-1})                           -> XC
+// The embedding part of dX is not recurrent: one GEMM after the kernel (asr_dec_seq_bwd_persist).
+constexpr int BX_C = 0;                      // [2][4][512]
+constexpr int BX_W = BX_C + 2 * 4 * 512;     // [2][4][TPM]
+constexpr int BX_D = BX_W + 2 * 4 * DP_TPM;  // [2][4][512]
+constexpr int BX_G = BX_D + 2 * 4 * 512;     // [2][4][2048]
+constexpr int BX_GROUP = BX_G + 2 * 4 * 2048;
+
+struct DecPersistBwdArgs {
+  int B, nb, Tp, C, K, L;
+  float scaling;
+  const float *Q, *wcatT, *wdecT, *convw, *watt, *gvec, *w0, *xmask;
+  const float *gates, *cstate, *S, *fconv, *ws, *Mf, *dws;
+  float *G, *dgates, *dD, *dP, *dgvec_part, *dwatt_part, *dconv_part;
+  float* xch;
+  unsigned* ctrl;
+};
+
+template <int DD, int AA, int OO>
+struct DecBwdDims {
+  static constexpr int GK = 4 * DD;        // K of the dX product
+  static constexpr int GKW = GK / 8;       // per wave
+  static constexpr int GKS = GK / 16;      // per (wave, k-sub): registers per lane
+  static constexpr int GS = GK + 4;        // padded LDS row of the gathered dgates
+  static constexpr int DU = DD / 32, AU = AA / 32, OU = OO / 32;
+  static constexpr int AKW = AA / 8, AQ = AA / 32;   // dz product: k's per wave / per (wave, k-sub)
+  static constexpr int DS = AA + 4;        // padded LDS row of the gathered dD
+  static_assert(DD % 32 == 0 && AA % 32 == 0 && OO % 32 == 0 && GKS % 4 == 0, "slice sizes");
+  static_assert(DU <= 16 && AU <= 16 && OU <= 16 && DD <= 512 && OO <= 512 && AA <= 512, "mappings");
+};
+
+// LDS plan of the backward kernel (floats), sized from the run-time T', C, K
+struct BwdLds {
+  int dgs, part, qs, dcx, fs, dps, Fs, dfh, wph, des, dwr, wsl, dds, ddp, dwext, ugs, total;
+  int dfs_stride, taps4;
+};
+template <int DD, int AA, int OO>
+__host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K) {
+  using BM = DecBwdDims<DD, AA, OO>;
+  const int TpP = (Tp + 3) & ~3;
+  BwdLds l;
+  int o = 0;
+  l.taps4 = ((2 * K + 1) + 3) & ~3;
+  l.dfs_stride = TpP + 2 * K + 4;
+  l.dgs = o; o += 4 * BM::GS;
+  l.part = o; o += 8 * 64 * 5;
+  l.qs = o; o += 16 * OO;
+  l.dcx = o; o += OO;
+  l.fs = o; o += 4 * C * TpP;
+  l.dps = o; o += TpP * 64;
+  l.Fs = o; o += C * l.taps4;
+  l.dfh = o; o += C * l.dfs_stride;
+  l.wph = o; o += l.dfs_stride;
+  l.des = o; o += 4 * DP_TPM;
+  l.dwr = o; o += 4 * DP_TPM;
+  l.wsl = o; o += 4 * DP_TPM;
+  l.dds = o; o += 4 * BM::DS;
+  l.ddp = o; o += 8 * 4 * 16;
+  l.dwext = o; o += 16;
+  l.ugs = o; o += 16;
+  l.total = o + 8;
+  return l;
+}
+
+template <int DD, int AA, int OO, int EE>
+__global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArgs a) {
+  using BM = DecBwdDims<DD, AA, OO>;
+  constexpr int KX = DD + OO + EE;
+  constexpr int GK = BM::GK, GKW = BM::GKW, GKS = BM::GKS, GS = BM::GS, DU = BM::DU, AU = BM::AU, OU = BM::OU;
+  constexpr int AKW = BM::AKW, AQ = BM::AQ, DS = BM::DS;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Tp = a.Tp, C = a.C, K = a.K, B = a.B, L = a.L, nb = a.nb;
+  const int TpP = (Tp + 3) & ~3;
+  const BwdLds ld = bwd_lds_plan<DD, AA, OO>(Tp, C, K);
+  float* dgs = sm + ld.dgs;      // [4][GS]          gathered dgates of the 4 rows
+  float* part = sm + ld.part;    // [8][64][5]       K-partials of both MFMA products
+  float* Qs = sm + ld.qs;        // [16][OO]         Q rows of this CU's 16 frames
+  float* dcx = sm + ld.dcx;      // [OO]             total d(ctx_s) of this CU's row
+  float* fs = sm + ld.fs;        // [4][C][TpP]      conv features f_s of the 4 rows
+  float* dPs = sm + ld.dps;      // [TpP/4][4][64]   dP accumulators in the score-lane layout
+  float* Fs = sm + ld.Fs;        // [C][taps4]
+  float* dfh = sm + ld.dfh;      // [C][dfs_stride]  d(conv features) of this CU's row, zero halo of K
+  float* wph = sm + ld.wph;      // [dfs_stride]     w_{s-1} of this CU's row, zero halo of K
+  float* des = sm + ld.des;      // [4][TPM]         d(energy)
+  float* dwr = sm + ld.dwr;      // [4][TPM]         dw_raw
+  float* wsl = sm + ld.wsl;      // [4][TPM]         w_s
+  float* dDs = sm + ld.dds;      // [4][DS]          gathered dD
+  float* dDp = sm + ld.ddp;      // [8][4][16]       per-wave dD partials
+  float* dwext = sm + ld.dwext;  // [16]             conv-path dw of this CU's frames (for the next iteration)
+  float* ugs = sm + ld.ugs;      // [16]             UG[c] = sum_a U[a][c] g[a]
+  int* role = reinterpret_cast<int*>(sm + ld.total - 8);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int g, slice;
+  take_role(a.ctrl, role, g, slice);
+  if (slice < 0) return;
+  const int r0 = 4 * g;
+  if (r0 >= nb) return;
+  const int taps = 2 * K + 1, taps4 = ld.taps4, DFS = ld.dfs_stride;
+  const bool drop = a.xmask != nullptr;
+  float* xg = a.xch + (int64_t)g * BX_GROUP;
+  bool aborted = false;
+  const int ar = slice >> 3, aq = slice & 7;
+  const int ab = r0 + ar;
+  const bool ab_ok = ab < nb;
+  const int abc = ab_ok ? ab : r0;
+
+  // ---------------------------------------------------------------- weights in registers
+  // dX product: block = 2*cg + ks; column group cg < 4: z columns DU*slice + 4cg + i, cg >= 4: ctx columns
+  // D + OU*slice + 4(cg-4) + i; k = wave*GKW + ks*GKS + q
+  float wx[GKS];
+  {
+    const int blk = lane >> 2, i = lane & 3, cg = blk >> 1, ks = blk & 1;
+    const int cl = 4 * (cg & 3) + i;
+    const bool ok = cg < 4 ? cl < DU : cl < OU;
+    const int col = cg < 4 ? DU * slice + (ok ? cl : 0) : DD + OU * slice + (ok ? cl : 0);
+    const float* wr = a.wcatT + (int64_t)col * GK + wave * GKW + ks * GKS;
+#pragma unroll
+    for (int q4 = 0; q4 < GKS / 4; ++q4) {
+      const float4 v = *reinterpret_cast<const float4*>(wr + 4 * q4);
+      wx[4 * q4] = ok ? v.x : 0.f; wx[4 * q4 + 1] = ok ? v.y : 0.f;
+      wx[4 * q4 + 2] = ok ? v.z : 0.f; wx[4 * q4 + 3] = ok ? v.w : 0.f;
+    }
+  }
+  // dz product: block = 4*ks + ug; lane 4*blk+i holds unit DU*slice + 4ug + i, k (= attention column) = wave*AKW + ks*AQ + q
+  float wd[AQ];
+  {
+    const int blk = lane >> 2, ks = blk >> 2, ug = blk & 3, ul = 4 * ug + (lane & 3);
+    const bool ok = ul < DU;
+    const float* wr = a.wdecT + (int64_t)(DU * slice + (ok ? ul : 0)) * AA + wave * AKW + ks * AQ;
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) wd[q] = ok ? wr[q] : 0.f;
+  }
+  // ---------------------------------------------------------------- LDS images
+  for (int i = tid; i < ld.total - 8; i += DP_NT) sm[i] = 0.f;      // accumulators, halos, padding
+  __syncthreads();
+  for (int i = tid; i < 16 * OO; i += DP_NT) {
+    const int tl = i / OO, o = i - tl * OO;
+    const int t = 16 * aq + tl;
+    Qs[i] = a.Q[((int64_t)abc * Tp + (t < Tp ? t : Tp - 1)) * OO + o];
+  }
+  for (int i = tid; i < C * taps4; i += DP_NT) {
+    const int ch = i / taps4, j = i - ch * taps4;
+    Fs[i] = j < taps ? a.convw[ch * taps + j] : 0.f;
+  }
+  if (tid < 16) {
+    float v = 0.f;
+    if (tid < C)
+      for (int aa = 0; aa < AA; ++aa) v += a.watt[(int64_t)aa * C + tid] * a.gvec[aa];
+    ugs[tid] = v;
+  }
+  // score lanes (as in the forward kernel): column a_l = lane&15 of this CU's slice, frame quarter lane>>4
+  const float gv = (lane & 15) < AU ? a.gvec[AU * slice + (lane & 15)] : 0.f;
+  // persistent accumulators
+  f32x4 acc_watt = (f32x4){0.f, 0.f, 0.f, 0.f};   // dW_att[a = 4*(lane>>4)+i][c = lane&15] partial of this wave
+  float dgl = 0.f;                                // dgvec partial of this lane's column
+  float acc_conv = 0.f;                           // dconv[c][j] of this thread's tap
+  float dcarry = 0.f, dxz = 0.f;
+  // conv-weight gradient ownership: this CU owns taps idx = aq*NCJ + tid (tid < NCJ) of its row's C*taps
+  const int NCJ = (C * taps + 7) / 8;
+  // pointwise threads of the cell (tid < 4*DU): unit tid>>2, row tid&3
+  const bool pw_thread = tid < 4 * DU;
+  const int punit = DU * slice + (pw_thread ? (tid >> 2) : 0);
+  const int pb = r0 + (tid & 3);
+  const bool pb_ok = pw_thread && pb < nb;
+  const int pbc = pb < nb ? pb : r0;
+  // ctx-column threads of the dX result (64 <= tid < 64 + 4*OU): column OU*slice + ((tid-64)>>2), row tid&3
+  const bool cx_thread = tid >= 64 && tid < 64 + 4 * OU;
+  const int cxcol = OU * slice + (cx_thread ? ((tid - 64) >> 2) : 0);
+
+  // ---------------------------------------------------------------- prefetch registers (data of iteration n)
+  float sreg[16];      // S[s][row i][frame 4*tile+q4][acol], tile = wave + 8*it
+  float freg[8];       // conv features of the 4 rows (ids tid + 512 k over [4][C][TpP])
+  float mreg[2];       // M[s][row ar][c][t] (ids tid + 512 k over [C][TpP])
+  float wsreg = 0.f, wpreg = 0.f, dwsreg = 0.f;
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ct = 0.f, cp = 0.f, gz = 0.f, gc = 0.f, xm = 1.f;
+  // forward data of step s (no dependence on the recurrence), issued ~one iteration before use.  Indices are derived
+  // from an opaque copy of the thread id (see the forward kernel) and addresses are uniform base + 32-bit lane offset.
+  auto prefetchA = [&](int s, int zq) {
+    const int tidq = tid + zq, laneq = lane + zq;
+    const int q4q = laneq >> 4, alq = laneq & 15;
+    const int acolq = AU * slice + (alq < AU ? alq : 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int t = 32 * it + 4 * wave + q4q;
+      const int voff = (t < Tp ? t : Tp - 1) * AA + acolq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int b = r0 + i;
+        const float* sb = a.S + ((int64_t)s * B + (b < nb ? b : r0)) * Tp * AA;
+        sreg[it * 4 + i] = sb[voff];
+      }
+    }
+    const float rct = 1.0f / (float)(C * TpP), rtp = 1.0f / (float)TpP;
+    const float* fb = a.fconv + (int64_t)s * B * C * Tp;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int id = tidq + DP_NT * k;
+      const int row = (int)(((float)id + 0.5f) * rct), rem = id - row * C * TpP;
+      const int c = (int)(((float)rem + 0.5f) * rtp), t = rem - c * TpP;
+      const int b = r0 + (row < 4 ? row : 0);
+      freg[k] = fb[((b < nb ? b : r0) * C + (row < 4 ? c : 0)) * Tp + (t < Tp ? t : Tp - 1)];
+    }
+    const float* mb = a.Mf + ((int64_t)s * B + abc) * C * Tp;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int id = tidq + DP_NT * k;
+      const int c = (int)(((float)id + 0.5f) * rtp), t = id - c * TpP;
+      mreg[k] = mb[(c < C ? c : 0) * Tp + (t < Tp ? t : Tp - 1)];
+    }
+    {
+      const int row = tidq >> 7, t = tidq & 127, b = r0 + row;      // w_s of the 4 rows: 4 x 128 threads
+      wsreg = a.ws[((int64_t)s * B + (b < nb ? b : r0)) * Tp + (t < Tp ? t : Tp - 1)];
+      const float* wprev = s > 0 ? a.ws + ((int64_t)(s - 1) * B + abc) * Tp : a.w0 + (int64_t)abc * Tp;
+      wpreg = wprev[t < Tp ? t : Tp - 1];                            // (threads tid < 128 use it)
+      const int tq = 16 * aq + (tidq >> 5);
+      dwsreg = a.dws ? a.dws[((int64_t)s * B + abc) * Tp + (tq < Tp ? tq : Tp - 1)] : 0.f;
+    }
+  };
+  auto prefetchB = [&](int s, int zq) {
+    const int tidq = tid + zq;
+    const int pbq = r0 + (tidq & 3);
+    const int pbcq = pbq < nb ? pbq : r0;
+    if (tidq < 4 * DU) {
+      const int un = DU * slice + (tidq >> 2);
+      ga = *reinterpret_cast<const float4*>(a.gates + ((int64_t)s * B + pbcq) * 4 * DD + un * 4);
+      ct = a.cstate[((int64_t)s * B + pbcq) * DD + un];
+      cp = s > 0 ? a.cstate[((int64_t)(s - 1) * B + pbcq) * DD + un] : 0.f;
+      gz = a.G[((int64_t)(s + 1) * B + pbcq) * KX + un];
+    }
+    if (tidq >= 64 && tidq < 64 + 4 * OU) {
+      const int col = OU * slice + ((tidq - 64) >> 2);
+      gc = a.G[((int64_t)s * B + pbcq) * KX + DD + col];            // G_out part of d(ctx_{s-1}) (row tid&3)
+      xm = drop ? a.xmask[((int64_t)s * B + pbcq) * (OO + EE) + col] : 1.f;
+    }
+  };
+  {
+    int z0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z0));
+    prefetchA(L - 1, z0);
+    prefetchB(L - 1, z0);
+  }
+  // prologue: the total d(ctx_{L-1}) is the output-layer gradient alone
+  if (cx_thread)
+    word_store(xg + BX_C + 0 * 4 * 512 + (tid & 3) * 512 + cxcol,
+               a.G[((int64_t)L * B + pbc) * KX + DD + cxcol], tag_bit_of_step(0));
+  __syncthreads();
+
+  for (int n = 0; n < L; ++n) {
+    const int s = L - 1 - n;
+    const unsigned bit = tag_bit_of_step(n);
+    const int slot = n & 1;
+    int zv;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
+    const int tid_ = tid + zv, lane_ = lane + zv;
+    const int a_l_ = lane_ & 15, q4_ = lane_ >> 4;
+    const bool sc_ok_ = a_l_ < AU;
+    // ------------------------------------------------------------ (0) prefetched forward data -> LDS
+    {
+      const float rct = 1.0f / (float)(C * TpP), rtp = 1.0f / (float)TpP;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int id = tid_ + DP_NT * k;
+        if (id < 4 * C * TpP) {
+          const int row = (int)(((float)id + 0.5f) * rct), rem = id - row * C * TpP;
+          const int c = (int)(((float)rem + 0.5f) * rtp), t = rem - c * TpP;
+          fs[id] = t < Tp ? freg[k] : 0.f;
+        }
+      }
+      const int t = tid_ & 127;
+      wsl[tid_] = t < Tp ? wsreg : 0.f;                           // [row = tid>>7][t]
+      if (tid_ < 128 && t < Tp) wph[K + t] = wpreg;
+    }
+    // ------------------------------------------------------------ (a) total d(ctx_s) of my row -> dw_raw of my frames
+    {
+      const float* cx = xg + BX_C + slot * 4 * 512 + ar * 512;
+      const u64* p[1];
+      u64 v[1];
+      p[0] = reinterpret_cast<const u64*>(cx + (tid_ < OO / 2 ? 2 * tid_ : 0));
+      poll_pairs<1, true>(p, bit, v, a.ctrl, aborted, 21u);
+      if (tid_ < OO / 2) { dcx[2 * tid_] = pair_lo(v[0]); dcx[2 * tid_ + 1] = pair_hi(v[0]); }
+    }
+    __syncthreads();
+    {
+      const int tl = tid_ >> 5, op = tid_ & 31;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < OO / 32; ++k) acc += Qs[tl * OO + op + 32 * k] * dcx[op + 32 * k];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      acc += __shfl_xor(acc, 8, 64);
+      acc += __shfl_xor(acc, 16, 64);
+      const int t = 16 * aq + tl;
+      if (op == 0 && t < TpP) word_store(xg + BX_W + (slot * 4 + ar) * DP_TPM + t, t < Tp ? acc + dwext[tl] + dwsreg : 0.f, bit);
+    }
+    // ------------------------------------------------------------ (c) dw_raw of the 4 rows -> softmax backward
+    {
+      const int hp = TpP >> 1;
+      const int row = (int)(((float)tid_ + 0.5f) * (1.0f / (float)hp)), t2 = tid_ - row * hp;
+      const bool ok = row < 4;
+      const u64* p[1];
+      u64 v[1];
+      p[0] = reinterpret_cast<const u64*>(xg + BX_W + slot * 4 * DP_TPM + (ok ? row * DP_TPM + 2 * t2 : 0));
+      poll_pairs<1, true>(p, bit, v, a.ctrl, aborted, 22u);
+      if (ok) { dwr[row * DP_TPM + 2 * t2] = pair_lo(v[0]); dwr[row * DP_TPM + 2 * t2 + 1] = pair_hi(v[0]); }
+    }
+    __syncthreads();
+    if (wave < 4) {
+      float w[2], dv[2], dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = lane_ + 64 * k;
+        w[k] = t < Tp ? wsl[wave * DP_TPM + t] : 0.f;
+        dv[k] = t < Tp ? dwr[wave * DP_TPM + t] : 0.f;
+        dot += w[k] * dv[k];
+      }
+      dot = wave_sum(dot);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)     // rows beyond the batch contribute nothing to the sequence-long accumulators
+        des[wave * DP_TPM + lane_ + 64 * k] = r0 + wave < nb ? a.scaling * w[k] * (dv[k] - dot) : 0.f;
+    }
+    __syncthreads();
+    // ------------------------------------------------------------ (d) score backward for my attention columns
+    {
+      float dDl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int tile = wave + 8 * it;
+        if (4 * tile < TpP) {
+          const int t = 4 * tile + q4_;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float sv = sreg[it * 4 + i];
+            const float det = des[i * DP_TPM + t];
+            const float duv = sc_ok_ ? det * gv * (1.f - sv * sv) : 0.f;
+            dPs[(tile * 4 + i) * 64 + lane_] += duv;
+            dDl[i] += duv;
+            dgl += sc_ok_ ? det * sv : 0.f;
+            // dW_att[a][c] += sum over this k-group of 4 frames: A[m = a][k = q4] = du, B[k = q4][n = c] = f[i][c][4 tile + q4]
+            const float fb = fs[(i * C + (a_l_ < C ? a_l_ : 0)) * TpP + t];
+            acc_watt = __builtin_amdgcn_mfma_f32_16x16x4f32(duv, a_l_ < C ? fb : 0.f, acc_watt, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = dDl[i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q4_ == 0) dDp[(wave * 4 + i) * 16 + a_l_] = v;
+      }
+    }
+    __syncthreads();
+    if (tid_ < 64) {
+      const int row = tid_ >> 4, al = tid_ & 15;
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 8; ++w2) v += dDp[(w2 * 4 + row) * 16 + al];
+      const int b = r0 + row;
+      if (al < AU) {
+        if (b < nb) a.dD[((int64_t)s * B + b) * AA + AU * slice + al] = v;
+        word_store(xg + BX_D + (slot * 4 + row) * 512 + AU * slice + al, v, bit);
+      }
+    }
+    // ------------------------------------------------------------ (e) d(conv features) of my row, conv backward
+    {
+      const float rtp = 1.0f / (float)TpP;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int id = tid_ + DP_NT * k;
+        if (id < C * TpP) {
+          const int c = (int)(((float)id + 0.5f) * rtp), t = id - c * TpP;
+          if (t < Tp) dfh[c * DFS + K + t] = des[ar * DP_TPM + t] * (ugs[c] - mreg[k]);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // dw path for the next iteration: dwext[t'] = sum_c sum_j F[c][j] df[c][t' - j + K], my 16 frames x 32 parts
+      const int tl = tid_ >> 5, pr = tid_ & 31;
+      const int tq = 16 * aq + tl;
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float* Fc = Fs + c * taps4;
+        const float* dc = dfh + c * DFS + tq + 2 * K;
+        for (int j = pr; j < (tq < Tp ? taps : 0); j += 32) acc += Fc[j] * dc[-j];
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      acc += __shfl_xor(acc, 8, 64);
+      acc += __shfl_xor(acc, 16, 64);
+      if (pr == 0) dwext[tl] = acc;
+      // dconv[c][j] += sum_t df[c][t] w_{s-1}[t + j - K] for the taps this thread owns
+      const int cj_idx = aq * NCJ + tid_;
+      const bool cj_ok = tid_ < NCJ && cj_idx < C * taps;
+      const int cj_c = cj_ok ? (int)(((float)cj_idx + 0.5f) * (1.0f / (float)taps)) : 0;
+      const int cj_j = cj_ok ? cj_idx - cj_c * taps : 0;
+      if (cj_ok) {
+        const float* dc = dfh + cj_c * DFS + K;
+        const float* wq = wph + cj_j;
+        float v0 = 0.f, v1 = 0.f;
+        int t = 0;
+        for (; t + 1 < Tp; t += 2) { v0 += dc[t] * wq[t]; v1 += dc[t + 1] * wq[t + 1]; }
+        if (t < Tp) v0 += dc[t] * wq[t];
+        acc_conv += v0 + v1;
+      }
+    }
+    // forward data of the next iteration (independent of the recurrence; most of an iteration to arrive)
+    if (s > 0) prefetchA(s - 1, zv);
+    // ------------------------------------------------------------ (f) dz_s for my units, LSTM cell backward
+    {
+      const float* dx = xg + BX_D + slot * 4 * 512;
+      constexpr int ND = (2 * AA + DP_NT - 1) / DP_NT;
+      const u64* p[ND];
+      u64 v[ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int id = tid_ + DP_NT * i;
+        const int row = (2 * id) / AA, c2 = 2 * id - row * AA;
+        p[i] = reinterpret_cast<const u64*>(dx + ((2 * id < 4 * AA) ? row * 512 + c2 : 0));
+      }
+      poll_pairs<ND, true>(p, bit, v, a.ctrl, aborted, 23u);
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int id = tid_ + DP_NT * i;
+        const int row = (2 * id) / AA, c2 = 2 * id - row * AA;
+        if (2 * id < 4 * AA) { dDs[row * DS + c2] = pair_lo(v[i]); dDs[row * DS + c2 + 1] = pair_hi(v[i]); }
+      }
+    }
+    __syncthreads();
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* dr = dDs + (lane_ & 3) * DS + wave * AKW + (lane_ >> 4) * AQ;
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[q], dr[q], acc, 0, 0, 0);
+      float* pp = part + (wave * 64 + lane_) * 5;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pp[i] = acc[i];
+    }
+    __syncthreads();
+    if (tid_ < 4 * DU) {
+      const int ul = tid_ >> 2, row = tid_ & 3, ug = ul >> 2, ii = ul & 3;
+      float dh = gz + dxz;
+#pragma unroll
+      for (int w2 = 0; w2 < 8; ++w2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dh += part[(w2 * 64 + 4 * (4 * ks + ug) + row) * 5 + ii];
+      const float tc = tanhf(ct);
+      const float dc = dcarry + dh * ga.w * (1.f - tc * tc);
+      float4 da;
+      da.x = dc * ga.z * ga.x * (1.f - ga.x);
+      da.y = dc * cp * ga.y * (1.f - ga.y);
+      da.z = dc * ga.x * (1.f - ga.z * ga.z);
+      da.w = dh * tc * ga.w * (1.f - ga.w);
+      dcarry = dc * ga.y;
+      if (aborted || flag_load(a.ctrl + 8) != 0u) da.x = __builtin_nanf("");
+      const int un = DU * slice + ul, b = r0 + row;
+      if (b < nb) *reinterpret_cast<float4*>(a.dgates + ((int64_t)s * B + b) * GK + un * 4) = da;
+      float* dst = xg + BX_G + (slot * 4 + row) * 2048 + un * 4;
+      word_store(dst, da.x, bit); word_store(dst + 1, da.y, bit);
+      word_store(dst + 2, da.z, bit); word_store(dst + 3, da.w, bit);
+    }
+    if (s == 0) break;
+    // ------------------------------------------------------------ (g) dX = dgates W_cat for my z / ctx columns
+    {
+      const float* gx = xg + BX_G + slot * 4 * 2048;
+      constexpr int NG = (2 * GK + DP_NT - 1) / DP_NT;        // pairs per thread over [4][GK/2]
+#pragma unroll
+      for (int h = 0; h < NG; h += 4) {
+        const u64* p[4];
+        u64 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int id = tid_ + DP_NT * (h + i);
+          const int row = (2 * id) / GK, c2 = 2 * id - row * GK;
+          p[i] = reinterpret_cast<const u64*>(gx + ((2 * id < 4 * GK) ? row * 2048 + c2 : 0));
+        }
+        poll_pairs<4, true>(p, bit, v, a.ctrl, aborted, 24u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int id = tid_ + DP_NT * (h + i);
+          const int row = (2 * id) / GK, c2 = 2 * id - row * GK;
+          if (2 * id < 4 * GK) { dgs[row * GS + c2] = pair_lo(v[i]); dgs[row * GS + c2 + 1] = pair_hi(v[i]); }
+        }
+      }
+    }
+    __syncthreads();
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* gr = dgs + (lane_ & 3) * GS + wave * GKW + ((lane_ >> 2) & 1) * GKS;
+#pragma unroll
+      for (int q4 = 0; q4 < GKS / 4; ++q4) {
+        const float4 b = *reinterpret_cast<const float4*>(gr + 4 * q4);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4], b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 1], b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 2], b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 3], b.w, acc, 0, 0, 0);
+      }
+      float* pp = part + (wave * 64 + lane_) * 5;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pp[i] = acc[i];
+    }
+    __syncthreads();
+    if (tid_ < 128) {
+      // (column index ci = tid>>2: 0..15 z, 16..31 ctx; row = tid&3): lanes 4*(2*cg + ks) + row, register ci&3
+      const int ci = tid_ >> 2, row = tid_ & 3, cg = ci >> 2, ii = ci & 3;
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 8; ++w2)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) v += part[(w2 * 64 + 4 * (2 * cg + ks) + row) * 5 + ii];
+      if (ci < 16) {
+        dxz = v;                                                  // gradient wrt z_{s-1} of my unit (same thread as in (f))
+      } else if (ci - 16 < OU) {
+        const int col = OU * slice + ci - 16, b = r0 + row;
+        const float tot = gc + v * xm;                        // total d(ctx_{s-1}) = output layer + masked cell input
+        if (b < nb) a.G[((int64_t)s * B + b) * KX + DD + col] = tot;
+        word_store(xg + BX_C + (((n + 1) & 1) * 4 + row) * 512 + col, tot, tag_bit_of_step(n + 1));
+      }
+    }
+    prefetchB(s - 1, zv);
+  }
+  // ---------------------------------------------------------------- epilogue: sequence-long accumulators
+  __syncthreads();
+  int ze;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(ze));
+  const int lane_e = lane + ze, a_le = lane_e & 15, q4e = lane_e >> 4;
+  const bool sc_oke = a_le < AU;
+  const int acole = AU * slice + (sc_oke ? a_le : 0);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int tile = wave + 8 * it;
+    if (4 * tile < TpP) {
+      const int t = 4 * tile + q4e;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int b = r0 + i;
+        if (sc_oke && b < nb && t < Tp) a.dP[((int64_t)b * Tp + t) * AA + acole] = dPs[(tile * 4 + i) * 64 + lane_e];
+      }
+    }
+  }
+  if (sc_oke) atomicAdd(a.dgvec_part + (int64_t)r0 * AA + acole, dgl);
+  {
+    const int c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int al = 4 * (lane >> 4) + i;
+      if (c < C && al < AU) atomicAdd(a.dwatt_part + ((int64_t)r0 * AA + AU * slice + al) * C + c, acc_watt[i]);
+    }
+  }
+  {
+    const int cj_idx = aq * NCJ + tid;
+    const bool cj_ok = tid < NCJ && cj_idx < C * taps;
+    const int cj_c = cj_ok ? cj_idx / taps : 0, cj_j = cj_ok ? cj_idx - cj_c * taps : 0;
+    if (cj_ok && ab_ok) atomicAdd(a.dconv_part + ((int64_t)ab * C + cj_c) * taps + cj_j, acc_conv);
+  }
+}
+
+// M[s][b][c][t] = sum_a U[a][c] g[a] S[s][b][t][a]^2  (forward data only).  grid (B, L), 256 threads; wave w owns the
+// 16-frame tiles w, w+4, ...; contraction on the 16x16x4 MFMA with the k-permutation of common.h (a lane's float4 of
+// S feeds 4 MFMAs).  LDS: UG[a][16] = U[a][c] g[a], zero beyond C.
+template <int AA>
+__global__ __launch_bounds__(256) void att_m_kernel(int B, int Tp, int C, const float* __restrict__ S,
+                                                    const float* __restrict__ watt, const float* __restrict__ gvec,
+                                                    float* __restrict__ Mf) {
+  __shared__ __attribute__((aligned(16))) float UG[AA * 16];
+  const int b = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < AA * 16; i += 256) {
+    const int aa = i >> 4, c = i & 15;
+    UG[i] = c < C ? watt[(int64_t)aa * C + c] * gvec[aa] : 0.f;
+  }
+  __syncthreads();
+  const float* Sb = S + ((int64_t)s * B + b) * Tp * AA;
+  const int r = lane & 15, q = lane >> 4;
+  for (int tile = wave; 16 * tile < Tp; tile += 4) {
+    const int t = 16 * tile + r;
+    const float* row = Sb + (int64_t)(t < Tp ? t : Tp - 1) * AA + 4 * q;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int kq = 0; kq < AA / 16; ++kq) {
+      const float4 sv = *reinterpret_cast<const float4*>(row + 16 * kq);
+      const float* ub = UG + (16 * kq + 4 * q) * 16 + r;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.x * sv.x, ub[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.y * sv.y, ub[16], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.z * sv.z, ub[32], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.w * sv.w, ub[48], acc, 0, 0, 0);
+    }
+    // D: lane holds frames 16*tile + 4q + i of channel r
+    if (r < C) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tt = 16 * tile + 4 * q + i;
+        if (tt < Tp) Mf[(((int64_t)s * B + b) * C + r) * Tp + tt] = acc[i];
+      }
+    }
+  }
+}
+
+// G[s][b][D+O+e] *= xmask[s][b][O+e]  (dropout on the embedding part of the cell input, model.py:284-285)
+__global__ void mask_emb_kernel(int L, int B, int nb, int D, int O, int E, const float* __restrict__ xmask,
+                                float* __restrict__ G) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)L * nb * E) return;
+  const int e = (int)(idx % E);
+  const int64_t rb = idx / E;
+  const int b = (int)(rb % nb), s = (int)(rb / nb);
+  G[((int64_t)s * B + b) * (D + O + E) + D + O + e] *= xmask[((int64_t)s * B + b) * (O + E) + O + e];
+}
+
+template <int DD, int AA, int OO, int EE>
+int launch_dec_bwd(const DecPersistBwdArgs& a, hipStream_t stream) {
+  const BwdLds ld = bwd_lds_plan<DD, AA, OO>(a.Tp, a.C, a.K);
+  const size_t lds = (size_t)ld.total * sizeof(float);
+  if (lds > 160 * 1024 || lds <= 82 * 1024) return ASR_E_SHAPE;     // must fit, and must force one workgroup per CU
+  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_bwd_kernel<DD, AA, OO, EE>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((dec_persist_bwd_kernel<DD, AA, OO, EE>), dim3(256), dim3(DP_NT), lds, stream, a);
+  return 0;
+}
+
 }  // namespace
 
 bool asr_persist_device_ok();
@@ -538,5 +1178,70 @@ extern "C" int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* 
     if (rc) return rc;
   }
   ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+// Persistent fast path of asr_dec_seq_bwd(q, 0, L) for sequences produced by the teacher-forced forward (either
+// forward path): same results in G[:, :, D:], dgates, dD, dP and the partial-sum buffers (dgvec_part / dwatt_part /
+// dconv_part hold the sums in other rows than the per-step path does; the caller reduces over rows either way).
+// mbuf: scratch [L][B][C][Tp].  dwext / dwraw / dfpart / dcell of q are not used.  Returns ASR_E_SHAPE when the
+// fast path does not apply.
+extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void* xch, void* ctrl,
+                                       asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!q || !mbuf || !xch || !ctrl) return ASR_E_ARG;
+  const asr_dec_fwd_t* p = &q->f;
+  if (!p->Q || !p->wcat || !p->convw || !p->watt || !p->gvec || !p->w0 || !p->gates || !p->cstate || !p->fconv ||
+      !p->S || !p->ws || !q->wcatT || !q->wdecT || !q->G || !q->dgates || !q->dD || !q->dP || !q->dgvec_part ||
+      !q->dwatt_part || !q->dconv_part)
+    return ASR_E_ARG;
+  if (p->B <= 0 || p->nb <= 0 || p->nb > p->B || p->Tp <= 0 || p->L <= 0) return ASR_E_ARG;
+  const bool cfg2 = p->D == 512 && p->A == 512 && p->O == 512 && p->E == 128;
+  const bool cfg1 = p->D == 320 && p->A == 320 && p->O == 320 && p->E == 128;
+  if (!cfg1 && !cfg2) return ASR_E_SHAPE;
+  const int TpP = (p->Tp + 3) & ~3;
+  if (p->Tp > DP_TPM || p->C <= 0 || p->C > 16 || p->K < 0 || p->K > DP_KMAX || p->C * TpP > 2 * DP_NT ||
+      4 * p->C * TpP > 8 * DP_NT || p->nb > 128)
+    return ASR_E_SHAPE;
+  if (!asr_persist_device_ok()) return ASR_E_SHAPE;
+  const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;
+  const int taps = 2 * p->K + 1;
+  for (int rb = 0; rb < p->nb; rb += 32) {
+    const int nbb = p->nb - rb < 32 ? p->nb - rb : 32;
+    hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(xch, 0, (size_t)8 * BX_GROUP * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    if (cfg2)
+      hipLaunchKernelGGL((att_m_kernel<512>), dim3(nbb, p->L), dim3(256), 0, stream, B, Tp, C,
+                         p->S + (int64_t)rb * Tp * A, p->watt, p->gvec, mbuf + (int64_t)rb * C * Tp);
+    else
+      hipLaunchKernelGGL((att_m_kernel<320>), dim3(nbb, p->L), dim3(256), 0, stream, B, Tp, C,
+                         p->S + (int64_t)rb * Tp * A, p->watt, p->gvec, mbuf + (int64_t)rb * C * Tp);
+    DecPersistBwdArgs a;
+    a.B = B; a.nb = nbb; a.Tp = Tp; a.C = C; a.K = p->K; a.L = p->L; a.scaling = p->scaling;
+    a.Q = p->Q + (int64_t)rb * Tp * O; a.wcatT = q->wcatT; a.wdecT = q->wdecT; a.convw = p->convw; a.watt = p->watt;
+    a.gvec = p->gvec; a.w0 = p->w0 + (int64_t)rb * Tp; a.xmask = p->xmask ? p->xmask + (int64_t)rb * (O + E) : nullptr;
+    a.gates = p->gates + (int64_t)rb * 4 * D; a.cstate = p->cstate + (int64_t)rb * D;
+    a.S = p->S + (int64_t)rb * Tp * A; a.fconv = p->fconv + (int64_t)rb * C * Tp; a.ws = p->ws + (int64_t)rb * Tp;
+    a.Mf = mbuf + (int64_t)rb * C * Tp; a.dws = q->dws ? q->dws + (int64_t)rb * Tp : nullptr;
+    a.G = q->G + (int64_t)rb * KX; a.dgates = q->dgates + (int64_t)rb * 4 * D; a.dD = q->dD + (int64_t)rb * A;
+    a.dP = q->dP + (int64_t)rb * Tp * A; a.dgvec_part = q->dgvec_part + (int64_t)rb * A;
+    a.dwatt_part = q->dwatt_part + (int64_t)rb * A * C; a.dconv_part = q->dconv_part + (int64_t)rb * C * taps;
+    a.xch = (float*)xch; a.ctrl = (unsigned*)ctrl;
+    const int rc = cfg2 ? launch_dec_bwd<512, 512, 512, 128>(a, stream) : launch_dec_bwd<320, 320, 320, 128>(a, stream);
+    if (rc) return rc;
+  }
+  ASR_CHECK_LAUNCH();
+  // embedding part of dX (not recurrent): G[s][:, D+O:] += dgates[s] Wcat[:, D+O:], batched over the L steps
+  int rc = asr_gemm_f32(0, 0, p->nb, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX, nullptr, 0, 1,
+                        p->L, (int64_t)B * 4 * D, 0, (int64_t)B * KX, 1, stream_);
+  if (rc) return rc;
+  if (p->xmask) {
+    const int64_t n = (int64_t)p->L * p->nb * E;
+    hipLaunchKernelGGL(mask_emb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p->L, B, p->nb, D, O, E,
+                       p->xmask, q->G);
+    ASR_CHECK_LAUNCH();
+  }
   return 0;
 }

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
-    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_step_bwd", "asr_dec_seq_bwd",
+    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
 
@@ -73,6 +73,7 @@ def load():
     lib.asr_dec_seq_fwd_persist.argtypes = [ctypes.POINTER(DecFwd), c_p, c_p, c_p]
     lib.asr_dec_step_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_p]
     lib.asr_dec_seq_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_i, c_p, c_p]
+    lib.asr_dec_seq_bwd_persist.argtypes = [ctypes.POINTER(DecBwd), c_p, c_p, c_p, c_p]
     lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                       c_f, c_p]
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]
@@ -270,6 +271,7 @@ def _off(t, elems):
 
 USE_PERSIST = os.environ.get("ASR_PERSIST", "1") != "0"
 USE_PERSIST_DEC = USE_PERSIST and os.environ.get("ASR_PERSIST_DEC", "1") != "0"   # persistent decoder forward
+USE_PERSIST_DEC_BWD = USE_PERSIST and os.environ.get("ASR_PERSIST_DEC_BWD", "1") != "0"   # ... and backward
 _persist_scratch = {}
 
 

@@ -256,7 +256,8 @@ def _dec_workspace(B, Tp, A, D, O, E, C, K, L, drop, dev, with_bwd):
             dfpart=torch.empty(ntile, B, C, Tp, **f32), dP=torch.empty(B, Tp, A, **f32),
             dgates=torch.empty(L, B, 4 * D, **f32), dD=torch.empty(L, B, A, **f32), dcell=torch.empty(B, D, **f32),
             dgvec_part=torch.empty(B, A, **f32), dwatt_part=torch.empty(B, A, C, **f32),
-            dconv_part=torch.empty(B, C, 2 * K + 1, **f32), dws=torch.empty(L, B, Tp, **f32))
+            dconv_part=torch.empty(B, C, 2 * K + 1, **f32), dws=torch.empty(L, B, Tp, **f32),
+            Mf=torch.empty(L, B, C, Tp, **f32))
     return ws
 
 
@@ -380,6 +381,7 @@ class _DecoderSeq(torch.autograd.Function):
         ctx.keep = (wdec_c, watt_c, bo_c, fed, probs_saved, w_out_c, emb_w)
         ctx.dims = (B, Tp, A, O, D, E, V, C, K, L, KX)
         ctx.smooth = smooth and tokens is None
+        ctx.all_teacher = all_teacher
         ctx.smooth_scaling = float(opts.get("smooth_scaling", 1.0))
         ctx.mark_non_differentiable(pred)
         return logits, ws["ws"].clone(), pred
@@ -413,13 +415,24 @@ class _DecoderSeq(torch.autograd.Function):
         demb_w = torch.zeros_like(emb_w)
         if not ctx.smooth:
             groups = hb.row_groups(B)
-            gh = [hb.graphs_for(i) for i in range(len(groups))]
+            done = False
+            if hb.USE_PERSIST_DEC_BWD and ctx.all_teacher and len(groups) == 1:
+                bg = _dec_bwd_struct(d, w, 0, B)
+                xch, ctrl = hb.persist_scratch(dev)
+                rc = lib.asr_dec_seq_bwd_persist(ctypes.byref(bg), _p(wk["Mf"]), ctypes.c_void_p(xch.data_ptr()),
+                                                 ctypes.c_void_p(ctrl.data_ptr()), hb.stream())
+                if rc == 0:
+                    done = True
+                elif rc != -2:
+                    hb.check(rc, "asr_dec_seq_bwd_persist")
+            if not done:
+                gh = [hb.graphs_for(i) for i in range(len(groups))]
 
-            def run(gi, grp, st):
-                bg = _dec_bwd_struct(d, w, grp[0], grp[1])
-                hb.check(lib.asr_dec_seq_bwd(ctypes.byref(bg), 0, L, gh[gi], st), "asr_dec_seq_bwd")
+                def run(gi, grp, st):
+                    bg = _dec_bwd_struct(d, w, grp[0], grp[1])
+                    hb.check(lib.asr_dec_seq_bwd(ctypes.byref(bg), 0, L, gh[gi], st), "asr_dec_seq_bwd")
 
-            hb.run_grouped(groups, run)
+                hb.run_grouped(groups, run)
         else:
             # smooth-embedding feedback (model.py:341): emb_s = softmax(logit_{s-1}*k) @ E couples step s to
             # the logits of step s-1, so the extra gradient is injected between the per-step kernels.

@@ -551,9 +551,9 @@ def test_decoder_persistent_path(dim, B, Tp, L, drop):
     dws = rnd(L, B, Tp, sc=0.1)
     names = list(base.keys())
 
-    def run(persist):
-        old = hb.USE_PERSIST_DEC
-        hb.USE_PERSIST_DEC = persist
+    def run(persist, persist_bwd=False):
+        old = hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD
+        hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = persist, persist_bwd
         try:
             par = {k: v.clone().requires_grad_(True) for k, v in base.items()}
             opts = dict(L=L, tokens=tokens, tf_flags=None, smooth=False, sample=False, scaling=2.0, xmask=xmask, bos=1)
@@ -564,15 +564,16 @@ def test_decoder_persistent_path(dim, B, Tp, L, drop):
             torch.cuda.synchronize()
             return logits.detach(), ws.detach(), {k: par[k].grad.detach() for k in names}
         finally:
-            hb.USE_PERSIST_DEC = old
+            hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = old
 
     lr, wr, gr = run(False)
-    lp, wpp, gp = run(True)
-    assert not hb.persist_aborted(dev)
-    assert torch.isfinite(lp).all()
-    _close(lp, lr, rtol=2e-4, atol=2e-5, what="logits (persistent decoder)")
-    _close(wpp, wr, rtol=2e-4, atol=2e-5, what="attention weights (persistent decoder)")
-    for k in names:
-        scale = float(gr[k].abs().max()) + 1e-12
-        err = float((gp[k] - gr[k]).abs().max()) / scale
-        assert err < 2e-4, (k, err)
+    for mode in ((True, False), (False, True), (True, True)):      # persistent forward / backward / both
+        lp, wpp, gp = run(*mode)
+        assert not hb.persist_aborted(dev), mode
+        assert torch.isfinite(lp).all()
+        _close(lp, lr, rtol=2e-4, atol=2e-5, what="logits (persistent decoder %s)" % (mode,))
+        _close(wpp, wr, rtol=2e-4, atol=2e-5, what="attention weights (persistent decoder %s)" % (mode,))
+        for k in names:
+            scale = float(gr[k].abs().max()) + 1e-12
+            err = float((gp[k] - gr[k]).abs().max()) / scale
+            assert err < 2e-4, (mode, k, err)
