@@ -60,7 +60,8 @@ int asr_graphs_stats(void* graphs, int64_t* hits, int64_t* captures, int64_t* ea
  *             transB=0: B is [K][N] (ldb>=N); transB=1: B is [N][K] (ldb>=K).
  * batch>1 runs `batch` independent GEMMs with element strides sA,sB,sC.
  * split_k>1 splits K over grid.z and accumulates with fp32 atomics (C is zero-filled on
- * the stream first unless accumulate!=0); bias/relu are rejected with split_k>1.
+ * the stream first unless accumulate!=0); with split_k>1, bias/relu are applied by a second
+ * pass over C (not combinable with accumulate).
  * Replaces torch.nn.Linear / mm / bmm on the path: the LSTM input-gate product inside
  * torch.nn.LSTM (model.py:67-68,80), project_layer (model.py:93-94), mlp_enc
  * (model.py:144), output_layer (model.py:293) and every autograd mm behind them.

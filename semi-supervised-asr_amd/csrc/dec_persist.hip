@@ -1234,8 +1234,13 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
   }
   ASR_CHECK_LAUNCH();
   // embedding part of dX (not recurrent): G[s][:, D+O:] += dgates[s] Wcat[:, D+O:], batched over the L steps
-  int rc = asr_gemm_f32(0, 0, p->nb, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX, nullptr, 0, 1,
-                        p->L, (int64_t)B * 4 * D, 0, (int64_t)B * KX, 1, stream_);
+  int rc;
+  if (p->nb == B)      // all rows: one GEMM over the L*B rows, K = 4D split so that the few output tiles fill the chip
+    rc = asr_gemm_f32(0, 0, (int64_t)p->L * B, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX,
+                      nullptr, 0, 1, 1, 0, 0, 0, 16, stream_);
+  else
+    rc = asr_gemm_f32(0, 0, p->nb, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX, nullptr, 0, 1,
+                      p->L, (int64_t)B * 4 * D, 0, (int64_t)B * KX, 4, stream_);
   if (rc) return rc;
   if (p->xmask) {
     const int64_t n = (int64_t)p->L * p->nb * E;

@@ -217,6 +217,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// bias (+ReLU) pass after a split-K product (the atomics cannot carry an epilogue)
+__global__ void bias_act_kernel(float* C, int64_t ldc, int64_t M, int64_t N, int64_t sC, const float* __restrict__ bias,
+                                int relu) {
+  float* p = C + blockIdx.z * sC;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M * N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / N, n = i % N;
+    float v = p[m * ldc + n] + (bias ? bias[n] : 0.f);
+    if (relu) v = fmaxf(v, 0.f);
+    p[m * ldc + n] = v;
+  }
+}
+
 __global__ void zero_rows_kernel(float* C, int64_t ldc, int64_t M, int64_t N, int64_t sC) {
   float* p = C + blockIdx.z * sC;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M * N; i += (int64_t)gridDim.x * blockDim.x) {
@@ -293,7 +305,12 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return ASR_E_ARG;
   if (split_k < 1) split_k = 1;
-  if (split_k > 1 && (bias || relu)) return ASR_E_SHAPE;
+  // split-K with an epilogue: the product is formed without it (atomics) and a second pass applies bias / ReLU
+  const bool late_epilogue = split_k > 1 && (bias || relu);
+  if (late_epilogue && accumulate) return ASR_E_SHAPE;
+  const float* bias_late = bias;
+  const int relu_late = relu;
+  if (late_epilogue) { bias = nullptr; relu = 0; }
   GemmArgs g;
   const bool akc = !transA, bkc = transB != 0;
   g.A.p = A; g.A.ld = lda;
@@ -318,6 +335,10 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
   else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
   else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
+  if (late_epilogue) {
+    dim3 eg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
+    hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, bias_late, relu_late);
+  }
   ASR_CHECK_LAUNCH();
   return 0;
 }

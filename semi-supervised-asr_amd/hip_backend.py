@@ -110,12 +110,19 @@ def _rowmajor(t):
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1))
 
 
-def auto_split_k(M, N, K, batch=1):
-    """Split-K factor for GEMMs without an epilogue (partials are added with f32 atomics).  Measured on MI355X
-    (tools/gemm_split_sweep.py): with K >= 2048 the 128x128 tiling leaves the 256 CUs unevenly loaded unless there
-    are several workgroups per CU, and ~6 K-slices is the sweet spot from 100 to 400 output tiles."""
+def auto_split_k(M, N, K, batch=1, epilogue=False):
+    """Split-K factor (partials are added with f32 atomics; a bias/ReLU epilogue then needs a second pass over C).
+    Measured on MI355X (tools/gemm_split_sweep.py): with K >= 2048 the 128x128 tiling leaves the 256 CUs unevenly
+    loaded unless there are several workgroups per CU, and ~6 K-slices is the sweet spot from 100 to 400 output
+    tiles; below ~128 tiles even K = 512 is worth splitting (a workgroup's K loop is a serial chain)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    if K < 2048 or tiles >= 1024:
+    if tiles >= 1024 or K < 512:
+        return 1
+    if K < 2048:
+        if tiles > 128 or epilogue:
+            return 1
+        return int(max(1, min(4, K // 128)))
+    if epilogue and tiles > 256:
         return 1
     want = 6 if tiles >= 100 else (8 if tiles >= 48 else 16)
     return int(max(1, min(want, K // 256)))
@@ -133,7 +140,9 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, ac
     out, ldc = _rowmajor(out)
     assert out.shape == (M, N)
     if split_k is None:
-        split_k = 1 if (bias is not None or relu) else auto_split_k(M, N, K)
+        split_k = auto_split_k(M, N, K, epilogue=(bias is not None or relu))
+        if accumulate and (bias is not None or relu):
+            split_k = 1
     check(load().asr_gemm_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
                               ptr(bias), int(relu), int(accumulate), 1, 0, 0, 0, split_k, stream()), "asr_gemm_f32")
     return out
