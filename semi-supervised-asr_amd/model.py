@@ -194,11 +194,42 @@ class Decoder(torch.nn.Module):
         self.dropout_layer = torch.nn.Dropout(p=dropout_rate)
         self.attention = attention
         self.hidden_dim, self.att_odim, self.dropout_rate = hidden_dim, att_odim, dropout_rate
+        self._tok_const = {}
         self.ls_weight = ls_weight
         self.labeldist = labeldist
         if labeldist is not None:
             # plain attribute, not a buffer -> absent from state_dict
             self.vlabeldist = cc(torch.from_numpy(np.array(labeldist, dtype=np.float32)))
+
+    def _label_matrices(self, ys, olength=None):
+        """ys_in = [BOS, y], ys_out = [y, EOS], both padded with EOS (model.py:301-306), as [B, L] matrices.
+        One concatenation + one gather on the device with indices built on the host from the (host-known) label
+        lengths, instead of 2B concatenations and 2B row copies that leave the GPU idle behind the launch queue."""
+        lens = [int(y.size(0)) for y in ys]
+        bsz, n = len(ys), int(sum(lens))
+        steps = max(lens) + 1
+        if olength is not None and olength > steps:
+            steps = int(olength)
+        dev = ys[0].device
+        key = (str(dev), str(ys[0].dtype))
+        const = self._tok_const.get(key)
+        if const is None:
+            const = torch.tensor([self.bos, self.eos], dtype=ys[0].dtype, device=dev)
+            self._tok_const[key] = const
+        flat = torch.cat([y.reshape(-1) for y in ys] + [const])          # [n + 2]; n = BOS slot, n + 1 = EOS slot
+        idx = np.full((2, bsz, steps), n + 1, dtype=np.int32)
+        off = 0
+        for b, ln in enumerate(lens):
+            idx[0, b, 0] = n
+            idx[0, b, 1:1 + ln] = np.arange(off, off + ln)
+            idx[1, b, :ln] = np.arange(off, off + ln)
+            off += ln
+        if dev.type == "cuda":
+            didx = hb_to_device(idx, dev).to(torch.long)
+        else:
+            didx = torch.from_numpy(idx).to(torch.long)
+        both = flat[didx]
+        return both[0], both[1]
 
     def forward(self, enc_pad, enc_len, ys=None, tf_rate=1.0, max_dec_timesteps=500, sample=False, smooth=False,
                 scaling=1.0, label_smoothing=True, olength=None):
@@ -213,14 +244,7 @@ class Decoder(torch.nn.Module):
         opts = dict(scaling=2.0, smooth=bool(smooth), smooth_scaling=float(scaling), sample=bool(sample),
                     bos=self.bos)                    # attention temperature is the AttLoc default
         if ys is not None:
-            bos = ys[0].new_tensor([self.bos])
-            eos = ys[0].new_tensor([self.eos])
-            tok_in = pad_list([torch.cat([bos, y]) for y in ys], self.eos)
-            tok_out = pad_list([torch.cat([y, eos]) for y in ys], self.eos)
-            if olength is not None and olength > tok_out.size(1):
-                extra = olength - tok_out.size(1)
-                tok_in = F.pad(tok_in, (0, extra), value=self.eos)
-                tok_out = F.pad(tok_out, (0, extra), value=self.eos)
+            tok_in, tok_out = self._label_matrices(ys, olength)
             steps = tok_out.size(1)
             # one numpy draw per step, also at tf_rate=1 and for step 0 (model.py:328)
             draws = [np.random.random_sample() <= tf_rate for _ in range(steps)]
