@@ -277,10 +277,10 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       for (int w2 = 0; w2 < 8; ++w2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) pre[i] += part[(w2 * 64 + tid_) * 5 + i];
-      const float gi = asr_sigmoid(pre[0]), gf = asr_sigmoid(pre[1]);
-      const float gg = tanhf(pre[2]), go = asr_sigmoid(pre[3]);
+      const float gi = asr_fast_sigmoid(pre[0]), gf = asr_fast_sigmoid(pre[1]);
+      const float gg = asr_fast_tanh(pre[2]), go = asr_fast_sigmoid(pre[3]);
       const float cn = gf * c_prev + gi * gg;
-      float zn = go * tanhf(cn);
+      float zn = go * asr_fast_tanh(cn);
       if (aborted || flag_load(a.ctrl + 8) != 0u) zn = __builtin_nanf("");
       c_prev = cn;
       if (pb_ok_ && !(ASR_DP_ABL & 32)) {
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       for (int w2 = 0; w2 < 8; ++w2)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dh += part[(w2 * 64 + 4 * (4 * ks + ug) + row) * 5 + ii];
-      const float tc = tanhf(ct);
+      const float tc = asr_fast_tanh(ct);
       const float dc = dcarry + dh * ga.w * (1.f - tc * tc);
       float4 da;
       da.x = dc * ga.z * ga.x * (1.f - ga.x);

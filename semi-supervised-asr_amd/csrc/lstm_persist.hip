@@ -160,10 +160,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       for (int w2 = 0; w2 < PW; ++w2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) pre[i] += part[s & 1][w2][pl][pr + i];
-      const float gi = asr_sigmoid(pre[0]), gf = asr_sigmoid(pre[1]);
-      const float gg = tanhf(pre[2]), go = asr_sigmoid(pre[3]);
+      const float gi = asr_fast_sigmoid(pre[0]), gf = asr_fast_sigmoid(pre[1]);
+      const float gg = asr_fast_tanh(pre[2]), go = asr_fast_sigmoid(pre[3]);
       float cn = gf * c_prev + gi * gg;
-      float hn = go * tanhf(cn);
+      float hn = go * asr_fast_tanh(cn);
       if (t >= plen) { cn = 0.f; hn = 0.f; }
       if (aborted || flag_load(a.ctrl + 8) != 0u) hn = __builtin_nanf("");
       c_prev = cn;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       for (int w2 = 0; w2 < PW; ++w2)
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) dh += part[s & 1][w2][pl + 4 * k2][pr];
-      const float tc = tanhf(ct);
+      const float tc = asr_fast_tanh(ct);
       const float dc = dcarry + dh * av.w * (1.f - tc * tc);
       float4 da;
       da.x = dc * av.z * av.x * (1.f - av.x);
