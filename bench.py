@@ -206,7 +206,7 @@ def kernel_roofline(dev):
         torch.cuda.synchronize()
         e0.record(stream)
         rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c),
-                                          hb.ptr(y), hb.ptr(dw), hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()),
+                                          hb.ptr(y), hb.ptr(dw), None, hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()),
                                           hb.stream())
         e1.record(stream)
         torch.cuda.synchronize()

@@ -137,10 +137,11 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
  * xch >= 1 MB).  The exchanged copy of dG carries a 1-bit tag in each mantissa LSB; the in-place dG is exact.
  * If y (forward hidden states) and dw_hh ([ndir][4H][H], gate-interleaved, zero-filled or holding a running sum)
  * are given, the recurrent weight gradient sum_t dG_t^T h_{t-1} is accumulated into dw_hh inside the kernel
- * (fp32 atomics across the row groups) and the caller skips that GEMM. */
+ * (fp32 atomics across the row groups) and the caller skips that GEMM.  If db ([ndir][4H], gate-interleaved,
+ * zero-filled) is given, the bias gradient sum_{t,b} dG is accumulated into it as well. */
 int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                              const int32_t* lens, const float* dy, const float* c, const float* y,
-                             float* dw_hh, void* xch, void* ctrl, asr_stream_t stream);
+                             float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pyramidal pair-concat (model.py:85-92), time-major:

@@ -18,6 +18,9 @@
 // placement the kernel raises an abort word, poisons its outputs with NaN and drains — the host falls back to
 // the per-step kernels.  1 workgroup per CU is enforced by the LDS request, so 256 workgroups are co-resident.
 #include "persist.h"
+#ifndef ASR_LP_ABL
+#define ASR_LP_ABL 0
+#endif
 
 namespace {
 
@@ -37,6 +40,7 @@ struct PersistArgs {
   const float* dy;      // bwd
   const float* yfwd;    // bwd: forward hidden states [T][B][ndir*H] (partner of dG in dW_hh), or NULL
   float* dw;            // bwd: dW_hh [ndir][4H][H] gate-interleaved, accumulated with atomics, or NULL
+  float* db;            // bwd: bias gradient [ndir][4H] gate-interleaved (sum of dG over time and rows), or NULL
   u64* xch;             // fwd: [2][8][PRG][H] granules;  bwd: [2][8][PRG][4H]
   unsigned* ctrl;       // [0..7] tickets per XCC, [8] abort, [9] error code
 };
@@ -114,6 +118,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
           for (int rr = 0; rr < PRG - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
           if (__all(!gl || ok)) break;
         }
+#ifdef ASR_NO_POLL
+        break;
+#endif
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
           if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
           aborted = true;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       // (wave-private LDS region: program order within the wave is enough)
       const int j = lane & 3;
 #pragma unroll
-      for (int k4 = 0; k4 < PKW / 4; ++k4) {
+      for (int k4 = 0; k4 < ((ASR_LP_ABL & 1) ? 1 : PKW / 4); ++k4) {
         const float4 b0 = *reinterpret_cast<const float4*>(&hs[wave][j][4 * k4]);
         const float4 b1 = *reinterpret_cast<const float4*>(&hs[wave][4 + j][4 * k4]);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b0.x, acc0, 0, 0, 0);
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
   float dcarry = 0.f;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of this thread's (unit, row): sum of dG over time
   float* xch_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * PRG * 4 * PH;   // + parity * 8*PRG*4H
   const int64_t par_stride = (int64_t)8 * PRG * 4 * PH;
   bool aborted = false;
@@ -296,6 +304,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
           for (int rr = 0; rr < PRG - 1; ++rr) bits &= row_bits(rr);
           if (__all(!gl || bits == 0xFu)) break;
         }
+#ifdef ASR_NO_POLL
+        break;
+#endif
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
           if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
           aborted = true;
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       const float* h0 = &hs[wave][li][PQS * ks];
       const float* h1 = &hs[wave][4 + li][PQS * ks];
 #pragma unroll
-      for (int q4 = 0; q4 < PQ / 4; ++q4) {
+      for (int q4 = 0; q4 < ((ASR_LP_ABL & 1) ? 1 : PQ / 4); ++q4) {
         const float4 b0 = *reinterpret_cast<const float4*>(h0 + 4 * q4);
         const float4 b1 = *reinterpret_cast<const float4*>(h1 + 4 * q4);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b0.x, acc0, 0, 0, 0);
@@ -347,7 +358,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       if (t >= plen) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
       if (aborted || flag_load(a.ctrl + 8) != 0u) da.x = __builtin_nanf("");
       dcarry = dcn;
-      if (prow_ok) *gp = da;
+      if (prow_ok) {
+        *gp = da;
+        dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
+      }
       const unsigned bit = (((unsigned)s >> 1) & 1u) ^ 1u;
       float4 tg;
       tg.x = tag_word(da.x, bit); tg.y = tag_word(da.y, bit); tg.z = tag_word(da.z, bit); tg.w = tag_word(da.w, bit);
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     // tile is still in this wave's LDS region and h_t is the partner of dG_{t_next} in both directions.  Placed
     // after the publish so that it fills the wait for the next hand-off.  Blocks = 16 groups of 4 gate columns,
     // A = dG (4 columns), B = h (4 units), K = one batch row per instruction.
-    if (fuse_dw && s > 0) {
+    if (fuse_dw && s > 0 && !(ASR_LP_ABL & 2)) {
       const int kb4 = lane;                      // column within the 64-column chunk (= 4*block + i)
       const int jj = lane & 3;
 #pragma unroll
@@ -379,6 +393,20 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
             dwacc[kq][u4] = __builtin_amdgcn_mfma_f32_4x4x1f32(av2, bv[u4], dwacc[kq][u4], 0, 0, 0);
         }
       }
+    }
+  }
+  if (a.db != nullptr && pw_thread) {
+    // rows of a unit sit in 8 consecutive lanes (pj = tid & 7); the 4 row groups (XCDs) of a direction add up
+    float v[4] = {dbacc.x, dbacc.y, dbacc.z, dbacc.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] += __shfl_xor(v[k], 1, 64);
+      v[k] += __shfl_xor(v[k], 2, 64);
+      v[k] += __shfl_xor(v[k], 4, 64);
+    }
+    if (pj == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(a.db + (int64_t)d * 4 * PH + punit * 4 + k, v[k]);
     }
   }
   if (fuse_dw) {
@@ -461,7 +489,7 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
     a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
     a.y = y + (int64_t)rb * ndir * H; a.c = c + (int64_t)rb * ndir * H;
-    a.dy = nullptr; a.yfwd = nullptr; a.dw = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
+    a.dy = nullptr; a.yfwd = nullptr; a.dw = nullptr; a.db = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
     int rc = H == 512 ? launch_fwd<512>(a, stream) : H == 320 ? launch_fwd<320>(a, stream)
            : H == 256 ? launch_fwd<256>(a, stream) : launch_fwd<128>(a, stream);
     if (rc) return rc;
@@ -473,7 +501,7 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
 // Persistent fast path of asr_lstm_seq_bwd (same arguments and results except that no dcarry scratch is needed).
 extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                                         const int32_t* lens, const float* dy, const float* c, const float* y,
-                                        float* dw_hh, void* xch, void* ctrl, asr_stream_t stream_) {
+                                        float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hhT || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
   if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
@@ -489,6 +517,7 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
     a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hhT; a.lens = lens + rb; a.y = nullptr;
     a.c = const_cast<float*>(c) + (int64_t)rb * ndir * H; a.dy = dy + (int64_t)rb * ndir * H;
     a.yfwd = (y && dw_hh) ? y + (int64_t)rb * ndir * H : nullptr; a.dw = (y && dw_hh) ? dw_hh : nullptr;
+    a.db = db;
     a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
     int rc = H == 512 ? launch_bwd<512>(a, stream) : H == 320 ? launch_bwd<320>(a, stream)
            : H == 256 ? launch_bwd<256>(a, stream) : launch_bwd<128>(a, stream);

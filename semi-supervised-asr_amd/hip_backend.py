@@ -63,7 +63,7 @@ def load():
     lib.asr_colsum_f32.argtypes = [c_i64, c_i64, c_p, c_i64, c_p, c_i, c_p]
     lib.asr_lstm_seq_fwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_lstm_seq_fwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
-    lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -322,15 +322,15 @@ def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
     run_grouped(groups, one)
 
 
-def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None):
-    """Returns True when dW_hh was accumulated into `dw_hh` by the (persistent) kernel itself."""
+def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None):
+    """Returns True when dW_hh (and the bias gradient `db`, if given) were accumulated by the persistent kernel itself."""
     T, B, ndir, H4 = gates.shape
     H = H4 // 4
     lib = load()
     if USE_PERSIST:
         xch, ctrl = persist_scratch(gates.device)
         rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hhT), ptr(lens), ptr(dy), ptr(c),
-                                          ptr(y), ptr(dw_hh), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
+                                          ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
         if rc == 0:
             return y is not None and dw_hh is not None
         if rc != -2:

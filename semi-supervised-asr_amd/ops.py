@@ -100,7 +100,8 @@ def _lstm_workspace(T, B, H, ndir, dev, with_bwd):
               lens=torch.empty(B, dtype=torch.int32, device=dev))
     if with_bwd:
         ws.update(w_hhT=torch.empty(ndir, H, 4 * H, **f32), dy=torch.empty(T, B, ndir * H, **f32),
-                  dcarry=torch.empty(B, ndir * H, **f32), dw_hh=torch.empty(ndir, 4 * H, H, **f32))
+                  dcarry=torch.empty(B, ndir * H, **f32), dw_hh=torch.empty(ndir, 4 * H, H, **f32),
+                  db=torch.empty(ndir * 4 * H, **f32))
     return ws
 
 
@@ -147,12 +148,13 @@ class _LstmLayer(torch.autograd.Function):
         ws["dcarry"].zero_()
         gates, y = ws["gates"], ws["y"]
         ws["dw_hh"].zero_()
+        ws["db"].zero_()
         fused_dw = hb.lstm_seq_bwd(gates, ws["w_hhT"], ws["lens"], ws["dy"], ws["c"], ws["dcarry"], y=y,
-                                   dw_hh=ws["dw_hh"])                                     # gates <- dG in place
+                                   dw_hh=ws["dw_hh"], db=ws["db"])                        # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = hb.gemm(dG, x2, trans_a=True)                     # [ndir*4H, I]
-        db = hb.colsum(dG)
+        db = ws["db"] if fused_dw else hb.colsum(dG)       # the persistent kernel sums the bias gradient itself
         y2 = y.view(T * B, ndir * H)
         unperm = gate_unperm(H, dev)
         grads = []
