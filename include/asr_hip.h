@@ -261,6 +261,25 @@ int asr_dec_seq_bwd(const asr_dec_bwd_t* p, int s_begin, int s_end, void* graphs
 int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* p, float* mbuf, void* xch, void* ctrl, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Parameter layout conversion: torch layout of nn.LSTM / nn.LSTMCell (gate-major rows i,f,g,o; model.py:67-68,262)
+ * <-> the kernels' gate-interleaved rows (unit*4+gate).  w_ih/w_hh/b_ih/b_hh: arrays of `ndir` device pointers.
+ *   asr_lstm_pack_f32    -> w_ih_cat [ndir*4H][I], w_hh_il [ndir][4H][H], bias [ndir*4H] = b_ih + b_hh
+ *   asr_lstm_unpack_f32  gradients in the interleaved layout -> per-direction torch-layout dw_ih [4H][I],
+ *                        dw_hh [4H][H], db [4H] (the gradient of b_ih and of b_hh)
+ *   asr_cell_pack_f32    decoder cell: wcat [4D][D+O+E] = [w_hh | w_ih[:, E:E+O] | w_ih[:, :E]] interleaved, bcat
+ *   asr_cell_unpack_f32  dwcat, db (interleaved) -> dw_ih [4D][E+O], dw_hh [4D][D], db [4D]
+ * ------------------------------------------------------------------------------------- */
+int asr_lstm_pack_f32(int H, int I, int ndir, const float* const* w_ih, const float* const* w_hh,
+                      const float* const* b_ih, const float* const* b_hh, float* w_ih_cat, float* w_hh_il,
+                      float* bias, asr_stream_t stream);
+int asr_lstm_unpack_f32(int H, int I, int ndir, const float* dw_ih_cat, const float* dw_hh_il, const float* db_il,
+                        float* const* dw_ih, float* const* dw_hh, float* const* db, asr_stream_t stream);
+int asr_cell_pack_f32(int D, int O, int E, const float* w_ih, const float* w_hh, const float* b_ih,
+                      const float* b_hh, float* wcat, float* bcat, asr_stream_t stream);
+int asr_cell_unpack_f32(int D, int O, int E, const float* dwcat, const float* db_il, float* dw_ih, float* dw_hh,
+                        float* db, asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser on a flat fp32 buffer (solver.py:152-153,384-385: clip_grad_norm_ + Adam(amsgrad,
  * weight_decay).step).  asr_sumsq_f32 adds sum(g^2) into the device scalar out[0] (caller zeroes
  * it); asr_adam_clip_f32 scales g by min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) (skipped when

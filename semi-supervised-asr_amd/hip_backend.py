@@ -17,6 +17,7 @@ EXPORTS = (
     "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
+    "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
 
@@ -77,6 +78,11 @@ def load():
     lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                       c_f, c_p]
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]
+    pp = ctypes.POINTER(c_p)
+    lib.asr_lstm_pack_f32.argtypes = [c_i, c_i, c_i, pp, pp, pp, pp, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_unpack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, pp, pp, pp, c_p]
+    lib.asr_cell_pack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_cell_unpack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]
     if lib.asr_abi_version() != ABI_VERSION:
         raise RuntimeError("libasr_hip.so ABI %d != expected %d" % (lib.asr_abi_version(), ABI_VERSION))
     _lib = lib
@@ -272,6 +278,44 @@ def to_device_i32(values, device):
     ring["i"] += 1
     buf.copy_(torch.from_numpy(arr.reshape(-1)))
     return buf.to(device, non_blocking=True).view(arr.shape)
+
+
+def _ptr_array(tensors):
+    return (c_p * len(tensors))(*[_dev(t).data_ptr() for t in tensors])
+
+
+def lstm_pack(params, ndir, w_ih_cat, w_hh_il, bias):
+    """params: per direction (w_ih, w_hh, b_ih, b_hh) in torch layout -> interleaved kernel layout (one launch)."""
+    H, I = params[1].shape[1], params[0].shape[1]
+    ps = [p if p.is_contiguous() else p.contiguous() for p in params]
+    check(load().asr_lstm_pack_f32(H, I, ndir, _ptr_array(ps[0::4]), _ptr_array(ps[1::4]), _ptr_array(ps[2::4]),
+                                   _ptr_array(ps[3::4]), ptr(w_ih_cat), ptr(w_hh_il), ptr(bias), stream()),
+          "asr_lstm_pack_f32")
+
+
+def lstm_unpack(H, I, ndir, dw_ih_cat, dw_hh_il, db_il):
+    """Interleaved gradients -> [dw_ih, dw_hh, db] per direction in torch layout (one launch)."""
+    dev = dw_ih_cat.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    dw_ih = [torch.empty(4 * H, I, **f32) for _ in range(ndir)]
+    dw_hh = [torch.empty(4 * H, H, **f32) for _ in range(ndir)]
+    db = [torch.empty(4 * H, **f32) for _ in range(ndir)]
+    check(load().asr_lstm_unpack_f32(H, I, ndir, ptr(dw_ih_cat), ptr(dw_hh_il), ptr(db_il), _ptr_array(dw_ih),
+                                     _ptr_array(dw_hh), _ptr_array(db), stream()), "asr_lstm_unpack_f32")
+    return dw_ih, dw_hh, db
+
+
+def cell_pack(w_ih, w_hh, b_ih, b_hh, D, O, E, wcat, bcat):
+    check(load().asr_cell_pack_f32(D, O, E, ptr(w_ih.contiguous()), ptr(w_hh.contiguous()), ptr(b_ih.contiguous()),
+                                   ptr(b_hh.contiguous()), ptr(wcat), ptr(bcat), stream()), "asr_cell_pack_f32")
+
+
+def cell_unpack(dwcat, db_il, D, O, E):
+    f32 = dict(device=dwcat.device, dtype=torch.float32)
+    dw_ih, dw_hh, db = torch.empty(4 * D, E + O, **f32), torch.empty(4 * D, D, **f32), torch.empty(4 * D, **f32)
+    check(load().asr_cell_unpack_f32(D, O, E, ptr(dwcat), ptr(db_il), ptr(dw_ih), ptr(dw_hh), ptr(db), stream()),
+          "asr_cell_unpack_f32")
+    return dw_ih, dw_hh, db
 
 
 def _off(t, elems):

@@ -57,7 +57,7 @@ class _CellWeights(torch.nn.Module):
 
 def _drop_mask(shape, p, device):
     """Inverted-dropout mask, already scaled by 1/(1-p)."""
-    return torch.bernoulli(torch.full(shape, 1.0 - p, device=device)) / (1.0 - p)
+    return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
 
 
 def padded_lengths(t_max, n_layers, subsample):

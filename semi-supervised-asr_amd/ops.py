@@ -114,18 +114,17 @@ class _LstmLayer(torch.autograd.Function):
         T, B, I = x.shape
         H = params[1].shape[1]
         dev = x.device
-        perm = gate_perm(H, dev)
         x2 = x.reshape(T * B, I)
-        w_ih = torch.cat([params[4 * d][perm] for d in range(ndir)], 0)                       # [ndir*4H, I]
-        bias = torch.cat([(params[4 * d + 2] + params[4 * d + 3])[perm] for d in range(ndir)], 0)
         if pooled:
             lease = _POOL.acquire(("lstm", dev.index, T, B, H, ndir),
                                   lambda: _lstm_workspace(T, B, H, ndir, dev, True))
             ws = lease.ws
         else:
             lease, ws = None, _lstm_workspace(T, B, H, ndir, dev, False)
-        for d in range(ndir):
-            ws["w_hh"][d].copy_(params[4 * d + 1][perm])
+        # torch layout -> gate-interleaved kernel layout, one launch: w_ih [ndir*4H, I], w_hh [ndir, 4H, H], b_ih + b_hh
+        w_ih = torch.empty(ndir * 4 * H, I, device=dev, dtype=torch.float32)
+        bias = torch.empty(ndir * 4 * H, device=dev, dtype=torch.float32)
+        hb.lstm_pack(params, ndir, w_ih, ws["w_hh"], bias)
         ws["lens"].copy_(lens)
         hb.gemm(x2, w_ih, trans_b=True, bias=bias, out=ws["gates"].view(T * B, ndir * 4 * H))
         hb.lstm_seq_fwd(ws["gates"], ws["w_hh"], ws["lens"], ws["y"], ws["c"], use_graphs=pooled)
@@ -143,36 +142,36 @@ class _LstmLayer(torch.autograd.Function):
             "(autograd was off in forward, or backward ran twice)"
         ws = lease.ws
         dev = dy.device
-        ws["dy"].copy_(dy)
+        dyc = dy if dy.is_contiguous() else ws["dy"].copy_(dy)
         ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2))
         ws["dcarry"].zero_()
         gates, y = ws["gates"], ws["y"]
         ws["dw_hh"].zero_()
         ws["db"].zero_()
-        fused_dw = hb.lstm_seq_bwd(gates, ws["w_hhT"], ws["lens"], ws["dy"], ws["c"], ws["dcarry"], y=y,
+        fused_dw = hb.lstm_seq_bwd(gates, ws["w_hhT"], ws["lens"], dyc, ws["c"], ws["dcarry"], y=y,
                                    dw_hh=ws["dw_hh"], db=ws["db"])                        # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = hb.gemm(dG, x2, trans_a=True)                     # [ndir*4H, I]
         db = ws["db"] if fused_dw else hb.colsum(dG)       # the persistent kernel sums the bias gradient itself
-        y2 = y.view(T * B, ndir * H)
-        unperm = gate_unperm(H, dev)
+        if not fused_dw:
+            y2 = y.view(T * B, ndir * H)
+            for d in range(ndir):
+                if T > 1:
+                    if d == 0:     # h_{t-1} = y[t-1]
+                        a = dG[B:, d * 4 * H:(d + 1) * 4 * H]
+                        hprev = y2[:(T - 1) * B, d * H:(d + 1) * H]
+                    else:          # reverse direction: predecessor in processing order is y[t+1]
+                        a = dG[:(T - 1) * B, d * 4 * H:(d + 1) * 4 * H]
+                        hprev = y2[B:, d * H:(d + 1) * H]
+                    hb.gemm(a, hprev, trans_a=True, out=ws["dw_hh"][d])
+                else:
+                    ws["dw_hh"][d].zero_()
+        # gate-interleaved gradients -> torch layout, one launch
+        g_ih, g_hh, g_b = hb.lstm_unpack(H, I, ndir, dw_ih, ws["dw_hh"], db)
         grads = []
         for d in range(ndir):
-            if fused_dw:       # accumulated inside the persistent kernel
-                dw_hh = ws["dw_hh"][d]
-            elif T > 1:
-                if d == 0:     # h_{t-1} = y[t-1]
-                    a = dG[B:, d * 4 * H:(d + 1) * 4 * H]
-                    hprev = y2[:(T - 1) * B, d * H:(d + 1) * H]
-                else:          # reverse direction: predecessor in processing order is y[t+1]
-                    a = dG[:(T - 1) * B, d * 4 * H:(d + 1) * 4 * H]
-                    hprev = y2[B:, d * H:(d + 1) * H]
-                dw_hh = hb.gemm(a, hprev, trans_a=True)
-            else:
-                dw_hh = torch.zeros(4 * H, H, device=dev)
-            dbd = db[d * 4 * H:(d + 1) * 4 * H][unperm]
-            grads += [dw_ih[d * 4 * H:(d + 1) * 4 * H][unperm], dw_hh[unperm], dbd, dbd]
+            grads += [g_ih[d], g_hh[d], g_b[d], g_b[d]]
         lease.release()
         return (dx, None, None, None) + tuple(grads)
 
@@ -296,17 +295,14 @@ class _DecoderSeq(torch.autograd.Function):
             ws = lease.ws
         else:
             lease, ws = None, _dec_workspace(B, Tp, A, D, O, E, C, K, L, drop, dev, False)
-        perm = gate_perm(D, dev)
-        ws["wcat"].copy_(torch.cat([w_hh, w_ih[:, E:E + O], w_ih[:, :E]], 1)[perm])          # [4D, KX]
-        ws["bcat"].copy_((b_ih + b_hh)[perm])
-        ws["convw"].copy_(convw.reshape(C, 2 * K + 1))
-        ws["gvec"].copy_(gvec.reshape(A))
+        hb.cell_pack(w_ih, w_hh, b_ih, b_hh, D, O, E, ws["wcat"], ws["bcat"])       # [4D, KX] gate-interleaved rows
         ws["wattT"].copy_(watt.t())
-        ws["P"].copy_(P)
-        ws["Q"].copy_(Q)
-        ws["w0"].copy_(w0)
+        # inputs used as they are (no staging copies); the dict keeps them alive until the backward has run
+        ws["convw"] = convw.reshape(C, 2 * K + 1).contiguous()
+        ws["gvec"] = gvec.reshape(A).contiguous()
+        ws["P"], ws["Q"], ws["w0"] = P.contiguous(), Q.contiguous(), w0.contiguous()
         if drop:
-            ws["xmask"].copy_(xmask_in)
+            ws["xmask"] = xmask_in.contiguous()
         X, Xd, xmask = ws["X"], ws["Xd"], ws["xmask"]
         X.zero_()
         if drop:
@@ -455,11 +451,7 @@ class _DecoderSeq(torch.autograd.Function):
         dg2 = wk["dgates"].view(L * B, 4 * D)
         Xin = X[:L] if Xd is None else Xd[:L]
         dwcat = hb.gemm(dg2, Xin.reshape(L * B, KX), trans_a=True)               # [4D, KX] gate-interleaved rows
-        unperm = gate_unperm(D, dev)
-        dwcat = dwcat[unperm]
-        dw_hh = dwcat[:, :D].contiguous()
-        dw_ih = torch.cat([dwcat[:, D + O:], dwcat[:, D:D + O]], 1)
-        dbias = hb.colsum(dg2)[unperm]
+        dw_ih, dw_hh, dbias = hb.cell_unpack(dwcat, hb.colsum(dg2), D, O, E)         # -> torch layout, one launch
         dwdec = hb.gemm(wk["dD"].view(L * B, A), X[1:].view(L * B, KX)[:, :D], trans_a=True)
         dgvec = wk["dgvec_part"].sum(0).view(1, A)
         dwatt = wk["dwatt_part"].sum(0)

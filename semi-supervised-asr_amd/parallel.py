@@ -74,13 +74,35 @@ class FlatBuffers(object):
             p.grad = self.flat_g[o:o + n].view_as(p.data)
 
     def zero_grad(self):
-        self.flat_g.zero_()
-        for p, o in zip(self.params, self.offsets):     # re-attach in case something detached .grad
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
-                p.grad = self.flat_g[o:o + p.numel()].view_as(p.data)
+        """Detach every .grad: autograd then stores each gradient by reference instead of launching one add kernel per
+        parameter into the flat buffer; collect() gathers them with a single multi-tensor copy before the step."""
+        for p in self.params:
+            p.grad = None
+
+    def _view(self, i):
+        p, o = self.params[i], self.offsets[i]
+        return self.flat_g[o:o + p.numel()].view_as(p.data)
+
+    def collect(self):
+        """Move the gradients autograd produced into the flat buffer and re-attach .grad to its views."""
+        dst, src, missing = [], [], False
+        for i, p in enumerate(self.params):
+            v = self._view(i)
+            if p.grad is None:
+                missing = True
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+        if missing:
+            self.flat_g.zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for i, p in enumerate(self.params):
+            p.grad = self._view(i)
 
     def allreduce_grads(self, group=None):
         """THE collective of the step: one SUM all-reduce over the flat gradient buffer."""
+        self.collect()
         if world() > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
 
@@ -113,7 +135,7 @@ class FlatAdam(object):
         holding ||g||^2 (read it with .item() only if you need the number)."""
         import hip_backend as hb
         clip = self.max_grad_norm if max_grad_norm is None else max_grad_norm
-        self.buf.allreduce_grads(group)
+        self.buf.allreduce_grads(group)                # gathers the gradients into the flat buffer first
         g = self.param_groups[0]
         self.t += 1
         b1, b2 = g["betas"]

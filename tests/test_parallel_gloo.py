@@ -53,6 +53,7 @@ def _grads_for(rank, world, tf_rate=1.0):
     loss = parallel.local_loss(lp, info)
     buf.zero_grad()
     loss.backward()
+    buf.collect()                                        # gradients -> flat buffer (FlatAdam.step does this itself)
     return buf, names, float(loss.detach())
 
 
@@ -107,6 +108,8 @@ def test_flat_buffers_alias_params_and_grads():
     buf.zero_grad()
     (lin(torch.ones(2, 5)).sum() + (shared * 2).sum()).backward()
     assert torch.equal(lin.bias.grad, torch.full((3,), 2.0))
+    buf.collect()
+    assert lin.bias.grad.data_ptr() == buf.flat_g.data_ptr() + 4 * buf.offsets[1]
     o = buf.offsets[2]
     assert torch.equal(buf.flat_g[o:o + 7], torch.full((7,), 2.0))
     buf.flat_p[buf.offsets[1]:buf.offsets[1] + 3] = 5.0
