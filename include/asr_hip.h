@@ -280,6 +280,18 @@ int asr_cell_unpack_f32(int D, int O, int E, const float* dwcat, const float* db
                         float* db, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Label log-probabilities with label smoothing (Decoder.forward, model.py:354-366):
+ *   out[r] = (1-ls) * log_softmax(logits[r])[index[r]] + ls * sum_v labeldist[v] * log_softmax(logits[r])[v]
+ * (labeldist NULL: plain gather of the log-softmax).  rows = L*B; index is int64 (torch long).  The backward writes
+ * d(logits) for an upstream gradient grad_out[rows].
+ * ------------------------------------------------------------------------------------- */
+int asr_label_logprob_fwd(int64_t rows, int V, const float* logits, int64_t ld, const int64_t* index,
+                          const float* labeldist, float ls_weight, float* out, asr_stream_t stream);
+int asr_label_logprob_bwd(int64_t rows, int V, const float* logits, int64_t ld, const int64_t* index,
+                          const float* labeldist, float ls_weight, const float* grad_out, float* dlogits,
+                          int64_t lddz, asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser on a flat fp32 buffer (solver.py:152-153,384-385: clip_grad_norm_ + Adam(amsgrad,
  * weight_decay).step).  asr_sumsq_f32 adds sum(g^2) into the device scalar out[0] (caller zeroes
  * it); asr_adam_clip_f32 scales g by min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) (skipped when

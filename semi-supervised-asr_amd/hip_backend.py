@@ -18,6 +18,7 @@ EXPORTS = (
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
+    "asr_label_logprob_fwd", "asr_label_logprob_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
 
@@ -78,6 +79,8 @@ def load():
     lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                       c_f, c_p]
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]
+    lib.asr_label_logprob_fwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p]
+    lib.asr_label_logprob_bwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p, c_i64, c_p]
     pp = ctypes.POINTER(c_p)
     lib.asr_lstm_pack_f32.argtypes = [c_i, c_i, c_i, pp, pp, pp, pp, c_p, c_p, c_p, c_p]
     lib.asr_lstm_unpack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, pp, pp, pp, c_p]

@@ -195,6 +195,7 @@ class Decoder(torch.nn.Module):
         self.attention = attention
         self.hidden_dim, self.att_odim, self.dropout_rate = hidden_dim, att_odim, dropout_rate
         self._tok_const = {}
+        self._dist_dev = {}
         self.ls_weight = ls_weight
         self.labeldist = labeldist
         if labeldist is not None:
@@ -264,16 +265,18 @@ class Decoder(torch.nn.Module):
             P, Q, self.embedding.weight, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh,
             att.mlp_dec.weight, att.loc_conv.weight, att.mlp_att.weight, att.gvec.weight, att.mlp_o.bias,
             self.output_layer.weight, self.output_layer.bias, w0, opts)
-        logits = logits.transpose(0, 1)
         prediction = pred.transpose(0, 1)
         ws = ws.transpose(0, 1)
-        log_probs = F.log_softmax(logits, dim=2)
-        index = tok_out.to(dev) if have_ys else prediction
-        ys_log_probs = torch.gather(log_probs, dim=2, index=index.unsqueeze(2)).squeeze(2)
-        if label_smoothing and self.ls_weight > 0 and self.training:
-            reg = torch.sum(log_probs * self.vlabeldist.to(dev), dim=2)
-            ys_log_probs = (1 - self.ls_weight) * ys_log_probs + self.ls_weight * reg
-        return logits, ys_log_probs, prediction, ws
+        # log_softmax -> gather target (or own prediction) -> label smoothing (model.py:354-366), one kernel each way
+        index_lb = (tok_out.to(dev) if have_ys else prediction).t()              # [L, B] like the time-major logits
+        smooth_on = label_smoothing and self.ls_weight > 0 and self.training
+        if smooth_on:
+            key = str(dev)
+            if key not in self._dist_dev:
+                self._dist_dev[key] = self.vlabeldist.to(dev).float().contiguous()
+        ys_log_probs = ops.label_logprob(logits, index_lb, self._dist_dev[str(dev)] if smooth_on else None,
+                                         self.ls_weight if smooth_on else 0.0).transpose(0, 1)
+        return logits.transpose(0, 1), ys_log_probs, prediction, ws
 
 
 class E2E(torch.nn.Module):

@@ -475,6 +475,40 @@ class _DecoderSeq(torch.autograd.Function):
                 None, None)
 
 
+class _LabelLogProb(torch.autograd.Function):
+    """(1-ls) log_softmax(logits)[target] + ls sum_v labeldist_v log_softmax(logits)_v  (model.py:354-366) in one
+    kernel each way.  logits [..., V] contiguous, index [...] long -> [...]"""
+
+    @staticmethod
+    def forward(ctx, logits, index, labeldist, ls_weight):
+        lg = logits.contiguous()
+        V = lg.shape[-1]
+        rows = lg.numel() // V
+        idx = index.contiguous()
+        out = torch.empty(lg.shape[:-1], device=lg.device, dtype=torch.float32)
+        dist = labeldist.contiguous() if labeldist is not None else None
+        hb.check(hb.load().asr_label_logprob_fwd(rows, V, hb.ptr(lg), V, ctypes.c_void_p(idx.data_ptr()), hb.ptr(dist),
+                                                 float(ls_weight), hb.ptr(out), hb.stream()), "asr_label_logprob_fwd")
+        ctx.save_for_backward(lg, idx, dist)
+        ctx.ls = float(ls_weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, idx, dist = ctx.saved_tensors
+        V = lg.shape[-1]
+        rows = lg.numel() // V
+        gc = g.contiguous()
+        dz = torch.empty_like(lg)
+        hb.check(hb.load().asr_label_logprob_bwd(rows, V, hb.ptr(lg), V, ctypes.c_void_p(idx.data_ptr()), hb.ptr(dist),
+                                                 ctx.ls, hb.ptr(gc), hb.ptr(dz), V, hb.stream()), "asr_label_logprob_bwd")
+        return dz, None, None, None
+
+
+def label_logprob(logits, index, labeldist=None, ls_weight=0.0):
+    return _LabelLogProb.apply(logits, index, labeldist, ls_weight)
+
+
 def decoder_sequence(P, Q, emb_w, w_ih, w_hh, b_ih, b_hh, wdec, convw, watt, gvec, bo, w_out, b_out, w0, opts):
     opts = dict(opts)
     opts["pooled"] = torch.is_grad_enabled() and (P.requires_grad or w_hh.requires_grad)
