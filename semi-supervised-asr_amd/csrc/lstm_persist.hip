@@ -21,6 +21,9 @@
 #ifndef ASR_LP_ABL
 #define ASR_LP_ABL 0
 #endif
+#ifndef ASR_POLL_SLEEP
+#define ASR_POLL_SLEEP 1
+#endif
 
 namespace {
 
@@ -110,10 +113,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       unsigned spins = 0;
       while (true) {
         gr[PRG - 1] = granule_load(src + (int64_t)(PRG - 1) * PH);          // sentinel row first (see backward)
+#ifdef ASR_LSTM_FULL
+        if (true) {
+#else
         if (__all(!gl || (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
+#endif
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
-          bool ok = true;
+          bool ok = (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s;
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
           if (__all(!gl || ok)) break;
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
           aborted = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
 #pragma unroll
       for (int rr = 0; rr < PRG; ++rr)
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
           aborted = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
 #pragma unroll
       for (int rr = 0; rr < PRG; ++rr)
