@@ -21,6 +21,13 @@
 // Everything the backward needs (gates, c, S = tanh(..), conv features, attention weights, X/Xd) is written to
 // the same buffers as the per-step path, so asr_dec_seq_bwd runs unchanged on the result.
 #include "persist.h"
+// measurement only: per-phase shader-clock stamps of workgroup (group 0, slice 0), steps 8..15, into ctrl[16..]
+#ifdef ASR_DP_TRACE
+#define DP_MARK(k) do { if (tid == 0 && g == 0 && slice == 0 && TRS >= 8 && TRS < 16) \
+    ((unsigned long long*)(a.ctrl + 16))[(TRS - 8) * 16 + (k)] = clock64(); } while (0)
+#else
+#define DP_MARK(k) do {} while (0)
+#endif
 
 #ifndef ASR_DP_ABL
 #define ASR_DP_ABL 0
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     int zv;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
     const int tid_ = tid + zv, lane_ = lane + zv;
+    const unsigned abort_seen = tid < 64 ? flag_load(a.ctrl + 8) : 0u;   // sampled early, consumed by the pointwise phase
     const bool pw_thread_ = tid_ < 4 * DU;
     const int punit_ = DU * slice + (pw_thread_ ? (tid_ >> 2) : 0);
     const int pb_ = r0 + (tid_ & 3);
@@ -216,6 +224,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     const bool ctx_thread_ = tid_ < OQ;
     const unsigned bit = tag_bit_of_step(s);
     const int par = s & 1;
+#define TRS s
+    DP_MARK(0);
     // ------------------------------------------------------------ (1) cell operand: ctx_{s-1} (exchange) + emb_s
     if (s > 0) {
       const float* cx = xg + DX_C + ((s - 1) & 1) * 4 * 512;
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     if (drop && ctx_thread_ && s + 2 < L)
       mask_next = a.xmask[((int64_t)(s + 2) * B + abc) * (OO + EE) + OQ * aq + tid_];
     __syncthreads();
+    DP_MARK(1);
     // ------------------------------------------------------------ (2) gates = x Wcat^T on the 4x4x1 MFMA
     {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -270,6 +281,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       for (int i = 0; i < 4; ++i) pp[i] = acc[i];
     }
     __syncthreads();
+    DP_MARK(2);
     // ------------------------------------------------------------ (3) pointwise LSTM update, publish z_s
     if (pw_thread_) {
       float pre[4] = {pbias.x, pbias.y, pbias.z, pbias.w};
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       const float gg = asr_fast_tanh(pre[2]), go = asr_fast_sigmoid(pre[3]);
       const float cn = gf * c_prev + gi * gg;
       float zn = go * asr_fast_tanh(cn);
-      if (aborted || flag_load(a.ctrl + 8) != 0u) zn = __builtin_nanf("");
+      if (aborted || abort_seen != 0u) zn = __builtin_nanf("");
       c_prev = cn;
       if (pb_ok_ && !(ASR_DP_ABL & 32)) {
         *reinterpret_cast<float4*>(a.gates + ((int64_t)s * B + pb_) * 4 * DD + punit_ * 4) = make_float4(gi, gf, gg, go);
@@ -291,6 +303,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       }
       word_store(xg + DX_Z + par * 4 * 512 + (tid_ & 3) * 512 + punit_, zn, bit);
     }
+    DP_MARK(3);
     // ------------------------------------------------------------ (3b) location conv of w_{s-1} -> f_s (16 frames)
     {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -314,6 +327,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         word_store(xg + DX_F + ((par * 4 + ar) * 16 + ch) * DP_TPM + t, v, bit);
       }
     }
+    DP_MARK(4);
     // ------------------------------------------------------------ (4)+(5) z_s and f_s (exchange) -> W_dec z_s for AU columns
     {
       // one poll for both: z_s pairs over [4][DD/2] and the conv features f_s (published ~2 us ago) as pairs
@@ -340,6 +354,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         p[4 + i] = reinterpret_cast<const u64*>(zx + ((2 * id < 4 * DD) ? row * 512 + d : 0));
       }
       poll_pairs<NZ + 4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 12u);
+      DP_MARK(5);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (foff[i] >= 0) { fs[foff[i]] = pair_lo(v[i]); fs[foff[i] + 1] = pair_hi(v[i]); }
@@ -372,6 +387,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       dps[row * 16 + al] = v;
     }
     __syncthreads();
+    DP_MARK(6);
     // ------------------------------------------------------------ (6) energies: partial sums over this CU's columns
     {
       const int m = lane_ & 15;                       // A operand: pair m of the tile = (row m&3, frame 4*tile + (m>>2))
@@ -386,21 +402,25 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
           for (int kk = 0; kk < 4; ++kk)
             if (kk < nkk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * kk * DP_TPM], ub[kk], acc, 0, 0, 0);
           const int t = 4 * tile + sq_;
+          // uniform row bases + one 32-bit lane offset per tile (no 64-bit index math per element)
+          const int soff = t * AA + acol_;
+          const bool sst = sc_ok_ && t < Tp && !(ASR_DP_ABL & 16);
+          float pe[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float sv = dp_tanh(acc[i] + Ps[(tile * 4 + i) * 64 + lane_] + dps[i * 16 + a_l_]);
-            const int b = r0 + i;
-            if (sc_ok_ && b < nb && t < Tp && !(ASR_DP_ABL & 16)) a.S[(((int64_t)s * B + b) * Tp + t) * AA + acol_] = sv;
-            float pe = sc_ok_ ? gv * sv : 0.f;
-            pe += __shfl_xor(pe, 1, 64);
-            pe += __shfl_xor(pe, 2, 64);
-            pe += __shfl_xor(pe, 4, 64);
-            pe += __shfl_xor(pe, 8, 64);
-            if (a_l_ == 0) word_store(xg + DX_E + ((par * 32 + slice) * 4 + i) * DP_TPM + t, t < Tp ? pe : 0.f, bit);
+            float* Srow = a.S + ((int64_t)s * B + r0 + i) * Tp * AA;
+            if (sst && r0 + i < nb) Srow[soff] = sv;
+            pe[i] = row16_sum(sc_ok_ ? gv * sv : 0.f);
+          }
+          if (a_l_ < 4) {      // lane i of each 16-lane group publishes row i (every lane of the group holds all four sums)
+            const float pv_ = a_l_ == 0 ? pe[0] : a_l_ == 1 ? pe[1] : a_l_ == 2 ? pe[2] : pe[3];
+            word_store(xg + DX_E + ((par * 32 + slice) * 4 + a_l_) * DP_TPM + t, t < Tp ? pv_ : 0.f, bit);
           }
         }
       }
     }
+    DP_MARK(7);
     // ------------------------------------------------------------ (7) full energies of this CU's row -> softmax
     {
       const float* ex = xg + DX_E + par * 32 * 4 * DP_TPM + ar * DP_TPM;
@@ -412,6 +432,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       for (int i = 0; i < 4; ++i)
         p[i] = reinterpret_cast<const u64*>(ex + (4 * wave + i) * 4 * DP_TPM + (ok ? 2 * t2 : 0));
       poll_pairs<4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 14u);
+      DP_MARK(8);
       float e0 = 0.f, e1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { e0 += pair_lo(v[i]); e1 += pair_hi(v[i]); }
@@ -433,15 +454,15 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         ev[k] = e;
         if (t < Tp) mx = fmaxf(mx, a.scaling * e);
       }
-      mx = wave_max(mx);
+      mx = wave_max_dpp(mx);
       float sum = 0.f;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int t = lane_ + 64 * k;
-        wv[k] = t < Tp ? expf(a.scaling * ev[k] - mx) : 0.f;
+        wv[k] = t < Tp ? __expf(a.scaling * ev[k] - mx) : 0.f;
         sum += wv[k];
       }
-      sum = wave_sum(sum);
+      sum = wave_sum_dpp(sum);
       const float inv = 1.0f / sum;
       if (wave == 0) {
 #pragma unroll
@@ -460,6 +481,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       }
     }
     __syncthreads();
+    DP_MARK(9);
     // ------------------------------------------------------------ (8) context slice, publish (masked) for the cell
     {
       float acc = 0.f;
@@ -480,6 +502,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       }
       word_store(xg + DX_C + par * 4 * 512 + ar * 512 + o, vm, bit);
     }
+    DP_MARK(10);
+#undef TRS
   }
 }
 
@@ -553,14 +577,17 @@ __host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K) {
   BwdLds l;
   int o = 0;
   l.taps4 = ((2 * K + 1) + 3) & ~3;
+  // row stride of dfh == 13 (mod 32): the Toeplitz products read dfh[c][4 i + const] for 10 channels x 4 offsets in one
+  // wave instruction; a stride that is a multiple of 16 puts every second channel on the same LDS bank (5-way conflict)
   l.dfs_stride = TpP + 2 * K + 4;
+  l.dfs_stride += (13 - (l.dfs_stride & 31) + 32) & 31;
   l.dgs = o; o += 4 * BM::GS;
   l.part = o; o += 8 * 64 * 5;
   l.qs = o; o += 16 * OO;
   l.dcx = o; o += OO;
   l.fs = o; o += 4 * C * TpP;
   l.dps = o; o += TpP * 64;
-  l.Fs = o; o += C * l.taps4;
+  l.Fs = o; o += C * (l.taps4 + 8);     // rows zero padded by 8: the Toeplitz products read up to 6 taps past the end
   l.dfh = o; o += C * l.dfs_stride;
   l.wph = o; o += l.dfs_stride;
   l.des = o; o += 4 * DP_TPM;
@@ -590,7 +617,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
   float* dcx = sm + ld.dcx;      // [OO]             total d(ctx_s) of this CU's row
   float* fs = sm + ld.fs;        // [4][C][TpP]      conv features f_s of the 4 rows
   float* dPs = sm + ld.dps;      // [TpP/4][4][64]   dP accumulators in the score-lane layout
-  float* Fs = sm + ld.Fs;        // [C][taps4]
+  float* Fs = sm + ld.Fs;        // [C][taps4 + 8]
   float* dfh = sm + ld.dfh;      // [C][dfs_stride]  d(conv features) of this CU's row, zero halo of K
   float* wph = sm + ld.wph;      // [dfs_stride]     w_{s-1} of this CU's row, zero halo of K
   float* des = sm + ld.des;      // [4][TPM]         d(energy)
@@ -652,8 +679,9 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     const int t = 16 * aq + tl;
     Qs[i] = a.Q[((int64_t)abc * Tp + (t < Tp ? t : Tp - 1)) * OO + o];
   }
-  for (int i = tid; i < C * taps4; i += DP_NT) {
-    const int ch = i / taps4, j = i - ch * taps4;
+  const int FSS = taps4 + 8;
+  for (int i = tid; i < C * FSS; i += DP_NT) {
+    const int ch = i / FSS, j = i - ch * FSS;
     Fs[i] = j < taps ? a.convw[ch * taps + j] : 0.f;
   }
   if (tid < 16) {
@@ -667,10 +695,9 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
   // persistent accumulators
   f32x4 acc_watt = (f32x4){0.f, 0.f, 0.f, 0.f};   // dW_att[a = 4*(lane>>4)+i][c = lane&15] partial of this wave
   float dgl = 0.f;                                // dgvec partial of this lane's column
-  float acc_conv = 0.f;                           // dconv[c][j] of this thread's tap
+  f32x4 acc_cv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc_cv1 = (f32x4){0.f, 0.f, 0.f, 0.f};   // dconv tiles aq, aq+8 (see (e))
   float dcarry = 0.f, dxz = 0.f;
   // conv-weight gradient ownership: this CU owns taps idx = aq*NCJ + tid (tid < NCJ) of its row's C*taps
-  const int NCJ = (C * taps + 7) / 8;
   // pointwise threads of the cell (tid < 4*DU): unit tid>>2, row tid&3
   const bool pw_thread = tid < 4 * DU;
   const int punit = DU * slice + (pw_thread ? (tid >> 2) : 0);
@@ -767,8 +794,11 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     int zv;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zv));
     const int tid_ = tid + zv, lane_ = lane + zv;
+    const unsigned abort_seen = tid < 64 ? flag_load(a.ctrl + 8) : 0u;   // sampled early, consumed by the pointwise phase
     const int a_l_ = lane_ & 15, q4_ = lane_ >> 4;
     const bool sc_ok_ = a_l_ < AU;
+#define TRS n
+    DP_MARK(0);
     // ------------------------------------------------------------ (0) prefetched forward data -> LDS
     {
       const float rct = 1.0f / (float)(C * TpP), rtp = 1.0f / (float)TpP;
@@ -785,6 +815,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       wsl[tid_] = t < Tp ? wsreg : 0.f;                           // [row = tid>>7][t]
       if (tid_ < 128 && t < Tp) wph[K + t] = wpreg;
     }
+    DP_MARK(1);
     // ------------------------------------------------------------ (a) total d(ctx_s) of my row -> dw_raw of my frames
     {
       const float* cx = xg + BX_C + slot * 4 * 512 + ar * 512;
@@ -800,14 +831,12 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < OO / 32; ++k) acc += Qs[tl * OO + op + 32 * k] * dcx[op + 32 * k];
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
-      acc += __shfl_xor(acc, 8, 64);
+      acc = row16_sum(acc);
       acc += __shfl_xor(acc, 16, 64);
       const int t = 16 * aq + tl;
       if (op == 0 && t < TpP) word_store(xg + BX_W + (slot * 4 + ar) * DP_TPM + t, t < Tp ? acc + dwext[tl] + dwsreg : 0.f, bit);
     }
+    DP_MARK(2);
     // ------------------------------------------------------------ (c) dw_raw of the 4 rows -> softmax backward
     {
       const int hp = TpP >> 1;
@@ -829,12 +858,13 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
         dv[k] = t < Tp ? dwr[wave * DP_TPM + t] : 0.f;
         dot += w[k] * dv[k];
       }
-      dot = wave_sum(dot);
+      dot = wave_sum_dpp(dot);
 #pragma unroll
       for (int k = 0; k < 2; ++k)     // rows beyond the batch contribute nothing to the sequence-long accumulators
         des[wave * DP_TPM + lane_ + 64 * k] = r0 + wave < nb ? a.scaling * w[k] * (dv[k] - dot) : 0.f;
     }
     __syncthreads();
+    DP_MARK(3);
     // ------------------------------------------------------------ (d) score backward for my attention columns
     {
       float dDl[4] = {0.f, 0.f, 0.f, 0.f};
@@ -877,6 +907,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
         word_store(xg + BX_D + (slot * 4 + row) * 512 + AU * slice + al, v, bit);
       }
     }
+    DP_MARK(4);
     // ------------------------------------------------------------ (e) d(conv features) of my row, conv backward
     {
       const float rtp = 1.0f / (float)TpP;
@@ -891,38 +922,79 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     }
     __syncthreads();
     {
-      // dw path for the next iteration: dwext[t'] = sum_c sum_j F[c][j] df[c][t' - j + K], my 16 frames x 32 parts
-      const int tl = tid_ >> 5, pr = tid_ & 31;
-      const int tq = 16 * aq + tl;
-      float acc = 0.f;
-      for (int c = 0; c < C; ++c) {
-        const float* Fc = Fs + c * taps4;
-        const float* dc = dfh + c * DFS + tq + 2 * K;
-        for (int j = pr; j < (tq < Tp ? taps : 0); j += 32) acc += Fc[j] * dc[-j];
+      DP_MARK(10);
+      // Both conv-backward contractions are Toeplitz products on the 4x4x1 MFMA with block = channel:
+      //   D[c][i][jj] += A[c][i] * B[c][jj], one instruction per summation index, K range dealt round-robin to waves.
+      // (1) dw path of the next iteration, dwext[t'] = sum_c sum_j F[c][j] df[c][t' - j + K] for t' = t0 + 4i + jj:
+      //     A = dfh[c][t0 + 4i + 2K - j], B = F[c][j + jj]   (substituting j -> j + jj keeps A independent of jj)
+      const int cb = lane_ >> 2, li = lane_ & 3;
+      const bool cok = cb < C;
+      const int cc = cok ? cb : 0;
+      {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* ap = dfh + cc * DFS + 16 * aq + 4 * li + 2 * K;
+        const float* bp = Fs + cc * FSS + li;
+        const int jend = taps + 3;
+        for (int j = wave; j < jend; j += 32) {      // 4 taps per trip: 8 LDS reads in flight, then 4 MFMAs
+          float av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int jc = j + 8 * u < jend ? j + 8 * u : j;
+            av[u] = ap[-jc];
+            bv[u] = bp[jc];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32((cok && j + 8 * u < jend) ? av[u] : 0.f, bv[u], acc, 0, 0, 0);
+        }
+        float* pp = part + (wave * 64 + lane_) * 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pp[i] = acc[i];
       }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
-      acc += __shfl_xor(acc, 8, 64);
-      acc += __shfl_xor(acc, 16, 64);
-      if (pr == 0) dwext[tl] = acc;
-      // dconv[c][j] += sum_t df[c][t] w_{s-1}[t + j - K] for the taps this thread owns
-      const int cj_idx = aq * NCJ + tid_;
-      const bool cj_ok = tid_ < NCJ && cj_idx < C * taps;
-      const int cj_c = cj_ok ? (int)(((float)cj_idx + 0.5f) * (1.0f / (float)taps)) : 0;
-      const int cj_j = cj_ok ? cj_idx - cj_c * taps : 0;
-      if (cj_ok) {
-        const float* dc = dfh + cj_c * DFS + K;
-        const float* wq = wph + cj_j;
-        float v0 = 0.f, v1 = 0.f;
-        int t = 0;
-        for (; t + 1 < Tp; t += 2) { v0 += dc[t] * wq[t]; v1 += dc[t + 1] * wq[t + 1]; }
-        if (t < Tp) v0 += dc[t] * wq[t];
-        acc_conv += v0 + v1;
+      // (2) dconv[c][j0 + 4i + jj] += sum_u w_{s-1}[u + j0 + 4i - K] df[c][u - jj]: A = wph[u + j0 + 4i], B = dfh[c][K + u - jj];
+      //     this CU owns the 16-tap tiles aq and aq + 8 of its row; accumulators live in registers for the whole sequence
+      {
+        const float* bq = dfh + cc * DFS + K - li;
+        const float* a0 = wph + 16 * aq + 4 * li;
+        const bool two = 16 * (aq + 8) < taps;
+        const int uend = Tp + 3;
+        for (int u = wave; u < uend; u += 32) {
+          float bv[4], a0v[4], a1v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int uc = u + 8 * k < uend ? u + 8 * k : u;
+            bv[k] = bq[uc];
+            a0v[k] = a0[uc];
+            a1v[k] = a0[uc + 128];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float b = (cok && u + 8 * k < uend) ? bv[k] : 0.f;
+            acc_cv0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0v[k], b, acc_cv0, 0, 0, 0);
+            acc_cv1 = __builtin_amdgcn_mfma_f32_4x4x1f32(two ? a1v[k] : 0.f, b, acc_cv1, 0, 0, 0);
+          }
+        }
       }
+      DP_MARK(11);
+      __syncthreads();
+      if (tid_ < 128) {      // (wave w, output o = 4i + jj): sum over channels
+        const int w2 = tid_ >> 4, o = tid_ & 15, i = o >> 2, jj = o & 3;
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) v += part[(w2 * 64 + 4 * c + jj) * 5 + i];
+        dDp[w2 * 16 + o] = v;
+      }
+      __syncthreads();
+      if (tid_ < 16) {
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 8; ++w2) v += dDp[w2 * 16 + tid_];
+        dwext[tid_] = 16 * aq + tid_ < Tp ? v : 0.f;
+      }
+      DP_MARK(12);
     }
     // forward data of the next iteration (independent of the recurrence; most of an iteration to arrive)
     if (s > 0) prefetchA(s - 1, zv);
+    DP_MARK(5);
     // ------------------------------------------------------------ (f) dz_s for my units, LSTM cell backward
     {
       const float* dx = xg + BX_D + slot * 4 * 512;
@@ -936,6 +1008,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
         p[i] = reinterpret_cast<const u64*>(dx + ((2 * id < 4 * AA) ? row * 512 + c2 : 0));
       }
       poll_pairs<ND, true>(p, bit, v, a.ctrl, aborted, 23u);
+      DP_MARK(6);
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
         const int id = tid_ + DP_NT * i;
@@ -969,13 +1042,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       da.z = dc * ga.x * (1.f - ga.z * ga.z);
       da.w = dh * tc * ga.w * (1.f - ga.w);
       dcarry = dc * ga.y;
-      if (aborted || flag_load(a.ctrl + 8) != 0u) da.x = __builtin_nanf("");
+      if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
       const int un = DU * slice + ul, b = r0 + row;
       if (b < nb) *reinterpret_cast<float4*>(a.dgates + ((int64_t)s * B + b) * GK + un * 4) = da;
       float* dst = xg + BX_G + (slot * 4 + row) * 2048 + un * 4;
       word_store(dst, da.x, bit); word_store(dst + 1, da.y, bit);
       word_store(dst + 2, da.z, bit); word_store(dst + 3, da.w, bit);
     }
+    DP_MARK(7);
     if (s == 0) break;
     // ------------------------------------------------------------ (g) dX = dgates W_cat for my z / ctx columns
     {
@@ -1003,6 +1077,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     __syncthreads();
     {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      DP_MARK(8);
       const float* gr = dgs + (lane_ & 3) * GS + wave * GKW + ((lane_ >> 2) & 1) * GKS;
 #pragma unroll
       for (int q4 = 0; q4 < GKS / 4; ++q4) {
@@ -1034,6 +1109,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
         word_store(xg + BX_C + (((n + 1) & 1) * 4 + row) * 512 + col, tot, tag_bit_of_step(n + 1));
       }
     }
+    DP_MARK(9);
+#undef TRS
     prefetchB(s - 1, zv);
   }
   // ---------------------------------------------------------------- epilogue: sequence-long accumulators
@@ -1065,10 +1142,17 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     }
   }
   {
-    const int cj_idx = aq * NCJ + tid;
-    const bool cj_ok = tid < NCJ && cj_idx < C * taps;
-    const int cj_c = cj_ok ? cj_idx / taps : 0, cj_j = cj_ok ? cj_idx - cj_c * taps : 0;
-    if (cj_ok && ab_ok) atomicAdd(a.dconv_part + ((int64_t)ab * C + cj_c) * taps + cj_j, acc_conv);
+    // lane (channel c = lane>>2, jj = lane&3), register i: tap j0 + 4i + jj of tiles aq (j0 = 16 aq) and aq + 8; every wave
+    // holds a partial sum over its share of the frames
+    const int c = lane_e >> 2, jj = lane_e & 3;
+    if (c < C && ab_ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j0 = 16 * aq + 4 * i + jj, j1 = j0 + 128;
+        if (j0 < taps) atomicAdd(a.dconv_part + ((int64_t)ab * C + c) * taps + j0, acc_cv0[i]);
+        if (j1 < taps) atomicAdd(a.dconv_part + ((int64_t)ab * C + c) * taps + j1, acc_cv1[i]);
+      }
+    }
   }
 }
 

@@ -101,6 +101,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   }
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
+    // abort word sampled at the top of the step: consumed by the pointwise phase long after it has arrived (an L2
+    // round trip issued there would sit on the serial chain of every time step)
+    const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;
     const float4 gx = gx_next;
     float4* gp = nullptr;
     if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       float cn = gf * c_prev + gi * gg;
       float hn = go * asr_fast_tanh(cn);
       if (t >= plen) { cn = 0.f; hn = 0.f; }
-      if (aborted || flag_load(a.ctrl + 8) != 0u) hn = __builtin_nanf("");
+      if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
       if (prow_ok) {
         *gp = make_float4(gi, gf, gg, go);
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   if (prow_ok) fetch_step(0);
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? T - 1 - s : s;
+    const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;     // see the forward kernel
     const float dyv = n_dy, ct = n_ct, cp = n_cp;
     const float4 av = n_av;
     float4* gp = nullptr;
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       da.w = dh * tc * av.w * (1.f - av.w);
       float dcn = dc * av.y;
       if (t >= plen) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
-      if (aborted || flag_load(a.ctrl + 8) != 0u) da.x = __builtin_nanf("");
+      if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
       dcarry = dcn;
       if (prow_ok) {
         *gp = da;

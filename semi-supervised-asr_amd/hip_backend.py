@@ -336,7 +336,7 @@ def persist_scratch(device):
     key = str(device)
     if key not in _persist_scratch:
         _persist_scratch[key] = (torch.zeros(2 * 8 * 8 * 2048, dtype=torch.int64, device=device),
-                                 torch.zeros(16, dtype=torch.int32, device=device))
+                                 torch.zeros(1024, dtype=torch.int32, device=device))   # [0..15] control words, rest: optional trace
     return _persist_scratch[key]
 
 
