@@ -128,12 +128,14 @@ def auto_split_k(M, N, K, batch=1, epilogue=False):
     if tiles >= 1024 or K < 512:
         return 1
     if K < 2048:
-        if tiles > 128 or epilogue:
+        if tiles > 128 or (epilogue and tiles > 64):
             return 1
-        return int(max(1, min(4, K // 128)))
+        return int(max(1, min(8 if tiles <= 32 else 4, K // 128)))
     if epilogue and tiles > 256:
         return 1
     want = 6 if tiles >= 100 else (8 if tiles >= 48 else 16)
+    if 700 <= tiles * want <= 800:       # exactly 3 workgroups per CU measured 15 % slower than 2 or 4 (cold operands)
+        want = 8
     return int(max(1, min(want, K // 256)))
 
 
