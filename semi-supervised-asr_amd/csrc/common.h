@@ -39,6 +39,22 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
   return v;
 }
+// Four independent 16-lane sums, stage by stage: consecutive DPP instructions never depend on each other, so the
+// compiler does not have to pad the VALU-write -> DPP-read hazard with s_nop.
+__device__ __forceinline__ void row16_sum4(float (&v)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), 0xB1, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), 0x4E, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), 0x141, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[k]), 0x140, 0xf, 0xf, true));
+}
 // Whole-wave sum / max from the row totals: 4 DPP steps inside each row of 16, then the four row totals are read
 // with v_readlane (every lane of a row holds its total).  ~12 instructions instead of 6 ds_bpermute round trips.
 __device__ __forceinline__ float wave_sum_dpp(float v) {

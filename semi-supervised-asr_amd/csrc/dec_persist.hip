@@ -405,14 +405,18 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
           // uniform row bases + one 32-bit lane offset per tile (no 64-bit index math per element)
           const int soff = t * AA + acol_;
           const bool sst = sc_ok_ && t < Tp && !(ASR_DP_ABL & 16);
-          float pe[4];
+          float pe[4], sv[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float sv = dp_tanh(acc[i] + Ps[(tile * 4 + i) * 64 + lane_] + dps[i * 16 + a_l_]);
-            float* Srow = a.S + ((int64_t)s * B + r0 + i) * Tp * AA;
-            if (sst && r0 + i < nb) Srow[soff] = sv;
-            pe[i] = row16_sum(sc_ok_ ? gv * sv : 0.f);
+            sv[i] = dp_tanh(acc[i] + Ps[(tile * 4 + i) * 64 + lane_] + dps[i * 16 + a_l_]);
+            pe[i] = sc_ok_ ? gv * sv[i] : 0.f;
           }
+          if (sst) {                                   // one lane predicate per tile; the row test is wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (r0 + i < nb) (a.S + ((int64_t)s * B + r0 + i) * Tp * AA)[soff] = sv[i];
+          }
+          row16_sum4(pe);
           if (a_l_ < 4) {      // lane i of each 16-lane group publishes row i (every lane of the group holds all four sums)
             const float pv_ = a_l_ == 0 ? pe[0] : a_l_ == 1 ? pe[1] : a_l_ == 2 ? pe[2] : pe[3];
             word_store(xg + DX_E + ((par * 32 + slice) * 4 + a_l_) * DP_TPM + t, t < Tp ? pv_ : 0.f, bit);
