@@ -455,6 +455,34 @@ def test_attloc_forward_standalone(golden_dir):
     _close(c1, g["att_c1"], what="c1"); _close(w1, g["att_w1"], what="w1")
 
 
+def test_long_utterances_cfg5_extent():
+    """cfg-5's time extent (80 x 1600 frames -> T' = 200 encoder frames, 201-tap location conv) at small widths:
+    exercises the T' > 128 / T' > 256-lane loops of the attention kernels and 1600-step recurrences against the oracle."""
+    dev = _gpu()
+    cfg = dict(input_dim=16, enc_hidden_dim=32, enc_n_layers=3, subsample=[2, 2, 2], dropout_rate=0.0,
+               dec_hidden_dim=32, att_dim=32, conv_channels=10, conv_kernel_size=100, att_odim=32, embedding_dim=16,
+               output_dim=12, ls_weight=0.05)
+    ld = synth.labeldist(12, 5)
+    w = synth.e2e_weights(cfg, 55)
+    ilens = [1600, 1411, 977]
+    xs, ilens, ys = synth.batch(16, 12, ilens, [9, 7, 5], 56)
+    net = _product(cfg, w, ld, dev)
+    np.random.seed(2)
+    logits, lp, _, ws = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
+    assert ws.shape[-1] == 200
+    sd = O.make_leaf_state(w)
+    np.random.seed(2)
+    rl, rlp, _, rws = O.e2e_forward(sd, dict(cfg, labeldist=ld), torch.from_numpy(xs), ilens,
+                                    [torch.from_numpy(y) for y in ys])
+    _close(logits, rl, what="logits"); _close(lp, rlp, what="lp"); _close(ws, rws, what="ws")
+    names = O.unique_param_names(sd)
+    rg = dict(zip(names, torch.autograd.grad(-rlp.mean(), [sd[n] for n in names])))
+    net.zero_grad()
+    (-lp.mean()).backward()
+    for n, gr in _grads(net).items():
+        _close(gr, rg[n], atol=1e-6, what="grad " + n)
+
+
 @pytest.mark.parametrize("B,T", [(1, 7), (2, 1), (5, 2)])
 def test_edge_shapes(B, T):
     """Single utterance, single frame, two frames: model vs oracle (forward + gradients)."""
@@ -517,7 +545,6 @@ def test_lstm_persistent_path(ndir, B, T, lens, H):
         _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("dim,B,Tp,L,drop", [(512, 32, 100, 6, True), (512, 7, 37, 4, False), (320, 32, 100, 5, True),
                                              (512, 40, 100, 3, False), (512, 32, 128, 3, True), (320, 5, 9, 4, False)])
 def test_decoder_persistent_path(dim, B, Tp, L, drop):
