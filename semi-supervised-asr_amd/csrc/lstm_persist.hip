@@ -24,6 +24,13 @@
 #ifndef ASR_POLL_SLEEP
 #define ASR_POLL_SLEEP 1
 #endif
+// measurement only: shader-clock stamps of workgroup (group 0, slice 0), time steps 8..15, into ctrl[16..]
+#ifdef ASR_LP_TRACE
+#define LP_MARK(k) do { if (tid == 0 && g == 0 && slice == 0 && s >= 8 && s < 16) \
+    ((unsigned long long*)(a.ctrl + 16))[(s - 8) * 16 + (k)] = clock64(); } while (0)
+#else
+#define LP_MARK(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     const int t = d == 0 ? s : T - 1 - s;
     // abort word sampled at the top of the step: consumed by the pointwise phase long after it has arrived (an L2
     // round trip issued there would sit on the serial chain of every time step)
+    LP_MARK(0);
     const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;
     const float4 gx = gx_next;
     float4* gp = nullptr;
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         }
         __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
+      LP_MARK(1);
 #pragma unroll
       for (int rr = 0; rr < PRG; ++rr)
         if (gl) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
@@ -165,10 +174,13 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       const int tn1 = d == 0 ? 1 : T - 2;
       gx_next = *reinterpret_cast<const float4*>(a.gates + (((int64_t)tn1 * B + prow) * ndir + d) * 4 * PH + punit * 4);
     }
+    LP_MARK(2);
     float* pp = &part[s & 1][wave][lane][0];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; pp[4 + i] = acc1[i]; }
+    LP_MARK(3);
     __syncthreads();
+    LP_MARK(4);
     if (pw_thread) {
       // lane holding (unit pu, row pj): 4*pu + (pj&3); registers 4*(pj>>2) + gate
       float pre[4] = {gx.x, gx.y, gx.z, gx.w};
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       if (t >= plen) { cn = 0.f; hn = 0.f; }
       if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
+      LP_MARK(5);
       if (prow_ok) {
         *gp = make_float4(gi, gf, gg, go);
         const int64_t so = ((int64_t)t * B + prow) * ldy + d * PH + punit;
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         a.y[so] = hn;
       }
       granule_store(xch_g + (s & 1) * par_stride + (int64_t)pj * PH + punit, (unsigned)(s + 1), hn);
+      LP_MARK(6);
     }
   }
 }
@@ -277,6 +291,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   if (prow_ok) fetch_step(0);
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? T - 1 - s : s;
+    LP_MARK(0);
     const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;     // see the forward kernel
     const float dyv = n_dy, ct = n_ct, cp = n_cp;
     const float4 av = n_av;
@@ -304,13 +319,15 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       };
       while (true) {
         // cheap sentinel poll: the last row of this wave's K range (1 KB, touches all 4 producer CUs); a failed
-        // poll of the whole 64 KB per CU would saturate the XCD's L2 and delay the producers themselves
+        // poll of the whole 64 KB per CU would saturate the XCD's L2 and delay the producers themselves.  (Fetching
+        // the whole tile optimistically on the first attempt, or reading the sentinel ahead of the dW_hh MFMAs, both
+        // measured slower: the rows are not yet visible when this poll starts.)
         load_row(PRG - 1);
         bool ok = !gl || row_bits(PRG - 1) == 0xFu;
         if (__all(ok)) {
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) load_row(rr);
-          unsigned bits = 0xFu;
+          unsigned bits = row_bits(PRG - 1);
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) bits &= row_bits(rr);
           if (__all(!gl || bits == 0xFu)) break;
@@ -325,6 +342,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
         }
         __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
+      LP_MARK(1);
 #pragma unroll
       for (int rr = 0; rr < PRG; ++rr)
         if (gl) *reinterpret_cast<float4*>(&hs[wave][rr][PQS * ((4 * lane) / PQ) + (4 * lane) % PQ]) = gr[rr];
@@ -346,10 +364,13 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       }
     }
     if (s == 0 && prow_ok && T > 1) fetch_step(1);
+    LP_MARK(2);
     float* pp = &part[s & 1][wave][lane][0];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; pp[4 + i] = acc1[i]; }
+    LP_MARK(3);
     __syncthreads();
+    LP_MARK(4);
     if (pw_thread) {
       // dh_rec[unit pu][row pj]: lanes 16*(pu>>2) + 4*ks + (pj&3), register 4*(pj>>2) + (pu&3), all ks, all waves
       float dh = dyv;
@@ -383,6 +404,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       __hip_atomic_store((gu64*)dst + 1, ((u64)__float_as_uint(tg.w) << 32) | __float_as_uint(tg.z), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    LP_MARK(5);
     // Fused recurrent weight gradient: dW_hh[k][u] += sum_rows dG_{t_next}[row][k] * h_t[row][u].  The gathered dG
     // tile is still in this wave's LDS region and h_t is the partner of dG_{t_next} in both directions.  Placed
     // after the publish so that it fills the wait for the next hand-off.  Blocks = 16 groups of 4 gate columns,

@@ -1,0 +1,35 @@
+"""Per-phase timing of the persistent LSTM kernels from shader-clock stamps (library built with -DASR_LP_TRACE in
+scratchlibs/lib_lptrace.so): mean cycles between marks over time steps 8..15 of workgroup (group 0, slice 0)."""
+import ctypes, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, ROOT + '/semi-supervised-asr_amd']
+import torch, numpy as np
+import hip_backend as hb
+dev = torch.device('cuda')
+H, B, T = 512, 32, 64
+g = torch.Generator().manual_seed(3)
+gates0 = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).to(dev)
+wf = (torch.randn(2, 4 * H, H, generator=g) / np.sqrt(H)).to(dev)
+w = (torch.randn(2, H, 4 * H, generator=g) / np.sqrt(H)).to(dev)
+lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+y = torch.empty(T, B, 2 * H, device=dev); c = torch.empty(T, B, 2 * H, device=dev)
+gact = (torch.rand(T, B, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
+dy = (torch.randn(T, B, 2 * H, generator=g) * 0.01).to(dev); cc = torch.randn(T, B, 2 * H, generator=g).to(dev)
+yy = torch.tanh(torch.randn(T, B, 2 * H, generator=g)).to(dev); dw = torch.zeros(2, 4 * H, H, device=dev)
+db = torch.zeros(2 * 4 * H, device=dev)
+xch, ctrl = hb.persist_scratch(dev)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+st = hb.stream()
+l = ctypes.CDLL(ROOT + '/scratchlibs/lib_lptrace.so')
+def report(name, n):
+    t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)[:, :n]
+    print(name, 'cycles/step %.0f' % (t[1:, 0] - t[:-1, 0]).mean(), ' deltas:', ' '.join('%d:%.0f' % (i + 1, x) for i, x in enumerate(np.diff(t, axis=1).mean(0))),
+          ' tail->next top: %.0f' % (t[1:, 0] - t[:-1, n - 1]).mean())
+for _ in range(2):
+    ga = gates0.clone(); ctrl.zero_()
+    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), st) == 0
+    torch.cuda.synchronize(); report('fwd', 7)
+for _ in range(2):
+    gb = gact.clone(); ctrl.zero_()
+    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), st) == 0
+    torch.cuda.synchronize(); report('bwd', 6)
