@@ -24,6 +24,9 @@
 #ifndef ASR_POLL_SLEEP
 #define ASR_POLL_SLEEP 1
 #endif
+#ifndef ASR_LSTM_FULL_WAVES
+#define ASR_LSTM_FULL_WAVES 2      /* waves 0..1 hold the pointwise threads (PUC*PRG <= 128) */
+#endif
 // measurement only: shader-clock stamps of workgroup (group 0, slice 0), time steps 8..15, into ctrl[16..]
 #ifdef ASR_LP_TRACE
 #define LP_MARK(k) do { if (tid == 0 && g == 0 && slice == 0 && s >= 8 && s < 16) \
@@ -124,11 +127,12 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       unsigned spins = 0;
       while (true) {
         gr[PRG - 1] = granule_load(src + (int64_t)(PRG - 1) * PH);          // sentinel row first (see backward)
-#ifdef ASR_LSTM_FULL
-        if (true) {
-#else
-        if (__all(!gl || (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
-#endif
+        // The pointwise waves reach this poll last (after the cell update and its stores), when the other CUs' rows
+        // have already landed (0 failed polls in tools/lstm_trace.py): they fetch the whole tile at once and save one
+        // ~1 250-cycle L2 round trip on the step's critical path.  The other waves arrive early and spin, so they
+        // keep the cheap sentinel read.
+        if (wave < ASR_LSTM_FULL_WAVES || __all(!gl || (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
+          LP_MARK(7);
 #pragma unroll
           for (int rr = 0; rr < PRG - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
           bool ok = (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s;
@@ -147,6 +151,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
       LP_MARK(1);
+#ifdef ASR_LP_TRACE
+      if (tid == 0 && g == 0 && slice == 0 && s >= 8 && s < 16) ((unsigned long long*)(a.ctrl + 16))[(s - 8) * 16 + 8] = spins;
+#endif
 #pragma unroll
       for (int rr = 0; rr < PRG; ++rr)
         if (gl) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
@@ -197,13 +204,13 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
       LP_MARK(5);
+      granule_store(xch_g + (s & 1) * par_stride + (int64_t)pj * PH + punit, (unsigned)(s + 1), hn);   // hand-off first
       if (prow_ok) {
         *gp = make_float4(gi, gf, gg, go);
         const int64_t so = ((int64_t)t * B + prow) * ldy + d * PH + punit;
         a.c[so] = cn;
         a.y[so] = hn;
       }
-      granule_store(xch_g + (s & 1) * par_stride + (int64_t)pj * PH + punit, (unsigned)(s + 1), hn);
       LP_MARK(6);
     }
   }
@@ -390,10 +397,6 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       if (t >= plen) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
       if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
       dcarry = dcn;
-      if (prow_ok) {
-        *gp = da;
-        dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
-      }
       const unsigned bit = (((unsigned)s >> 1) & 1u) ^ 1u;
       float4 tg;
       tg.x = tag_word(da.x, bit); tg.y = tag_word(da.y, bit); tg.z = tag_word(da.z, bit); tg.w = tag_word(da.w, bit);
@@ -403,6 +406,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
                          __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_store((gu64*)dst + 1, ((u64)__float_as_uint(tg.w) << 32) | __float_as_uint(tg.z), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (prow_ok) {     // after the hand-off: the bulk store and the bias-gradient sum are off the serial chain
+        *gp = da;
+        dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
+      }
     }
     LP_MARK(5);
     // Fused recurrent weight gradient: dW_hh[k][u] += sum_rows dG_{t_next}[row][k] * h_t[row][u].  The gathered dG

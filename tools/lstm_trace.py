@@ -29,6 +29,8 @@ for _ in range(2):
     ga = gates0.clone(); ctrl.zero_()
     assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), st) == 0
     torch.cuda.synchronize(); report('fwd', 7)
+    t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    print('   fwd poll split: top->sentinel ok %.0f | sentinel ok->tile gathered %.0f | failed polls %.1f' % ((t[:, 7] - t[:, 0]).mean(), (t[:, 1] - t[:, 7]).mean(), t[:, 8].mean()))
 for _ in range(2):
     gb = gact.clone(); ctrl.zero_()
     assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), st) == 0
