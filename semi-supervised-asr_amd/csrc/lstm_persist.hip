@@ -29,8 +29,8 @@
 #endif
 // measurement only: shader-clock stamps of workgroup (group 0, slice 0), time steps 8..15, into ctrl[16..]
 #ifdef ASR_LP_TRACE
-#define LP_MARK(k) do { if (tid == 0 && g == 0 && slice == 0 && s >= 8 && s < 16) \
-    ((unsigned long long*)(a.ctrl + 16))[(s - 8) * 16 + (k)] = clock64(); } while (0)
+#define LP_MARK(k) do { if ((tid == 0 || tid == 448) && g == 0 && slice == 0 && s >= 8 && s < 16) \
+    ((unsigned long long*)(a.ctrl + 16))[(tid ? 128 : 0) + (s - 8) * 16 + (k)] = clock64(); } while (0)
 #else
 #define LP_MARK(k) do {} while (0)
 #endif
@@ -102,20 +102,33 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   u64* xch_g = a.xch + (int64_t)g * PRG * PH;          // + parity * 8*PRG*PH
   const int64_t par_stride = (int64_t)8 * PRG * PH;
   bool aborted = false;
-  // x-projection of the NEXT step is fetched one step ahead: vmcnt retires in order, so an HBM first-touch load
-  // issued just before the poll would hold back this wave's poll loads for ~2 us every step
-  float4 gx_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  // The x-projection rows are fetched TWO steps ahead: they are HBM first-touch loads (~2 us under load, about one
+  // forward step), vmcnt retires in order, and the row is consumed at the top of its step -- one step of distance
+  // left the pointwise waves waiting ~1 300 cycles there (tools/lstm_trace.py).
+  auto gx_ptr = [&](int sn) {
+    const int tt = d == 0 ? sn : T - 1 - sn;
+    return reinterpret_cast<const float4*>(a.gates + (((int64_t)tt * B + prow) * ndir + d) * 4 * PH + punit * 4);
+  };
+  float4 gx_n1 = make_float4(0.f, 0.f, 0.f, 0.f), gx_n2 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (prow_ok) {
-    const int t0 = d == 0 ? 0 : T - 1;
-    gx_next = *reinterpret_cast<const float4*>(a.gates + (((int64_t)t0 * B + prow) * ndir + d) * 4 * PH + punit * 4);
+    gx_n1 = *gx_ptr(0);
+    if (T > 1) gx_n2 = *gx_ptr(1);
   }
+  // Bulk outputs of a step (gates, c, y) are stored AFTER the next step's gather: vmcnt counts stores too and retires
+  // in order, so a store issued just before the poll keeps the poll's loads waiting for its write acknowledgement
+  // (~1 000+ cycles on the serial chain of the pointwise waves).  Deferred, the acknowledgements overlap the MFMAs.
+  float4 st_g = make_float4(0.f, 0.f, 0.f, 0.f);
+  float st_c = 0.f, st_y = 0.f;
+  float4* st_gp = nullptr;
+  int64_t st_so = 0;
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
     // abort word sampled at the top of the step: consumed by the pointwise phase long after it has arrived (an L2
     // round trip issued there would sit on the serial chain of every time step)
     LP_MARK(0);
     const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;
-    const float4 gx = gx_next;
+    const float4 gx = gx_n1;
+    gx_n1 = gx_n2;
     float4* gp = nullptr;
     if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -126,20 +139,33 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       u64 gr[PRG];
       unsigned spins = 0;
       while (true) {
-        gr[PRG - 1] = granule_load(src + (int64_t)(PRG - 1) * PH);          // sentinel row first (see backward)
-        // The pointwise waves reach this poll last (after the cell update and its stores), when the other CUs' rows
-        // have already landed (0 failed polls in tools/lstm_trace.py): they fetch the whole tile at once and save one
-        // ~1 250-cycle L2 round trip on the step's critical path.  The other waves arrive early and spin, so they
-        // keep the cheap sentinel read.
-        if (wave < ASR_LSTM_FULL_WAVES || __all(!gl || (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
+        bool done = false;
+        if (wave < ASR_LSTM_FULL_WAVES) {
+          // The pointwise waves reach this poll last (after the cell update), when the other CUs' rows have already
+          // landed (0 failed polls in tools/lstm_trace.py): all 8 rows are requested at once, one L2 round trip
+          // (~1 200 cycles under load) instead of sentinel + tile on the step's critical path.  Separate code path:
+          // written as `full || sentinel_ok` the compiler still waited for the sentinel before issuing the rest.
+#pragma unroll
+          for (int rr = 0; rr < PRG; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
+          bool ok = true;
+#pragma unroll
+          for (int rr = 0; rr < PRG; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
           LP_MARK(7);
+          done = __all(!gl || ok);
+        } else {
+          // the other waves arrive early and spin: cheap sentinel read of the last row first (see backward)
+          gr[PRG - 1] = granule_load(src + (int64_t)(PRG - 1) * PH);
+          if (__all(!gl || (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
+            LP_MARK(7);
 #pragma unroll
-          for (int rr = 0; rr < PRG - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
-          bool ok = (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s;
+            for (int rr = 0; rr < PRG - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
+            bool ok = true;
 #pragma unroll
-          for (int rr = 0; rr < PRG - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
-          if (__all(!gl || ok)) break;
+            for (int rr = 0; rr < PRG - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
+            done = __all(!gl || ok);
+          }
         }
+        if (done) break;
 #ifdef ASR_NO_POLL
         break;
 #endif
@@ -157,10 +183,13 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
 #pragma unroll
       for (int rr = 0; rr < PRG; ++rr)
         if (gl) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
-      if (prow_ok && s + 1 < T) {     // next step's x-projection, in flight during MFMA / reduce / pointwise / hand-off
-        const int tn1 = d == 0 ? s + 1 : T - 2 - s;
-        gx_next = *reinterpret_cast<const float4*>(a.gates + (((int64_t)tn1 * B + prow) * ndir + d) * 4 * PH + punit * 4);
+      if (st_gp) {                    // previous step's outputs (see above)
+        *st_gp = st_g;
+        a.c[st_so] = st_c;
+        a.y[st_so] = st_y;
+        st_gp = nullptr;
       }
+      if (prow_ok && s + 2 < T) gx_n2 = *gx_ptr(s + 2);     // in flight for two steps
       // (wave-private LDS region: program order within the wave is enough)
       const int j = lane & 3;
 #pragma unroll
@@ -177,10 +206,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b1.w, acc1, 0, 0, 0);
       }
     }
-    if (s == 0 && prow_ok && T > 1) {
-      const int tn1 = d == 0 ? 1 : T - 2;
-      gx_next = *reinterpret_cast<const float4*>(a.gates + (((int64_t)tn1 * B + prow) * ndir + d) * 4 * PH + punit * 4);
-    }
+    if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
     LP_MARK(2);
     float* pp = &part[s & 1][wave][lane][0];
 #pragma unroll
@@ -206,13 +232,17 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       LP_MARK(5);
       granule_store(xch_g + (s & 1) * par_stride + (int64_t)pj * PH + punit, (unsigned)(s + 1), hn);   // hand-off first
       if (prow_ok) {
-        *gp = make_float4(gi, gf, gg, go);
-        const int64_t so = ((int64_t)t * B + prow) * ldy + d * PH + punit;
-        a.c[so] = cn;
-        a.y[so] = hn;
+        st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
+        st_gp = gp;
+        st_so = ((int64_t)t * B + prow) * ldy + d * PH + punit;
       }
       LP_MARK(6);
     }
+  }
+  if (st_gp) {
+    *st_gp = st_g;
+    a.c[st_so] = st_c;
+    a.y[st_so] = st_y;
   }
 }
 

@@ -31,6 +31,10 @@ for _ in range(2):
     torch.cuda.synchronize(); report('fwd', 7)
     t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     print('   fwd poll split: top->sentinel ok %.0f | sentinel ok->tile gathered %.0f | failed polls %.1f' % ((t[:, 7] - t[:, 0]).mean(), (t[:, 1] - t[:, 7]).mean(), t[:, 8].mean()))
+    t7 = ctrl[16 + 256:16 + 256 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    print('   wave 7 relative to wave 0 top of the same step: top %.0f | sentinel ok %.0f | gathered %.0f | MFMA done %.0f | barrier passed %.0f ; wave 0: gathered %.0f | MFMA done %.0f | barrier %.0f | published %.0f' % (
+        (t7[:, 0] - t[:, 0]).mean(), (t7[:, 7] - t[:, 0]).mean(), (t7[:, 1] - t[:, 0]).mean(), (t7[:, 2] - t[:, 0]).mean(), (t7[:, 4] - t[:, 0]).mean(),
+        (t[:, 1] - t[:, 0]).mean(), (t[:, 2] - t[:, 0]).mean(), (t[:, 4] - t[:, 0]).mean(), (t[:, 6] - t[:, 0]).mean()))
 for _ in range(2):
     gb = gact.clone(); ctrl.zero_()
     assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), st) == 0
