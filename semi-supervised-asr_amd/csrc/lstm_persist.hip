@@ -24,6 +24,9 @@
 #ifndef ASR_POLL_SLEEP
 #define ASR_POLL_SLEEP 1
 #endif
+#ifndef ASR_LSTM_BWD_FULL_WAVES
+#define ASR_LSTM_BWD_FULL_WAVES 2
+#endif
 #ifndef ASR_LSTM_FULL_WAVES
 #define ASR_LSTM_FULL_WAVES 2      /* waves 0..1 hold the pointwise threads (PUC*PRG <= 128) */
 #endif
@@ -354,20 +357,31 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
                            ((__float_as_uint(gr[rr].z) & 1u) << 2) | ((__float_as_uint(gr[rr].w) & 1u) << 3);
         return want ? m : (~m & 0xFu);
       };
+      bool first = wave < ASR_LSTM_BWD_FULL_WAVES;
       while (true) {
-        // cheap sentinel poll: the last row of this wave's K range (1 KB, touches all 4 producer CUs); a failed
-        // poll of the whole 64 KB per CU would saturate the XCD's L2 and delay the producers themselves.  (Fetching
-        // the whole tile optimistically on the first attempt, or reading the sentinel ahead of the dW_hh MFMAs, both
-        // measured slower: the rows are not yet visible when this poll starts.)
-        load_row(PRG - 1);
-        bool ok = !gl || row_bits(PRG - 1) == 0xFu;
-        if (__all(ok)) {
+        if (first) {
+          // the pointwise waves poll last: first attempt requests the whole tile at once (one L2 round trip); as a
+          // separate code path -- folded into the sentinel condition the compiler still waited for the sentinel
+          first = false;
 #pragma unroll
-          for (int rr = 0; rr < PRG - 1; ++rr) load_row(rr);
-          unsigned bits = row_bits(PRG - 1);
+          for (int rr = 0; rr < PRG; ++rr) load_row(rr);
+          unsigned bits = 0xFu;
 #pragma unroll
-          for (int rr = 0; rr < PRG - 1; ++rr) bits &= row_bits(rr);
+          for (int rr = 0; rr < PRG; ++rr) bits &= row_bits(rr);
           if (__all(!gl || bits == 0xFu)) break;
+        } else {
+          // cheap sentinel poll: the last row of this wave's K range (1 KB, touches all 4 producer CUs); a failed
+          // poll of the whole 64 KB per CU would saturate the XCD's L2 and delay the producers themselves
+          load_row(PRG - 1);
+          bool ok = !gl || row_bits(PRG - 1) == 0xFu;
+          if (__all(ok)) {
+#pragma unroll
+            for (int rr = 0; rr < PRG - 1; ++rr) load_row(rr);
+            unsigned bits = row_bits(PRG - 1);
+#pragma unroll
+            for (int rr = 0; rr < PRG - 1; ++rr) bits &= row_bits(rr);
+            if (__all(!gl || bits == 0xFu)) break;
+          }
         }
 #ifdef ASR_NO_POLL
         break;
