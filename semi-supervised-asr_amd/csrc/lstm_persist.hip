@@ -24,6 +24,9 @@
 #ifndef ASR_POLL_SLEEP
 #define ASR_POLL_SLEEP 1
 #endif
+#ifndef ASR_LSTM_TOUCH
+#define ASR_LSTM_TOUCH 1
+#endif
 #ifndef ASR_LSTM_BWD_FULL_WAVES
 #define ASR_LSTM_BWD_FULL_WAVES 2
 #endif
@@ -296,10 +299,15 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       wreg[4 * q4] = v.x; wreg[4 * q4 + 1] = v.y; wreg[4 * q4 + 2] = v.z; wreg[4 * q4 + 3] = v.w;
     }
   }
-  const int pu = tid >> 3, pj = tid & 7;
+  // Waves 6-7 mirror the pointwise threads' (unit, row) mapping: they issue the SAME forward-data loads two steps
+  // further ahead and discard them, which pulls those HBM rows into this XCD's L2 before the pointwise threads ask
+  // (their own loads, one step ahead, were HBM first touches: ~0.3 us of every step with a cached row, see DESIGN).
+  const int mt = tid & 127;
+  const int pu = mt >> 3, pj = mt & 7;
   const bool pw_thread = tid < PUC * PRG;
   const int prow = r0 + pj;
   const bool prow_ok = pw_thread && prow < a.nb;
+  const bool touch_ok = ASR_LSTM_TOUCH && tid >= 384 && mt < PUC * PRG && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
   float dcarry = 0.f;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
 #pragma unroll
     for (int u4 = 0; u4 < 4; ++u4) dwacc[kq][u4] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto fetch_step = [&](int sn) {
-    const int tt = d == 0 ? T - 1 - sn : sn;
+    const int tt = (ASR_LP_ABL & 8) ? 1 : (d == 0 ? T - 1 - sn : sn);      // bit 8 (measurement): always the same, cached row
     const int ttp = d == 0 ? tt - 1 : tt + 1;
     const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
     const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
@@ -398,6 +406,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       for (int rr = 0; rr < PRG; ++rr)
         if (gl) *reinterpret_cast<float4*>(&hs[wave][rr][PQS * ((4 * lane) / PQ) + (4 * lane) % PQ]) = gr[rr];
       if (prow_ok && s + 1 < T) fetch_step(s + 1);
+      else if (touch_ok && s + 3 < T) fetch_step(s + 3);       // L2 warm-up for the pointwise threads (results unused)
       const float* h0 = &hs[wave][li][PQS * ks];
       const float* h1 = &hs[wave][4 + li][PQS * ks];
 #pragma unroll
