@@ -460,7 +460,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       __hip_atomic_store((gu64*)dst + 1, ((u64)__float_as_uint(tg.w) << 32) | __float_as_uint(tg.z), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
       if (prow_ok) {     // after the hand-off: the bulk store and the bias-gradient sum are off the serial chain
-        *gp = da;
+        if (!(ASR_LP_ABL & 16)) *gp = da;
         dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
       }
     }
