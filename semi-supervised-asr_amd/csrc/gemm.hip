@@ -10,6 +10,9 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef ASR_GEMM_TOUCH
+#define ASR_GEMM_TOUCH 3      /* L2 warm-up distance in K tiles (0 = off) */
+#endif
 
 // A "stored matrix" view: element (r, c) at p[r*ld + c], valid for r < R, c < Cn.
 struct MatView {
@@ -131,6 +134,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     tile_fetch<AKC>(A, m0, kt_begin * BK, ra);
     tile_fetch<BKC>(B, n0, kt_begin * BK, rb);
   }
+  // L2 warm-up: the register prefetch runs one K tile ahead, which does not cover an HBM first touch (operands of the
+  // train step are cold: +15-25 % time on the weight-gradient shapes).  Each thread therefore also touches ONE
+  // 128-byte line of the tile two further ahead (256 threads = the 2 x 128 lines of an A and a B tile); the value
+  // is discarded (ASR_GEMM_TOUCH).
+  const int tt = threadIdx.x & 127;
+  const bool touch_a = threadIdx.x < 128;
+  float touched = 0.f;
+  const bool do_touch = kt_end - kt_begin > 16;      // short K loops (K <= 512) measured 5 % slower with it
+  auto touch_tile = [&](int64_t ktt) {
+    const MatView& m = touch_a ? A : B;
+    const bool kc = touch_a ? AKC : BKC;
+    const int64_t r0t = touch_a ? m0 : n0;
+    int64_t rr, cc;
+    if (kc) { rr = r0t + tt; cc = ktt * BK; }                       // [rows][K]: one 128-byte row segment per row
+    else { rr = ktt * BK + (tt >> 2); cc = r0t + 32 * (tt & 3); }   // [K][rows]: four segments per k row
+    rr = rr < m.R ? rr : m.R - 1;
+    cc = cc < m.Cn ? cc : m.Cn - 1;
+    touched = m.p[rr * m.ld + cc];
+  };
   for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
     tile_store<AKC>(As, ra);
     tile_store<BKC>(Bs, rb);
@@ -139,6 +161,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       tile_fetch<AKC>(A, m0, (kt + 1) * BK, ra);
       tile_fetch<BKC>(B, n0, (kt + 1) * BK, rb);
     }
+#if ASR_GEMM_TOUCH
+    asm volatile("" ::"v"(touched));                 // retire the previous touch (issued one tile ago)
+    if (do_touch && kt + ASR_GEMM_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_TOUCH);
+#endif
     const float* ap = As + kh * SA + wm * 64 + l31;
     const float* bp = Bs + kh * SB + wn * 64 + l31;
 #pragma unroll
