@@ -27,6 +27,9 @@
 #ifndef ASR_LSTM_TOUCH
 #define ASR_LSTM_TOUCH 1
 #endif
+#ifndef ASR_LSTM_TOUCH_DIST
+#define ASR_LSTM_TOUCH_DIST 3
+#endif
 #ifndef ASR_LSTM_BWD_FULL_WAVES
 #define ASR_LSTM_BWD_FULL_WAVES 2
 #endif
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       for (int rr = 0; rr < PRG; ++rr)
         if (gl) *reinterpret_cast<float4*>(&hs[wave][rr][PQS * ((4 * lane) / PQ) + (4 * lane) % PQ]) = gr[rr];
       if (prow_ok && s + 1 < T) fetch_step(s + 1);
-      else if (touch_ok && s + 3 < T) fetch_step(s + 3);       // L2 warm-up for the pointwise threads (results unused)
+      else if (touch_ok && s + ASR_LSTM_TOUCH_DIST < T) fetch_step(s + ASR_LSTM_TOUCH_DIST);   // L2 warm-up (results unused)
       const float* h0 = &hs[wave][li][PQS * ks];
       const float* h1 = &hs[wave][4 + li][PQS * ks];
 #pragma unroll
