@@ -192,8 +192,15 @@ def init_distributed():
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if torch.cuda.is_available():
-        local = local % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one card
+        ndev = max(1, torch.cuda.device_count())
+        local = local % ndev                                    # rehearsal: several ranks may share one card
         torch.cuda.set_device(local)
+        if w > ndev:
+            # The persistent kernels need all 256 CUs of a device co-resident (one workgroup per CU).  Two processes
+            # sharing a card could each get part of it and starve each other until the bounded spins abort, so a
+            # shared-card rehearsal takes the per-step kernels.
+            import hip_backend as hb
+            hb.USE_PERSIST = hb.USE_PERSIST_DEC = hb.USE_PERSIST_DEC_BWD = False
         backend = os.environ.get("ASR_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
     else:
         backend = "gloo"
