@@ -200,18 +200,24 @@ def kernel_roofline(dev):
     dw = torch.zeros(2, 4 * H, H, device=dev)
     xch, ctrl = hb.persist_scratch(dev)
     lstm_s, lstm_flops = 0.0, 0.0
+    db = torch.zeros(2 * 4 * H, device=dev)
     for T in layers:
-        gates.copy_(gates0)
         lens.fill_(T)
-        torch.cuda.synchronize()
-        e0.record(stream)
-        rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c),
-                                          hb.ptr(y), hb.ptr(dw), None, hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()),
-                                          hb.stream())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        hb.check(rc, "asr_lstm_seq_bwd_persist")
-        lstm_s += e0.elapsed_time(e1) * 1e-3
+        best = None
+        for _rep in range(3):                      # first pass warms clocks / code; report the best of the next two
+            gates.copy_(gates0)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy),
+                                              hb.ptr(c), hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
+                                              hb.c_p(ctrl.data_ptr()), hb.stream())
+            e1.record(stream)
+            torch.cuda.synchronize()
+            hb.check(rc, "asr_lstm_seq_bwd_persist")
+            if _rep > 0:
+                dt = e0.elapsed_time(e1) * 1e-3
+                best = dt if best is None else min(best, dt)
+        lstm_s += best
         lstm_flops += T * 2.0 * (2.0 * B * 4 * H * H * 2)
     lstm = dict(bound="mfma", kernel="lstm_persist_bwd_kernel<512> (dG recurrence + fused dW_hh, 3 encoder layers)",
                 achieved=lstm_flops / lstm_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
