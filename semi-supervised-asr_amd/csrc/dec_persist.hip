@@ -80,7 +80,7 @@ struct DecDims {
   static constexpr int NE = (4 * EE + DP_NT - 1) / DP_NT;     // embedding values per thread
   static constexpr size_t lds_floats = 4 * XS + 8 * 64 * 5 + 64 + 4 * 16 * DP_TPM + DP_TPM * OQ + 16 * DP_TAPS4 +
                                        DP_WLEN + 8 * 16 * 17 + 8 * DP_TPM + DP_TPM + 8 * 64 + 32 * 4 * 64 + 8;
-  static_assert(KX % 32 == 0 && DD % 32 == 0 && AA % 32 == 0 && OO % 8 == 0, "slice sizes");
+  static_assert(KX % 32 == 0 && DD % 32 == 0 && AA % 32 == 0 && OO % 8 == 0 && (EE & (EE - 1)) == 0, "slice sizes");
   static_assert(DU <= 16 && AU <= 16 && OQ <= 64 && DD <= 512 && OO <= 512, "per-CU slices must fit the mappings");
 };
 
@@ -250,17 +250,23 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       const int id = tid_ + DP_NT * i, er = id / EE, ee = id - er * EE;
       if (er < 4) xs[er * XS + DD + OO + ee] = emb_next[i];
     }
-    if (s + 1 < L) {
+    {
+      // next step's operands: UNGUARDED loads from clamped addresses (a load under a lane predicate or a uniform branch
+      // is waited for at the join: a memory round trip on the serial chain of every step); invalid lanes discard
+      const int sn = s + 1 < L ? s + 1 : s;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
-        const int id = tid_ + DP_NT * i, er = id / EE, ee = id - er * EE;
+        const int id = tid_ + DP_NT * i, er = (id / EE) & 3, ee = id & (EE - 1);
         const int eb = r0 + er;
-        emb_next[i] = (er < 4) ? Xin[((int64_t)(s + 1) * B + (eb < nb ? eb : r0)) * KX + DD + OO + ee] : 0.f;
+        emb_next[i] = Xin[((int64_t)sn * B + (eb < nb ? eb : r0)) * KX + DD + OO + ee];
       }
     }
     const float mask_cur = mask_next;
-    if (drop && ctx_thread_ && s + 2 < L)
-      mask_next = a.xmask[((int64_t)(s + 2) * B + abc) * (OO + EE) + OQ * aq + tid_];
+    {
+      const int sm = s + 2 < L ? s + 2 : (L > 1 ? 1 : 0);
+      const float* mp = drop ? a.xmask + ((int64_t)sm * B + abc) * (OO + EE) + OQ * aq : a.bo + OQ * aq;
+      mask_next = mp[tid_ < OQ ? tid_ : 0];                    // only the context threads (tid < OQ) use it
+    }
     __syncthreads();
     DP_MARK(1);
     // ------------------------------------------------------------ (2) gates = x Wcat^T on the 4x4x1 MFMA
