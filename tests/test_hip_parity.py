@@ -604,3 +604,71 @@ def test_decoder_persistent_path(dim, B, Tp, L, drop):
             scale = float(gr[k].abs().max()) + 1e-12
             err = float((gp[k] - gr[k]).abs().max()) / scale
             assert err < 2e-4, (mode, k, err)
+
+
+@pytest.mark.parametrize("V,ls", [(34, 0.05), (34, 0.0), (100, 0.1), (7, 0.3)])
+def test_label_logprob_kernels(V, ls):
+    """asr_label_logprob_fwd/bwd against log_softmax -> gather -> label smoothing in torch (model.py:354-366)."""
+    dev = _gpu()
+    import ops
+    g = torch.Generator().manual_seed(V)
+    L, B = 5, 7
+    logits = (torch.randn(L, B, V, generator=g) * 3).to(dev).requires_grad_(True)
+    idx = torch.randint(0, V, (L, B), generator=g).to(dev)
+    dist = torch.rand(V, generator=g)
+    dist = (dist / dist.sum()).to(dev)
+    up = torch.randn(L, B, generator=g).to(dev)
+    got = ops.label_logprob(logits, idx, dist if ls > 0 else None, ls)
+    got.backward(up)
+    g_got = logits.grad.clone()
+    ref_in = logits.detach().clone().requires_grad_(True)
+    lp = torch.log_softmax(ref_in, dim=2)
+    ref = torch.gather(lp, 2, idx.unsqueeze(2)).squeeze(2)
+    if ls > 0:
+        ref = (1 - ls) * ref + ls * torch.sum(lp * dist, dim=2)
+    ref.backward(up)
+    _close(got, ref, rtol=1e-5, atol=1e-6, what="label log-probs")
+    _close(g_got, ref_in.grad, rtol=1e-5, atol=1e-6, what="d(logits)")
+
+
+@pytest.mark.parametrize("H,I,ndir", [(16, 12, 2), (128, 80, 2), (32, 32, 1)])
+def test_lstm_pack_unpack_roundtrip(H, I, ndir):
+    """asr_lstm_pack_f32 produces the gate-interleaved layout (row = unit*4 + gate) and asr_lstm_unpack_f32 inverts it."""
+    dev = _gpu()
+    import hip_backend as hb
+    import ops
+    g = torch.Generator().manual_seed(H + I)
+    prm = []
+    for _ in range(ndir):
+        prm += [torch.randn(4 * H, I, generator=g).to(dev), torch.randn(4 * H, H, generator=g).to(dev),
+                torch.randn(4 * H, generator=g).to(dev), torch.randn(4 * H, generator=g).to(dev)]
+    w_ih = torch.empty(ndir * 4 * H, I, device=dev)
+    w_hh = torch.empty(ndir, 4 * H, H, device=dev)
+    bias = torch.empty(ndir * 4 * H, device=dev)
+    hb.lstm_pack(prm, ndir, w_ih, w_hh, bias)
+    perm = ops.gate_perm(H, dev)
+    for d in range(ndir):
+        assert torch.equal(w_ih[d * 4 * H:(d + 1) * 4 * H], prm[4 * d][perm])
+        assert torch.equal(w_hh[d], prm[4 * d + 1][perm])
+        assert torch.equal(bias[d * 4 * H:(d + 1) * 4 * H], (prm[4 * d + 2] + prm[4 * d + 3])[perm])
+    g_ih, g_hh, g_b = hb.lstm_unpack(H, I, ndir, w_ih, w_hh, bias)
+    for d in range(ndir):
+        assert torch.equal(g_ih[d], prm[4 * d]) and torch.equal(g_hh[d], prm[4 * d + 1])
+        assert torch.equal(g_b[d], prm[4 * d + 2] + prm[4 * d + 3])
+
+
+def test_cell_pack_unpack_roundtrip():
+    dev = _gpu()
+    import hip_backend as hb
+    import ops
+    D, O, E = 32, 16, 8
+    g = torch.Generator().manual_seed(9)
+    w_ih, w_hh = torch.randn(4 * D, E + O, generator=g).to(dev), torch.randn(4 * D, D, generator=g).to(dev)
+    b_ih, b_hh = torch.randn(4 * D, generator=g).to(dev), torch.randn(4 * D, generator=g).to(dev)
+    wcat, bcat = torch.empty(4 * D, D + O + E, device=dev), torch.empty(4 * D, device=dev)
+    hb.cell_pack(w_ih, w_hh, b_ih, b_hh, D, O, E, wcat, bcat)
+    perm = ops.gate_perm(D, dev)
+    assert torch.equal(wcat, torch.cat([w_hh, w_ih[:, E:E + O], w_ih[:, :E]], 1)[perm])
+    assert torch.equal(bcat, (b_ih + b_hh)[perm])
+    dw_ih, dw_hh, db = hb.cell_unpack(wcat, bcat, D, O, E)
+    assert torch.equal(dw_ih, w_ih) and torch.equal(dw_hh, w_hh) and torch.equal(db, b_ih + b_hh)
