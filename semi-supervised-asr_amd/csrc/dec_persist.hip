@@ -494,9 +494,21 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     DP_MARK(9);
     // ------------------------------------------------------------ (8) context slice, publish (masked) for the cell
     {
+      // frames wave, wave+8, ...: 4 per trip with the 8 LDS reads issued before the FMAs (a one-frame loop waits for
+      // its two reads every iteration); out-of-range frames are clamped and weighted 0
       float acc = 0.f;
-      if (o_l_ < OQ)
-        for (int t = wave; t < Tp; t += 8) acc += wsm[t] * Qs[t * OQ + o_l_];
+      const int oc = o_l_ < OQ ? o_l_ : 0;
+      for (int t0 = wave; t0 < Tp; t0 += 32) {
+        float wv[4], qv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + 8 * u < Tp ? t0 + 8 * u : t0;
+          wv[u] = wsm[t];
+          qv[u] = Qs[t * OQ + oc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += t0 + 8 * u < Tp ? wv[u] * qv[u] : 0.f;
+      }
       cpart[wave * 64 + o_l_] = acc;
     }
     __syncthreads();
@@ -1179,9 +1191,20 @@ __global__ __launch_bounds__(256) void att_m_kernel(int B, int Tp, int C, const 
                                                     float* __restrict__ Mf) {
   __shared__ __attribute__((aligned(16))) float UG[AA * 16];
   const int b = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < AA * 16; i += 256) {
-    const int aa = i >> 4, c = i & 15;
-    UG[i] = c < C ? watt[(int64_t)aa * C + c] * gvec[aa] : 0.f;
+  // unguarded, batched loads (a load under `c < C ?` is waited for on the spot: 32 serial L2 round trips per workgroup)
+  for (int i0 = 0; i0 < AA * 16; i0 += 256 * 8) {
+    float wv[8], gq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + 256 * k + tid, aa = (i >> 4) < AA ? (i >> 4) : AA - 1, c = i & 15;
+      wv[k] = watt[(int64_t)aa * C + (c < C ? c : 0)];
+      gq[k] = gvec[aa];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + 256 * k + tid;
+      if (i < AA * 16) UG[i] = (i & 15) < C ? wv[k] * gq[k] : 0.f;
+    }
   }
   __syncthreads();
   const float* Sb = S + ((int64_t)s * B + b) * Tp * AA;
