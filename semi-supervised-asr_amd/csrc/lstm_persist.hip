@@ -442,6 +442,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       for (int w2 = 0; w2 < PW; ++w2)
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) dh += part[s & 1][w2][pl + 4 * k2][pr];
+      LP_MARK(9);
       const float tc = asr_fast_tanh(ct);
       const float dc = dcarry + dh * av.w * (1.f - tc * tc);
       float4 da;
@@ -456,12 +457,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       const unsigned bit = (((unsigned)s >> 1) & 1u) ^ 1u;
       float4 tg;
       tg.x = tag_word(da.x, bit); tg.y = tag_word(da.y, bit); tg.z = tag_word(da.z, bit); tg.w = tag_word(da.w, bit);
+      LP_MARK(10);
       float* dst = xch_g + (s & 1) * par_stride + (int64_t)pj * 4 * PH + punit * 4;
       // two 8-byte workgroup-scope (plain, L2-resident) stores; every word carries its own tag
       __hip_atomic_store((gu64*)dst, ((u64)__float_as_uint(tg.y) << 32) | __float_as_uint(tg.x), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_store((gu64*)dst + 1, ((u64)__float_as_uint(tg.w) << 32) | __float_as_uint(tg.z), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
+      LP_MARK(11);
       if (prow_ok) {     // after the hand-off: the bulk store and the bias-gradient sum are off the serial chain
         if (!(ASR_LP_ABL & 16)) *gp = da;
         dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;

@@ -39,3 +39,5 @@ for _ in range(2):
     gb = gact.clone(); ctrl.zero_()
     assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), st) == 0
     torch.cuda.synchronize(); report('bwd', 6)
+    t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    print('   bwd pointwise split: partial sums %.0f | math+tags %.0f | publish %.0f | bulk store+db %.0f' % ((t[:, 9] - t[:, 4]).mean(), (t[:, 10] - t[:, 9]).mean(), (t[:, 11] - t[:, 10]).mean(), (t[:, 5] - t[:, 11]).mean()))
