@@ -40,6 +40,10 @@
 #ifdef ASR_LP_TRACE
 #define LP_MARK(k) do { if ((tid == 0 || tid == 448) && g == 0 && slice == 0 && s >= 8 && s < 16) \
     ((unsigned long long*)(a.ctrl + 16))[(tid ? 128 : 0) + (s - 8) * 16 + (k)] = clock64(); } while (0)
+#elif defined(ASR_LP_TRACE2)
+// per-CU imbalance probe: (top of step, tile gathered) of wave 0 of every slice of group 0, steps 8..15
+#define LP_MARK(k) do { if (tid == 0 && g == 0 && s >= 8 && s < 16 && ((k) == 0 || (k) == 1)) \
+    ((unsigned long long*)a.ctrl)[(slice * 8 + (s - 8)) * 2 + (k)] = clock64(); } while (0)
 #else
 #define LP_MARK(k) do {} while (0)
 #endif
