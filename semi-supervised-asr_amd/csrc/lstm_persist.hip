@@ -24,6 +24,10 @@
 #ifndef ASR_POLL_SLEEP
 #define ASR_POLL_SLEEP 1
 #endif
+#ifndef ASR_LSTM_FWD_WORDS
+#define ASR_LSTM_FWD_WORDS 0      /* forward hand-off: granules + sentinel (0, 2.35 us/step) or single-stage LSB-tagged
+                                    words (1, measured 2.38-2.45 us/step with poll sleeps 1..10: no gain) */
+#endif
 #ifndef ASR_LSTM_TOUCH
 #define ASR_LSTM_TOUCH 1
 #endif
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   const int plen = prow_ok ? a.lens[prow] : 0;
   float c_prev = 0.f;
   u64* xch_g = a.xch + (int64_t)g * PRG * PH;          // + parity * 8*PRG*PH
+  float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * PRG;   // word protocol: [parity][unit][row]
   const int64_t par_stride = (int64_t)8 * PRG * PH;
   bool aborted = false;
   // The x-projection rows are fetched TWO steps ahead: they are HBM first-touch loads (~2 us under load, about one
@@ -146,6 +151,35 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
+#if ASR_LSTM_FWD_WORDS
+      // Single-stage hand-off: h_{t-1} travels as LSB-tagged fp32 words laid out [unit][row], so a lane's 8 rows are
+      // 32 contiguous bytes = four 8-byte L1-bypassing loads that are data and flag at once (no sentinel round trip:
+      // publish -> first seen is ~0.5 us, a second dependent round trip for the tile costs another ~0.55 us).
+      const bool gl = lane < PKW;
+      const u64* src = reinterpret_cast<const u64*>(xw_g + ((s - 1) & 1) * (PH * PRG) +
+                                                    (int64_t)(wave * PKW + (gl ? lane : 0)) * PRG);
+      const u64 tm = 0x0000000100000001ull, texp = tag_bit_of_step(s - 1) ? tm : 0ull;
+      u64 gr[PRG / 2];
+      unsigned spins = 0;
+      while (true) {
+#pragma unroll
+        for (int rr = 0; rr < PRG / 2; ++rr) gr[rr] = granule_load(src + rr);
+        bool ok = true;
+#pragma unroll
+        for (int rr = 0; rr < PRG / 2; ++rr) ok = ok && ((gr[rr] & tm) == texp);
+        LP_MARK(7);
+        if (__all(!gl || ok)) break;
+#ifdef ASR_NO_POLL
+        break;
+#endif
+        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
+          aborted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+      }
+#else
       // gather this wave's K range of h_{t-1}: 8 rows x 64 units of granules tagged s
       const u64* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKW + (lane < PKW ? lane : 0);
       const bool gl = lane < PKW;                       // lanes beyond the wave's K range re-read column 0
@@ -168,6 +202,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         } else {
           // the other waves arrive early and spin: cheap sentinel read of the last row first (see backward)
           gr[PRG - 1] = granule_load(src + (int64_t)(PRG - 1) * PH);
+#ifdef ASR_LP_TRACE3   /* ... and when lane 0 of (slice 0, wave 7) first sees that granule valid */
+          if (g == 0 && slice == 0 && tid == 448 && s - 1 < 64 && (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s &&
+              ((unsigned long long*)a.ctrl)[16 + 2 * (s - 1) + 1] == 0ull)
+            ((unsigned long long*)a.ctrl)[16 + 2 * (s - 1) + 1] = wall_clock64();
+#endif
           if (__all(!gl || (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
             LP_MARK(7);
 #pragma unroll
@@ -189,13 +228,20 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         }
         __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
+#endif
       LP_MARK(1);
 #ifdef ASR_LP_TRACE
       if (tid == 0 && g == 0 && slice == 0 && s >= 8 && s < 16) ((unsigned long long*)(a.ctrl + 16))[(s - 8) * 16 + 8] = spins;
 #endif
+#if ASR_LSTM_FWD_WORDS
+#pragma unroll
+      for (int rr = 0; rr < PRG / 2; ++rr)
+        if (gl) { hs[wave][2 * rr][lane] = pair_lo(gr[rr]); hs[wave][2 * rr + 1][lane] = pair_hi(gr[rr]); }
+#else
 #pragma unroll
       for (int rr = 0; rr < PRG; ++rr)
         if (gl) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
+#endif
       if (st_gp) {                    // previous step's outputs (see above)
         *st_gp = st_g;
         a.c[st_so] = st_c;
@@ -243,7 +289,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
       LP_MARK(5);
+#if ASR_LSTM_FWD_WORDS
+      word_store(xw_g + (s & 1) * (PH * PRG) + (int64_t)punit * PRG + pj, hn, tag_bit_of_step(s));       // hand-off first
+#else
       granule_store(xch_g + (s & 1) * par_stride + (int64_t)pj * PH + punit, (unsigned)(s + 1), hn);   // hand-off first
+#endif
+#ifdef ASR_LP_TRACE3   /* visibility probe: global 100 MHz clock at the publish of (slice 28, row 7, its first unit) ... */
+      if (g == 0 && slice == 28 && tid == 7 && s < 64) ((unsigned long long*)a.ctrl)[16 + 2 * s] = wall_clock64();
+#endif
       if (prow_ok) {
         st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
         st_gp = gp;
