@@ -292,6 +292,30 @@ int asr_label_logprob_bwd(int64_t rows, int V, const float* logits, int64_t ld, 
                           int64_t lddz, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Free-running decoder feedback (Decoder.forward loop, model.py:329-351): one launch per decoder step each way for
+ * what sits between two steps when the next input is not a stored teacher token.
+ *   forward : logits[b] = w_out [z_s, c_s] + b_out (x: row-strided [B, DO] slice of the step-input buffer, ldx);
+ *             pred[b] = argmax (int64, lowest index on ties); then the embedding input of step s+1 into x_emb_next
+ *             (same buffer layout, ldx) by mode:  0 = emb[pred[b]]  (greedy, model.py:336-337)
+ *                                                 1 = softmax(scaling * logits[b]) @ emb  (smooth, model.py:341), the
+ *                                                     probabilities are kept in probs [B, V] for the backward
+ *                                                 2 = emb[tok[b * tok_stride]]  (teacher token of a tf draw, 331-333)
+ *                                                 3 = nothing (last step).
+ *             fed[b] = the token used (-1 for mode 1); xd_emb_next (optional) = x_emb_next * mask (dropout
+ *             multipliers [B, ldm] of the embedding columns).  V <= 128.
+ *   backward (mode 1 only): with demb = d loss / d x_emb of step s (row-strided, ldg) and p = probs of step s-1:
+ *             dl = scaling * p * (demb emb^T - sum_v p_v (demb emb^T)_v);  dlog[b] += dl  (gradient of logits_{s-1},
+ *             from which the caller takes dW_out, db_out once per sequence);  gtop[b] += dl w_out  (gradient of
+ *             [z_{s-1}, c_{s-1}], same buffer layout as demb).
+ * ------------------------------------------------------------------------------------- */
+int asr_dec_feedback_fwd(int B, int V, int E, int DO, const float* x, int64_t ldx, const float* w_out,
+                         const float* b_out, const float* emb, float* logits, int64_t* pred, int mode, float scaling,
+                         const int64_t* tok, int64_t tok_stride, int64_t* fed, float* probs, float* x_emb_next,
+                         float* xd_emb_next, const float* mask, int64_t ldm, asr_stream_t stream);
+int asr_dec_feedback_bwd(int B, int V, int E, int DO, const float* demb, float* gtop, int64_t ldg, const float* probs,
+                         const float* emb, const float* w_out, float scaling, float* dlog, asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser on a flat fp32 buffer (solver.py:152-153,384-385: clip_grad_norm_ + Adam(amsgrad,
  * weight_decay).step).  asr_sumsq_f32 adds sum(g^2) into the device scalar out[0] (caller zeroes
  * it); asr_adam_clip_f32 scales g by min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) (skipped when

@@ -40,7 +40,7 @@ int asr_graph_run(AsrGraphCache* gc, const void* key, size_t key_bytes, hipStrea
       size_t victim = 0;
       for (size_t i = 1; i < gc->entries.size(); ++i)
         if (gc->entries[i].stamp < gc->entries[victim].stamp) victim = i;
-      if (gc->entries[victim].exec) hipGraphExecDestroy(gc->entries[victim].exec);
+      if (gc->entries[victim].exec) (void)hipGraphExecDestroy(gc->entries[victim].exec);
       gc->entries.erase(gc->entries.begin() + victim);
     }
     AsrGraphEntry ne;
@@ -70,12 +70,12 @@ int asr_graph_run(AsrGraphCache* gc, const void* key, size_t key_bytes, hipStrea
   if (rc != 0 || err != hipSuccess || !graph) {
     e->failed = true;
     (void)hipGetLastError();
-    if (graph) hipGraphDestroy(graph);
+    if (graph) (void)hipGraphDestroy(graph);
     return launch(stream);   // nothing ran during the failed capture: do the work now
   }
   hipGraphExec_t exec = nullptr;
   err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (err != hipSuccess || !exec) {
     e->failed = true;
     (void)hipGetLastError();

@@ -298,7 +298,7 @@ extern "C" void asr_graphs_destroy(void* graphs) {
   AsrGraphCache* gc = (AsrGraphCache*)graphs;
   if (!gc) return;
   for (auto& e : gc->entries)
-    if (e.exec) hipGraphExecDestroy(e.exec);
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
   delete gc;
 }
 

@@ -18,7 +18,7 @@ EXPORTS = (
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
-    "asr_label_logprob_fwd", "asr_label_logprob_bwd",
+    "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
 
@@ -81,6 +81,9 @@ def load():
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]
     lib.asr_label_logprob_fwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p]
     lib.asr_label_logprob_bwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p, c_i64, c_p]
+    lib.asr_dec_feedback_fwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_i64,
+                                         c_p, c_p, c_p, c_p, c_p, c_i64, c_p]
+    lib.asr_dec_feedback_bwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_f, c_p, c_p]
     pp = ctypes.POINTER(c_p)
     lib.asr_lstm_pack_f32.argtypes = [c_i, c_i, c_i, pp, pp, pp, pp, c_p, c_p, c_p, c_p]
     lib.asr_lstm_unpack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, pp, pp, pp, c_p]
@@ -178,6 +181,54 @@ def gemm_skinny(A, Bt, bias=None, out=None, accumulate=False):
     check(load().asr_gemm_skinny_f32(M, N, K, ptr(A), lda, ptr(Bt), ldb, ptr(out), ldc, ptr(bias), int(accumulate),
                                      None, 0, 0, stream()), "asr_gemm_skinny_f32")
     return out
+
+
+FEED_PREDICTED, FEED_SMOOTH, FEED_TEACHER, FEED_NONE = 0, 1, 2, 3
+
+
+def _lptr(t):
+    return None if t is None else c_p(t.data_ptr())
+
+
+def dec_feedback_fwd(x_top, w_out, b_out, emb_w, logits, pred, mode, scaling=1.0, tok=None, fed=None, probs=None,
+                     x_emb_next=None, xd_emb_next=None, mask=None):
+    """One decoder step's output side (model.py:329-351): logits = x_top w_out^T + b, pred = argmax, and the next
+    step's embedding input (teacher token / predicted token / softmax(scaling*logits) @ E), with its dropped-out copy.
+    x_top [B, D+O] and the embedding slots are row-strided views of the step input buffer; pred/fed/tok are int64."""
+    _dev(x_top, "x_top")
+    B, DO = x_top.shape
+    V, E = emb_w.shape
+    ldx = x_top.stride(0)
+    assert x_top.stride(1) == 1 and w_out.is_contiguous() and emb_w.is_contiguous() and logits.is_contiguous()
+    tok_stride = 0
+    if tok is not None:
+        assert tok.dim() == 1 and tok.dtype == torch.long and tok.shape[0] == B
+        tok_stride = tok.stride(0)
+    for t in (pred, fed):
+        assert t is None or (t.dtype == torch.long and t.is_contiguous() and t.numel() == B)
+    ldm = 0
+    if x_emb_next is not None:
+        assert x_emb_next.stride(0) == ldx and x_emb_next.stride(1) == 1 and x_emb_next.shape == (B, E)
+    if xd_emb_next is not None:
+        assert xd_emb_next.stride(0) == ldx and xd_emb_next.stride(1) == 1 and mask.stride(1) == 1
+        ldm = mask.stride(0)
+    check(load().asr_dec_feedback_fwd(B, V, E, DO, ptr(x_top), ldx, ptr(w_out), ptr(b_out), ptr(emb_w), ptr(logits),
+                                      _lptr(pred), int(mode), float(scaling), _lptr(tok), tok_stride, _lptr(fed),
+                                      ptr(probs), ptr(x_emb_next), ptr(xd_emb_next), ptr(mask), ldm, stream()),
+          "asr_dec_feedback_fwd")
+
+
+def dec_feedback_bwd(demb, gtop, probs, emb_w, w_out, scaling, dlog):
+    """Backward of the smooth embedding feedback: demb [B,E] (grad of step s's embedding input) -> dlog [B,V] (+=, grad
+    of logits_{s-1}) -> gtop [B,D+O] (+=, grad of [z_{s-1}, c_{s-1}])."""
+    _dev(demb, "demb")
+    B, E = demb.shape
+    V, DO = w_out.shape
+    ldg = demb.stride(0)
+    assert demb.stride(1) == 1 and gtop.stride(1) == 1 and gtop.stride(0) == ldg and gtop.shape == (B, DO)
+    assert probs.is_contiguous() and dlog.is_contiguous() and w_out.is_contiguous() and emb_w.is_contiguous()
+    check(load().asr_dec_feedback_bwd(B, V, E, DO, ptr(demb), ptr(gtop), ldg, ptr(probs), ptr(emb_w), ptr(w_out),
+                                      float(scaling), ptr(dlog), stream()), "asr_dec_feedback_bwd")
 
 
 def colsum(X, out=None, accumulate=False):
@@ -330,6 +381,8 @@ def _off(t, elems):
 USE_PERSIST = os.environ.get("ASR_PERSIST", "1") != "0"
 USE_PERSIST_DEC = USE_PERSIST and os.environ.get("ASR_PERSIST_DEC", "1") != "0"   # persistent decoder forward
 USE_PERSIST_DEC_BWD = USE_PERSIST and os.environ.get("ASR_PERSIST_DEC_BWD", "1") != "0"   # ... and backward
+# free-running decode: fused logits/argmax/next-embedding kernel per step (off: the same steps through torch glue)
+USE_FEEDBACK_KERNEL = os.environ.get("ASR_FEEDBACK_KERNEL", "1") != "0"
 _persist_scratch = {}
 
 

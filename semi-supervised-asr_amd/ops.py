@@ -350,30 +350,58 @@ class _DecoderSeq(torch.autograd.Function):
             fs = _dec_fwd_struct(d, 0, B)
             logits = torch.empty(L, B, V, **f32)
             pred = torch.empty(L, B, dtype=torch.long, device=dev)
-            for s in range(L):
-                if s == 0:
-                    tok = tokens[:, 0] if tokens is not None else torch.full((B,), opts["bos"], dtype=torch.long,
-                                                                             device=dev)
-                    fed[0] = tok
-                    X[0, :, D + O:] = emb_w[tok]
-                elif tokens is not None:
-                    tok = tokens[:, s] if tf_flags[s] else pred[s - 1]
-                    fed[s] = tok
-                    X[s, :, D + O:] = emb_w[tok]
-                elif not smooth:
-                    fed[s] = pred[s - 1]
-                    X[s, :, D + O:] = emb_w[pred[s - 1]]
-                else:
-                    pr = torch.softmax(logits[s - 1] * opts["smooth_scaling"], dim=-1)
-                    probs_saved.append(pr)
-                    fed[s] = -1
-                    hb.gemm(pr, emb_w, out=X[s][:, D + O:])
+            if hb.USE_FEEDBACK_KERNEL and not sample and V <= 128:
+                # free-running steps: per step the decoder chain, then ONE kernel for logits + argmax + the next
+                # step's embedding input (teacher / predicted token, or the smooth embedding softmax(k*logit) @ E)
+                emb_c = emb_w.contiguous()
+                if smooth and tokens is None:
+                    probs_saved = torch.empty(max(L - 1, 1), B, V, **f32)
+                tok_c = tokens.contiguous() if tokens is not None else None
+                fed[0] = tok_c[:, 0] if tok_c is not None else opts["bos"]
+                X[0, :, D + O:] = emb_c[fed[0]]
                 if drop:
-                    Xd[s, :, D + O:] = X[s, :, D + O:] * xmask[s, :, O:]
-                hb.check(lib.asr_dec_step_fwd(ctypes.byref(fs), s, hb.stream()), "asr_dec_step_fwd")
-                hb.gemm_skinny(X[s + 1][:, :D + O], w_out_c, bias=b_out, out=logits[s])
-                pred[s] = torch.distributions.Categorical(logits=logits[s]).sample() if sample \
-                    else logits[s].argmax(-1)
+                    Xd[0, :, D + O:] = X[0, :, D + O:] * xmask[0, :, O:]
+                for s in range(L):
+                    hb.check(lib.asr_dec_step_fwd(ctypes.byref(fs), s, hb.stream()), "asr_dec_step_fwd")
+                    last = s == L - 1
+                    if last:
+                        mode = hb.FEED_NONE
+                    elif tok_c is not None:
+                        mode = hb.FEED_TEACHER if (tf_flags is None or tf_flags[s + 1]) else hb.FEED_PREDICTED
+                    else:
+                        mode = hb.FEED_SMOOTH if smooth else hb.FEED_PREDICTED
+                    hb.dec_feedback_fwd(
+                        X[s + 1][:, :D + O], w_out_c, b_out, emb_c, logits[s], pred[s], mode, opts["smooth_scaling"],
+                        tok=tok_c[:, s + 1] if mode == hb.FEED_TEACHER else None, fed=None if last else fed[s + 1],
+                        probs=probs_saved[s] if mode == hb.FEED_SMOOTH else None,
+                        x_emb_next=None if last else X[s + 1][:, D + O:],
+                        xd_emb_next=Xd[s + 1][:, D + O:] if (drop and not last) else None,
+                        mask=xmask[s + 1][:, O:] if (drop and not last) else None)
+            else:
+                for s in range(L):
+                    if s == 0:
+                        tok = tokens[:, 0] if tokens is not None else torch.full((B,), opts["bos"], dtype=torch.long,
+                                                                                 device=dev)
+                        fed[0] = tok
+                        X[0, :, D + O:] = emb_w[tok]
+                    elif tokens is not None:
+                        tok = tokens[:, s] if tf_flags[s] else pred[s - 1]
+                        fed[s] = tok
+                        X[s, :, D + O:] = emb_w[tok]
+                    elif not smooth:
+                        fed[s] = pred[s - 1]
+                        X[s, :, D + O:] = emb_w[pred[s - 1]]
+                    else:
+                        pr = torch.softmax(logits[s - 1] * opts["smooth_scaling"], dim=-1)
+                        probs_saved.append(pr)
+                        fed[s] = -1
+                        hb.gemm(pr, emb_w, out=X[s][:, D + O:])
+                    if drop:
+                        Xd[s, :, D + O:] = X[s, :, D + O:] * xmask[s, :, O:]
+                    hb.check(lib.asr_dec_step_fwd(ctypes.byref(fs), s, hb.stream()), "asr_dec_step_fwd")
+                    hb.gemm_skinny(X[s + 1][:, :D + O], w_out_c, bias=b_out, out=logits[s])
+                    pred[s] = torch.distributions.Categorical(logits=logits[s]).sample() if sample \
+                        else logits[s].argmax(-1)
         ctx.d = d
         ctx.lease = lease
         ctx.keep = (wdec_c, watt_c, bo_c, fed, probs_saved, w_out_c, emb_w)
@@ -436,7 +464,23 @@ class _DecoderSeq(torch.autograd.Function):
             # the logits of step s-1, so the extra gradient is injected between the per-step kernels.
             bs = _dec_bwd_struct(d, w, 0, B)
             k = ctx.smooth_scaling
-            for s in range(L - 1, -1, -1):
+            fused = torch.is_tensor(probs_saved)
+            if fused:
+                # one kernel per step carries the embedding gradient back into logit_{s-1} and [z_{s-1}, c_{s-1}];
+                # the weight gradients that depend on it are taken once over the whole sequence afterwards
+                dtot = dlog2.clone().view(L, B, V)
+                emb_c, w_out_c = emb_w.contiguous(), w_out.contiguous()
+                for s in range(L - 1, -1, -1):
+                    hb.check(lib.asr_dec_step_bwd(ctypes.byref(bs), s, hb.stream()), "asr_dec_step_bwd")
+                    if s >= 1:
+                        hb.dec_feedback_bwd(G[s][:, D + O:], G[s][:, :D + O], probs_saved[s - 1], emb_c, w_out_c, k,
+                                            dtot[s - 1])
+                dw_out = hb.gemm(dtot.view(L * B, V), XO, trans_a=True)
+                db_out = hb.colsum(dtot.view(L * B, V))
+                if L > 1:
+                    hb.gemm(probs_saved[:L - 1].view((L - 1) * B, V), G[1:L].view((L - 1) * B, KX)[:, D + O:], trans_a=True,
+                            out=demb_w, accumulate=True, split_k=1)
+            for s in (range(L - 1, -1, -1) if not fused else ()):
                 hb.check(lib.asr_dec_step_bwd(ctypes.byref(bs), s, hb.stream()), "asr_dec_step_bwd")
                 if s >= 1:
                     demb = G[s][:, D + O:]
@@ -464,7 +508,9 @@ class _DecoderSeq(torch.autograd.Function):
         dbo = hb.colsum(dctx_base.view(L * B, KX)[:, D:D + O])
         # embedding gradient for token-fed steps
         demb_all = G[:L, :, D + O:]
-        if not probs_saved:          # every step was fed a token (decided on the host: no device sync here)
+        if torch.is_tensor(probs_saved):   # smooth feedback: only step 0 was fed a token (<BOS>)
+            demb_w.index_add_(0, fed[0], demb_all[0])
+        elif not probs_saved:        # every step was fed a token (decided on the host: no device sync here)
             demb_w.index_add_(0, fed.view(-1), demb_all.reshape(L * B, E))
         else:
             tokfed = fed >= 0

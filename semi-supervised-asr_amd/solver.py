@@ -310,7 +310,11 @@ class Solver(object):
             unlab_xs, unlab_ilens, ys=None, sample=False, label_smoothing=False,
             max_dec_timesteps=int(unlab_xs.size(1) * self.proportion), smooth=cfg["smooth_embedding"],
             scaling=cfg["softmax_scaling"])
-        _, lm_probs, _ = self.judge(ys=u_pred, discrete_input=False)
+        # The judge scores an integer hypothesis, so no gradient reaches the model through it, and gen_opt does not hold
+        # its parameters (solver.py:484-488 builds that graph and never uses it): the forward alone gives the same
+        # losses and model gradients.
+        with torch.no_grad():
+            _, lm_probs, _ = self.judge(ys=u_pred, discrete_input=False)
         mask = (u_pred != self.vocab["<EOS>"]).float()
         unsup_loss = -torch.sum(lm_probs * u_lp * mask) / torch.sum(mask)
         _, lab_lp, _, _ = self.model(lab_xs, lab_ilens, ys=lab_ys, tf_rate=1.0, sample=False)

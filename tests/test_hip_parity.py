@@ -672,3 +672,122 @@ def test_cell_pack_unpack_roundtrip():
     assert torch.equal(bcat, (b_ih + b_hh)[perm])
     dw_ih, dw_hh, db = hb.cell_unpack(wcat, bcat, D, O, E)
     assert torch.equal(dw_ih, w_ih) and torch.equal(dw_hh, w_hh) and torch.equal(db, b_ih + b_hh)
+
+
+@pytest.mark.parametrize("B,V,E,DO", [(32, 34, 128, 1024), (5, 7, 12, 40), (3, 100, 64, 640)])
+def test_decoder_feedback_kernels(B, V, E, DO):
+    """asr_dec_feedback_fwd/bwd (logits + argmax + next-step embedding; smooth-embedding backward) against the torch
+    expressions of model.py:329-351 on strided step-input buffers, all four feed modes."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(5 + B + V)
+    KX = DO + E
+    X = torch.randn(2, B, KX, generator=g).to(dev)
+    w_out = (torch.randn(V, DO, generator=g) / np.sqrt(DO)).to(dev)
+    b_out = torch.randn(V, generator=g).to(dev)
+    emb = torch.randn(V, E, generator=g).to(dev)
+    mask = ((torch.rand(B, 7 + E, generator=g) > 0.3).float() / 0.7).to(dev)
+    toks = torch.randint(0, V, (B, 3), generator=g).to(dev)
+    ref_logits = X[0][:, :DO] @ w_out.t() + b_out
+    ref_pred = ref_logits.argmax(-1)
+    k = 3.0
+    for mode in (hb.FEED_PREDICTED, hb.FEED_SMOOTH, hb.FEED_TEACHER, hb.FEED_NONE):
+        Xn, Xd = X.clone(), torch.zeros_like(X)
+        logits = torch.empty(B, V, device=dev)
+        pred = torch.empty(B, dtype=torch.long, device=dev)
+        fed = torch.full((B,), -7, dtype=torch.long, device=dev)
+        probs = torch.empty(B, V, device=dev)
+        last = mode == hb.FEED_NONE
+        hb.dec_feedback_fwd(Xn[0][:, :DO], w_out, b_out, emb, logits, pred, mode, k,
+                            tok=toks[:, 1] if mode == hb.FEED_TEACHER else None, fed=None if last else fed,
+                            probs=probs if mode == hb.FEED_SMOOTH else None, x_emb_next=None if last else Xn[1][:, DO:],
+                            xd_emb_next=None if last else Xd[1][:, DO:], mask=None if last else mask[:, 7:])
+        _close(logits, ref_logits, rtol=1e-5, atol=1e-5, what="feedback logits")
+        assert torch.equal(pred, ref_pred)
+        assert torch.equal(Xn[1][:, :DO], X[1][:, :DO]) and torch.equal(Xn[0], X[0])
+        if last:
+            assert torch.equal(Xn[1], X[1])
+            continue
+        if mode == hb.FEED_SMOOTH:
+            p = torch.softmax(ref_logits * k, -1)
+            want, want_fed = p @ emb, torch.full((B,), -1, dtype=torch.long, device=dev)
+            _close(probs, p, rtol=1e-5, atol=1e-6, what="feedback probs")
+        else:
+            want_fed = toks[:, 1] if mode == hb.FEED_TEACHER else ref_pred
+            want = emb[want_fed]
+        assert torch.equal(fed, want_fed)
+        _close(Xn[1][:, DO:], want, rtol=1e-5, atol=1e-6, what="next embedding")
+        _close(Xd[1][:, DO:], want * mask[:, 7:], rtol=1e-5, atol=1e-6, what="dropped next embedding")
+    # backward of the smooth feedback
+    G = torch.randn(B, KX, generator=g).to(dev)
+    p = torch.softmax(ref_logits * k, -1)
+    dlog0 = torch.randn(B, V, generator=g).to(dev)
+    dp = G[:, DO:] @ emb.t()
+    dl = k * p * (dp - (p * dp).sum(-1, keepdim=True))
+    want_top = G[:, :DO] + dl @ w_out
+    Gk, dlog = G.clone(), dlog0.clone()
+    hb.dec_feedback_bwd(Gk[:, DO:], Gk[:, :DO], p.contiguous(), emb, w_out, k, dlog)
+    _close(dlog, dlog0 + dl, rtol=1e-4, atol=1e-5, what="feedback dlogits")
+    _close(Gk[:, :DO], want_top, rtol=1e-4, atol=1e-5, what="feedback d[z,c]")
+    assert torch.equal(Gk[:, DO:], G[:, DO:])
+
+
+@pytest.mark.parametrize("dim,B,Tp,L,drop,kind", [(512, 32, 100, 6, True, "smooth"), (512, 32, 100, 5, True, "greedy"),
+                                                  (320, 7, 37, 5, False, "smooth"), (512, 9, 60, 6, True, "mixed")])
+def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
+    """Free-running decoder sequences (smooth embedding with grad as in solver.py:460-495, greedy, scheduled sampling)
+    with the fused per-step feedback kernel against the same steps through torch glue: outputs and every gradient.
+    The tiny golden tests hold both to the reference's numbers at small shapes."""
+    dev = _gpu()
+    import ops
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(31 + B + Tp)
+    D = A = O = dim
+    E, C, K, V = 128, 10, 100, 34
+    sc0 = 1.0 / np.sqrt(D)
+
+    def rnd(*sh, sc=1.0):
+        return (torch.randn(*sh, generator=g) * sc).to(dev)
+
+    base = dict(P=rnd(B, Tp, A, sc=0.5), Q=rnd(B, Tp, O, sc=0.5), emb_w=rnd(V, E, sc=0.5),
+                w_ih=rnd(4 * D, E + O, sc=sc0), w_hh=rnd(4 * D, D, sc=sc0), b_ih=rnd(4 * D, sc=sc0),
+                b_hh=rnd(4 * D, sc=sc0), wdec=rnd(A, D, sc=sc0), convw=rnd(C, 1, 1, 2 * K + 1, sc=0.1),
+                watt=rnd(A, C, sc=0.3), gvec=rnd(1, A, sc=sc0), bo=rnd(O, sc=sc0), w_out=rnd(V, D + O, sc=0.3),
+                b_out=rnd(V, sc=0.3))
+    lens = torch.randint(max(1, Tp // 2), Tp + 1, (B,), generator=g)
+    w0 = torch.zeros(B, Tp)
+    for b in range(B):
+        w0[b, :lens[b]] = 1.0 / float(lens[b])
+    w0 = w0.to(dev)
+    tokens = torch.randint(0, V, (B, L), generator=g).to(dev) if kind == "mixed" else None
+    flags = [True, False, True, False, False, True][:L] if kind == "mixed" else None
+    xmask = ((torch.rand(L, B, O + E, generator=g) > 0.3).float() / 0.7).to(dev) if drop else None
+    dlog = rnd(L, B, V)
+    dws = rnd(L, B, Tp, sc=0.1)
+    names = list(base.keys())
+
+    def run(fused):
+        old = hb.USE_FEEDBACK_KERNEL
+        hb.USE_FEEDBACK_KERNEL = fused
+        try:
+            par = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            opts = dict(L=L, tokens=tokens, tf_flags=flags, smooth=kind == "smooth", smooth_scaling=3.0, sample=False,
+                        scaling=2.0, xmask=xmask, bos=1, pooled=True)
+            logits, ws, pred = ops.decoder_sequence(par["P"], par["Q"], par["emb_w"], par["w_ih"], par["w_hh"],
+                                                    par["b_ih"], par["b_hh"], par["wdec"], par["convw"], par["watt"],
+                                                    par["gvec"], par["bo"], par["w_out"], par["b_out"], w0, opts)
+            ((logits * dlog).sum() + (ws * dws).sum()).backward()
+            torch.cuda.synchronize()
+            return logits.detach(), ws.detach(), pred.clone(), {k: par[k].grad.detach() for k in names}
+        finally:
+            hb.USE_FEEDBACK_KERNEL = old
+
+    lr, wr, pr, gr = run(False)
+    lf, wf, pf, gf = run(True)
+    assert torch.equal(pf, pr), "predictions differ"
+    _close(lf, lr, rtol=2e-4, atol=2e-5, what="logits (fused feedback, %s)" % kind)
+    _close(wf, wr, rtol=2e-4, atol=2e-5, what="attention weights (fused feedback, %s)" % kind)
+    for k in names:
+        scale = float(gr[k].abs().max()) + 1e-12
+        err = float((gf[k] - gr[k]).abs().max()) / scale
+        assert err < 2e-4, (kind, k, err)
