@@ -216,6 +216,27 @@ int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, void* graphs
  * xch >= 2 MB and ctrl >= 64 B are caller-allocated scratch (shared with the LSTM fast path); abort convention as
  * asr_lstm_seq_fwd_persist. */
 int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream);
+/* Free-running variant (greedy / smooth-embedding decode, model.py:334-341; solver.py:230-231,466-470): the embedding
+ * input of step s >= 1 is made inside the kernel from the logits of step s-1: mode 1 = emb[argmax], mode 2 =
+ * softmax(scaling * logits) @ emb.  The caller fills X[0] / Xd[0] (embedding columns of <BOS>) and fed[0].  Written:
+ * logits[s] [B][V] and pred[s] [B] (int64) for s < L-1; fed[s] [B] (int64, -1 in mode 2) and the embedding columns of
+ * X[s] / Xd[s] for 1 <= s < L; probs[s] [B][V] for s < L-1 (mode 2, for the backward).  The last step's logits / pred
+ * come from asr_dec_feedback_fwd(mode 3) on X[L].  V <= 64.  Same applicability rule, scratch and abort convention as
+ * asr_dec_seq_fwd_persist. */
+typedef struct {
+  int mode;
+  int V;
+  float scaling;
+  const float* w_out;  /* [V][D+O] */
+  const float* b_out;  /* [V] or NULL */
+  const float* emb;    /* [V][E] */
+  float* logits;       /* [L][B][V] */
+  float* probs;        /* [L-1][B][V], mode 2 */
+  int64_t* pred;       /* [L][B] */
+  int64_t* fed;        /* [L][B] */
+} asr_dec_feedback_t;
+int asr_dec_seq_fwd_persist_free(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, void* xch, void* ctrl,
+                                 asr_stream_t stream);
 
 /* Backward of one decoder step (reverse order s = L-1..0).
  *   G     [L+1][B][KX]  gradient wrt X; on entry G[s+1][:, 0:D+O] holds every other

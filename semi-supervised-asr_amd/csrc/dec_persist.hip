@@ -50,7 +50,9 @@ constexpr int DX_Z = 0;                            // [2][4][512]
 constexpr int DX_C = DX_Z + 2 * 4 * 512;           // [2][4][512]
 constexpr int DX_F = DX_C + 2 * 4 * 512;           // [2][4][16][TPM]
 constexpr int DX_E = DX_F + 2 * 4 * 16 * DP_TPM;   // [2][32][4][TPM]
-constexpr int DX_GROUP = DX_E + 2 * 32 * 4 * DP_TPM;
+constexpr int DX_U = DX_E + 2 * 32 * 4 * DP_TPM;  // [2][4][512]  free-running only: ctx before the dropout mask
+constexpr int DX_M = DX_U + 2 * 4 * 512;           // [2][4][128]  free-running only: embedding input of the step
+constexpr int DX_GROUP = DX_M + 2 * 4 * 128;
 
 struct DecPersistArgs {
   int B, nb, Tp, C, K, L;
@@ -59,6 +61,12 @@ struct DecPersistArgs {
   float *X, *Xd, *gates, *cstate, *fconv, *S, *energy, *ws;
   float* xch;
   unsigned* ctrl;
+  // free-running feedback (kernel template FB): 1 = embedding of the predicted token, 2 = smooth embedding
+  int fb_mode, V;
+  float fb_scale;
+  const float *w_out, *b_out, *emb;
+  float *logits, *probs;
+  long long *pred, *fed;
 };
 
 __device__ __forceinline__ float dp_tanh(float x) {   // same formula as decoder.hip:fast_tanh
@@ -84,7 +92,13 @@ struct DecDims {
   static_assert(DU <= 16 && AU <= 16 && OQ <= 64 && DD <= 512 && OO <= 512, "per-CU slices must fit the mappings");
 };
 
-template <int DD, int AA, int OO, int EE>
+// FB = free-running decode (model.py:334-341): the embedding input of step s > 0 is not read from X but made from the
+// logits of step s-1 inside the kernel.  Slice 0 of every group does that for the group's 4 rows at the top of the
+// step (it holds z_{s-1} and receives ctx_{s-1} like every CU, plus the unmasked ctx when dropout is on): logits =
+// W_out [z, ctx] + b (W_out streamed from L2, one wave per output), argmax / softmax(scale * logits), embedding row or
+// p @ E, dropout mask, -> X/Xd, logits, pred, fed, probs in global memory and one more exchange (DX_M) from which all
+// 32 CUs take the 4 x 128 embedding values.  The logits of the last step are left to the caller.
+template <int DD, int AA, int OO, int EE, bool FB>
 __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a) {
   using DM = DecDims<DD, AA, OO, EE>;
   constexpr int KX = DM::KX, KXW = DM::KXW, DU = DM::DU, AU = DM::AU, OQ = DM::OQ, DKW = DM::DKW, DKQ = DM::DKQ;
@@ -245,10 +259,141 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         if (2 * id < 4 * OO) { xs[row * XS + DD + o] = pair_lo(v[i]); xs[row * XS + DD + o + 1] = pair_hi(v[i]); }
       }
     }
+    if (FB && s > 0) {
+      if (slice == 0) {
+        float* cu = part;                      // [4][512] unmasked ctx_{s-1} (scratch: free until phase 2)
+        float* lgs = cred;                     // [4][64] logits      (scratch: free until phase 3b)
+        float* prs = cred + 256;               // [4][64] probabilities / the chosen token
+        if (drop) {
+          const float* ux = xg + DX_U + ((s - 1) & 1) * 4 * 512;
+          const u64* p[NC];
+          u64 v[NC];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int id = tid_ + DP_NT * i, er = id / EE, ee = id - er * EE;
-      if (er < 4) xs[er * XS + DD + OO + ee] = emb_next[i];
+          for (int i = 0; i < NC; ++i) {
+            const int id = tid_ + DP_NT * i;
+            const int row = (2 * id) / OO, o = 2 * id - row * OO;
+            p[i] = reinterpret_cast<const u64*>(ux + ((2 * id < 4 * OO) ? row * 512 + o : 0));
+          }
+          poll_pairs<NC, ASR_DP_FULL>(p, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 16u);
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            const int id = tid_ + DP_NT * i;
+            const int row = (2 * id) / OO, o = 2 * id - row * OO;
+            if (2 * id < 4 * OO) { cu[row * 512 + o] = pair_lo(v[i]); cu[row * 512 + o + 1] = pair_hi(v[i]); }
+          }
+        }
+        __syncthreads();
+        const float* cb = drop ? cu : xs + DD;
+        const int cst = drop ? 512 : XS;
+        for (int v = wave; v < a.V; v += 8) {
+          // one output per wave and trip: the lanes stride the D+O inputs in float4 (coalesced rows of W_out from L2)
+          const float4* wr = reinterpret_cast<const float4*>(a.w_out + (int64_t)v * (DD + OO));
+          constexpr int NJZ = (DD / 4 + 63) / 64, NJC = (OO / 4 + 63) / 64;
+          float4 wz[NJZ], wc[NJC];
+#pragma unroll
+          for (int j = 0; j < NJZ; ++j) {
+            const int q = lane_ + 64 * j;
+            wz[j] = wr[q < DD / 4 ? q : 0];
+          }
+#pragma unroll
+          for (int j = 0; j < NJC; ++j) {
+            const int q = lane_ + 64 * j;
+            wc[j] = wr[DD / 4 + (q < OO / 4 ? q : 0)];
+          }
+          float ac[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < NJZ; ++j) {
+            const int q = lane_ + 64 * j;
+            if (q < DD / 4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float4 x = *reinterpret_cast<const float4*>(xs + i * XS + 4 * q);
+                ac[i] += wz[j].x * x.x + wz[j].y * x.y + wz[j].z * x.z + wz[j].w * x.w;
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NJC; ++j) {
+            const int q = lane_ + 64 * j;
+            if (q < OO / 4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float4 x = *reinterpret_cast<const float4*>(cb + i * cst + 4 * q);
+                ac[i] += wc[j].x * x.x + wc[j].y * x.y + wc[j].z * x.z + wc[j].w * x.w;
+              }
+            }
+          }
+          const float bv = a.b_out ? a.b_out[v] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float t = wave_sum_dpp(ac[i]);
+            if (lane_ == 0) lgs[i * 64 + v] = t + bv;
+          }
+        }
+        __syncthreads();
+        if (wave < 4) {
+          const int b = r0 + wave;
+          const bool bok = b < nb, lv = lane_ < a.V;
+          const float l = lv ? lgs[wave * 64 + lane_] : -INFINITY;
+          const float mx = wave_max_dpp(l);
+          const unsigned long long hit = __ballot(lv && l == mx);
+          const int am = hit ? __ffsll(hit) - 1 : 0;          // lowest index among the maxima; all-NaN row: 0
+          if (lv && bok) a.logits[((int64_t)(s - 1) * B + b) * a.V + lane_] = l;
+          if (lane_ == 0 && bok) {
+            a.pred[(int64_t)(s - 1) * B + b] = am;
+            a.fed[(int64_t)s * B + b] = a.fb_mode == 2 ? -1 : am;
+          }
+          if (a.fb_mode == 2) {
+            const float sl = lv ? a.fb_scale * l : -INFINITY;
+            const float smx = wave_max_dpp(sl);
+            const float e = lv ? expf(sl - smx) : 0.f;
+            const float p = e / wave_sum_dpp(e);
+            if (lv) {
+              prs[wave * 64 + lane_] = p;
+              if (bok) a.probs[((int64_t)(s - 1) * B + b) * a.V + lane_] = p;
+            }
+          } else if (lane_ == 0) {
+            prs[wave * 64] = __int_as_float(am);
+          }
+        }
+        __syncthreads();
+        {
+          const int row = tid_ >> 7, e = tid_ & 127, b = r0 + row;
+          const bool bok = b < nb;
+          const int bc = bok ? b : r0;
+          float v = 0.f;
+          if (a.fb_mode == 2) {
+            for (int u = 0; u < a.V; ++u) v += prs[row * 64 + u] * a.emb[u * EE + e];
+          } else {
+            v = a.emb[__float_as_int(prs[row * 64]) * EE + e];
+          }
+          const float mk = drop ? a.xmask[((int64_t)s * B + bc) * (OO + EE) + OO + e] : 1.f;
+          const float vm = v * mk;
+          if (bok) {
+            a.X[((int64_t)s * B + b) * KX + DD + OO + e] = v;
+            if (drop) a.Xd[((int64_t)s * B + b) * KX + DD + OO + e] = vm;
+          }
+          word_store(xg + DX_M + ((s - 1) & 1) * 512 + row * 128 + e, vm, tag_bit_of_step(s - 1));
+        }
+      }
+      {
+        const int id = tid_ & 255;                       // 256 pairs over [4][128]; the upper half mirrors
+        // (this exchange is first used at step 1: slot and tag follow s - 1, so that the zeroed buffer reads invalid)
+        const u64* p1[1] = {reinterpret_cast<const u64*>(xg + DX_M + ((s - 1) & 1) * 512 + 2 * id)};
+        u64 v1[1];
+        poll_pairs<1, true>(p1, tag_bit_of_step(s - 1), v1, a.ctrl, aborted, 17u);
+        if (tid_ < 256) {
+          const int row = id >> 6, e2 = 2 * (id & 63);
+          xs[row * XS + DD + OO + e2] = pair_lo(v1[0]);
+          xs[row * XS + DD + OO + e2 + 1] = pair_hi(v1[0]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int id = tid_ + DP_NT * i, er = id / EE, ee = id - er * EE;
+        if (er < 4) xs[er * XS + DD + OO + ee] = emb_next[i];
+      }
     }
     {
       // next step's operands: UNGUARDED loads from clamped addresses (a load under a lane predicate or a uniform branch
@@ -523,21 +668,23 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         if (drop && s + 1 < L) a.Xd[((int64_t)(s + 1) * B + ab) * KX + DD + o] = vm;
       }
       word_store(xg + DX_C + par * 4 * 512 + ar * 512 + o, vm, bit);
+      if (FB && drop) word_store(xg + DX_U + par * 4 * 512 + ar * 512 + o, v, bit);
     }
     DP_MARK(10);
 #undef TRS
   }
 }
 
-template <int DD, int AA, int OO, int EE>
+template <int DD, int AA, int OO, int EE, bool FB>
 int launch_dec_fwd(const DecPersistArgs& a, hipStream_t stream) {
   using DM = DecDims<DD, AA, OO, EE>;
   const size_t lds = DM::lds_floats * sizeof(float);     // > 80 KB: one workgroup per CU
   static_assert(DM::lds_floats * sizeof(float) > 82 * 1024 && DM::lds_floats * sizeof(float) <= 160 * 1024, "LDS budget");
-  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_fwd_kernel<DD, AA, OO, EE>,
+  static_assert(!FB || (EE == 128 && DD % 64 == 0 && OO % 64 == 0), "free-running feedback mapping");
+  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_fwd_kernel<DD, AA, OO, EE, FB>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((dec_persist_fwd_kernel<DD, AA, OO, EE>), dim3(256), dim3(DP_NT), lds, stream, a);
+  hipLaunchKernelGGL((dec_persist_fwd_kernel<DD, AA, OO, EE, FB>), dim3(256), dim3(DP_NT), lds, stream, a);
   return 0;
 }
 
@@ -1260,16 +1407,20 @@ int launch_dec_bwd(const DecPersistBwdArgs& a, hipStream_t stream) {
 
 bool asr_persist_device_ok();
 
-// Whole teacher-forced decoder sequence (steps 0..L-1) in one launch per block of 32 rows.  Same operands and
-// results as asr_dec_seq_fwd(p, 0, L) except that Dproj is not written.  Returns ASR_E_SHAPE when the fast path
-// does not apply (the caller then uses asr_dec_seq_fwd).  xch >= 2 MB, ctrl >= 64 B (zeroed here on the stream).
-extern "C" int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+
+int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, void* xch, void* ctrl, hipStream_t stream) {
   if (!p || !xch || !ctrl || !p->P || !p->Q || !p->bo || !p->wcat || !p->bcat || !p->wdec || !p->convw || !p->watt ||
       !p->gvec || !p->w0 || !p->X || !p->gates || !p->cstate || !p->fconv || !p->S || !p->energy || !p->ws)
     return ASR_E_ARG;
   if (p->B <= 0 || p->nb <= 0 || p->nb > p->B || p->Tp <= 0 || p->L <= 0) return ASR_E_ARG;
   if (p->xmask && !p->Xd) return ASR_E_ARG;
+  if (f) {
+    if ((f->mode != 1 && f->mode != 2) || !f->w_out || !f->emb || !f->logits || !f->pred || !f->fed || f->V <= 0)
+      return ASR_E_ARG;
+    if (f->mode == 2 && !f->probs) return ASR_E_ARG;
+    if (f->V > 64) return ASR_E_SHAPE;
+  }
   const bool cfg2 = p->D == 512 && p->A == 512 && p->O == 512 && p->E == 128;
   const bool cfg1 = p->D == 320 && p->A == 320 && p->O == 320 && p->E == 128;
   if (!cfg1 && !cfg2) return ASR_E_SHAPE;
@@ -1295,11 +1446,40 @@ extern "C" int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* 
     a.fconv = p->fconv + (int64_t)rb * C * Tp; a.S = p->S + (int64_t)rb * Tp * A;
     a.energy = p->energy + (int64_t)rb * Tp; a.ws = p->ws + (int64_t)rb * Tp;
     a.xch = (float*)xch; a.ctrl = (unsigned*)ctrl;
-    const int rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128>(a, stream) : launch_dec_fwd<320, 320, 320, 128>(a, stream);
+    a.fb_mode = 0; a.V = 0; a.fb_scale = 1.f; a.w_out = a.b_out = a.emb = nullptr; a.logits = a.probs = nullptr;
+    a.pred = a.fed = nullptr;
+    int rc;
+    if (f) {
+      a.fb_mode = f->mode; a.V = f->V; a.fb_scale = f->scaling; a.w_out = f->w_out; a.b_out = f->b_out; a.emb = f->emb;
+      a.logits = f->logits + (int64_t)rb * f->V; a.probs = f->probs ? f->probs + (int64_t)rb * f->V : nullptr;
+      a.pred = (long long*)f->pred + rb; a.fed = (long long*)f->fed + rb;
+      rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true>(a, stream) : launch_dec_fwd<320, 320, 320, 128, true>(a, stream);
+    } else {
+      rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, false>(a, stream) : launch_dec_fwd<320, 320, 320, 128, false>(a, stream);
+    }
     if (rc) return rc;
   }
   ASR_CHECK_LAUNCH();
   return 0;
+}
+
+}  // namespace
+
+// Whole teacher-forced decoder sequence (steps 0..L-1) in one launch per block of 32 rows.  Same operands and
+// results as asr_dec_seq_fwd(p, 0, L) except that Dproj is not written.  Returns ASR_E_SHAPE when the fast path
+// does not apply (the caller then uses asr_dec_seq_fwd).  xch >= 2 MB, ctrl >= 64 B (zeroed here on the stream).
+extern "C" int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream_) {
+  return dec_fwd_persist_impl(p, nullptr, xch, ctrl, (hipStream_t)stream_);
+}
+
+// Free-running variant: steps 1..L-1 take their embedding input from the previous step's logits (f->mode 1: row of the
+// argmax token, 2: softmax(f->scaling * logits) @ emb).  The caller provides X[0] / Xd[0] (embedding of <BOS>) and
+// fed[0]; the kernel writes logits[s], pred[s] for s < L-1, fed[s] and the embedding columns of X[s] / Xd[s] for
+// s >= 1, probs[s] for s < L-1 (mode 2).  logits / pred of the last step: asr_dec_feedback_fwd(mode 3) on X[L].
+extern "C" int asr_dec_seq_fwd_persist_free(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, void* xch, void* ctrl,
+                                            asr_stream_t stream_) {
+  if (!f) return ASR_E_ARG;
+  return dec_fwd_persist_impl(p, f, xch, ctrl, (hipStream_t)stream_);
 }
 
 // Persistent fast path of asr_dec_seq_bwd(q, 0, L) for sequences produced by the teacher-forced forward (either

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
-    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
+    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
@@ -25,6 +25,12 @@ EXPORTS = (
 _lib = None
 
 c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class DecFeedback(ctypes.Structure):
+    """asr_dec_feedback_t"""
+    _fields_ = [("mode", c_i), ("V", c_i), ("scaling", c_f), ("w_out", c_p), ("b_out", c_p), ("emb", c_p), ("logits", c_p),
+                ("probs", c_p), ("pred", c_p), ("fed", c_p)]
 
 
 class DecFwd(ctypes.Structure):
@@ -73,6 +79,7 @@ def load():
     lib.asr_att_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_dec_seq_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_i, c_p, c_p]
     lib.asr_dec_seq_fwd_persist.argtypes = [ctypes.POINTER(DecFwd), c_p, c_p, c_p]
+    lib.asr_dec_seq_fwd_persist_free.argtypes = [ctypes.POINTER(DecFwd), ctypes.POINTER(DecFeedback), c_p, c_p, c_p]
     lib.asr_dec_step_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_p]
     lib.asr_dec_seq_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_i, c_p, c_p]
     lib.asr_dec_seq_bwd_persist.argtypes = [ctypes.POINTER(DecBwd), c_p, c_p, c_p, c_p]

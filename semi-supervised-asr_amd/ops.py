@@ -350,6 +350,7 @@ class _DecoderSeq(torch.autograd.Function):
             fs = _dec_fwd_struct(d, 0, B)
             logits = torch.empty(L, B, V, **f32)
             pred = torch.empty(L, B, dtype=torch.long, device=dev)
+            done = False
             if hb.USE_FEEDBACK_KERNEL and not sample and V <= 128:
                 # free-running steps: per step the decoder chain, then ONE kernel for logits + argmax + the next
                 # step's embedding input (teacher / predicted token, or the smooth embedding softmax(k*logit) @ E)
@@ -361,7 +362,22 @@ class _DecoderSeq(torch.autograd.Function):
                 X[0, :, D + O:] = emb_c[fed[0]]
                 if drop:
                     Xd[0, :, D + O:] = X[0, :, D + O:] * xmask[0, :, O:]
-                for s in range(L):
+                if hb.USE_PERSIST_DEC and tok_c is None and V <= 64 and len(hb.row_groups(B)) == 1:
+                    # no teacher tokens at all: the whole sequence in one launch, the feedback computed in the kernel
+                    fb = hb.DecFeedback(
+                        mode=2 if smooth else 1, V=V, scaling=float(opts.get("smooth_scaling", 1.0)), w_out=_p(w_out_c),
+                        b_out=_p(b_out.contiguous()), emb=_p(emb_c), logits=_p(logits),
+                        probs=_p(probs_saved) if smooth else None, pred=ctypes.c_void_p(pred.data_ptr()),
+                        fed=ctypes.c_void_p(fed.data_ptr()))
+                    xch, ctrl = hb.persist_scratch(dev)
+                    rc = lib.asr_dec_seq_fwd_persist_free(ctypes.byref(fs), ctypes.byref(fb), ctypes.c_void_p(xch.data_ptr()),
+                                                          ctypes.c_void_p(ctrl.data_ptr()), hb.stream())
+                    if rc == 0:
+                        done = True
+                        hb.dec_feedback_fwd(X[L][:, :D + O], w_out_c, b_out, emb_c, logits[L - 1], pred[L - 1], hb.FEED_NONE)
+                    elif rc != -2:
+                        hb.check(rc, "asr_dec_seq_fwd_persist_free")
+                for s in (range(L) if not done else ()):
                     hb.check(lib.asr_dec_step_fwd(ctypes.byref(fs), s, hb.stream()), "asr_dec_step_fwd")
                     last = s == L - 1
                     if last:
@@ -377,7 +393,7 @@ class _DecoderSeq(torch.autograd.Function):
                         x_emb_next=None if last else X[s + 1][:, D + O:],
                         xd_emb_next=Xd[s + 1][:, D + O:] if (drop and not last) else None,
                         mask=xmask[s + 1][:, O:] if (drop and not last) else None)
-            else:
+            elif not done:
                 for s in range(L):
                     if s == 0:
                         tok = tokens[:, 0] if tokens is not None else torch.full((B,), opts["bos"], dtype=torch.long,

@@ -733,7 +733,8 @@ def test_decoder_feedback_kernels(B, V, E, DO):
 
 
 @pytest.mark.parametrize("dim,B,Tp,L,drop,kind", [(512, 32, 100, 6, True, "smooth"), (512, 32, 100, 5, True, "greedy"),
-                                                  (320, 7, 37, 5, False, "smooth"), (512, 9, 60, 6, True, "mixed")])
+                                                  (320, 7, 37, 5, False, "smooth"), (512, 9, 60, 6, True, "mixed"),
+                                                  (512, 40, 100, 4, False, "greedy"), (320, 6, 50, 7, True, "smooth")])
 def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
     """Free-running decoder sequences (smooth embedding with grad as in solver.py:460-495, greedy, scheduled sampling)
     with the fused per-step feedback kernel against the same steps through torch glue: outputs and every gradient.
@@ -766,9 +767,9 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
     dws = rnd(L, B, Tp, sc=0.1)
     names = list(base.keys())
 
-    def run(fused):
-        old = hb.USE_FEEDBACK_KERNEL
-        hb.USE_FEEDBACK_KERNEL = fused
+    def run(fused, persist=False):
+        old = hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC
+        hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC = fused, persist
         try:
             par = {k: v.clone().requires_grad_(True) for k, v in base.items()}
             opts = dict(L=L, tokens=tokens, tf_flags=flags, smooth=kind == "smooth", smooth_scaling=3.0, sample=False,
@@ -780,14 +781,18 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
             torch.cuda.synchronize()
             return logits.detach(), ws.detach(), pred.clone(), {k: par[k].grad.detach() for k in names}
         finally:
-            hb.USE_FEEDBACK_KERNEL = old
+            hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC = old
 
     lr, wr, pr, gr = run(False)
-    lf, wf, pf, gf = run(True)
-    assert torch.equal(pf, pr), "predictions differ"
-    _close(lf, lr, rtol=2e-4, atol=2e-5, what="logits (fused feedback, %s)" % kind)
-    _close(wf, wr, rtol=2e-4, atol=2e-5, what="attention weights (fused feedback, %s)" % kind)
-    for k in names:
-        scale = float(gr[k].abs().max()) + 1e-12
-        err = float((gf[k] - gr[k]).abs().max()) / scale
-        assert err < 2e-4, (kind, k, err)
+    # per-step kernels + fused feedback kernel, then (sequences without teacher tokens) the whole sequence in the
+    # persistent kernel with the feedback computed inside it
+    for persist in ((False, True) if kind != "mixed" else (False,)):
+        lf, wf, pf, gf = run(True, persist)
+        assert not hb.persist_aborted(dev), persist
+        assert torch.equal(pf, pr), "predictions differ (persist=%s)" % persist
+        _close(lf, lr, rtol=2e-4, atol=2e-5, what="logits (fused feedback, %s, persist=%s)" % (kind, persist))
+        _close(wf, wr, rtol=2e-4, atol=2e-5, what="attention weights (fused feedback, %s, persist=%s)" % (kind, persist))
+        for k in names:
+            scale = float(gr[k].abs().max()) + 1e-12
+            err = float((gf[k] - gr[k]).abs().max()) / scale
+            assert err < 2e-4, (kind, persist, k, err)

@@ -2,7 +2,7 @@
 encoder, dec 320, batch 4, T=200), cfg-2 (the bench line), cfg-5 (T=1600, batch 8) and the semi-supervised generator
 step of cfg-4 at cfg-2's shape (labeled 32x800 + unlabeled 32x800, judge LM 2x640).  One line per workload.
 
-    python tools/workload_times.py [cfg1 cfg2 cfg5 ssl]
+    python tools/workload_times.py [cfg1 cfg2 cfg5 ssl decode]
 """
 import os
 import sys
@@ -25,7 +25,8 @@ from parallel import FlatAdam
 
 dev = torch.device("cuda", 0)
 CFG1 = dict(bench.CFG2, enc_hidden_dim=128, enc_n_layers=1, subsample=[2], dec_hidden_dim=320, att_dim=320, att_odim=320)
-WORK = {"cfg1": (CFG1, 4, 200), "cfg2": (bench.CFG2, 32, 800), "cfg5": (bench.CFG2, 8, 1600), "ssl": (bench.CFG2, 32, 800)}
+WORK = {"cfg1": (CFG1, 4, 200), "cfg2": (bench.CFG2, 32, 800), "cfg5": (bench.CFG2, 8, 1600), "ssl": (bench.CFG2, 32, 800),
+        "decode": (bench.CFG2, 32, 800)}
 
 
 def timed(step, warm=3, n=8):
@@ -55,6 +56,16 @@ def run(name):
     xs_d = torch.from_numpy(np.ascontiguousarray(xs_r)).to(dev)
     ys_d = [torch.from_numpy(y).to(dev) for y in ys_r]
     tl = M.padded_lengths(info["t_max"], cfg["enc_n_layers"], cfg["subsample"])
+    if name == "decode":
+        # validation decode (solver.py:212-242): eval mode, no autograd, greedy, a fixed 230 steps like the reference
+        net.eval()
+
+        def dec():
+            with torch.no_grad():
+                return net(xs_d, lens_r, ys=None, max_dec_timesteps=230)[2]
+        ms, pred = timed(dec)
+        print("%-6s B=%d T=%d greedy x 230 steps: %.2f ms/batch = %.0f utt/s" % (name, B, T, ms, B / ms * 1e3), flush=True)
+        return
     if name != "ssl":
         def step():
             _, lp, _, _ = net(xs_d, lens_r, ys_d, tf_rate=1.0, total_length=tl, olength=info["olength"])
@@ -81,7 +92,8 @@ def run(name):
         _, u_lp, u_pred, _ = net(uxs_d, ulens, ys=None, sample=False, label_smoothing=False,
                                  max_dec_timesteps=int(uxs_d.size(1) * proportion), smooth=True, scaling=3)
         e[1].record()
-        _, lm_probs, _ = judge(ys=u_pred, discrete_input=False)
+        with torch.no_grad():                       # as solver.gen_train_one_iteration: the judge only scores
+            _, lm_probs, _ = judge(ys=u_pred, discrete_input=False)
         mask = (u_pred != 2).float()
         unsup = -torch.sum(lm_probs * u_lp * mask) / torch.sum(mask)
         e[2].record()
@@ -102,5 +114,5 @@ def run(name):
         name, B, B, T, ms, 2 * B / ms * 1e3, float(loss.detach()), det), flush=True)
 
 
-for w in (sys.argv[1:] or ["cfg1", "cfg2", "cfg5", "ssl"]):
+for w in (sys.argv[1:] or ["cfg1", "cfg2", "cfg5", "ssl", "decode"]):
     run(w)
