@@ -402,6 +402,21 @@ def persist_scratch(device):
     return _persist_scratch[key]
 
 
+def persist_abort_code(device):
+    """Which wait gave up (ctrl[9]; 2 = unexpected workgroup placement, others = the poll site).  Synchronises."""
+    key = str(device)
+    return int(_persist_scratch[key][1][9].item()) if key in _persist_scratch else 0
+
+
+def disable_persistent(device=None):
+    """Route every sequence operator of this process to the per-step HIP kernels (after an abort, or when several
+    processes share one GPU) and clear the abort word."""
+    global USE_PERSIST, USE_PERSIST_DEC, USE_PERSIST_DEC_BWD
+    USE_PERSIST = USE_PERSIST_DEC = USE_PERSIST_DEC_BWD = False
+    if device is not None and str(device) in _persist_scratch:
+        _persist_scratch[str(device)][1].zero_()
+
+
 def persist_aborted(device):
     """True if the last persistent launch on `device` aborted (synchronises; for tests / end-of-step checks)."""
     key = str(device)

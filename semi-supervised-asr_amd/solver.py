@@ -5,12 +5,14 @@ clip+Adam(amsgrad)), gradients of a data-parallel run are exchanged with ONE RCC
 under torch.distributed every rank collates the same global batch and keeps its strided shard padded
 to the global extents (parallel.py), which reproduces the single-process numbers exactly.
 """
+import math
 import os
 import pickle
 
 import numpy as np
 import torch
 
+import hip_backend as hb
 import parallel
 from dataloader import get_data_loader
 from dataset import PickleDataset
@@ -194,14 +196,35 @@ class Solver(object):
         return cer
 
     # ------------------------------------------------------------------ judge (LM) pre-training
-    def judge_train_one_iteration(self, unlab_ys):
-        log_probs, probs, _ = self.judge(ys=unlab_ys, discrete_input=True)
-        loss = -self.judge.mask_and_cal_sum(log_probs, ys=unlab_ys, mask=None)
-        avg_prob = self.judge.mask_and_cal_sum(probs, ys=unlab_ys, mask=None)
-        self.dis_opt.zero_grad()
+    def _backward_guarded(self, make_loss, opt):
+        """zero_grad -> backward, then look at the loss BEFORE the optimiser step (the reference reads loss.item() every
+        step anyway, solver.py:379).  The persistent XCD-local kernels poison their output with NaN when they abort (a
+        workgroup placement other than one per CU, or a bounded spin expiring, e.g. on a shared or partitioned GPU):
+        in that case this process switches to the per-step HIP kernels for good and repeats the step, so an abort costs
+        one step instead of the run.  A non-finite loss without the abort word set is the model's own and passes through
+        unchanged, as in the reference.  -> (loss, aux, float(loss))"""
+        loss, aux = make_loss()
+        opt.zero_grad()
         loss.backward()
+        value = loss.item()
+        if not math.isfinite(value) and loss.is_cuda and hb.persist_aborted(loss.device):
+            print("persistent kernels aborted (code %d): continuing on the per-step kernels"
+                  % hb.persist_abort_code(loss.device))
+            hb.disable_persistent(loss.device)
+            loss, aux = make_loss()
+            opt.zero_grad()
+            loss.backward()
+            value = loss.item()
+        return loss, aux, value
+
+    def judge_train_one_iteration(self, unlab_ys):
+        def make_loss():
+            log_probs, probs, _ = self.judge(ys=unlab_ys, discrete_input=True)
+            return (-self.judge.mask_and_cal_sum(log_probs, ys=unlab_ys, mask=None),
+                    self.judge.mask_and_cal_sum(probs, ys=unlab_ys, mask=None))
+        _, avg_prob, value = self._backward_guarded(make_loss, self.dis_opt)
         self.dis_opt.step()
-        return {"loss": loss.item(), "avg_prob": avg_prob.item()}
+        return {"loss": value, "avg_prob": avg_prob.item()}
 
     def judge_pretrain(self):
         cfg = self.config
@@ -259,11 +282,10 @@ class Solver(object):
             if cfg["add_gaussian"] and epoch >= cfg["gaussian_epoch"]:
                 noise = np.random.normal(0, cfg["gaussian_std"], tuple(xs.shape)).astype(np.float32)
                 xs = xs + cc(torch.from_numpy(noise))
-            loss = self._sharded_forward(xs, ilens, ys, tf_rate)
-            self.gen_opt.zero_grad()
-            loss.backward()
+            _, _, value = self._backward_guarded(lambda: (self._sharded_forward(xs, ilens, ys, tf_rate), None),
+                                                 self.gen_opt)
             self.gen_opt.step()                      # all-reduce -> clip -> Adam, no host sync
-            value = loss.item() * (self.world if self.world > 1 else 1)   # local losses sum to the global mean
+            value *= self.world if self.world > 1 else 1                  # local losses sum to the global mean
             running += value
             if self.rank == 0:
                 print(f"epoch: {epoch}, [{it + 1}/{steps_per_epoch}], loss: {value:.3f}", end="\r")
@@ -306,24 +328,25 @@ class Solver(object):
         speech WITH grad, judge probabilities of the hypothesis, unsup = -sum(p_LM * log p_model * mask)/sum(mask);
         loss = sup + unsup_weight * unsup; only the generator is stepped."""
         cfg = self.config
-        _, u_lp, u_pred, _ = self.model(
-            unlab_xs, unlab_ilens, ys=None, sample=False, label_smoothing=False,
-            max_dec_timesteps=int(unlab_xs.size(1) * self.proportion), smooth=cfg["smooth_embedding"],
-            scaling=cfg["softmax_scaling"])
-        # The judge scores an integer hypothesis, so no gradient reaches the model through it, and gen_opt does not hold
-        # its parameters (solver.py:484-488 builds that graph and never uses it): the forward alone gives the same
-        # losses and model gradients.
-        with torch.no_grad():
-            _, lm_probs, _ = self.judge(ys=u_pred, discrete_input=False)
-        mask = (u_pred != self.vocab["<EOS>"]).float()
-        unsup_loss = -torch.sum(lm_probs * u_lp * mask) / torch.sum(mask)
-        _, lab_lp, _, _ = self.model(lab_xs, lab_ilens, ys=lab_ys, tf_rate=1.0, sample=False)
-        sup_loss = -torch.mean(lab_lp)
-        loss = sup_loss + cfg["unsup_weight"] * unsup_loss
-        self.gen_opt.zero_grad()
-        loss.backward()
+
+        def make_loss():
+            _, u_lp, u_pred, _ = self.model(
+                unlab_xs, unlab_ilens, ys=None, sample=False, label_smoothing=False,
+                max_dec_timesteps=int(unlab_xs.size(1) * self.proportion), smooth=cfg["smooth_embedding"],
+                scaling=cfg["softmax_scaling"])
+            # The judge scores an integer hypothesis, so no gradient reaches the model through it, and gen_opt does not
+            # hold its parameters (solver.py:484-488 builds that graph and never uses it): the forward alone gives the
+            # same losses and model gradients.
+            with torch.no_grad():
+                _, lm_probs, _ = self.judge(ys=u_pred, discrete_input=False)
+            mask = (u_pred != self.vocab["<EOS>"]).float()
+            unsup_loss = -torch.sum(lm_probs * u_lp * mask) / torch.sum(mask)
+            _, lab_lp, _, _ = self.model(lab_xs, lab_ilens, ys=lab_ys, tf_rate=1.0, sample=False)
+            sup_loss = -torch.mean(lab_lp)
+            return sup_loss + cfg["unsup_weight"] * unsup_loss, (unsup_loss, sup_loss)
+        _, (unsup_loss, sup_loss), value = self._backward_guarded(make_loss, self.gen_opt)
         self.gen_opt.step()
-        return {"unsup_loss": unsup_loss.item(), "sup_loss": sup_loss.item(), "loss": loss.item()}
+        return {"unsup_loss": unsup_loss.item(), "sup_loss": sup_loss.item(), "loss": value}
 
     def ssl_train_one_iteration(self, iteration):
         lab_data, unlab_data = next(self.lab_iter), next(self.unlab_x_iter)

@@ -73,3 +73,40 @@ def test_solver_end_to_end(tmp_path, monkeypatch):
         assert n1 == n2
     sd = solver.gen_opt.state_dict()
     assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
+
+
+def test_solver_recovers_from_aborted_persistent_kernel(tmp_path, monkeypatch):
+    """A persistent kernel that aborts poisons its output with NaN; the solver must notice before the optimiser step,
+    switch this process to the per-step kernels and repeat the step (the parameters never see the NaN)."""
+    import __graft_entry__ as entry
+    entry.build()
+    import hip_backend as hb
+    from solver import Solver
+    root = str(tmp_path)
+    vocab = _vocab()
+    _write_data(root, vocab)
+    monkeypatch.chdir(root)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    solver = Solver(_config(root))
+    state = {"calls": 0}
+    real_forward = solver._sharded_forward
+
+    def poisoned_once(xs, ilens, ys, tf_rate):
+        loss = real_forward(xs, ilens, ys, tf_rate)
+        state["calls"] += 1
+        return loss * float("nan") if state["calls"] == 2 else loss
+
+    flags = (hb.USE_PERSIST, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD)
+    monkeypatch.setattr(solver, "_sharded_forward", poisoned_once)
+    monkeypatch.setattr(hb, "persist_aborted", lambda device: state["calls"] == 2)
+    try:
+        mean_loss = solver.sup_train_one_epoch(0, 1.0)
+        steps = len(solver.train_lab_loader)
+        assert state["calls"] == steps + 1, "the poisoned step is repeated once"
+        assert np.isfinite(mean_loss)
+        assert not (hb.USE_PERSIST or hb.USE_PERSIST_DEC or hb.USE_PERSIST_DEC_BWD)
+        for name, prm in solver.model.named_parameters():
+            assert torch.isfinite(prm).all(), name
+    finally:
+        hb.USE_PERSIST, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = flags
