@@ -29,7 +29,42 @@ def _text_collate_fn(batch):
     return [torch.from_numpy(np.asarray(t, dtype=np.int64)) for _, t in items]
 
 
-def get_data_loader(dataset, batch_size, shuffle, drop_last, speech_only=False, text_only=False, generator=None):
+class BucketBatchSampler(object):
+    """Length-bucketed batches (BASELINE configs[4] "bucketed padding").  The datasets keep their keys
+    sorted by frame count (dataset.py:54-71 in the reference), but its loader then draws uniformly (shuffle=True), so a
+    batch is padded to the longest of `batch_size` random utterances.  Here a batch is `batch_size` NEIGHBOURS of the
+    length-sorted order and shuffling permutes whole batches, which keeps the padded frames (compute of every layer,
+    and - through the unmasked attention softmax, SURVEY F1/F2 - part of the result) close to the minimum.  The
+    permutation comes from the loader's seeded generator, so every data-parallel rank draws the same global batches."""
+
+    def __init__(self, n, batch_size, shuffle, drop_last, generator=None):
+        self.n, self.batch_size, self.shuffle, self.drop_last, self.generator = n, batch_size, shuffle, drop_last, generator
+
+    def __len__(self):
+        return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        starts = list(range(0, self.n, self.batch_size))
+        if self.drop_last and starts and self.n - starts[-1] < self.batch_size:
+            starts.pop()
+        if self.shuffle:
+            starts = [starts[i] for i in torch.randperm(len(starts), generator=self.generator).tolist()]
+        for b0 in starts:
+            yield list(range(b0, min(b0 + self.batch_size, self.n)))
+
+
+def padded_fraction(lengths, batches):
+    """Share of padded frames over the given batches (lists of dataset indices): 1 - sum(len) / sum(B * max len)."""
+    real = sum(lengths[i] for b in batches for i in b)
+    padded = sum(len(b) * max(lengths[i] for i in b) for b in batches)
+    return 1.0 - real / float(padded)
+
+
+def get_data_loader(dataset, batch_size, shuffle, drop_last, speech_only=False, text_only=False, generator=None,
+                    bucket=False):
     fn = _speech_collate_fn if speech_only else (_text_collate_fn if text_only else _collate_fn)
+    if bucket:
+        sampler = BucketBatchSampler(len(dataset), batch_size, shuffle, drop_last, generator=generator)
+        return DataLoader(dataset, batch_sampler=sampler, collate_fn=fn, num_workers=0)
     return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=fn, num_workers=0,
                       drop_last=drop_last, generator=generator)

@@ -93,10 +93,12 @@ class Solver(object):
     def get_data_loaders(self):
         cfg = self.config
         bs, shuffle = cfg["batch_size"] * self.world, cfg["shuffle"]     # batch_size is per GPU
+        bucket = bool(cfg.get("bucket_batches", False))     # not a reference key: length-bucketed speech batches
         self.train_lab_dataset = self._dataset(cfg["labeled_set"], cfg)
-        self.train_lab_loader = self._loader(self.train_lab_dataset, bs, shuffle, False)
+        self.train_lab_loader = self._loader(self.train_lab_dataset, bs, shuffle, False, bucket=bucket)
         self.train_unlab_x_dataset = self._dataset(cfg["unlabeled_speech_set"], cfg)
-        self.train_unlab_x_loader = self._loader(self.train_unlab_x_dataset, bs, shuffle, False, speech_only=True)
+        self.train_unlab_x_loader = self._loader(self.train_unlab_x_dataset, bs, shuffle, False, speech_only=True,
+                                                 bucket=bucket)
         self.train_unlab_y_dataset = self._dataset(cfg["unlabeled_text_set"], cfg)
         self.train_unlab_y_loader = self._loader(self.train_unlab_y_dataset, bs, shuffle, True, text_only=True)
         self.dev_dataset = self._dataset(cfg["dev_set"], None)
