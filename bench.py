@@ -292,9 +292,23 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    import hip_backend as hb
+    # The persistent XCD-local kernels need one workgroup per CU (an exclusive, unpartitioned MI355X).  If one aborted
+    # during the warm-up (NaN-poisoned outputs, abort word set) every rank falls back to the per-step HIP kernels and the
+    # timed steps measure those; `config.persistent_kernels` says which path the number is for.
+    aborted = torch.tensor([1.0 if hb.persist_aborted(dev) else 0.0], device=dev)
+    if world > 1:
+        dist.all_reduce(aborted, op=dist.ReduceOp.MAX)
+    if aborted.item() > 0:
+        note("persistent kernel aborted in the warm-up (code %d): timing the per-step kernels" % hb.persist_abort_code(dev))
+        hb.disable_persistent(dev)
+        net.load_state_dict({k: torch.from_numpy(v).to(dev) for k, v in synth.e2e_weights(cfg, 99).items()})
+        opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0)
+        for _ in range(max(1, args.warmup)):
+            step()
+        fence()
     # launch-mode autotune (untimed): eager launches on the current stream vs hipGraph replay of the per-step chains.
     # Replay costs ~0.8 us more per kernel on the GPU but frees the host; which wins depends on the host CPU.
-    import hip_backend as hb
     mode_ms = {}
     if os.environ.get("ASR_GRAPHS") is None:
         for mode in (False, True):
@@ -341,7 +355,8 @@ def main():
                                    "batch 32 per GPU, 80x800 synthetic fbank (ragged 0.6T..T), V=34, L+1=%d, "
                                    "dropout %.2f, Adam(amsgrad)+clip 5" % (info["olength"], args.dropout),
                        "global_batch": n_global, "frames": T_FRAMES, "parallelism": "dp%d" % world,
-                       "pad_mode": "global-exact", "launch_mode": launch_mode, "launch_mode_probe_ms": mode_ms},
+                       "pad_mode": "global-exact", "launch_mode": launch_mode, "launch_mode_probe_ms": mode_ms,
+                       "persistent_kernels": bool(hb.USE_PERSIST)},
             "loss": final_loss,
             "model_tflops": value * f_train / 1e12,
         }
