@@ -17,6 +17,7 @@
 // Roles come from HW_REG_XCC_ID + a per-XCC ticket.  Every spin is bounded; on a timeout or an unexpected
 // placement the kernel raises an abort word, poisons its outputs with NaN and drains — the host falls back to
 // the per-step kernels.  1 workgroup per CU is enforced by the LDS request, so 256 workgroups are co-resident.
+#include <cstdlib>
 #include "persist.h"
 #ifndef ASR_LP_ABL
 #define ASR_LP_ABL 0
@@ -76,8 +77,14 @@ struct PersistArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------- forward
-template <int PH>
+// NR = batch rows per group actually used (8, or 4 for small batches: half the MFMA work and half the gather per step;
+// the exchange and LDS layouts keep their 8-row shape, rows NR..7 are simply never touched).
+template <int PH, int NR>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
+  static_assert(NR == 4 || NR == PRG, "rows per group");
+#if ASR_LSTM_FWD_WORDS
+  static_assert(NR == PRG, "the word protocol is only written for 8 rows");
+#endif
   constexpr int PKW = PH / PW;     // K columns per wave
   constexpr int PUC = PH / 32;     // hidden units per CU (<= 16 MFMA blocks)
   // this wave's K range of h_{t-1}; rows padded by 4 floats so the 4 rows a ds_read_b128 touches (the MFMA blocks
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   const int T = a.T, B = a.B, ndir = a.ndir;
   const int d = ndir == 2 ? (g & 1) : 0;
   const int rowgroup = ndir == 2 ? (g >> 1) : g;
-  const int r0 = rowgroup * PRG;
+  const int r0 = rowgroup * NR;
   if (r0 >= a.nb) return;                      // this group has no rows (nobody waits for it)
   const int64_t ldy = (int64_t)ndir * PH;
   // recurrent weights of this CU -> registers: lane owns gate-interleaved row 64*slice+lane, wave owns 64 k's
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   }
   // pointwise ownership: thread (pu, pj) for tid < 128 -> unit 16*slice+pu, row r0+pj
   const int pu = tid >> 3, pj = tid & 7;
-  const bool pw_thread = tid < PUC * PRG;
+  const bool pw_thread = tid < PUC * PRG && pj < NR;
   const int prow = r0 + pj;
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUC * slice + pu;
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       // gather this wave's K range of h_{t-1}: 8 rows x 64 units of granules tagged s
       const u64* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKW + (lane < PKW ? lane : 0);
       const bool gl = lane < PKW;                       // lanes beyond the wave's K range re-read column 0
-      u64 gr[PRG];
+      u64 gr[NR];
       unsigned spins = 0;
       while (true) {
         bool done = false;
@@ -193,27 +200,27 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
           // (~1 200 cycles under load) instead of sentinel + tile on the step's critical path.  Separate code path:
           // written as `full || sentinel_ok` the compiler still waited for the sentinel before issuing the rest.
 #pragma unroll
-          for (int rr = 0; rr < PRG; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
+          for (int rr = 0; rr < NR; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
           bool ok = true;
 #pragma unroll
-          for (int rr = 0; rr < PRG; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
+          for (int rr = 0; rr < NR; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
           LP_MARK(7);
           done = __all(!gl || ok);
         } else {
           // the other waves arrive early and spin: cheap sentinel read of the last row first (see backward)
-          gr[PRG - 1] = granule_load(src + (int64_t)(PRG - 1) * PH);
+          gr[NR - 1] = granule_load(src + (int64_t)(NR - 1) * PH);
 #ifdef ASR_LP_TRACE3   /* ... and when lane 0 of (slice 0, wave 7) first sees that granule valid */
-          if (g == 0 && slice == 0 && tid == 448 && s - 1 < 64 && (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s &&
+          if (g == 0 && slice == 0 && tid == 448 && s - 1 < 64 && (unsigned)(gr[NR - 1] >> 32) == (unsigned)s &&
               ((unsigned long long*)a.ctrl)[16 + 2 * (s - 1) + 1] == 0ull)
             ((unsigned long long*)a.ctrl)[16 + 2 * (s - 1) + 1] = wall_clock64();
 #endif
-          if (__all(!gl || (unsigned)(gr[PRG - 1] >> 32) == (unsigned)s)) {
+          if (__all(!gl || (unsigned)(gr[NR - 1] >> 32) == (unsigned)s)) {
             LP_MARK(7);
 #pragma unroll
-            for (int rr = 0; rr < PRG - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
+            for (int rr = 0; rr < NR - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
             bool ok = true;
 #pragma unroll
-            for (int rr = 0; rr < PRG - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
+            for (int rr = 0; rr < NR - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
             done = __all(!gl || ok);
           }
         }
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         if (gl) { hs[wave][2 * rr][lane] = pair_lo(gr[rr]); hs[wave][2 * rr + 1][lane] = pair_hi(gr[rr]); }
 #else
 #pragma unroll
-      for (int rr = 0; rr < PRG; ++rr)
+      for (int rr = 0; rr < NR; ++rr)
         if (gl) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
 #endif
       if (st_gp) {                    // previous step's outputs (see above)
@@ -254,22 +261,24 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
 #pragma unroll
       for (int k4 = 0; k4 < ((ASR_LP_ABL & 1) ? 1 : PKW / 4); ++k4) {
         const float4 b0 = *reinterpret_cast<const float4*>(&hs[wave][j][4 * k4]);
-        const float4 b1 = *reinterpret_cast<const float4*>(&hs[wave][4 + j][4 * k4]);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b1.x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b1.y, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b1.z, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b1.w, acc1, 0, 0, 0);
+        if (NR > 4) {
+          const float4 b1 = *reinterpret_cast<const float4*>(&hs[wave][4 + j][4 * k4]);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b1.x, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b1.y, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b1.z, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b1.w, acc1, 0, 0, 0);
+        }
       }
     }
     if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
     LP_MARK(2);
     float* pp = &part[s & 1][wave][lane][0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; pp[4 + i] = acc1[i]; }
+    for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; if (NR > 4) pp[4 + i] = acc1[i]; }
     LP_MARK(3);
     __syncthreads();
     LP_MARK(4);
@@ -321,8 +330,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
 // (the in-place dG used by the weight-gradient GEMMs is untouched).  Float4 traffic both ways.
 // MFMA blocks: 16 = 4 unit-groups x 4 k-subs; A[blk][i] = W_hhT[unit 4ug+i][k], B[blk][j] = dG[row j][k],
 // k = 256*wave + 64*ks + q.  The 4 k-sub partials and the 8 waves' partials are summed by the pointwise thread.
-template <int PH>
+template <int PH, int NR>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
+  static_assert(NR == 4 || NR == PRG, "rows per group (see the forward kernel)");
   constexpr int PUC = PH / 32;       // hidden units per CU
   constexpr int PKB = 4 * PH / PW;   // gate columns per wave
   constexpr int PQ = PKB / 4;        // k's per (wave, k-sub)
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   const int T = a.T, B = a.B, ndir = a.ndir;
   const int d = ndir == 2 ? (g & 1) : 0;
   const int rowgroup = ndir == 2 ? (g >> 1) : g;
-  const int r0 = rowgroup * PRG;
+  const int r0 = rowgroup * NR;
   if (r0 >= a.nb) return;
   const int64_t ldy = (int64_t)ndir * PH, ldg = (int64_t)ndir * 4 * PH;
   // W_hhT slice -> registers: lane (ug = lane>>4, ks = (lane>>2)&3, i = lane&3) holds unit 16*slice+4ug+i,
@@ -364,10 +374,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   // (their own loads, one step ahead, were HBM first touches: ~0.3 us of every step with a cached row, see DESIGN).
   const int mt = tid & 127;
   const int pu = mt >> 3, pj = mt & 7;
-  const bool pw_thread = tid < PUC * PRG;
+  const bool pw_lane = tid < PUC * PRG;                 // all 8 row lanes of a unit (bias-gradient reduction)
+  const bool pw_thread = pw_lane && pj < NR;
   const int prow = r0 + pj;
   const bool prow_ok = pw_thread && prow < a.nb;
-  const bool touch_ok = ASR_LSTM_TOUCH && tid >= 384 && mt < PUC * PRG && prow < a.nb;
+  const bool touch_ok = ASR_LSTM_TOUCH && tid >= 384 && mt < PUC * PRG && pj < NR && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
   float dcarry = 0.f;
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;      // tag bit of the data written at step s-1
       const bool gl = 4 * lane < PKB;                   // lanes beyond the wave's K range re-read column 0
       const float* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKB + (gl ? 4 * lane : 0);
-      float4 gr[PRG];
+      float4 gr[NR];
       unsigned spins = 0;
       auto load_row = [&](int rr) {
         // L1-bypassing 16-byte read as two 8-byte agent-scope atomics
@@ -432,22 +443,22 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
           // separate code path -- folded into the sentinel condition the compiler still waited for the sentinel
           first = false;
 #pragma unroll
-          for (int rr = 0; rr < PRG; ++rr) load_row(rr);
+          for (int rr = 0; rr < NR; ++rr) load_row(rr);
           unsigned bits = 0xFu;
 #pragma unroll
-          for (int rr = 0; rr < PRG; ++rr) bits &= row_bits(rr);
+          for (int rr = 0; rr < NR; ++rr) bits &= row_bits(rr);
           if (__all(!gl || bits == 0xFu)) break;
         } else {
           // cheap sentinel poll: the last row of this wave's K range (1 KB, touches all 4 producer CUs); a failed
           // poll of the whole 64 KB per CU would saturate the XCD's L2 and delay the producers themselves
-          load_row(PRG - 1);
-          bool ok = !gl || row_bits(PRG - 1) == 0xFu;
+          load_row(NR - 1);
+          bool ok = !gl || row_bits(NR - 1) == 0xFu;
           if (__all(ok)) {
 #pragma unroll
-            for (int rr = 0; rr < PRG - 1; ++rr) load_row(rr);
-            unsigned bits = row_bits(PRG - 1);
+            for (int rr = 0; rr < NR - 1; ++rr) load_row(rr);
+            unsigned bits = row_bits(NR - 1);
 #pragma unroll
-            for (int rr = 0; rr < PRG - 1; ++rr) bits &= row_bits(rr);
+            for (int rr = 0; rr < NR - 1; ++rr) bits &= row_bits(rr);
             if (__all(!gl || bits == 0xFu)) break;
           }
         }
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       }
       LP_MARK(1);
 #pragma unroll
-      for (int rr = 0; rr < PRG; ++rr)
+      for (int rr = 0; rr < NR; ++rr)
         if (gl) *reinterpret_cast<float4*>(&hs[wave][rr][PQS * ((4 * lane) / PQ) + (4 * lane) % PQ]) = gr[rr];
       if (prow_ok && s + 1 < T) fetch_step(s + 1);
       else if (touch_ok && s + ASR_LSTM_TOUCH_DIST < T) fetch_step(s + ASR_LSTM_TOUCH_DIST);   // L2 warm-up (results unused)
@@ -472,22 +483,24 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
 #pragma unroll
       for (int q4 = 0; q4 < ((ASR_LP_ABL & 1) ? 1 : PQ / 4); ++q4) {
         const float4 b0 = *reinterpret_cast<const float4*>(h0 + 4 * q4);
-        const float4 b1 = *reinterpret_cast<const float4*>(h1 + 4 * q4);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b1.x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b1.y, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b1.z, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b1.w, acc1, 0, 0, 0);
+        if (NR > 4) {
+          const float4 b1 = *reinterpret_cast<const float4*>(h1 + 4 * q4);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b1.x, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b1.y, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b1.z, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b1.w, acc1, 0, 0, 0);
+        }
       }
     }
     if (s == 0 && prow_ok && T > 1) fetch_step(1);
     LP_MARK(2);
     float* pp = &part[s & 1][wave][lane][0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; pp[4 + i] = acc1[i]; }
+    for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; if (NR > 4) pp[4 + i] = acc1[i]; }
     LP_MARK(3);
     __syncthreads();
     LP_MARK(4);
@@ -536,7 +549,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       const int kb4 = lane;                      // column within the 64-column chunk (= 4*block + i)
       const int jj = lane & 3;
 #pragma unroll
-      for (int rr = 0; rr < PRG; ++rr) {
+      for (int rr = 0; rr < NR; ++rr) {
         float bv[4];
 #pragma unroll
         for (int u4 = 0; u4 < 4; ++u4) bv[u4] = ysl[s & 1][rr][4 * u4 + jj];
@@ -551,7 +564,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       }
     }
   }
-  if (a.db != nullptr && pw_thread) {
+  if (a.db != nullptr && pw_lane) {
     // rows of a unit sit in 8 consecutive lanes (pj = tid & 7); the 4 row groups (XCDs) of a direction add up
     float v[4] = {dbacc.x, dbacc.y, dbacc.z, dbacc.w};
 #pragma unroll
@@ -586,29 +599,47 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
 
 namespace {
 
-template <int PH>
+template <int PH, int NR>
 int launch_fwd(const PersistArgs& a, hipStream_t stream) {
   const size_t stat = sizeof(float) * ((size_t)PW * PRG * (PH / PW + 4) + 2 * PW * 64 * 9) + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_kernel<PH>,
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_kernel<PH, NR>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_fwd_kernel<PH>), dim3(256), dim3(PNT), pad, stream, a);
+  hipLaunchKernelGGL((lstm_persist_fwd_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
-template <int PH>
+template <int PH, int NR>
 int launch_bwd(const PersistArgs& a, hipStream_t stream) {
   const size_t stat = sizeof(float) * ((size_t)PW * PRG * 4 * (PH / 2 / 4 + 4) + 2 * PW * 64 * 9) + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel<PH>,
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel<PH, NR>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_bwd_kernel<PH>), dim3(256), dim3(PNT), pad, stream, a);
+  hipLaunchKernelGGL((lstm_persist_bwd_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
 bool persist_supported(int H) { return H == 128 || H == 256 || H == 320 || H == 512; }
+
+// rows per XCD group: 4 when the whole batch fits 4-row groups (half the MFMA work and gather per step), else 8
+int rows_per_group(int nb, int ndir) {
+  static const int forced = [] { const char* e = getenv("ASR_LSTM_ROWS"); return e ? atoi(e) : 0; }();   // measurement
+  if (forced == 4 || forced == PRG) return forced;
+  return nb <= 4 * (8 / ndir) ? 4 : PRG;
+}
+
+template <int NR>
+int dispatch_fwd(int H, const PersistArgs& a, hipStream_t stream) {
+  return H == 512 ? launch_fwd<512, NR>(a, stream) : H == 320 ? launch_fwd<320, NR>(a, stream)
+       : H == 256 ? launch_fwd<256, NR>(a, stream) : launch_fwd<128, NR>(a, stream);
+}
+template <int NR>
+int dispatch_bwd(int H, const PersistArgs& a, hipStream_t stream) {
+  return H == 512 ? launch_bwd<512, NR>(a, stream) : H == 320 ? launch_bwd<320, NR>(a, stream)
+       : H == 256 ? launch_bwd<256, NR>(a, stream) : launch_bwd<128, NR>(a, stream);
+}
 
 }  // namespace
 
@@ -634,7 +665,8 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
   if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
-  const int rows_per_launch = PRG * (8 / ndir);
+  const int nr = rows_per_group(nb, ndir);
+  const int rows_per_launch = nr * (8 / ndir);
   if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;          // large batches: the per-step kernels are the better fit
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
     hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
@@ -646,8 +678,7 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
     a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
     a.y = y + (int64_t)rb * ndir * H; a.c = c + (int64_t)rb * ndir * H;
     a.dy = nullptr; a.yfwd = nullptr; a.dw = nullptr; a.db = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
-    int rc = H == 512 ? launch_fwd<512>(a, stream) : H == 320 ? launch_fwd<320>(a, stream)
-           : H == 256 ? launch_fwd<256>(a, stream) : launch_fwd<128>(a, stream);
+    int rc = nr == 4 ? dispatch_fwd<4>(H, a, stream) : dispatch_fwd<PRG>(H, a, stream);
     if (rc) return rc;
   }
   ASR_CHECK_LAUNCH();
@@ -661,7 +692,8 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hhT || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
   if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
-  const int rows_per_launch = PRG * (8 / ndir);
+  const int nr = rows_per_group(nb, ndir);
+  const int rows_per_launch = nr * (8 / ndir);
   if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
     hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
@@ -675,8 +707,7 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
     a.yfwd = (y && dw_hh) ? y + (int64_t)rb * ndir * H : nullptr; a.dw = (y && dw_hh) ? dw_hh : nullptr;
     a.db = db;
     a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
-    int rc = H == 512 ? launch_bwd<512>(a, stream) : H == 320 ? launch_bwd<320>(a, stream)
-           : H == 256 ? launch_bwd<256>(a, stream) : launch_bwd<128>(a, stream);
+    int rc = nr == 4 ? dispatch_bwd<4>(H, a, stream) : dispatch_bwd<PRG>(H, a, stream);
     if (rc) return rc;
   }
   ASR_CHECK_LAUNCH();
