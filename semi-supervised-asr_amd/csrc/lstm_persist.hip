@@ -260,18 +260,29 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       const int j = lane & 3;
 #pragma unroll
       for (int k4 = 0; k4 < ((ASR_LP_ABL & 1) ? 1 : PKW / 4); ++k4) {
+        // consecutive MFMAs alternate between two accumulators (a dependent chain on one would stall the pipe): rows
+        // 0-3 / 4-7 with 8 rows per group, even / odd k (summed below) with 4
         const float4 b0 = *reinterpret_cast<const float4*>(&hs[wave][j][4 * k4]);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b0.x, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b0.y, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b0.z, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b0.w, acc0, 0, 0, 0);
         if (NR > 4) {
           const float4 b1 = *reinterpret_cast<const float4*>(&hs[wave][4 + j][4 * k4]);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b0.x, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b1.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b0.y, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b0.z, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b1.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b0.w, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b1.w, acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b0.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b0.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b0.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b0.w, acc1, 0, 0, 0);
         }
+      }
+      if (NR <= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc0[i] += acc1[i];
       }
     }
     if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
@@ -483,17 +494,26 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
 #pragma unroll
       for (int q4 = 0; q4 < ((ASR_LP_ABL & 1) ? 1 : PQ / 4); ++q4) {
         const float4 b0 = *reinterpret_cast<const float4*>(h0 + 4 * q4);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b0.x, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b0.y, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b0.z, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b0.w, acc0, 0, 0, 0);
-        if (NR > 4) {
+        if (NR > 4) {                      // alternating accumulators, see the forward kernel
           const float4 b1 = *reinterpret_cast<const float4*>(h1 + 4 * q4);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b0.x, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b1.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b0.y, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b0.z, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b1.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b0.w, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b1.w, acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4], b0.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 1], b0.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 2], b0.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * q4 + 3], b0.w, acc1, 0, 0, 0);
         }
+      }
+      if (NR <= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc0[i] += acc1[i];
       }
     }
     if (s == 0 && prow_ok && T > 1) fetch_step(1);
