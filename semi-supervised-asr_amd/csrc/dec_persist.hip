@@ -416,17 +416,21 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     DP_MARK(1);
     // ------------------------------------------------------------ (2) gates = x Wcat^T on the 4x4x1 MFMA
     {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // two partial accumulators (even / odd k), summed once: a chain of dependent MFMAs on one accumulator waits
+      // for the predecessor's passes every time
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* xr = xs + (lane_ & 3) * XS + wave * KXW;
 #pragma unroll
       for (int k4 = 0; k4 < ((ASR_DP_ABL & 2) ? 1 : KXW / 4); ++k4) {
         const float4 b = *reinterpret_cast<const float4*>(xr + 4 * k4);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4], b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b.y, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 1], b.y, accb, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 2], b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b.w, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[4 * k4 + 3], b.w, accb, 0, 0, 0);
         if ((k4 & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most 4 operand reads in flight (VGPRs)
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += accb[i];
       float* pp = part + (wave * 64 + lane_) * 5;
 #pragma unroll
       for (int i = 0; i < 4; ++i) pp[i] = acc[i];
@@ -518,10 +522,15 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     }
     __syncthreads();
     {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};   // even / odd k partials
       const float* zr = xs + (lane_ & 3) * XS + wave * DKW + (lane_ >> 4) * DKQ;
 #pragma unroll
-      for (int q = 0; q < DKQ; ++q) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wdreg[q], zr[q], acc, 0, 0, 0);
+      for (int q = 0; q < DKQ; q += 2) {
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wdreg[q], zr[q], acc, 0, 0, 0);
+        if (q + 1 < DKQ) accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wdreg[q + 1], zr[q + 1], accb, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += accb[i];
       float* pp = part + (wave * 64 + lane_) * 5;
 #pragma unroll
       for (int i = 0; i < 4; ++i) pp[i] = acc[i];
@@ -1187,10 +1196,15 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     }
     __syncthreads();
     {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};   // even / odd k partials
       const float* dr = dDs + (lane_ & 3) * DS + wave * AKW + (lane_ >> 4) * AQ;
 #pragma unroll
-      for (int q = 0; q < AQ; ++q) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[q], dr[q], acc, 0, 0, 0);
+      for (int q = 0; q < AQ; q += 2) {
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[q], dr[q], acc, 0, 0, 0);
+        if (q + 1 < AQ) accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[q + 1], dr[q + 1], accb, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += accb[i];
       float* pp = part + (wave * 64 + lane_) * 5;
 #pragma unroll
       for (int i = 0; i < 4; ++i) pp[i] = acc[i];
@@ -1249,17 +1263,19 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     // from here the next poll is ~2 us away and the data is consumed ~4 us later.
     prefetchA(s - 1, zv);
     {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};   // even / odd k partials
       DP_MARK(8);
       const float* gr = dgs + (lane_ & 3) * GS + wave * GKW + ((lane_ >> 2) & 1) * GKS;
 #pragma unroll
       for (int q4 = 0; q4 < GKS / 4; ++q4) {
         const float4 b = *reinterpret_cast<const float4*>(gr + 4 * q4);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4], b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 1], b.y, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 1], b.y, accb, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 2], b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 3], b.w, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 3], b.w, accb, 0, 0, 0);
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += accb[i];
       float* pp = part + (wave * 64 + lane_) * 5;
 #pragma unroll
       for (int i = 0; i < 4; ++i) pp[i] = acc[i];
