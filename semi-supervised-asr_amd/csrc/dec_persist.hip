@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       const bool cok = cb < C;
       const int cc = cok ? cb : 0;
       {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};   // alternating partials
         const float* ap = dfh + cc * DFS + 16 * aq + 4 * li + 2 * K;
         const float* bp = Fs + cc * FSS + li;
         const int jend = taps + 3;
@@ -1124,12 +1124,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
             bv[u] = bp[jc];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < 4; u += 2) {
             acc = __builtin_amdgcn_mfma_f32_4x4x1f32((cok && j + 8 * u < jend) ? av[u] : 0.f, bv[u], acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_4x4x1f32((cok && j + 8 * (u + 1) < jend) ? av[u + 1] : 0.f, bv[u + 1], accb, 0, 0, 0);
+          }
         }
         float* pp = part + (wave * 64 + lane_) * 5;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pp[i] = acc[i];
+        for (int i = 0; i < 4; ++i) pp[i] = acc[i] + accb[i];
       }
       // (2) dconv[c][j0 + 4i + jj] += sum_u w_{s-1}[u + j0 + 4i - K] df[c][u - jj]: A = wph[u + j0 + 4i], B = dfh[c][K + u - jj];
       //     this CU owns the 16-tap tiles aq and aq + 8 of its row; accumulators live in registers for the whole sequence
