@@ -157,6 +157,24 @@ int asr_pyramid_concat_bwd(int T, int B, int C, const float* dout, const float* 
                            float* din, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Counter-based dropout (the shared torch.nn.Dropout of model.py:73,82,95): inverted dropout whose mask is a pure
+ * function of (seed, flat element index), mask(i) = [hash(seed, i) >= p * 2^32] / (1 - p), so nothing is stored
+ * between forward and backward.  p in [0, 1); n % 4 == 0; pointers 16-byte aligned.
+ *   asr_dropout_seeded_f32      x[i] *= mask(i), in place (after relu(x W^T + b), model.py:94-95)
+ *   asr_relu_dropout_bwd_f32    out[i] = grad[i] * mask(i) * (y[i] > 0), y = the dropped-out relu output
+ *   asr_dropout_mask_f32        mask[i] = mask(i) (tests; the decoder's [L][B][O+E] operand mask)
+ *   asr_pyramid_concat_*_seeded the pair-concat kernels with mask(i) over the [T][B][C] input regenerated in flight
+ * ------------------------------------------------------------------------------------- */
+int asr_dropout_seeded_f32(int64_t n, float* x, uint64_t seed, float p, asr_stream_t stream);
+int asr_relu_dropout_bwd_f32(int64_t n, const float* grad, const float* y, uint64_t seed, float p, float* out,
+                             asr_stream_t stream);
+int asr_dropout_mask_f32(int64_t n, float* mask, uint64_t seed, float p, asr_stream_t stream);
+int asr_pyramid_concat_fwd_seeded(int T, int B, int C, const float* in, uint64_t seed, float p, float* out,
+                                  asr_stream_t stream);
+int asr_pyramid_concat_bwd_seeded(int T, int B, int C, const float* dout, uint64_t seed, float p, float* din,
+                                  asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Decoder step = LSTMCell + location-aware attention (Decoder.forward_step model.py:283-294,
  * AttLoc.forward model.py:139-173).  Per-sequence constants:
  *   P   [B][Tp][A]   mlp_enc(enc_h)                     (model.py:144)

@@ -24,6 +24,24 @@ __device__ __forceinline__ float asr_fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
 }
 
+// Counter-based dropout: keep(element) is a pure function of (seed, flat element index), so the forward and the
+// backward regenerate the same mask instead of writing / reading it (229 MB per cfg-2 step).  Two rounds of the
+// "lowbias32" integer mixer over the 64-bit index and the 64-bit seed; an element is kept when the hash is >= thresh
+// = p * 2^32.  Kept elements are scaled by 1/(1-p) (inverted dropout, as torch.nn.Dropout).
+__device__ __forceinline__ unsigned asr_mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool asr_drop_keep(unsigned long long seed, long long idx, unsigned thresh) {
+  unsigned h = asr_mix32((unsigned)idx ^ (unsigned)seed);
+  h = asr_mix32(h + (unsigned)((unsigned long long)idx >> 32) * 0x9e3779b9u + (unsigned)(seed >> 32));
+  return h >= thresh;
+}
+static inline unsigned asr_drop_thresh(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

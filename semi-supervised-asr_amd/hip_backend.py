@@ -16,6 +16,8 @@ ABI_VERSION = 1
 EXPORTS = (
     "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
+    "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
+    "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
@@ -75,6 +77,12 @@ def load():
     lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
+    c_u64 = ctypes.c_uint64
+    lib.asr_pyramid_concat_fwd_seeded.argtypes = [c_i, c_i, c_i, c_p, c_u64, c_f, c_p, c_p]
+    lib.asr_pyramid_concat_bwd_seeded.argtypes = [c_i, c_i, c_i, c_p, c_u64, c_f, c_p, c_p]
+    lib.asr_dropout_seeded_f32.argtypes = [c_i64, c_p, c_u64, c_f, c_p]
+    lib.asr_relu_dropout_bwd_f32.argtypes = [c_i64, c_p, c_p, c_u64, c_f, c_p, c_p]
+    lib.asr_dropout_mask_f32.argtypes = [c_i64, c_p, c_u64, c_f, c_p]
     lib.asr_dec_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_att_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_dec_seq_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_i, c_p, c_p]
@@ -472,11 +480,54 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None)
     return False
 
 
+# dropout masks regenerated inside the consuming kernels from a seed (off: materialised fp32 masks, as injected by tests)
+USE_SEEDED_DROPOUT = os.environ.get("ASR_SEEDED_DROPOUT", "1") != "0"
+
+
+class SeededMask(object):
+    """Inverted-dropout mask given by (seed, p) over a tensor shape: mask(i) = keep(seed, i) / (1 - p) (dropout.hip)."""
+
+    def __init__(self, shape, p, device, seed=None):
+        self.shape, self.p, self.device = tuple(int(v) for v in shape), float(p), device
+        # seeds come from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+
+    def tensor(self):
+        n = 1
+        for v in self.shape:
+            n *= v
+        pad = torch.empty((n + 3) // 4 * 4, device=self.device, dtype=torch.float32)
+        check(load().asr_dropout_mask_f32(pad.numel(), ptr(pad), self.seed, self.p, stream()), "asr_dropout_mask_f32")
+        return pad[:n].view(self.shape)
+
+
+def dropout_seeded_(x, m):
+    """x *= mask in place (x contiguous, numel % 4 == 0)."""
+    check(load().asr_dropout_seeded_f32(x.numel(), ptr(x), m.seed, m.p, stream()), "asr_dropout_seeded_f32")
+    return x
+
+
+def relu_dropout_bwd(grad, y, seed, p):
+    """grad * mask * (y > 0) in one pass (p == 0: the plain relu gradient)."""
+    out = torch.empty_like(y)
+    check(load().asr_relu_dropout_bwd_f32(y.numel(), ptr(grad), ptr(y), int(seed), float(p), ptr(out), stream()),
+          "asr_relu_dropout_bwd_f32")
+    return out
+
+
 def pyramid_fwd(x, mask, out):
     T, B, C = x.shape
+    if isinstance(mask, SeededMask):
+        check(load().asr_pyramid_concat_fwd_seeded(T, B, C, ptr(x), mask.seed, mask.p, ptr(out), stream()),
+              "asr_pyramid_concat_fwd_seeded")
+        return
     check(load().asr_pyramid_concat_fwd(T, B, C, ptr(x), ptr(mask), ptr(out), stream()), "asr_pyramid_concat_fwd")
 
 
 def pyramid_bwd(dout, mask, din):
     T, B, C = din.shape
+    if isinstance(mask, SeededMask):
+        check(load().asr_pyramid_concat_bwd_seeded(T, B, C, ptr(dout), mask.seed, mask.p, ptr(din), stream()),
+              "asr_pyramid_concat_bwd_seeded")
+        return
     check(load().asr_pyramid_concat_bwd(T, B, C, ptr(dout), ptr(mask), ptr(din), stream()), "asr_pyramid_concat_bwd")

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+import hip_backend as hb
 import ops
 from hip_backend import to_device_i32 as hb_to_device
 from utils import cc, pad_list, _seq_mask
@@ -56,8 +57,16 @@ class _CellWeights(torch.nn.Module):
 
 
 def _drop_mask(shape, p, device):
-    """Inverted-dropout mask, already scaled by 1/(1-p)."""
+    """Inverted-dropout mask, already scaled by 1/(1-p): on the GPU a (seed, p) descriptor that the consuming kernels
+    expand in flight (hip_backend.SeededMask), otherwise / with ASR_SEEDED_DROPOUT=0 a materialised tensor.  Tests
+    replace this function to inject given masks."""
+    if hb.USE_SEEDED_DROPOUT and torch.device(device).type == "cuda":
+        return hb.SeededMask(shape, p, device)
     return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+
+
+def _mask_tensor(mask):
+    return mask.tensor() if isinstance(mask, hb.SeededMask) else mask
 
 
 def padded_lengths(t_max, n_layers, subsample):
@@ -110,10 +119,15 @@ class pBLSTM(torch.nn.Module):
                 y = ops.pyramid_concat(y, mask)                    # [ceil(T/2),B,4H]
                 lens = [(l + 1) // sub for l in lens]
             elif mask is not None:
-                y = y * mask
-            x = ops.linear(y, proj.weight, proj.bias, relu=True)
+                y = y * _mask_tensor(mask)
             if drop:
-                x = x * _drop_mask(x.shape, self.dropout_rate, dev)
+                m2 = _drop_mask((y.shape[0], y.shape[1], proj.weight.shape[0]), self.dropout_rate, dev)
+                if isinstance(m2, hb.SeededMask) and m2.shape[0] * m2.shape[1] * m2.shape[2] % 4 == 0:
+                    x = ops.linear(y, proj.weight, proj.bias, relu=True, drop=m2)      # relu -> dropout in the op
+                else:
+                    x = ops.linear(y, proj.weight, proj.bias, relu=True) * _mask_tensor(m2)
+            else:
+                x = ops.linear(y, proj.weight, proj.bias, relu=True)
         self.last_lens_dev = lens_all[-1]                          # device copy of the output lengths
         return x.transpose(0, 1).contiguous(), [int(l) for l in lens]
 
@@ -256,7 +270,7 @@ class Decoder(torch.nn.Module):
         opts["L"] = steps
         p = self.dropout_rate
         if self.training and p > 0:
-            opts["xmask"] = _drop_mask((steps, bsz, self.att_odim + self.embedding.embedding_dim), p, dev)
+            opts["xmask"] = _mask_tensor(_drop_mask((steps, bsz, self.att_odim + self.embedding.embedding_dim), p, dev))
         P = ops.linear(enc_pad, att.mlp_enc.weight, att.mlp_enc.bias)
         Q = ops.linear(enc_pad, att.mlp_o.weight, None)
         w0 = AttLoc.initial_weights(enc_len, frames, dev)

@@ -64,11 +64,16 @@ _POOL = _Pool()
 # --------------------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, drop):
         x2 = x.reshape(-1, x.shape[-1])
         y = hb.gemm(x2, weight, trans_b=True, bias=bias, relu=relu)
+        seeded = isinstance(drop, hb.SeededMask)
+        if seeded:                                   # relu -> dropout fused: mask regenerated in the backward
+            assert relu and y.numel() % 4 == 0
+            hb.dropout_seeded_(y, drop)
         ctx.save_for_backward(x2, weight, y if relu else None)
         ctx.relu = relu
+        ctx.drop = (drop.seed, drop.p) if seeded else None
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
         return y.view(*x.shape[:-1], weight.shape[0])
@@ -77,19 +82,23 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x2, weight, y = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        if ctx.relu:
-            dy2 = dy2 * (y > 0).to(dy2.dtype)
-        elif not dy2.is_contiguous():
+        if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        if ctx.relu and y.numel() % 4 == 0:
+            # one pass: relu gradient (and the dropout mask: y is the dropped-out output, y > 0 <=> kept and active)
+            seed, p = ctx.drop if ctx.drop is not None else (0, 0.0)
+            dy2 = hb.relu_dropout_bwd(dy2, y, seed, p)
+        elif ctx.relu:
+            dy2 = dy2 * (y > 0).to(dy2.dtype)
         dx = hb.gemm(dy2, weight).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
         dw = hb.gemm(dy2, x2, trans_a=True)
         db = hb.colsum(dy2) if ctx.has_bias else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, weight, bias=None, relu=False):
-    """nn.Linear (+ optional fused ReLU) on the f32 MFMA GEMM (model.py:93-94,144)."""
-    return _Linear.apply(x, weight, bias, relu)
+def linear(x, weight, bias=None, relu=False, drop=None):
+    """nn.Linear (+ optional fused ReLU, + optional seeded dropout after it) on the f32 MFMA GEMM (model.py:93-95,144)."""
+    return _Linear.apply(x, weight, bias, relu, drop)
 
 
 # --------------------------------------------------------------------------------------
@@ -189,15 +198,14 @@ class _Pyramid(torch.autograd.Function):
         T, B, C = x.shape
         out = torch.empty((T + 1) // 2, B, 2 * C, device=x.device, dtype=torch.float32)
         hb.pyramid_fwd(x.contiguous(), mask, out)
-        ctx.save_for_backward(mask)
+        ctx.mask = mask                            # tensor, hb.SeededMask (regenerated in the backward) or None
         ctx.shape = (T, B, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (mask,) = ctx.saved_tensors
         din = torch.empty(ctx.shape, device=dout.device, dtype=torch.float32)
-        hb.pyramid_bwd(dout.contiguous(), mask, din)
+        hb.pyramid_bwd(dout.contiguous(), ctx.mask, din)
         return din, None
 
 

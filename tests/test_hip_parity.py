@@ -798,3 +798,74 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
             scale = float(gr[k].abs().max()) + 1e-12
             err = float((gf[k] - gr[k]).abs().max()) / scale
             assert err < 2e-4, (kind, persist, k, err)
+
+
+@pytest.mark.parametrize("p", [0.3, 0.5])
+def test_seeded_dropout_kernels(p):
+    """Counter-based dropout (dropout.hip, pyramid.hip *_seeded): the mask is a pure function of (seed, index); every
+    consumer that regenerates it must agree with the materialised mask."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(21)
+    m = hb.SeededMask((7, 6, 40), p, dev, seed=123456789012345)
+    mask = m.tensor()
+    assert mask.shape == (7, 6, 40)
+    vals = torch.unique(mask).cpu().tolist()
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / (1.0 - p)) < 1e-6
+    big = hb.SeededMask((1 << 20,), p, dev, seed=987654321).tensor()
+    assert abs(float((big > 0).float().mean()) - (1.0 - p)) < 5e-3
+    assert not torch.equal(hb.SeededMask((7, 6, 40), p, dev, seed=5).tensor(), mask)
+    assert torch.equal(hb.SeededMask((7, 6, 40), p, dev, seed=123456789012345).tensor(), mask)
+    # in-place forward and the fused relu + dropout backward
+    x = torch.randn(7, 6, 40, generator=g).to(dev)
+    y = torch.relu(x) * mask
+    got = hb.dropout_seeded_(torch.relu(x).contiguous(), m)
+    assert torch.equal(got, y)
+    gr = torch.randn(7, 6, 40, generator=g).to(dev)
+    assert torch.equal(hb.relu_dropout_bwd(gr, y, m.seed, m.p), gr * mask * (y > 0).float())
+    assert torch.equal(hb.relu_dropout_bwd(gr, torch.relu(x), 0, 0.0), gr * (x > 0).float())
+    # pair-concat with the mask regenerated in flight, even and odd T
+    for T in (7, 8):
+        import ops
+        xin = torch.randn(T, 6, 40, generator=g).to(dev)
+        ms = hb.SeededMask((T, 6, 40), p, dev, seed=77 + T)
+        mt = ms.tensor()
+        a = xin.clone().requires_grad_(True)
+        b = xin.clone().requires_grad_(True)
+        ya, yb = ops.pyramid_concat(a, ms), ops.pyramid_concat(b, mt)
+        assert torch.equal(ya, yb)
+        go = torch.randn(ya.shape, generator=g).to(dev)
+        ya.backward(go); yb.backward(go)
+        assert torch.equal(a.grad, b.grad)
+
+
+def test_seeded_dropout_end_to_end_equals_explicit_masks(monkeypatch):
+    """The whole model with dropout: seeded in-kernel masks against the same masks materialised and passed as tensors
+    (the path the injected-mask oracle test pins)."""
+    dev = _gpu()
+    import model as M
+    import hip_backend as hb
+    cfg = dict(input_dim=12, enc_hidden_dim=16, enc_n_layers=2, subsample=[2, 2], dropout_rate=0.4,
+               dec_hidden_dim=32, att_dim=16, conv_channels=3, conv_kernel_size=4, att_odim=16, embedding_dim=16,
+               output_dim=10, ls_weight=0.05)
+    ld = synth.labeldist(10, 3)
+    w = synth.e2e_weights(cfg, 57)
+    xs, ilens, ys = synth.batch(12, 10, [13, 11, 8, 5], [3, 2, 2, 2], 58)
+    outs = []
+    for explicit in (False, True):
+        seeds = iter(range(1000, 1100))
+
+        def mask(shape, p, device, explicit=explicit, seeds=seeds):
+            sm = hb.SeededMask(shape, p, device, seed=next(seeds))
+            return sm.tensor() if explicit else sm
+
+        monkeypatch.setattr(M, "_drop_mask", mask)
+        net = _product(cfg, w, ld, dev)
+        np.random.seed(2)
+        logits, lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
+        net.zero_grad()
+        (-lp.mean()).backward()
+        outs.append((logits.detach().clone(), {n: g_.clone() for n, g_ in _grads(net).items()}))
+    _close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-7, what="seeded vs explicit logits")
+    for n in outs[0][1]:
+        _close(outs[0][1][n], outs[1][1][n], rtol=1e-5, atol=1e-7, what="seeded vs explicit grad " + n)
