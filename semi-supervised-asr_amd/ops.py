@@ -20,6 +20,7 @@ GPU only; see hip_backend for the no-fallback rule.
 """
 import ctypes
 
+import numpy as np
 import torch
 
 import hip_backend as hb
@@ -108,9 +109,12 @@ def _lstm_workspace(T, B, H, ndir, dev, with_bwd):
               c=torch.empty(T, B, ndir * H, **f32), w_hh=torch.empty(ndir, 4 * H, H, **f32),
               lens=torch.empty(B, dtype=torch.int32, device=dev))
     if with_bwd:
-        ws.update(w_hhT=torch.empty(ndir, H, 4 * H, **f32), dy=torch.empty(T, B, ndir * H, **f32),
-                  dcarry=torch.empty(B, ndir * H, **f32), dw_hh=torch.empty(ndir, 4 * H, H, **f32),
-                  db=torch.empty(ndir * 4 * H, **f32))
+        # the three accumulators the backward starts from zero share one buffer: one fill instead of three
+        n1, n2, n3 = B * ndir * H, ndir * 4 * H * H, ndir * 4 * H
+        zbuf = torch.empty(n1 + n2 + n3, **f32)
+        ws.update(w_hhT=torch.empty(ndir, H, 4 * H, **f32), dy=torch.empty(T, B, ndir * H, **f32), zbuf=zbuf,
+                  dcarry=zbuf[:n1].view(B, ndir * H), dw_hh=zbuf[n1:n1 + n2].view(ndir, 4 * H, H),
+                  db=zbuf[n1 + n2:].view(ndir * 4 * H))
     return ws
 
 
@@ -153,10 +157,8 @@ class _LstmLayer(torch.autograd.Function):
         dev = dy.device
         dyc = dy if dy.is_contiguous() else ws["dy"].copy_(dy)
         ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2))
-        ws["dcarry"].zero_()
+        ws["zbuf"].zero_()                     # dcarry, dw_hh, db
         gates, y = ws["gates"], ws["y"]
-        ws["dw_hh"].zero_()
-        ws["db"].zero_()
         fused_dw = hb.lstm_seq_bwd(gates, ws["w_hhT"], ws["lens"], dyc, ws["c"], ws["dcarry"], y=y,
                                    dw_hh=ws["dw_hh"], db=ws["db"])                        # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
@@ -259,14 +261,20 @@ def _dec_workspace(B, Tp, A, D, O, E, C, K, L, drop, dev, with_bwd):
         ws=torch.empty(L, B, Tp, **f32))
     if with_bwd:
         ntile = (A + 63) // 64
+        # everything the backward accumulates into lives in ONE buffer (16-byte aligned slices): one fill per step
+        shapes = dict(G=(L + 1, B, KX), dwext=(C, B, Tp), dP=(B, Tp, A), dcell=(B, D), dgvec_part=(B, A),
+                      dwatt_part=(B, A, C), dconv_part=(B, C, 2 * K + 1))
+        sizes = {k: (int(np.prod(v)) + 3) // 4 * 4 for k, v in shapes.items()}
+        zbuf = torch.empty(sum(sizes.values()), **f32)
+        off = 0
+        for k, shp in shapes.items():
+            ws[k] = zbuf[off:off + int(np.prod(shp))].view(*shp)
+            off += sizes[k]
         ws.update(
-            wcatT=torch.empty(KX, 4 * D, **f32), wdecT=torch.empty(D, A, **f32), G=torch.empty(L + 1, B, KX, **f32),
-            dwext=torch.empty(C, B, Tp, **f32), dwraw=torch.empty(B, Tp, **f32),
-            dfpart=torch.empty(ntile, B, C, Tp, **f32), dP=torch.empty(B, Tp, A, **f32),
-            dgates=torch.empty(L, B, 4 * D, **f32), dD=torch.empty(L, B, A, **f32), dcell=torch.empty(B, D, **f32),
-            dgvec_part=torch.empty(B, A, **f32), dwatt_part=torch.empty(B, A, C, **f32),
-            dconv_part=torch.empty(B, C, 2 * K + 1, **f32), dws=torch.empty(L, B, Tp, **f32),
-            Mf=torch.empty(L, B, C, Tp, **f32))
+            zbuf=zbuf, wcatT=torch.empty(KX, 4 * D, **f32), wdecT=torch.empty(D, A, **f32),
+            dwraw=torch.empty(B, Tp, **f32), dfpart=torch.empty(ntile, B, C, Tp, **f32),
+            dgates=torch.empty(L, B, 4 * D, **f32), dD=torch.empty(L, B, A, **f32),
+            dws=torch.empty(L, B, Tp, **f32), Mf=torch.empty(L, B, C, Tp, **f32))
     return ws
 
 
@@ -448,9 +456,7 @@ class _DecoderSeq(torch.autograd.Function):
         lib = hb.load()
         dlog2 = dlogits.contiguous().view(L * B, V)
         G = wk["G"]
-        G.zero_()
-        for k in ("dwext", "dP", "dcell", "dgvec_part", "dwatt_part", "dconv_part"):
-            wk[k].zero_()
+        wk["zbuf"].zero_()                     # G, dwext, dP, dcell, dgvec_part, dwatt_part, dconv_part
         wk["wcatT"].copy_(wk["wcat"].t())
         wk["wdecT"].copy_(wdec.t())
         XO = X[1:].view(L * B, KX)[:, :D + O]
