@@ -351,6 +351,19 @@ def to_device_i32(values, device):
     return buf.to(device, non_blocking=True).view(arr.shape)
 
 
+def to_device_f32(array, device):
+    """Host float32 array -> device tensor through the pinned ring (see to_device_i32)."""
+    import numpy as np
+    arr = np.ascontiguousarray(array, dtype=np.float32)
+    key = (str(device), "f32", arr.size)
+    ring = _pinned_ring.setdefault(key, dict(bufs=[torch.empty(arr.size, dtype=torch.float32).pin_memory()
+                                                   for _ in range(8)], i=0))
+    buf = ring["bufs"][ring["i"] % 8]
+    ring["i"] += 1
+    buf.copy_(torch.from_numpy(arr.reshape(-1)))
+    return buf.to(device, non_blocking=True).view(arr.shape)
+
+
 def _ptr_array(tensors):
     return (c_p * len(tensors))(*[_dev(t).data_ptr() for t in tensors])
 

@@ -169,11 +169,16 @@ class AttLoc(torch.nn.Module):
 
     @staticmethod
     def initial_weights(enc_len, frames, device):
-        """model.py:151-153: uniform over each utterance's valid frames, 0 on the padding.  Built on the device
-        from a non-blocking upload of the lengths (no host stall in the middle of the step)."""
-        lens = hb_to_device(enc_len, device).to(torch.float32).unsqueeze(1)
-        grid = torch.arange(frames, device=device, dtype=torch.float32).unsqueeze(0)
-        return (grid < lens).to(torch.float32) / lens
+        """model.py:151-153: uniform over each utterance's valid frames, 0 on the padding (no host stall in the
+        middle of the step: pinned staging + non-blocking copy)."""
+        if torch.device(device).type != "cuda":
+            lens = torch.tensor([float(l) for l in enc_len]).unsqueeze(1)
+            grid = torch.arange(frames, dtype=torch.float32).unsqueeze(0)
+            return (grid < lens).to(torch.float32) / lens
+        w0 = np.zeros((len(enc_len), int(frames)), dtype=np.float32)     # the lengths are host ints: build it there,
+        for b, l in enumerate(enc_len):                                 # one non-blocking upload instead of 5 launches
+            w0[b, :int(l)] = np.float32(1.0) / np.float32(int(l))
+        return hb.to_device_f32(w0, device)
 
     def forward(self, enc_pad, enc_len, dec_z, att_prev, scaling=2.0):
         """Single attention step with the reference's signature (model.py:139-173): returns (mlp_o(context), w).

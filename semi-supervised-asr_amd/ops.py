@@ -442,6 +442,7 @@ class _DecoderSeq(torch.autograd.Function):
         ctx.all_teacher = all_teacher
         ctx.smooth_scaling = float(opts.get("smooth_scaling", 1.0))
         ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)       # an unused `ws` output arrives as None instead of a zero tensor + copy
         return logits, ws["ws"].clone(), pred
 
     @staticmethod
@@ -454,6 +455,8 @@ class _DecoderSeq(torch.autograd.Function):
         X, Xd = wk["X"], wk["Xd"]
         dev = X.device
         lib = hb.load()
+        if dlogits is None:
+            dlogits = torch.zeros(L, B, V, device=dev, dtype=torch.float32)
         dlog2 = dlogits.contiguous().view(L * B, V)
         G = wk["G"]
         wk["zbuf"].zero_()                     # G, dwext, dP, dcell, dgvec_part, dwatt_part, dconv_part
