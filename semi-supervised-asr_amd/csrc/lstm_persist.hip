@@ -518,9 +518,21 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     }
     if (s == 0 && prow_ok && T > 1) fetch_step(1);
     LP_MARK(2);
+    // the 4 k-sub partials of a (unit, row) sit 4 lanes apart inside a row of 16: two DPP row rotations leave their
+    // sum in every one of those lanes, so the pointwise thread reads 8 values (one per wave) instead of 32.  (Done on
+    // scalar copies: applied to the elements of the MFMA accumulator vector in place, hipcc 7.2 paired the rotations
+    // with the wrong elements.)
+    float red[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[i] = acc0[i]; red[4 + i] = NR > 4 ? acc1[i] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < (NR > 4 ? 8 : 4); ++i) {
+      red[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, red[i]), 0x124, 0xf, 0xf, true));
+      red[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, red[i]), 0x128, 0xf, 0xf, true));
+    }
     float* pp = &part[s & 1][wave][lane][0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; if (NR > 4) pp[4 + i] = acc1[i]; }
+    for (int i = 0; i < (NR > 4 ? 8 : 4); ++i) pp[i] = red[i];
     LP_MARK(3);
     __syncthreads();
     LP_MARK(4);
@@ -529,9 +541,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       float dh = dyv;
       const int pl = 16 * (pu >> 2) + (pj & 3), pr = 4 * (pj >> 2) + (pu & 3);
 #pragma unroll
-      for (int w2 = 0; w2 < PW; ++w2)
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) dh += part[s & 1][w2][pl + 4 * k2][pr];
+      for (int w2 = 0; w2 < PW; ++w2) dh += part[s & 1][w2][pl][pr];      // k-subs already summed (DPP, above)
       LP_MARK(9);
       const float tc = asr_fast_tanh(ct);
       const float dc = dcarry + dh * av.w * (1.f - tc * tc);
