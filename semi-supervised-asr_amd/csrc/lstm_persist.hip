@@ -90,7 +90,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   // this wave's K range of h_{t-1}; rows padded by 4 floats so the 4 rows a ds_read_b128 touches (the MFMA blocks
   // broadcast) fall on different bank slots
   __shared__ __attribute__((aligned(16))) float hs[PW][PRG][PKW + 4];
-  __shared__ float part[2][PW][64][9];                                    // K-partials, double buffered (36 KB)
+  __shared__ __attribute__((aligned(16))) float part[2][PW][64][8];      // K-partials, double buffered (32 KB)
   __shared__ int role[2];
   extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
   const int tid = threadIdx.x, lane = tid & 63;
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
     LP_MARK(2);
     float* pp = &part[s & 1][wave][lane][0];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { pp[i] = acc0[i]; if (NR > 4) pp[4 + i] = acc1[i]; }
+    *reinterpret_cast<float4*>(pp) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+    if (NR > 4) *reinterpret_cast<float4*>(pp + 4) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
     LP_MARK(3);
     __syncthreads();
     LP_MARK(4);
@@ -298,9 +298,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       float pre[4] = {gx.x, gx.y, gx.z, gx.w};
       const int pl = 4 * pu + (pj & 3), pr = 4 * (pj >> 2);
 #pragma unroll
-      for (int w2 = 0; w2 < PW; ++w2)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pre[i] += part[s & 1][w2][pl][pr + i];
+      for (int w2 = 0; w2 < PW; ++w2) {          // one 16-byte read per wave (the 8 threads of a unit read 128 contiguous bytes)
+        const float4 v = *reinterpret_cast<const float4*>(&part[s & 1][w2][pl][pr]);
+        pre[0] += v.x; pre[1] += v.y; pre[2] += v.z; pre[3] += v.w;
+      }
       const float gi = asr_fast_sigmoid(pre[0]), gf = asr_fast_sigmoid(pre[1]);
       const float gg = asr_fast_tanh(pre[2]), go = asr_fast_sigmoid(pre[3]);
       float cn = gf * c_prev + gi * gg;
@@ -631,7 +632,7 @@ namespace {
 
 template <int PH, int NR>
 int launch_fwd(const PersistArgs& a, hipStream_t stream) {
-  const size_t stat = sizeof(float) * ((size_t)PW * PRG * (PH / PW + 4) + 2 * PW * 64 * 9) + 64;
+  const size_t stat = sizeof(float) * ((size_t)PW * PRG * (PH / PW + 4) + 2 * PW * 64 * 8) + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
   hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_kernel<PH, NR>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
