@@ -1449,9 +1449,7 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
   if (!asr_persist_device_ok()) return ASR_E_SHAPE;
   const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;
   for (int rb = 0; rb < p->nb; rb += 32) {
-    hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(xch, 0, (size_t)8 * DX_GROUP * sizeof(float), stream);
+    hipError_t e = persist_reset(xch, ctrl, (size_t)8 * DX_GROUP * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
     DecPersistArgs a;
     a.B = B; a.nb = p->nb - rb < 32 ? p->nb - rb : 32; a.Tp = Tp; a.C = C; a.K = p->K; a.L = p->L;
@@ -1527,9 +1525,7 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
   const int taps = 2 * p->K + 1;
   for (int rb = 0; rb < p->nb; rb += 32) {
     const int nbb = p->nb - rb < 32 ? p->nb - rb : 32;
-    hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(xch, 0, (size_t)8 * BX_GROUP * sizeof(float), stream);
+    hipError_t e = persist_reset(xch, ctrl, (size_t)8 * BX_GROUP * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
     if (cfg2)
       hipLaunchKernelGGL((att_m_kernel<512>), dim3(nbb, p->L), dim3(256), 0, stream, B, Tp, C,

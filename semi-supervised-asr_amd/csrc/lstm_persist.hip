@@ -700,9 +700,7 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
   const int rows_per_launch = nr * (8 / ndir);
   if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;          // large batches: the per-step kernels are the better fit
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
-    hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(xch, 0, (size_t)2 * 8 * PRG * H * sizeof(u64), stream);
+    hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * PRG * H * sizeof(u64), stream);
     if (e != hipSuccess) return (int)e;
     PersistArgs a;
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
@@ -727,9 +725,7 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
   const int rows_per_launch = nr * (8 / ndir);
   if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
-    hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(xch, 0, (size_t)2 * 8 * PRG * 4 * H * sizeof(float), stream);
+    hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * PRG * 4 * H * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
     PersistArgs a;
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;

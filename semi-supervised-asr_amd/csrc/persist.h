@@ -43,6 +43,15 @@ __device__ __forceinline__ void word_store(float* p, float v, unsigned bit) {
   __hip_atomic_store((gu32*)p, (__float_as_uint(v) & ~1u) | bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Host side: zero the control words and `bytes` of exchange before a launch.  When the caller placed the 64-byte
+// control block directly in front of the exchange buffer (hip_backend.persist_scratch does) it is ONE fill.
+static inline hipError_t persist_reset(void* xch, void* ctrl, size_t bytes, hipStream_t stream) {
+  if ((char*)ctrl + 64 == (char*)xch) return hipMemsetAsync(ctrl, 0, 64 + bytes, stream);
+  hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
+  if (e != hipSuccess) return e;
+  return hipMemsetAsync(xch, 0, bytes, stream);
+}
+
 // role of this workgroup: (group g in 0..7 = XCC id, slice in 0..31 = arrival ticket); slice < 0 = no role
 __device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g, int& slice) {
   if (threadIdx.x == 0) {

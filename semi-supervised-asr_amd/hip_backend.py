@@ -414,13 +414,22 @@ USE_FEEDBACK_KERNEL = os.environ.get("ASR_FEEDBACK_KERNEL", "1") != "0"
 _persist_scratch = {}
 
 
-def persist_scratch(device):
-    """(xch, ctrl) scratch of the persistent LSTM kernels, one pair per device (calls are stream-ordered)."""
+def persist_scratch(device, trace=False):
+    """(xch, ctrl) scratch of the persistent kernels, one pair per device (calls are stream-ordered).  trace=True: a
+    separate 4 KB control buffer whose words 16.. receive the clock stamps of the measurement builds (tools/)."""
+    if trace:
+        tkey = str(device) + "/trace"
+        if tkey not in _persist_scratch:
+            _persist_scratch[tkey] = (torch.zeros(2 * 8 * 8 * 2048, dtype=torch.int64, device=device),
+                                      torch.zeros(1024, dtype=torch.int32, device=device))
+        return _persist_scratch[tkey]
     key = str(device)
     if key not in _persist_scratch:
-        _persist_scratch[key] = (torch.zeros(2 * 8 * 8 * 2048, dtype=torch.int64, device=device),
-                                 torch.zeros(1024, dtype=torch.int32, device=device))   # [0..15] control words, rest: optional trace
-    return _persist_scratch[key]
+        # one allocation: [64-byte control block | 2 MB exchange] so that the pre-launch reset is a single fill
+        # (persist.h: persist_reset), plus a separate trace area used only by the measurement builds
+        base = torch.zeros(8 + 2 * 8 * 8 * 2048, dtype=torch.int64, device=device)
+        _persist_scratch[key] = (base[8:], base[:8].view(torch.int32), base)
+    return _persist_scratch[key][:2]
 
 
 def persist_abort_code(device):

@@ -138,7 +138,7 @@ class _LstmLayer(torch.autograd.Function):
         w_ih = torch.empty(ndir * 4 * H, I, device=dev, dtype=torch.float32)
         bias = torch.empty(ndir * 4 * H, device=dev, dtype=torch.float32)
         hb.lstm_pack(params, ndir, w_ih, ws["w_hh"], bias)
-        ws["lens"].copy_(lens)
+        ws["lens"] = lens                      # int32 device tensor, kept for the backward (no copy)
         hb.gemm(x2, w_ih, trans_b=True, bias=bias, out=ws["gates"].view(T * B, ndir * 4 * H))
         hb.lstm_seq_fwd(ws["gates"], ws["w_hh"], ws["lens"], ws["y"], ws["c"], use_graphs=pooled)
         ctx.save_for_backward(x2, w_ih)

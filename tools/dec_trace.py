@@ -28,7 +28,7 @@ ws["G"][1:, :, :D + O] = rnd(L, B, D + O, sc=0.01)
 ws["wcatT"].copy_(ws["wcat"].t()); ws["wdecT"].copy_(wdec.t())
 w = dict(ws); w["dws"] = None
 fs = ops._dec_fwd_struct(d, 0, B); bs = ops._dec_bwd_struct(d, w, 0, B)
-xch, ctrl = hb.persist_scratch(dev)
+xch, ctrl = hb.persist_scratch(dev, trace=True)
 st = hb.stream()
 l = ctypes.CDLL(ROOT + '/scratchlibs/lib_trace.so')
 l.asr_dec_seq_fwd_persist.argtypes = [ctypes.POINTER(hb.DecFwd), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]

@@ -17,7 +17,7 @@ gact = (torch.rand(T, B, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
 dy = (torch.randn(T, B, 2 * H, generator=g) * 0.01).to(dev); cc = torch.randn(T, B, 2 * H, generator=g).to(dev)
 yy = torch.tanh(torch.randn(T, B, 2 * H, generator=g)).to(dev); dw = torch.zeros(2, 4 * H, H, device=dev)
 db = torch.zeros(2 * 4 * H, device=dev)
-xch, ctrl = hb.persist_scratch(dev)
+xch, ctrl = hb.persist_scratch(dev, trace=True)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = hb.stream()
 l = ctypes.CDLL(ROOT + '/scratchlibs/lib_lptrace.so')
