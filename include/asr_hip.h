@@ -245,6 +245,9 @@ int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_s
 typedef struct {
   int mode;
   int V;
+  int eos;             /* >= 0: a group of 4 utterances stops once each has emitted this token (decoding without a
+                          backward: solver.py:212-242 strips everything after the first <EOS> anyway); the caller
+                          pre-fills pred / logits of the steps that are then not run.  -1: run all L steps. */
   float scaling;
   const float* w_out;  /* [V][D+O] */
   const float* b_out;  /* [V] or NULL */

@@ -52,7 +52,8 @@ constexpr int DX_F = DX_C + 2 * 4 * 512;           // [2][4][16][TPM]
 constexpr int DX_E = DX_F + 2 * 4 * 16 * DP_TPM;   // [2][32][4][TPM]
 constexpr int DX_U = DX_E + 2 * 32 * 4 * DP_TPM;  // [2][4][512]  free-running only: ctx before the dropout mask
 constexpr int DX_M = DX_U + 2 * 4 * 512;           // [2][4][128]  free-running only: embedding input of the step
-constexpr int DX_GROUP = DX_M + 2 * 4 * 128;
+constexpr int DX_S = DX_M + 2 * 4 * 128;           // [2][2]       free-running only: "every row of the group has emitted <EOS>"
+constexpr int DX_GROUP = DX_S + 2 * 2 + 4;
 
 struct DecPersistArgs {
   int B, nb, Tp, C, K, L;
@@ -62,7 +63,7 @@ struct DecPersistArgs {
   float* xch;
   unsigned* ctrl;
   // free-running feedback (kernel template FB): 1 = embedding of the predicted token, 2 = smooth embedding
-  int fb_mode, V;
+  int fb_mode, V, eos;     // eos >= 0: a group stops once all of its rows have emitted eos (decoding without autograd)
   float fb_scale;
   const float *w_out, *b_out, *emb;
   float *logits, *probs;
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     const int eb = r0 + er;
     emb_next[i] = (er < 4) ? Xin[((int64_t)0 * B + (eb < nb ? eb : r0)) * KX + DD + OO + ee] : 0.f;
   }
+  unsigned rows_done = 0u;                    // FB, slice 0: bit i = row i of the group has emitted <EOS>
   float mask_next = 1.f;                      // dropout mask of ctx_s as consumed by step s+1's cell
   if (drop && ctx_thread && L > 1) mask_next = a.xmask[((int64_t)1 * B + abc) * (OO + EE) + OQ * aq + tid];
   __syncthreads();
@@ -355,8 +357,16 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
           } else if (lane_ == 0) {
             prs[wave * 64] = __int_as_float(am);
           }
+          if (lane_ == 0) cred[512 + wave] = __int_as_float((am == a.eos || !bok) ? 1 : 0);
         }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows_done |= (unsigned)__float_as_int(cred[512 + i]) << i;
+        if (tid_ == 0) {
+          const float stop = (a.eos >= 0 && rows_done == 0xFu) ? 2.0f : 0.f;      // LSB carries the tag
+          word_store(xg + DX_S + ((s - 1) & 1) * 2, stop, tag_bit_of_step(s - 1));
+          word_store(xg + DX_S + ((s - 1) & 1) * 2 + 1, stop, tag_bit_of_step(s - 1));
+        }
         {
           const int row = tid_ >> 7, e = tid_ & 127, b = r0 + row;
           const bool bok = b < nb;
@@ -379,14 +389,18 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       {
         const int id = tid_ & 255;                       // 256 pairs over [4][128]; the upper half mirrors
         // (this exchange is first used at step 1: slot and tag follow s - 1, so that the zeroed buffer reads invalid)
-        const u64* p1[1] = {reinterpret_cast<const u64*>(xg + DX_M + ((s - 1) & 1) * 512 + 2 * id)};
-        u64 v1[1];
-        poll_pairs<1, true>(p1, tag_bit_of_step(s - 1), v1, a.ctrl, aborted, 17u);
+        const u64* p1[2] = {reinterpret_cast<const u64*>(xg + DX_S + ((s - 1) & 1) * 2),
+                            reinterpret_cast<const u64*>(xg + DX_M + ((s - 1) & 1) * 512 + 2 * id)};
+        u64 v1[2];
+        poll_pairs<2, true>(p1, tag_bit_of_step(s - 1), v1, a.ctrl, aborted, 17u);
         if (tid_ < 256) {
           const int row = id >> 6, e2 = 2 * (id & 63);
-          xs[row * XS + DD + OO + e2] = pair_lo(v1[0]);
-          xs[row * XS + DD + OO + e2 + 1] = pair_hi(v1[0]);
+          xs[row * XS + DD + OO + e2] = pair_lo(v1[1]);
+          xs[row * XS + DD + OO + e2 + 1] = pair_hi(v1[1]);
         }
+        // every row of this group has emitted <EOS>: all 32 CUs read the same word and leave together (the caller
+        // pre-fills the outputs of the steps that are not run)
+        if (pair_lo(v1[0]) >= 1.0f && !aborted) break;
       }
     } else {
 #pragma unroll
@@ -1462,11 +1476,11 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
     a.fconv = p->fconv + (int64_t)rb * C * Tp; a.S = p->S + (int64_t)rb * Tp * A;
     a.energy = p->energy + (int64_t)rb * Tp; a.ws = p->ws + (int64_t)rb * Tp;
     a.xch = (float*)xch; a.ctrl = (unsigned*)ctrl;
-    a.fb_mode = 0; a.V = 0; a.fb_scale = 1.f; a.w_out = a.b_out = a.emb = nullptr; a.logits = a.probs = nullptr;
+    a.fb_mode = 0; a.V = 0; a.eos = -1; a.fb_scale = 1.f; a.w_out = a.b_out = a.emb = nullptr; a.logits = a.probs = nullptr;
     a.pred = a.fed = nullptr;
     int rc;
     if (f) {
-      a.fb_mode = f->mode; a.V = f->V; a.fb_scale = f->scaling; a.w_out = f->w_out; a.b_out = f->b_out; a.emb = f->emb;
+      a.fb_mode = f->mode; a.V = f->V; a.eos = f->eos; a.fb_scale = f->scaling; a.w_out = f->w_out; a.b_out = f->b_out; a.emb = f->emb;
       a.logits = f->logits + (int64_t)rb * f->V; a.probs = f->probs ? f->probs + (int64_t)rb * f->V : nullptr;
       a.pred = (long long*)f->pred + rb; a.fed = (long long*)f->fed + rb;
       rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true>(a, stream) : launch_dec_fwd<320, 320, 320, 128, true>(a, stream);

@@ -31,7 +31,7 @@ c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_vo
 
 class DecFeedback(ctypes.Structure):
     """asr_dec_feedback_t"""
-    _fields_ = [("mode", c_i), ("V", c_i), ("scaling", c_f), ("w_out", c_p), ("b_out", c_p), ("emb", c_p), ("logits", c_p),
+    _fields_ = [("mode", c_i), ("V", c_i), ("eos", c_i), ("scaling", c_f), ("w_out", c_p), ("b_out", c_p), ("emb", c_p), ("logits", c_p),
                 ("probs", c_p), ("pred", c_p), ("fed", c_p)]
 
 
@@ -411,6 +411,9 @@ USE_PERSIST_DEC = USE_PERSIST and os.environ.get("ASR_PERSIST_DEC", "1") != "0" 
 USE_PERSIST_DEC_BWD = USE_PERSIST and os.environ.get("ASR_PERSIST_DEC_BWD", "1") != "0"   # ... and backward
 # free-running decode: fused logits/argmax/next-embedding kernel per step (off: the same steps through torch glue)
 USE_FEEDBACK_KERNEL = os.environ.get("ASR_FEEDBACK_KERNEL", "1") != "0"
+# greedy decode without autograd: a group of 4 utterances stops once all of them have emitted <EOS> (what follows the
+# first <EOS> is stripped by the CER path; the predictions of the skipped steps read <EOS>)
+DECODE_EARLY_STOP = os.environ.get("ASR_DECODE_EARLY_STOP", "1") != "0"
 _persist_scratch = {}
 
 

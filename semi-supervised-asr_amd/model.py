@@ -262,7 +262,7 @@ class Decoder(torch.nn.Module):
         att.reset()
         have_ys = ys is not None and len(ys) > 0
         opts = dict(scaling=2.0, smooth=bool(smooth), smooth_scaling=float(scaling), sample=bool(sample),
-                    bos=self.bos)                    # attention temperature is the AttLoc default
+                    bos=self.bos, eos=self.eos)      # attention temperature is the AttLoc default
         if ys is not None:
             tok_in, tok_out = self._label_matrices(ys, olength)
             steps = tok_out.size(1)

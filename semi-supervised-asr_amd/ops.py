@@ -380,8 +380,17 @@ class _DecoderSeq(torch.autograd.Function):
                     Xd[0, :, D + O:] = X[0, :, D + O:] * xmask[0, :, O:]
                 if hb.USE_PERSIST_DEC and tok_c is None and V <= 64 and len(hb.row_groups(B)) == 1:
                     # no teacher tokens at all: the whole sequence in one launch, the feedback computed in the kernel
+                    # decoding without autograd: a group of 4 utterances stops once all of them have emitted <EOS>; the
+                    # outputs of the steps that are not run read <EOS> / zero logits / zero attention weights
+                    eos = int(opts.get("eos", -1))
+                    stop = hb.DECODE_EARLY_STOP and eos >= 0 and not torch.is_grad_enabled()
+                    if stop:
+                        pred.fill_(eos)
+                        logits.zero_()
+                        ws["ws"].zero_()
                     fb = hb.DecFeedback(
-                        mode=2 if smooth else 1, V=V, scaling=float(opts.get("smooth_scaling", 1.0)), w_out=_p(w_out_c),
+                        mode=2 if smooth else 1, V=V, eos=eos if stop else -1,
+                        scaling=float(opts.get("smooth_scaling", 1.0)), w_out=_p(w_out_c),
                         b_out=_p(b_out.contiguous()), emb=_p(emb_c), logits=_p(logits),
                         probs=_p(probs_saved) if smooth else None, pred=ctypes.c_void_p(pred.data_ptr()),
                         fed=ctypes.c_void_p(fed.data_ptr()))
@@ -390,7 +399,17 @@ class _DecoderSeq(torch.autograd.Function):
                                                           ctypes.c_void_p(ctrl.data_ptr()), hb.stream())
                     if rc == 0:
                         done = True
-                        hb.dec_feedback_fwd(X[L][:, :D + O], w_out_c, b_out, emb_c, logits[L - 1], pred[L - 1], hb.FEED_NONE)
+                        if stop and L > 1:
+                            # the last step's logits come from X[L], which a stopped group never wrote: rows that had
+                            # already emitted <EOS> keep the pre-filled outputs
+                            lg_last, pr_last = torch.empty(B, V, **f32), torch.empty(B, dtype=torch.long, device=dev)
+                            hb.dec_feedback_fwd(X[L][:, :D + O], w_out_c, b_out, emb_c, lg_last, pr_last, hb.FEED_NONE)
+                            live = pred[:L - 1].ne(eos).all(0)
+                            pred[L - 1] = torch.where(live, pr_last, pred[L - 1])
+                            logits[L - 1] = torch.where(live.unsqueeze(1), lg_last, logits[L - 1])
+                        else:
+                            hb.dec_feedback_fwd(X[L][:, :D + O], w_out_c, b_out, emb_c, logits[L - 1], pred[L - 1],
+                                                hb.FEED_NONE)
                     elif rc != -2:
                         hb.check(rc, "asr_dec_seq_fwd_persist_free")
                 for s in (range(L) if not done else ()):

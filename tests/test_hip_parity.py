@@ -869,3 +869,44 @@ def test_seeded_dropout_end_to_end_equals_explicit_masks(monkeypatch):
     _close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-7, what="seeded vs explicit logits")
     for n in outs[0][1]:
         _close(outs[0][1][n], outs[1][1][n], rtol=1e-5, atol=1e-7, what="seeded vs explicit grad " + n)
+
+
+@pytest.mark.parametrize("eos_bias", [0.0, 1.5, 30.0])
+def test_greedy_decode_early_stop(eos_bias):
+    """Decoding without autograd may stop a group of 4 utterances once all of them have emitted <EOS>:
+    up to and including each utterance's first <EOS> the predictions equal those of the full-length decode, and the
+    CER path (utils.remove_pad_eos) sees identical hypotheses."""
+    dev = _gpu()
+    import hip_backend as hb
+    from utils import remove_pad_eos
+    cfg = dict(input_dim=16, enc_hidden_dim=128, enc_n_layers=1, subsample=[2], dropout_rate=0.0, dec_hidden_dim=320,
+               att_dim=320, conv_channels=10, conv_kernel_size=20, att_odim=320, embedding_dim=128, output_dim=12,
+               ls_weight=0.0)
+    w = synth.e2e_weights(cfg, 71)
+    w["decoder.output_layer.bias"] = w["decoder.output_layer.bias"].copy()
+    w["decoder.output_layer.bias"][2] += eos_bias
+    net = _product(cfg, w, synth.labeldist(12, 3), dev).eval()
+    xs, ilens, _ = synth.batch(16, 12, [40, 37, 33, 30, 28, 25, 21, 18, 12], [3] * 9, 72)
+    xs_d = torch.from_numpy(xs).to(dev)
+    outs = {}
+    for stop in (False, True):
+        old = hb.DECODE_EARLY_STOP
+        hb.DECODE_EARLY_STOP = stop
+        try:
+            with torch.no_grad():
+                _, _, pred, _ = net(xs_d, ilens, ys=None, max_dec_timesteps=25)
+            assert not hb.persist_aborted(dev)
+            outs[stop] = pred.cpu().numpy()
+        finally:
+            hb.DECODE_EARLY_STOP = old
+    full, early = outs[False], outs[True]
+    assert full.shape == early.shape == (9, 25)
+    assert remove_pad_eos(full.tolist(), eos=2) == remove_pad_eos(early.tolist(), eos=2)
+    for b in range(9):
+        hit = np.where(full[b] == 2)[0]
+        upto = int(hit[0]) + 1 if len(hit) else 25
+        assert (full[b, :upto] == early[b, :upto]).all(), b
+    if eos_bias >= 30.0:
+        assert (early == 2).all()
+    if eos_bias == 0.0:
+        assert (full == early).all() or (full == 2).any()
