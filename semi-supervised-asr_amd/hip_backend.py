@@ -139,9 +139,13 @@ def _rowmajor(t):
 
 def auto_split_k(M, N, K, batch=1, epilogue=False):
     """Split-K factor (partials are added with f32 atomics; a bias/ReLU epilogue then needs a second pass over C).
-    Measured on MI355X (tools/gemm_split_sweep.py): with K >= 2048 the 128x128 tiling leaves the 256 CUs unevenly
-    loaded unless there are several workgroups per CU, and ~6 K-slices is the sweet spot from 100 to 400 output
-    tiles; below ~128 tiles even K = 512 is worth splitting (a workgroup's K loop is a serial chain)."""
+    For K >= 2048 it minimises a wave-quantisation model fitted on MI355X with cold operands
+    (tools/gemm_cold_split_sweep.py): 256 CUs hold two 128x128 workgroups each, so tiles*s workgroups run as
+    full passes of 512 plus a remainder that costs a whole pass if it exceeds 256 (two workgroups share a CU) and
+    0.56 of one otherwise; each K slice adds ~1 % (zero fill + atomics), an epilogue pass ~8 %.  That picks 5 for
+    200 / 400 tiles (1 000 / 2 000 workgroups), 4 for 128, 7 for 144 and 8 for 64 tiles - within 2 % of the best
+    measured factor for every large GEMM of the cfg-2 step.  Below K = 2048 the earlier measured rule stands: even
+    K = 512 is worth splitting under ~128 tiles (a workgroup's K loop is a serial chain)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if tiles >= 1024 or K < 512:
         return 1
@@ -149,12 +153,17 @@ def auto_split_k(M, N, K, batch=1, epilogue=False):
         if tiles > 128 or (epilogue and tiles > 64):
             return 1
         return int(max(1, min(8 if tiles <= 32 else 4, K // 128)))
-    if epilogue and tiles > 256:
-        return 1
-    want = 6 if tiles >= 100 else (8 if tiles >= 48 else 16)
-    if 700 <= tiles * want <= 800:       # exactly 3 workgroups per CU measured 15 % slower than 2 or 4 (cold operands)
-        want = 8
-    return int(max(1, min(want, K // 256)))
+    best, best_cost = 1, None
+    for sk in range(1, 17):
+        if sk > 1 and K // sk < 256:
+            break
+        wgs = tiles * sk
+        rem = wgs % 512
+        passes = wgs // 512 + (0.0 if rem == 0 else (0.56 if rem <= 256 else 1.0))
+        cost = passes / sk * (1.0 + 0.01 * sk) * (1.08 if (epilogue and sk > 1) else 1.0)
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = sk, cost
+    return best
 
 
 def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, split_k=None):
