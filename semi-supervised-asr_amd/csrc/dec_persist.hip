@@ -1361,15 +1361,16 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
   }
 }
 
-// M[s][b][c][t] = sum_a U[a][c] g[a] S[s][b][t][a]^2  (forward data only).  grid (B, L), 256 threads; wave w owns the
-// 16-frame tiles w, w+4, ...; contraction on the 16x16x4 MFMA with the k-permutation of common.h (a lane's float4 of
-// S feeds 4 MFMAs).  LDS: UG[a][16] = U[a][c] g[a], zero beyond C.
+// M[s][b][c][t] = sum_a U[a][c] g[a] S[s][b][t][a]^2  (forward data only).  256 threads; a workgroup stages UG once and
+// then walks (b, s) pairs with a grid stride (one pair per workgroup re-staged 32 KB of UG 3 232 times); wave w owns
+// the 16-frame tiles w, w+4, ...; contraction on the 16x16x4 MFMA with the k-permutation of common.h (a lane's float4
+// of S feeds 4 MFMAs, alternating between two accumulators).  LDS: UG[a][16] = U[a][c] g[a], zero beyond C.
 template <int AA>
-__global__ __launch_bounds__(256) void att_m_kernel(int B, int Tp, int C, const float* __restrict__ S,
+__global__ __launch_bounds__(256) void att_m_kernel(int B, int nb, int L, int Tp, int C, const float* __restrict__ S,
                                                     const float* __restrict__ watt, const float* __restrict__ gvec,
                                                     float* __restrict__ Mf) {
   __shared__ __attribute__((aligned(16))) float UG[AA * 16];
-  const int b = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // unguarded, batched loads (a load under `c < C ?` is waited for on the spot: 32 serial L2 round trips per workgroup)
   for (int i0 = 0; i0 < AA * 16; i0 += 256 * 8) {
     float wv[8], gq[8];
@@ -1386,27 +1387,30 @@ __global__ __launch_bounds__(256) void att_m_kernel(int B, int Tp, int C, const 
     }
   }
   __syncthreads();
-  const float* Sb = S + ((int64_t)s * B + b) * Tp * AA;
   const int r = lane & 15, q = lane >> 4;
-  for (int tile = wave; 16 * tile < Tp; tile += 4) {
-    const int t = 16 * tile + r;
-    const float* row = Sb + (int64_t)(t < Tp ? t : Tp - 1) * AA + 4 * q;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int pair = blockIdx.x; pair < nb * L; pair += gridDim.x) {
+    const int s = pair / nb, b = pair - s * nb;
+    const float* Sb = S + ((int64_t)s * B + b) * Tp * AA;
+    for (int tile = wave; 16 * tile < Tp; tile += 4) {
+      const int t = 16 * tile + r;
+      const float* row = Sb + (int64_t)(t < Tp ? t : Tp - 1) * AA + 4 * q;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (int kq = 0; kq < AA / 16; ++kq) {
-      const float4 sv = *reinterpret_cast<const float4*>(row + 16 * kq);
-      const float* ub = UG + (16 * kq + 4 * q) * 16 + r;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.x * sv.x, ub[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.y * sv.y, ub[16], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.z * sv.z, ub[32], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.w * sv.w, ub[48], acc, 0, 0, 0);
-    }
-    // D: lane holds frames 16*tile + 4q + i of channel r
-    if (r < C) {
+      for (int kq = 0; kq < AA / 16; ++kq) {
+        const float4 sv = *reinterpret_cast<const float4*>(row + 16 * kq);
+        const float* ub = UG + (16 * kq + 4 * q) * 16 + r;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.x * sv.x, ub[0], acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.y * sv.y, ub[16], accb, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.z * sv.z, ub[32], acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(sv.w * sv.w, ub[48], accb, 0, 0, 0);
+      }
+      // D: lane holds frames 16*tile + 4q + i of channel r
+      if (r < C) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int tt = 16 * tile + 4 * q + i;
-        if (tt < Tp) Mf[(((int64_t)s * B + b) * C + r) * Tp + tt] = acc[i];
+        for (int i = 0; i < 4; ++i) {
+          const int tt = 16 * tile + 4 * q + i;
+          if (tt < Tp) Mf[(((int64_t)s * B + b) * C + r) * Tp + tt] = acc[i] + accb[i];
+        }
       }
     }
   }
@@ -1542,10 +1546,10 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
     hipError_t e = persist_reset(xch, ctrl, (size_t)8 * BX_GROUP * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
     if (cfg2)
-      hipLaunchKernelGGL((att_m_kernel<512>), dim3(nbb, p->L), dim3(256), 0, stream, B, Tp, C,
+      hipLaunchKernelGGL((att_m_kernel<512>), dim3(nbb * p->L < 1024 ? nbb * p->L : 1024), dim3(256), 0, stream, B, nbb, p->L, Tp, C,
                          p->S + (int64_t)rb * Tp * A, p->watt, p->gvec, mbuf + (int64_t)rb * C * Tp);
     else
-      hipLaunchKernelGGL((att_m_kernel<320>), dim3(nbb, p->L), dim3(256), 0, stream, B, Tp, C,
+      hipLaunchKernelGGL((att_m_kernel<320>), dim3(nbb * p->L < 1024 ? nbb * p->L : 1024), dim3(256), 0, stream, B, nbb, p->L, Tp, C,
                          p->S + (int64_t)rb * Tp * A, p->watt, p->gvec, mbuf + (int64_t)rb * C * Tp);
     DecPersistBwdArgs a;
     a.B = B; a.nb = nbb; a.Tp = Tp; a.C = C; a.K = p->K; a.L = p->L; a.scaling = p->scaling;
