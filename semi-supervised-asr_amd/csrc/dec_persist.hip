@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(256) void att_m_kernel(int B, int nb, int L, int Tp
       const int t = 16 * tile + r;
       const float* row = Sb + (int64_t)(t < Tp ? t : Tp - 1) * AA + 4 * q;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+#pragma unroll 16
       for (int kq = 0; kq < AA / 16; ++kq) {
         const float4 sv = *reinterpret_cast<const float4*>(row + 16 * kq);
         const float* ub = UG + (16 * kq + 4 * q) * 16 + r;
@@ -1546,10 +1546,10 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
     hipError_t e = persist_reset(xch, ctrl, (size_t)8 * BX_GROUP * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
     if (cfg2)
-      hipLaunchKernelGGL((att_m_kernel<512>), dim3(nbb * p->L < 1024 ? nbb * p->L : 1024), dim3(256), 0, stream, B, nbb, p->L, Tp, C,
+      hipLaunchKernelGGL((att_m_kernel<512>), dim3(nbb * p->L < 2048 ? nbb * p->L : 2048), dim3(256), 0, stream, B, nbb, p->L, Tp, C,
                          p->S + (int64_t)rb * Tp * A, p->watt, p->gvec, mbuf + (int64_t)rb * C * Tp);
     else
-      hipLaunchKernelGGL((att_m_kernel<320>), dim3(nbb * p->L < 1024 ? nbb * p->L : 1024), dim3(256), 0, stream, B, nbb, p->L, Tp, C,
+      hipLaunchKernelGGL((att_m_kernel<320>), dim3(nbb * p->L < 2048 ? nbb * p->L : 2048), dim3(256), 0, stream, B, nbb, p->L, Tp, C,
                          p->S + (int64_t)rb * Tp * A, p->watt, p->gvec, mbuf + (int64_t)rb * C * Tp);
     DecPersistBwdArgs a;
     a.B = B; a.nb = nbb; a.Tp = Tp; a.C = C; a.K = p->K; a.L = p->L; a.scaling = p->scaling;
