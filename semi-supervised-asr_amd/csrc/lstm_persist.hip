@@ -25,6 +25,9 @@
 #ifndef ASR_POLL_SLEEP
 #define ASR_POLL_SLEEP 1
 #endif
+#ifndef ASR_LSTM_BWD_B128      /* hand-off rows of the backward read with one 16-byte sc1 buffer load each */
+#define ASR_LSTM_BWD_B128 1
+#endif
 #ifndef ASR_LSTM_FWD_WORDS
 #define ASR_LSTM_FWD_WORDS 0      /* forward hand-off: granules + sentinel (0, 2.35 us/step) or single-stage LSB-tagged
                                     words (1, measured 2.38-2.45 us/step with poll sleeps 1..10: no gain) */
@@ -397,6 +400,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of this thread's (unit, row): sum of dG over time
   float* xch_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * PRG * 4 * PH;   // + parity * 8*PRG*4H
   const int64_t par_stride = (int64_t)8 * PRG * 4 * PH;
+#if ASR_LSTM_BWD_B128
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);   // raw dwords
+#endif
   bool aborted = false;
   // pointwise operands are fetched one step ahead (see the forward kernel)
   float n_dy = 0.f, n_ct = 0.f, n_cp = 0.f, n_y = 0.f;
@@ -437,11 +444,20 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
       float4 gr[NR];
       unsigned spins = 0;
       auto load_row = [&](int rr) {
+#if ASR_LSTM_BWD_B128
+        // L1-bypassing 16-byte read in ONE instruction: buffer load with the sc1 cache policy (the same policy the
+        // agent-scope atomic loads get, which exist only up to 8 bytes)
+        const u4v v = __builtin_amdgcn_raw_buffer_load_b128(
+            xrs, (unsigned)((src - reinterpret_cast<const float*>(a.xch)) + rr * 4 * PH) * 4u, 0, 16);
+        gr[rr].x = __uint_as_float(v.x); gr[rr].y = __uint_as_float(v.y);
+        gr[rr].z = __uint_as_float(v.z); gr[rr].w = __uint_as_float(v.w);
+#else
         // L1-bypassing 16-byte read as two 8-byte agent-scope atomics
         const u64 lo = granule_load(reinterpret_cast<const u64*>(src + (int64_t)rr * 4 * PH));
         const u64 hi = granule_load(reinterpret_cast<const u64*>(src + (int64_t)rr * 4 * PH) + 1);
         gr[rr].x = __uint_as_float((unsigned)lo); gr[rr].y = __uint_as_float((unsigned)(lo >> 32));
         gr[rr].z = __uint_as_float((unsigned)hi); gr[rr].w = __uint_as_float((unsigned)(hi >> 32));
+#endif
       };
       auto row_bits = [&](int rr) -> unsigned {
         const unsigned m = (__float_as_uint(gr[rr].x) & 1u) | ((__float_as_uint(gr[rr].y) & 1u) << 1) |
