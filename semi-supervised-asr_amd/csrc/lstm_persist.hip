@@ -29,8 +29,9 @@
 #define ASR_LSTM_BWD_B128 1
 #endif
 #ifndef ASR_LSTM_FWD_WORDS
-#define ASR_LSTM_FWD_WORDS 0      /* forward hand-off: granules + sentinel (0, 2.35 us/step) or single-stage LSB-tagged
-                                    words (1, measured 2.38-2.45 us/step with poll sleeps 1..10: no gain) */
+#define ASR_LSTM_FWD_WORDS 2      /* forward hand-off: 0 = 8-byte {tag,value} granules + sentinel (2.35 us/step),
+                                     1 = single-stage LSB-tagged words read as 8-byte atomics (2.38-2.45),
+                                     2 = the same words read with 16-byte sc1 buffer loads (2.05) */
 #endif
 #ifndef ASR_LSTM_TOUCH
 #define ASR_LSTM_TOUCH 1
@@ -85,8 +86,8 @@ struct PersistArgs {
 template <int PH, int NR>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   static_assert(NR == 4 || NR == PRG, "rows per group");
-#if ASR_LSTM_FWD_WORDS
-  static_assert(NR == PRG, "the word protocol is only written for 8 rows");
+#if ASR_LSTM_FWD_WORDS == 1
+  static_assert(NR == PRG, "the 8-byte word protocol is only written for 8 rows");
 #endif
   constexpr int PKW = PH / PW;     // K columns per wave
   constexpr int PUC = PH / 32;     // hidden units per CU (<= 16 MFMA blocks)
@@ -129,6 +130,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   u64* xch_g = a.xch + (int64_t)g * PRG * PH;          // + parity * 8*PRG*PH
   float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * PRG;   // word protocol: [parity][unit][row]
   const int64_t par_stride = (int64_t)8 * PRG * PH;
+#if ASR_LSTM_FWD_WORDS == 2
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
+#endif
   bool aborted = false;
   // The x-projection rows are fetched TWO steps ahead: they are HBM first-touch loads (~2 us under load, about one
   // forward step), vmcnt retires in order, and the row is consumed at the top of its step -- one step of distance
@@ -161,7 +166,35 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-#if ASR_LSTM_FWD_WORDS
+#if ASR_LSTM_FWD_WORDS == 2
+      // Single-stage hand-off, 16-byte reads: h_{t-1} travels as LSB-tagged fp32 words laid out [unit][row], so the rows
+      // of a lane's unit are contiguous and one sc1 buffer load (two for 8 rows) is data and flag at once: no sentinel
+      // round trip, and a quarter of the load instructions of the 8-byte granule protocol.
+      const bool gl = lane < PKW;
+      const unsigned boff = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
+                                       (wave * PKW + (gl ? lane : 0)) * PRG) * 4u;
+      const unsigned tb = tag_bit_of_step(s - 1);
+      u4v gw[NR / 4];
+      unsigned spins = 0;
+      while (true) {
+#pragma unroll
+        for (int j = 0; j < NR / 4; ++j) gw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff + 16u * j, 0, 16);
+        unsigned bits = 1u;
+#pragma unroll
+        for (int j = 0; j < NR / 4; ++j) bits &= ~(gw[j].x ^ tb) & ~(gw[j].y ^ tb) & ~(gw[j].z ^ tb) & ~(gw[j].w ^ tb);
+        LP_MARK(7);
+        if (__all(!gl || (bits & 1u))) break;
+#ifdef ASR_NO_POLL
+        break;
+#endif
+        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
+          aborted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+      }
+#elif ASR_LSTM_FWD_WORDS
       // Single-stage hand-off: h_{t-1} travels as LSB-tagged fp32 words laid out [unit][row], so a lane's 8 rows are
       // 32 contiguous bytes = four 8-byte L1-bypassing loads that are data and flag at once (no sentinel round trip:
       // publish -> first seen is ~0.5 us, a second dependent round trip for the tile costs another ~0.55 us).
@@ -243,7 +276,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
 #ifdef ASR_LP_TRACE
       if (tid == 0 && g == 0 && slice == 0 && s >= 8 && s < 16) ((unsigned long long*)(a.ctrl + 16))[(s - 8) * 16 + 8] = spins;
 #endif
-#if ASR_LSTM_FWD_WORDS
+#if ASR_LSTM_FWD_WORDS == 2
+#pragma unroll
+      for (int j = 0; j < NR / 4; ++j)
+        if (gl) {
+          hs[wave][4 * j][lane] = __uint_as_float(gw[j].x); hs[wave][4 * j + 1][lane] = __uint_as_float(gw[j].y);
+          hs[wave][4 * j + 2][lane] = __uint_as_float(gw[j].z); hs[wave][4 * j + 3][lane] = __uint_as_float(gw[j].w);
+        }
+#elif ASR_LSTM_FWD_WORDS
 #pragma unroll
       for (int rr = 0; rr < PRG / 2; ++rr)
         if (gl) { hs[wave][2 * rr][lane] = pair_lo(gr[rr]); hs[wave][2 * rr + 1][lane] = pair_hi(gr[rr]); }
