@@ -40,7 +40,7 @@
 #define ASR_LSTM_TOUCH_DIST 3
 #endif
 #ifndef ASR_LSTM_BWD_FULL_WAVES
-#define ASR_LSTM_BWD_FULL_WAVES 2
+#define ASR_LSTM_BWD_FULL_WAVES 8  /* waves whose first poll attempt requests the whole tile (16-byte loads: 8 per lane); with the 8-byte loads only the pointwise waves (2) paid off: 3.85 (2) -> 3.78 (4) -> 3.62 (8) us per step */
 #endif
 #ifndef ASR_LSTM_FULL_WAVES
 #define ASR_LSTM_FULL_WAVES 2      /* waves 0..1 hold the pointwise threads (PUC*PRG <= 128) */
