@@ -132,6 +132,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
   const bool drop = a.xmask != nullptr;
   const float* Xin = drop ? a.Xd : a.X;
   float* xg = a.xch + (int64_t)g * DX_GROUP;
+  const __amdgpu_buffer_rsrc_t xrs = make_xch_rsrc(a.xch);
   bool aborted = false;
 
   // ---------------------------------------------------------------- per-role constants
@@ -244,21 +245,25 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     DP_MARK(0);
     // ------------------------------------------------------------ (1) cell operand: ctx_{s-1} (exchange) + emb_s
     if (s > 0) {
-      const float* cx = xg + DX_C + ((s - 1) & 1) * 4 * 512;
-      const u64* p[NC];
-      u64 v[NC];
+      // quads over [4][OO/4] (16-byte sc1 buffer loads: half the load instructions of the pair poll)
+      constexpr int NQ = (OO + DP_NT - 1) / DP_NT;
+      const unsigned cbase = (unsigned)((xg - a.xch) + DX_C + ((s - 1) & 1) * 4 * 512) * 4u;
+      unsigned off[NQ];
+      u4v v[NQ];
 #pragma unroll
-      for (int i = 0; i < NC; ++i) {
-        const int id = tid_ + DP_NT * i;                 // pair id over [4][OO/2]
-        const int row = (2 * id) / OO, o = 2 * id - row * OO;
-        p[i] = reinterpret_cast<const u64*>(cx + ((2 * id < 4 * OO) ? row * 512 + o : 0));
+      for (int i = 0; i < NQ; ++i) {
+        const int id = tid_ + DP_NT * i;                 // quad id over [4][OO/4]
+        const int row = (4 * id) / OO, o = 4 * id - row * OO;
+        off[i] = cbase + (unsigned)((4 * id < 4 * OO) ? row * 512 + o : 0) * 4u;
       }
-      poll_pairs<NC, ASR_DP_FULL>(p, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 11u);
+      poll_quads<NQ, true>(xrs, off, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 11u);
 #pragma unroll
-      for (int i = 0; i < NC; ++i) {
+      for (int i = 0; i < NQ; ++i) {
         const int id = tid_ + DP_NT * i;
-        const int row = (2 * id) / OO, o = 2 * id - row * OO;
-        if (2 * id < 4 * OO) { xs[row * XS + DD + o] = pair_lo(v[i]); xs[row * XS + DD + o + 1] = pair_hi(v[i]); }
+        const int row = (4 * id) / OO, o = 4 * id - row * OO;
+        if (4 * id < 4 * OO)
+          *reinterpret_cast<float4*>(xs + row * XS + DD + o) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
+                                                                          __uint_as_float(v[i].z), __uint_as_float(v[i].w));
       }
     }
     if (FB && s > 0) {
@@ -499,39 +504,44 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     DP_MARK(4);
     // ------------------------------------------------------------ (4)+(5) z_s and f_s (exchange) -> W_dec z_s for AU columns
     {
-      // one poll for both: z_s pairs over [4][DD/2] and the conv features f_s (published ~2 us ago) as pairs
-      // id = tid + 512 i over [4 rows][C][TpP/2]; small-integer divisions via exact float reciprocals
-      const float* zx = xg + DX_Z + par * 4 * 512;
-      const float* fx = xg + DX_F + par * 4 * 16 * DP_TPM;
-      const int hp = TpP >> 1;
-      const float rhp = 1.0f / (float)hp, rC = 1.0f / (float)C;
-      int foff[4];
-      const u64* p[NZ + 4];
-      u64 v[NZ + 4];
+      // one poll for both, in 16-byte quads: z_s over [4][DD/4] and the conv features f_s (published ~2 us ago) over
+      // [4 rows][C][TpP/4], id = tid + 512 i; small-integer divisions via exact float reciprocals
+      constexpr int NZQ = (DD + DP_NT - 1) / DP_NT;
+      const unsigned zbase = (unsigned)((xg - a.xch) + DX_Z + par * 4 * 512) * 4u;
+      const unsigned fbase = (unsigned)((xg - a.xch) + DX_F + par * 4 * 16 * DP_TPM) * 4u;
+      const int hq = TpP >> 2;
+      const float rhq = 1.0f / (float)hq, rC = 1.0f / (float)C;
+      int foff[2];
+      unsigned off[NZQ + 2];
+      u4v v[NZQ + 2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 2; ++i) {
         const int id = tid_ + DP_NT * i;
-        const int rc = (int)(((float)id + 0.5f) * rhp), t2 = id - rc * hp;
+        const int rc = (int)(((float)id + 0.5f) * rhq), t4 = id - rc * hq;
         const int row = (int)(((float)rc + 0.5f) * rC), c = rc - row * C;
-        foff[i] = rc < 4 * C ? (row * 16 + c) * DP_TPM + 2 * t2 : -1;
-        p[i] = reinterpret_cast<const u64*>(fx + (foff[i] < 0 ? 0 : foff[i]));
+        foff[i] = rc < 4 * C ? (row * 16 + c) * DP_TPM + 4 * t4 : -1;
+        off[i] = fbase + (unsigned)(foff[i] < 0 ? 0 : foff[i]) * 4u;
       }
 #pragma unroll
-      for (int i = 0; i < NZ; ++i) {
+      for (int i = 0; i < NZQ; ++i) {
         const int id = tid_ + DP_NT * i;
-        const int row = (2 * id) / DD, d = 2 * id - row * DD;
-        p[4 + i] = reinterpret_cast<const u64*>(zx + ((2 * id < 4 * DD) ? row * 512 + d : 0));
+        const int row = (4 * id) / DD, d = 4 * id - row * DD;
+        off[2 + i] = zbase + (unsigned)((4 * id < 4 * DD) ? row * 512 + d : 0) * 4u;
       }
-      poll_pairs<NZ + 4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 12u);
+      poll_quads<NZQ + 2, true>(xrs, off, bit, v, a.ctrl, aborted, 12u);
       DP_MARK(5);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (foff[i] >= 0) { fs[foff[i]] = pair_lo(v[i]); fs[foff[i] + 1] = pair_hi(v[i]); }
+      for (int i = 0; i < 2; ++i)
+        if (foff[i] >= 0)
+          *reinterpret_cast<float4*>(fs + foff[i]) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
+                                                                 __uint_as_float(v[i].z), __uint_as_float(v[i].w));
 #pragma unroll
-      for (int i = 0; i < NZ; ++i) {
+      for (int i = 0; i < NZQ; ++i) {
         const int id = tid_ + DP_NT * i;
-        const int row = (2 * id) / DD, d = 2 * id - row * DD;
-        if (2 * id < 4 * DD) { xs[row * XS + d] = pair_lo(v[4 + i]); xs[row * XS + d + 1] = pair_hi(v[4 + i]); }
+        const int row = (4 * id) / DD, d = 4 * id - row * DD;
+        if (4 * id < 4 * DD)
+          *reinterpret_cast<float4*>(xs + row * XS + d) = make_float4(__uint_as_float(v[2 + i].x), __uint_as_float(v[2 + i].y),
+                                                                     __uint_as_float(v[2 + i].z), __uint_as_float(v[2 + i].w));
       }
     }
     __syncthreads();
