@@ -841,6 +841,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
   const int taps = 2 * K + 1, taps4 = ld.taps4, DFS = ld.dfs_stride;
   const bool drop = a.xmask != nullptr;
   float* xg = a.xch + (int64_t)g * BX_GROUP;
+  const __amdgpu_buffer_rsrc_t xrs = make_xch_rsrc(a.xch);
   bool aborted = false;
   const int ar = slice >> 3, aq = slice & 7;
   const int ab = r0 + ar;
@@ -1201,23 +1202,26 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     DP_MARK(5);
     // ------------------------------------------------------------ (f) dz_s for my units, LSTM cell backward
     {
-      const float* dx = xg + BX_D + slot * 4 * 512;
-      constexpr int ND = (2 * AA + DP_NT - 1) / DP_NT;
-      const u64* p[ND];
-      u64 v[ND];
+      // dD of the 4 rows in 16-byte quads over [4][AA/4]
+      constexpr int ND = (AA + DP_NT - 1) / DP_NT;
+      const unsigned dbase = (unsigned)((xg - a.xch) + BX_D + slot * 4 * 512) * 4u;
+      unsigned off[ND];
+      u4v v[ND];
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
         const int id = tid_ + DP_NT * i;
-        const int row = (2 * id) / AA, c2 = 2 * id - row * AA;
-        p[i] = reinterpret_cast<const u64*>(dx + ((2 * id < 4 * AA) ? row * 512 + c2 : 0));
+        const int row = (4 * id) / AA, c4 = 4 * id - row * AA;
+        off[i] = dbase + (unsigned)((4 * id < 4 * AA) ? row * 512 + c4 : 0) * 4u;
       }
-      poll_pairs<ND, true>(p, bit, v, a.ctrl, aborted, 23u);
+      poll_quads<ND, true>(xrs, off, bit, v, a.ctrl, aborted, 23u);
       DP_MARK(6);
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
         const int id = tid_ + DP_NT * i;
-        const int row = (2 * id) / AA, c2 = 2 * id - row * AA;
-        if (2 * id < 4 * AA) { dDs[row * DS + c2] = pair_lo(v[i]); dDs[row * DS + c2 + 1] = pair_hi(v[i]); }
+        const int row = (4 * id) / AA, c4 = 4 * id - row * AA;
+        if (4 * id < 4 * AA)
+          *reinterpret_cast<float4*>(dDs + row * DS + c4) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
+                                                                       __uint_as_float(v[i].z), __uint_as_float(v[i].w));
       }
     }
     __syncthreads();
@@ -1262,25 +1266,25 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     if (s == 0) break;
     // ------------------------------------------------------------ (g) dX = dgates W_cat for my z / ctx columns
     {
-      const float* gx = xg + BX_G + slot * 4 * 2048;
-      constexpr int NG = (2 * GK + DP_NT - 1) / DP_NT;        // pairs per thread over [4][GK/2]
+      // the dgates of the 4 rows in 16-byte quads over [4][GK/4]: 4 loads per thread in one poll (8 pairs in two before)
+      constexpr int NG = (GK + DP_NT - 1) / DP_NT;
+      const unsigned gbase = (unsigned)((xg - a.xch) + BX_G + slot * 4 * 2048) * 4u;
+      unsigned off[NG];
+      u4v v[NG];
 #pragma unroll
-      for (int h = 0; h < NG; h += 4) {
-        const u64* p[4];
-        u64 v[4];
+      for (int i = 0; i < NG; ++i) {
+        const int id = tid_ + DP_NT * i;
+        const int row = (4 * id) / GK, c4 = 4 * id - row * GK;
+        off[i] = gbase + (unsigned)((4 * id < 4 * GK) ? row * 2048 + c4 : 0) * 4u;
+      }
+      poll_quads<NG, true>(xrs, off, bit, v, a.ctrl, aborted, 24u);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int id = tid_ + DP_NT * (h + i);
-          const int row = (2 * id) / GK, c2 = 2 * id - row * GK;
-          p[i] = reinterpret_cast<const u64*>(gx + ((2 * id < 4 * GK) ? row * 2048 + c2 : 0));
-        }
-        poll_pairs<4, true>(p, bit, v, a.ctrl, aborted, 24u);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int id = tid_ + DP_NT * (h + i);
-          const int row = (2 * id) / GK, c2 = 2 * id - row * GK;
-          if (2 * id < 4 * GK) { dgs[row * GS + c2] = pair_lo(v[i]); dgs[row * GS + c2 + 1] = pair_hi(v[i]); }
-        }
+      for (int i = 0; i < NG; ++i) {
+        const int id = tid_ + DP_NT * i;
+        const int row = (4 * id) / GK, c4 = 4 * id - row * GK;
+        if (4 * id < 4 * GK)
+          *reinterpret_cast<float4*>(dgs + row * GS + c4) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
+                                                                       __uint_as_float(v[i].z), __uint_as_float(v[i].w));
       }
     }
     __syncthreads();
