@@ -113,8 +113,9 @@ int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const 
                      const int32_t* lens, float* y, float* c, void* graphs, asr_stream_t stream);
 
 /* Persistent fast path of asr_lstm_seq_fwd (same arguments and results; csrc/lstm_persist.hip): ONE launch runs
- * all T steps, each XCD owns a (direction, 8-row) group, W_hh stays in registers, h_t is exchanged inside the XCD
- * with tagged 8-byte granules.  Applies when H == 512 and nb <= 8 * (8 / ndir); otherwise returns ASR_E_SHAPE and
+ * all T steps, each XCD owns a (direction, 8- or 4-row) group, W_hh stays in registers, h_t is exchanged inside the
+ * XCD as LSB-tagged fp32 words.  Applies when H is 128, 256, 320 or 512 and nb <= 32 * (8 / ndir); otherwise returns
+ * ASR_E_SHAPE and
  * the caller uses asr_lstm_seq_fwd.  xch (>= 512 KB) and ctrl (>= 64 B) are caller-allocated scratch (both are zeroed
  * on the stream before the launch: one fill when ctrl sits exactly 64 bytes in front of xch, else two); after the
  * stream has drained ctrl[8] != 0 means the kernel aborted (bounded spin expired / unexpected placement) and

@@ -1,4 +1,5 @@
-// lstm_persist.hip — persistent, XCD-local LSTM sequence kernels (fast path for H = 512, <= 8 rows per XCD).
+// lstm_persist.hip — persistent, XCD-local LSTM sequence kernels (fast path for H in {128, 256, 320, 512}, 8 or 4
+// rows per XCD).
 //
 // Why: with one launch per time step every step pays a kernel boundary (~1.7 us) plus a cold start — L2 does not
 // survive the boundary, so the 8 MB of recurrent weights are re-streamed from Infinity Cache 1 400 times per
@@ -6,10 +7,11 @@
 //   * the 8 XCDs each take one (direction, 8-batch-row group); the XCD's 32 CUs each own 16 hidden units
 //     (64 gate-interleaved rows of W_hh) and keep that 128 KB slice in REGISTERS for all T steps
 //     (8 waves x 64 VGPRs: wave w holds the K range [64w, 64w+64));
-//   * per step only h_t of the group (8 rows x 512 units = 16 KB) is exchanged, inside the XCD, as 8-byte
-//     {tag = step+1, value} granules written and read with relaxed agent-scope atomics (sc1: the store is
-//     write-through, the load bypasses L1).  The data is the flag: no fences, no separate counters, and
-//     correctness does not depend on which CU/XCD a workgroup landed on — only the speed does;
+//   * per step only h_t of the group (8 rows x 512 units = 16 KB) is exchanged, inside the XCD, as fp32 words whose
+//     mantissa LSB is a validity tag, written with plain workgroup-scope stores (they stay in the XCD's L2) and read
+//     with 16-byte sc1 buffer loads that bypass L1.  The data is the flag: no fences, no separate counters, and
+//     correctness does not depend on which CU/XCD a workgroup landed on — only the speed does.  (The first version
+//     used 8-byte {tag = step+1, value} granules and agent-scope atomics: ASR_LSTM_FWD_WORDS 0.)
 //   * the gate product runs on v_mfma_f32_4x4x1_16b_f32: its 16 blocks are this CU's 16 units, A = the 4 gates
 //     of a unit (one W register per k), B = 4 batch rows of h; K accumulates over instructions, so the 4 gate
 //     pre-activations of a (unit, row) land in one lane and the pointwise update needs no shuffles.  The 8
