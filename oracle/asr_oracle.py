@@ -99,13 +99,16 @@ def lstm_direction(x, lens, w_ih, w_hh, b_ih, b_hh, reverse):
     bsz, steps, _ = x.shape
     hid = w_hh.shape[1]
     lens_t = torch.as_tensor(np.asarray(lens), dtype=torch.long)
-    gx = x @ w_ih.t() + (b_ih + b_hh)
+    # unbind once instead of indexing per step: the backward of a per-step select allocates a zero tensor of the whole
+    # [B,T,4H] sequence every step (the O(T^2) fill_/add_ that dominates the reference's own CPU step)
+    gx = (x @ w_ih.t() + (b_ih + b_hh)).unbind(1)
+    w_hh_t = w_hh.t()
     h = x.new_zeros(bsz, hid)
     c = x.new_zeros(bsz, hid)
     outs = [None] * steps
     order = range(steps - 1, -1, -1) if reverse else range(steps)
     for t in order:
-        gates = gx[:, t] + h @ w_hh.t()
+        gates = gx[t] + h @ w_hh_t
         gi, gf, gg, go = gates.split(hid, dim=1)
         c_new = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
         h_new = torch.sigmoid(go) * torch.tanh(c_new)
@@ -238,7 +241,7 @@ def decoder_forward(sd, enc_pad, enc_len, ys=None, tf_rate=1.0, max_dec_timestep
             tgt_in = F.pad(tgt_in, (0, extra), value=EOS)
             tgt_out = F.pad(tgt_out, (0, extra), value=EOS)
         olength = tgt_out.shape[1]
-        eys = emb_w[tgt_in]
+        eys = emb_w[tgt_in].unbind(1)
     z = enc_pad.new_zeros(bsz, dec_dim)
     cstate = enc_pad.new_zeros(bsz, dec_dim)
     ctx = enc_pad.new_zeros(bsz, odim)
@@ -252,7 +255,7 @@ def decoder_forward(sd, enc_pad, enc_len, ys=None, tf_rate=1.0, max_dec_timestep
         if ys is not None:
             # one numpy draw per step even at tf_rate=1
             use_truth = np.random.random_sample() <= tf_rate
-            emb = eys[:, t] if (use_truth or t == 0) else emb_w[preds[-1]]
+            emb = eys[t] if (use_truth or t == 0) else emb_w[preds[-1]]
         elif t == 0:
             emb = emb_w[torch.full((bsz,), BOS, dtype=torch.long)]
         elif not smooth:

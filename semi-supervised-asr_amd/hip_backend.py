@@ -425,6 +425,34 @@ USE_FEEDBACK_KERNEL = os.environ.get("ASR_FEEDBACK_KERNEL", "1") != "0"
 DECODE_EARLY_STOP = os.environ.get("ASR_DECODE_EARLY_STOP", "1") != "0"
 _persist_scratch = {}
 
+# Which path every sequence operator actually took, per process: "<op>_persist" counts launches of the persistent
+# XCD-local kernels, "<op>_step" counts sequences that ran on the per-step kernels instead (persistent path switched off,
+# or the launcher answered ASR_E_SHAPE = -2: unsupported sizes / not an 8 x 32-CU device).  Ops: lstm_fwd, lstm_bwd,
+# dec_fwd, dec_bwd, dec_free (free-running decode forward).  Tests assert on these so that a silent fallback cannot
+# pass for the fast path; `with require_persistent():` turns a fallback into an error.
+import collections
+LAUNCHES = collections.Counter()
+_REQUIRE_PERSIST = [os.environ.get("ASR_REQUIRE_PERSIST", "0") != "0"]
+
+
+def count_path(op, persistent, why=""):
+    LAUNCHES[op + ("_persist" if persistent else "_step")] += 1
+    if not persistent and _REQUIRE_PERSIST[0]:
+        raise RuntimeError("%s fell back to the per-step kernels (%s) while the persistent path was required" % (op, why))
+
+
+class require_persistent(object):
+    """Context manager: any sequence operator that does not run on its persistent kernel raises."""
+
+    def __enter__(self):
+        self._old = _REQUIRE_PERSIST[0]
+        _REQUIRE_PERSIST[0] = True
+        return LAUNCHES
+
+    def __exit__(self, *exc):
+        _REQUIRE_PERSIST[0] = self._old
+        return False
+
 
 def persist_scratch(device, trace=False):
     """(xch, ctrl) scratch of the persistent kernels, one pair per device (calls are stream-ordered).  trace=True: a
@@ -474,9 +502,11 @@ def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
         rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(y), ptr(c),
                                           c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
         if rc == 0:
+            count_path("lstm_fwd", True)
             return
         if rc != -2:                      # anything but ASR_E_SHAPE is an error
             check(rc, "asr_lstm_seq_fwd_persist")
+    count_path("lstm_fwd", False, "H=%d B=%d ndir=%d persist=%s" % (H, B, ndir, USE_PERSIST))
     groups = row_groups(B)
     gh = [graphs_for(i) if use_graphs else None for i in range(len(groups))]     # created on the calling thread
 
@@ -498,9 +528,11 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None)
         rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hhT), ptr(lens), ptr(dy), ptr(c),
                                           ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
         if rc == 0:
+            count_path("lstm_bwd", True)
             return y is not None and dw_hh is not None
         if rc != -2:
             check(rc, "asr_lstm_seq_bwd_persist")
+    count_path("lstm_bwd", False, "H=%d B=%d ndir=%d persist=%s" % (H, B, ndir, USE_PERSIST))
     groups = row_groups(B)
     gh = [graphs_for(i) for i in range(len(groups))]
 

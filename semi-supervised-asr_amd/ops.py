@@ -352,6 +352,7 @@ class _DecoderSeq(torch.autograd.Function):
                     done = True
                 elif rc != -2:                                  # -2: shape/device not covered by the fast path
                     hb.check(rc, "asr_dec_seq_fwd_persist")
+            hb.count_path("dec_fwd", done, "D=%d A=%d O=%d E=%d Tp=%d B=%d" % (D, A, O, E, Tp, B))
             if not done:
                 gh = [hb.graphs_for(i) if pooled else None for i in range(len(groups))]
 
@@ -412,6 +413,8 @@ class _DecoderSeq(torch.autograd.Function):
                                                 hb.FEED_NONE)
                     elif rc != -2:
                         hb.check(rc, "asr_dec_seq_fwd_persist_free")
+                hb.count_path("dec_free", done, "D=%d A=%d O=%d E=%d Tp=%d B=%d V=%d teacher=%s" % (
+                    D, A, O, E, Tp, B, V, tok_c is not None))
                 for s in (range(L) if not done else ()):
                     hb.check(lib.asr_dec_step_fwd(ctypes.byref(fs), s, hb.stream()), "asr_dec_step_fwd")
                     last = s == L - 1
@@ -503,6 +506,7 @@ class _DecoderSeq(torch.autograd.Function):
                     done = True
                 elif rc != -2:
                     hb.check(rc, "asr_dec_seq_bwd_persist")
+            hb.count_path("dec_bwd", done, "D=%d A=%d O=%d E=%d Tp=%d B=%d teacher=%s" % (D, A, O, E, Tp, B, ctx.all_teacher))
             if not done:
                 gh = [hb.graphs_for(i) for i in range(len(groups))]
 

@@ -10,10 +10,20 @@ Exact-parity rules under sharding are host-side only:
   * every shard is padded to the GLOBAL T_max and decodes the GLOBAL olength (the unmasked softmax
     and unmasked mean make results depend on both, SURVEY F1-F3);
   * local loss = -sum_local(log_probs) / (B_global * olength_global), so the all-reduced SUM of
-    gradients equals the single-process gradient.
+    gradients equals the single-process gradient;
+  * every rank consumes the numpy RNG identically (teacher-forcing draws; input noise is drawn for
+    the global batch), seeded once by the Solver.
+The three step kinds of the reference share these rules (`sup_local_loss`, `ssl_local_loss`,
+`judge_local_loss` below; solver.py:375-378, 460-483, 288-291).  The semi-supervised loss
+-sum(p_LM * log p * mask) / sum(mask) is normalised by the GLOBAL hypothesis-token count, which only exists on
+the devices after the free-running decode: it is summed over ranks by ONE 4-byte all-reduce, issued asynchronously
+right after the unlabeled decode and waited for after the labeled forward pass (it overlaps the judge and that
+pass); the gradient exchange itself stays the single flat-buffer all-reduce.  Scalars for logging ride in four
+spare floats at the end of that buffer (`FlatBuffers.aux`).
 """
 import math
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -28,9 +38,11 @@ def shard_batch(xs, ilens, ys, rank, world):
     """(xs [B,T,D] zero-padded to the global T_max, ilens desc, ys list) -> this rank's rows.
     xs keeps the global padded length; returns (xs_r, ilens_r, ys_r, info) where info carries the
     global constants every rank needs (B_global, T_max, olength)."""
-    idx = shard_indices(len(ilens), rank, world)
     info = dict(b_global=len(ilens), t_max=int(max(ilens)),
                 olength=(max(int(y.shape[0]) for y in ys) + 1) if ys is not None else None)
+    if world == 1:
+        return xs, list(ilens), ys, info
+    idx = shard_indices(len(ilens), rank, world)
     xs_r = xs[idx]
     return xs_r, [ilens[i] for i in idx], ([ys[i] for i in idx] if ys is not None else None), info
 
@@ -44,12 +56,93 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def padded_lengths(t_max, n_layers, subsample):
+    """Padded time extent entering each encoder layer (+ the output extent); model.padded_lengths without the
+    kernel imports."""
+    out = [int(t_max)]
+    for i in range(n_layers):
+        out.append((out[-1] + 1) // 2 if subsample[i] > 1 else out[-1])
+    return out
+
+
+def global_sum_async(t, group=None):
+    """In-place SUM of a small tensor over the ranks; returns a handle with .wait() (None in a single process)."""
+    if world() <= 1:
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def skip_decoder_draws(steps):
+    """A rank whose shard is empty still consumes the teacher-forcing draws of the step (model.py:328: one per decoder
+    step), so that every rank's numpy stream stays aligned."""
+    for _ in range(int(steps)):
+        np.random.random_sample()
+
+
+def sup_local_loss(model_fwd, xs, ilens, ys, tf_rate, rank, world_size, n_layers, subsample):
+    """Supervised step (solver.py:375-378) on this rank's shard -> local loss (None for an empty shard)."""
+    xs_r, il_r, ys_r, info = shard_batch(xs, ilens, ys, rank, world_size)
+    if not il_r:
+        skip_decoder_draws(info["olength"])
+        return None
+    _, log_probs, _, _ = model_fwd(xs_r, il_r, ys_r, tf_rate=tf_rate, sample=False,
+                                   total_length=padded_lengths(info["t_max"], n_layers, subsample),
+                                   olength=info["olength"])
+    return local_loss(log_probs, info)
+
+
+def ssl_local_loss(model_fwd, judge_probs, lab, unlab, rank, world_size, eos, unsup_weight, proportion, smooth,
+                   scaling, n_layers, subsample, group=None):
+    """Generator step of the semi-supervised training (solver.py:460-483) on this rank's shards of the labeled and
+    the unlabeled global batch.  model_fwd has E2E.forward's signature (+ total_length / olength), judge_probs maps
+    a hypothesis [b, L] (int64) to the judge's per-token probabilities [b, L] (no gradient flows through it: the
+    hypothesis is discrete).  Returns (local loss or None, (unsup_local, sup_local)); the three SUM over ranks to
+    the single-process values, and the all-reduced gradient of the local losses is the single-process gradient."""
+    lab_xs, lab_ilens, lab_ys = lab
+    unlab_xs, unlab_ilens = unlab
+    steps = int(unlab_xs.shape[1] * proportion)           # global padded length (solver.py:467)
+    u_xs, u_il, _, u_info = shard_batch(unlab_xs, unlab_ilens, None, rank, world_size)
+    dev = unlab_xs.device if torch.is_tensor(unlab_xs) else None
+    count = torch.zeros(1, dtype=torch.float32, device=dev)
+    num = None
+    if u_il:
+        _, u_lp, u_pred, _ = model_fwd(u_xs, u_il, ys=None, sample=False, label_smoothing=False,
+                                       max_dec_timesteps=steps, smooth=smooth, scaling=scaling,
+                                       total_length=padded_lengths(u_info["t_max"], n_layers, subsample))
+        mask = (u_pred != eos).float()
+        count += mask.sum()
+    work = global_sum_async(count, group)                 # 4 bytes; overlaps the judge and the labeled pass
+    if u_il:
+        num = -torch.sum(judge_probs(u_pred) * u_lp * mask)
+    sup = sup_local_loss(model_fwd, lab_xs, lab_ilens, lab_ys, 1.0, rank, world_size, n_layers, subsample)
+    if work is not None:
+        work.wait()
+    unsup = num / count[0] if num is not None else None   # 0/0 = nan for an all-<EOS> hypothesis, like the reference
+    parts = [p for p in (sup, unsup_weight * unsup if unsup is not None else None) if p is not None]
+    loss = sum(parts[1:], parts[0]) if parts else None
+    return loss, (unsup, sup)
+
+
+def judge_local_loss(judge_fwd, masked_sum, ys, rank, world_size):
+    """Judge (LM) step (solver.py:288-291): NLL normalised by the GLOBAL sum of (len + 5), known on the host.
+    -> (local loss, local avg_prob) or (None, None) for an empty shard."""
+    idx = shard_indices(len(ys), rank, world_size)
+    if not idx:
+        return None, None
+    ys_r = [ys[i] for i in idx]
+    frac = float(sum(int(y.shape[0]) + 5 for y in ys_r)) / float(sum(int(y.shape[0]) + 5 for y in ys))
+    log_probs, probs, _ = judge_fwd(ys_r)
+    return -masked_sum(log_probs, ys_r) * frac, masked_sum(probs, ys_r) * frac
+
+
 # ------------------------------------------------------------------------------ flat buffers
 class FlatBuffers(object):
     """Re-home every parameter (and its .grad) of a module into two flat fp32 buffers so that the
     gradient exchange is one collective and the optimiser one kernel.  Shared parameters (the
     attention module appears twice in E2E) are stored once.  Offsets are padded to 4
     floats so each view stays 16-byte aligned for the kernels."""
+
+    NAUX = 4
 
     def __init__(self, params):
         self.params = []
@@ -66,7 +159,9 @@ class FlatBuffers(object):
         self.total = off
         dev = self.params[0].device
         self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+        # NAUX spare floats behind the gradients travel in the same all-reduce (per-rank partial losses -> global values)
+        self.flat_g = torch.zeros(off + self.NAUX, device=dev, dtype=torch.float32)
+        self.aux = self.flat_g[off:]
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))
@@ -94,11 +189,18 @@ class FlatBuffers(object):
                 dst.append(v)
                 src.append(p.grad)
         if missing:
-            self.flat_g.zero_()
+            self.flat_g[:self.total].zero_()
         if dst:
             torch._foreach_copy_(dst, src)
         for i, p in enumerate(self.params):
             p.grad = self._view(i)
+
+    def set_aux(self, values):
+        """Scalars (tensors or floats, at most NAUX) that should come out of the step's all-reduce summed over ranks."""
+        vals = [v.detach().reshape(()).float() if torch.is_tensor(v) else torch.tensor(float(v)) for v in values]
+        self.aux.zero_()
+        if vals:
+            self.aux[:len(vals)].copy_(torch.stack([v.to(self.aux.device) for v in vals]))
 
     def allreduce_grads(self, group=None):
         """THE collective of the step: one SUM all-reduce over the flat gradient buffer."""

@@ -16,7 +16,7 @@ import hip_backend as hb
 import parallel
 from dataloader import get_data_loader
 from dataset import PickleDataset
-from model import E2E, LM, padded_lengths
+from model import E2E, LM
 from parallel import FlatAdam
 from utils import (Logger, adjust_learning_rate, calculate_cer, cc, infinite_iter, remove_pad_eos, to_gpu,
                    to_sents)
@@ -26,6 +26,12 @@ class Solver(object):
     def __init__(self, config, load_model=False):
         self.config = config
         self.rank, self.world, _ = parallel.init_distributed()
+        # The reference never seeds numpy (teacher-forcing draws model.py:328, input noise solver.py:370-373).  Data-parallel
+        # ranks must draw identical streams, so `numpy_seed` (not a reference key) defaults to 0 there;
+        # a single process stays unseeded like the reference unless the key is given.
+        seed = config.get("numpy_seed", 0 if self.world > 1 else None)
+        if seed is not None:
+            np.random.seed(int(seed))
         if self.rank == 0:
             print(self.config)
         self.logger = Logger(config["logdir"])
@@ -141,9 +147,21 @@ class Solver(object):
         return calculate_cer(hyps, refs), hyps, refs
 
     def _greedy(self, xs, ilens):
-        with torch.no_grad():
-            _, _, prediction, _ = self.model(xs, ilens, ys=None, max_dec_timesteps=self.config["max_dec_timesteps"])
-        return prediction.cpu().numpy().tolist()
+        """Greedy hypothesis ids for one batch.  No loss is read on this path, so the abort word of the persistent
+        kernels is checked explicitly after the decode (the copy to the host has synchronised anyway): an aborted
+        launch poisons its outputs, which would otherwise surface as a silently wrong CER.  On an abort this process
+        switches to the per-step kernels and decodes the batch again, as _backward_guarded does for a train step."""
+        def run():
+            with torch.no_grad():
+                _, _, prediction, _ = self.model(xs, ilens, ys=None, max_dec_timesteps=self.config["max_dec_timesteps"])
+            return prediction.cpu().numpy().tolist()
+        out = run()
+        if xs.is_cuda and hb.persist_aborted(xs.device):
+            print("persistent kernels aborted during greedy decoding (code %d): repeating the batch on the per-step "
+                  "kernels" % hb.persist_abort_code(xs.device))
+            hb.disable_persistent(xs.device)
+            out = run()
+        return out
 
     def validation(self):
         """Teacher-forced dev loss + greedy CER (solver.py:212-242); greedy pass runs without autograd."""
@@ -153,7 +171,12 @@ class Solver(object):
             xs, ilens, ys = to_gpu(data)
             with torch.no_grad():
                 _, log_probs, _, _ = self.model(xs, ilens, ys=ys)
-                total += self.model.mask_and_cal_loss(log_probs, ys).item()
+                value = self.model.mask_and_cal_loss(log_probs, ys).item()
+                if not math.isfinite(value) and xs.is_cuda and hb.persist_aborted(xs.device):
+                    hb.disable_persistent(xs.device)        # see _greedy
+                    _, log_probs, _, _ = self.model(xs, ilens, ys=ys)
+                    value = self.model.mask_and_cal_loss(log_probs, ys).item()
+                total += value
             preds += self._greedy(xs, ilens)
             refs += [y.cpu().numpy().tolist() for y in ys]
         self.model.train()
@@ -219,14 +242,44 @@ class Solver(object):
             value = loss.item()
         return loss, aux, value
 
+    def _dp_step(self, make_loss, opt, n_aux):
+        """One data-parallel step: zero_grad -> backward of this rank's local loss -> ONE all-reduce of the flat buffer
+        (gradients + the per-rank partial scalars in its aux slots) -> clip -> Adam.  make_loss() -> (local loss or None
+        for an empty shard, [scalars]); returns the scalars summed over ranks = the single-process values.  The only host
+        sync is the read of those scalars after the step.  Repeating a step locally (as _backward_guarded does after an
+        aborted persistent kernel) would desynchronise the collectives, so an abort is an error here."""
+        loss, scalars = make_loss()
+        opt.zero_grad()
+        if loss is not None:
+            loss.backward()
+        opt.buf.set_aux([v if v is not None else 0.0 for v in scalars[:n_aux]])
+        opt.step()
+        values = opt.buf.aux[:n_aux].tolist()
+        dev = opt.buf.flat_g.device
+        if not all(math.isfinite(v) for v in values) and dev.type == "cuda" and hb.persist_aborted(dev):
+            raise RuntimeError("persistent kernels aborted (code %d) in a data-parallel step; set ASR_PERSIST=0 on "
+                               "every rank to train on the per-step kernels" % hb.persist_abort_code(dev))
+        return values
+
+    def _step(self, make_local, opt, n_scalars):
+        """Run one optimiser step on make_local() -> (local loss, [scalar tensors]); returns the scalars as floats,
+        summed over the ranks of a data-parallel run (= the single-process values)."""
+        if self.world > 1:
+            return self._dp_step(make_local, opt, n_scalars)
+        _, scalars, _ = self._backward_guarded(make_local, opt)
+        opt.step()                                       # clip -> Adam, no host sync
+        return [float(v.item()) for v in scalars[:n_scalars]]
+
     def judge_train_one_iteration(self, unlab_ys):
-        def make_loss():
-            log_probs, probs, _ = self.judge(ys=unlab_ys, discrete_input=True)
-            return (-self.judge.mask_and_cal_sum(log_probs, ys=unlab_ys, mask=None),
-                    self.judge.mask_and_cal_sum(probs, ys=unlab_ys, mask=None))
-        _, avg_prob, value = self._backward_guarded(make_loss, self.dis_opt)
-        self.dis_opt.step()
-        return {"loss": value, "avg_prob": avg_prob.item()}
+        """solver.py:288-301.  `unlab_ys` is the global text batch: every rank of a data-parallel run takes its strided
+        shard and normalises by the global sum of (len + 5) (parallel.judge_local_loss; the identity for one process)."""
+        def make_local():
+            loss, avg_prob = parallel.judge_local_loss(
+                lambda ys: self.judge(ys=ys, discrete_input=True),
+                lambda v, ys: self.judge.mask_and_cal_sum(v, ys=ys, mask=None), unlab_ys, self.rank, self.world)
+            return loss, [loss, avg_prob]
+        value, avg_prob = self._step(make_local, self.dis_opt, 2)
+        return {"loss": value, "avg_prob": avg_prob}
 
     def judge_pretrain(self):
         cfg = self.config
@@ -263,17 +316,12 @@ class Solver(object):
     # ------------------------------------------------------------------ supervised training
     def _sharded_forward(self, xs, ilens, ys, tf_rate):
         """Model forward on this rank's strided shard of the (global) batch, padded to the global extents;
-        returns the local loss whose all-reduced gradient equals the single-process one."""
-        if self.world == 1:
-            _, log_probs, _, _ = self.model(xs, ilens, ys, tf_rate=tf_rate, sample=False)
-            return -torch.mean(log_probs)
-        xs_r, ilens_r, ys_r, info = parallel.shard_batch(xs, ilens, ys, self.rank, self.world)
+        returns the local loss whose all-reduced gradient equals the single-process one; None for a rank
+        whose shard is empty (fewer utterances than ranks in the last batch of an epoch).  One process: the whole
+        batch and -mean(log_probs) (solver.py:375-378)."""
         cfg = self.config
-        _, log_probs, _, _ = self.model(
-            xs_r, ilens_r, ys_r, tf_rate=tf_rate, sample=False,
-            total_length=padded_lengths(info["t_max"], cfg["enc_n_layers"], cfg["subsample"]),
-            olength=info["olength"])
-        return parallel.local_loss(log_probs, info)
+        return parallel.sup_local_loss(self.model, xs, ilens, ys, tf_rate, self.rank, self.world,
+                                       cfg["enc_n_layers"], cfg["subsample"])
 
     def sup_train_one_epoch(self, epoch, tf_rate):
         cfg = self.config
@@ -284,10 +332,10 @@ class Solver(object):
             if cfg["add_gaussian"] and epoch >= cfg["gaussian_epoch"]:
                 noise = np.random.normal(0, cfg["gaussian_std"], tuple(xs.shape)).astype(np.float32)
                 xs = xs + cc(torch.from_numpy(noise))
-            _, _, value = self._backward_guarded(lambda: (self._sharded_forward(xs, ilens, ys, tf_rate), None),
-                                                 self.gen_opt)
-            self.gen_opt.step()                      # all-reduce -> clip -> Adam, no host sync
-            value *= self.world if self.world > 1 else 1                  # local losses sum to the global mean
+            def make_local():
+                loss = self._sharded_forward(xs, ilens, ys, tf_rate)
+                return loss, [loss]
+            value, = self._step(make_local, self.gen_opt, 1)     # (all-reduce ->) clip -> Adam; local losses sum to the mean
             running += value
             if self.rank == 0:
                 print(f"epoch: {epoch}, [{it + 1}/{steps_per_epoch}], loss: {value:.3f}", end="\r")
@@ -328,27 +376,28 @@ class Solver(object):
     def gen_train_one_iteration(self, lab_xs, lab_ilens, lab_ys, unlab_xs, unlab_ilens):
         """The LM-judge auxiliary loss (solver.py:460-495): greedy smooth-embedding decode of unlabeled
         speech WITH grad, judge probabilities of the hypothesis, unsup = -sum(p_LM * log p_model * mask)/sum(mask);
-        loss = sup + unsup_weight * unsup; only the generator is stepped."""
+        loss = sup + unsup_weight * unsup; only the generator is stepped.
+        lab_* / unlab_* are the GLOBAL batches (the loaders draw batch_size * world utterances): every rank works on its
+        strided shards at the global padded extents and normalises the auxiliary loss by the global hypothesis-token
+        count (parallel.ssl_local_loss: one 4-byte all-reduce next to the gradient all-reduce; nothing in one process)."""
         cfg = self.config
 
-        def make_loss():
-            _, u_lp, u_pred, _ = self.model(
-                unlab_xs, unlab_ilens, ys=None, sample=False, label_smoothing=False,
-                max_dec_timesteps=int(unlab_xs.size(1) * self.proportion), smooth=cfg["smooth_embedding"],
-                scaling=cfg["softmax_scaling"])
+        def judge_probs(hyp):
             # The judge scores an integer hypothesis, so no gradient reaches the model through it, and gen_opt does not
             # hold its parameters (solver.py:484-488 builds that graph and never uses it): the forward alone gives the
             # same losses and model gradients.
             with torch.no_grad():
-                _, lm_probs, _ = self.judge(ys=u_pred, discrete_input=False)
-            mask = (u_pred != self.vocab["<EOS>"]).float()
-            unsup_loss = -torch.sum(lm_probs * u_lp * mask) / torch.sum(mask)
-            _, lab_lp, _, _ = self.model(lab_xs, lab_ilens, ys=lab_ys, tf_rate=1.0, sample=False)
-            sup_loss = -torch.mean(lab_lp)
-            return sup_loss + cfg["unsup_weight"] * unsup_loss, (unsup_loss, sup_loss)
-        _, (unsup_loss, sup_loss), value = self._backward_guarded(make_loss, self.gen_opt)
-        self.gen_opt.step()
-        return {"unsup_loss": unsup_loss.item(), "sup_loss": sup_loss.item(), "loss": value}
+                return self.judge(ys=hyp, discrete_input=False)[1]
+
+        def make_local():
+            loss, (unsup, sup) = parallel.ssl_local_loss(
+                self.model, judge_probs, (lab_xs, lab_ilens, lab_ys), (unlab_xs, unlab_ilens), self.rank, self.world,
+                eos=self.vocab["<EOS>"], unsup_weight=cfg["unsup_weight"], proportion=self.proportion,
+                smooth=cfg["smooth_embedding"], scaling=cfg["softmax_scaling"], n_layers=cfg["enc_n_layers"],
+                subsample=cfg["subsample"])
+            return loss, [unsup, sup, loss]
+        unsup, sup, value = self._step(make_local, self.gen_opt, 3)
+        return {"unsup_loss": unsup, "sup_loss": sup, "loss": value}
 
     def ssl_train_one_iteration(self, iteration):
         lab_data, unlab_data = next(self.lab_iter), next(self.unlab_x_iter)

@@ -280,6 +280,73 @@ def gen_cfg1():
     print("cfg1: loss %.6f" % float(loss))
 
 
+def gen_big(name, shape):
+    """cfg-2 / cfg-5 shapes held by the reference itself (model.py:408-456, solver.py:375-383): the 3x512 model,
+    ragged batch, dropout 0, tf_rate 1.  Weights and inputs are regenerated from synth seeds by the tests; stored are
+    the loss, the log-probs, slices of logits / attention weights / encoder output and per-parameter gradient
+    norms + 16-element heads (as gen_cfg1 does)."""
+    import time
+    cfg = synth.CFG2
+    m, ld = build_e2e(cfg, shape["wseed"], shape["ldseed"])
+    xs_np, ilens, ys_np = synth.ragged_batch(shape["n_utt"], shape["t_max"], cfg["input_dim"], cfg["output_dim"],
+                                             shape["bseed"])
+    xs, ys = to_t(xs_np, ys_np)
+    np.random.seed(5)
+    t0 = time.time()
+    enc_h, enc_lens = m.encoder(xs, ilens)
+    logits, lp, pred, ws = m.decoder(enc_h, enc_lens, ys, tf_rate=1.0)
+    loss = -torch.mean(lp)
+    m.zero_grad()
+    loss.backward()
+    print("%s: reference forward+backward %.1f s" % (name, time.time() - t0))
+    out = dict(ilens=np.asarray(ilens), ylens=np.asarray([len(y) for y in ys_np]), loss=npy(loss), lp=npy(lp),
+               pred=npy(pred), logits_head=npy(logits[:, :4]), logits_tail=npy(logits[:, -2:]),
+               ws_first=npy(ws[:, 0]), ws_mid=npy(ws[:, ws.size(1) // 2]), ws_last=npy(ws[:, -1]),
+               enc_h_b0=npy(enc_h[0]), enc_h_blast=npy(enc_h[-1]), enc_lens=np.asarray(enc_lens),
+               masked_loss=npy(m.mask_and_cal_loss(lp, ys)))
+    for n, p in m.named_parameters():
+        g = npy(p.grad).ravel()
+        out["gnorm/" + n] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["ghead/" + n] = g[:16].copy()
+        out["gtail/" + n] = g[-16:].copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%s: loss %.6f" % (name, float(loss)))
+
+
+def gen_tiny_opt():
+    """torch.optim.Adam's own state_dict() after step 1 of the tiny model (solver.py:38-46 writes exactly this to
+    `.opt`), so that loading a reference optimiser checkpoint into the flat optimiser can be tested: resuming from it
+    and running steps 2-3 must land on tiny_e2e.npz's after3/* weights."""
+    cfg = synth.TINY
+    m, _ = build_e2e(cfg, 11, 12)
+    xs_np, ilens, ys_np = synth.batch(cfg["input_dim"], cfg["output_dim"], synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    xs, ys = to_t(xs_np, ys_np)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4, weight_decay=1e-6, amsgrad=True)
+    np.random.seed(100)
+    _, lp, _, _ = m(xs, ilens, ys, tf_rate=1.0)
+    opt.zero_grad()
+    (-torch.mean(lp)).backward()
+    torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=5)
+    opt.step()
+    sd = opt.state_dict()
+    out = {}
+    names = [n for n, _ in m.named_parameters()]
+    out["param_order"] = np.asarray(names)
+    grp = sd["param_groups"][0]
+    out["group/params"] = np.asarray(grp["params"])
+    for k in ("lr", "eps", "weight_decay"):
+        out["group/" + k] = np.float64(grp[k])
+    out["group/betas"] = np.asarray(grp["betas"], dtype=np.float64)
+    out["group/amsgrad"] = np.asarray(bool(grp["amsgrad"]))
+    for i, ent in sd["state"].items():
+        for k, v in ent.items():
+            out["state/%d/%s" % (i, k)] = npy(v) if torch.is_tensor(v) else np.asarray(v)
+    for n, p in m.named_parameters():
+        out["after1/" + n] = npy(p)
+    np.savez_compressed(os.path.join(HERE, "tiny_opt.npz"), **out)
+    print("tiny_opt: %d arrays, %d state entries" % (len(out), len(sd["state"])))
+
+
 def gen_text():
     """utils.py:192-235 helpers on a toy vocabulary."""
     vocab = {"<PAD>": 0, "<BOS>": 1, "<EOS>": 2, "a": 3, "b": 4, "c": 5, "<space>": 6, "<NOISE>": 7,
@@ -299,9 +366,9 @@ def gen_text():
 
 
 if __name__ == "__main__":
-    torch.set_num_threads(4)
-    gen_tiny_e2e()
-    gen_tiny_lm()
-    gen_tiny_ssl()
-    gen_cfg1()
-    gen_text()
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "4")))
+    jobs = dict(tiny_e2e=gen_tiny_e2e, tiny_lm=gen_tiny_lm, tiny_ssl=gen_tiny_ssl, cfg1=gen_cfg1, text=gen_text,
+                tiny_opt=gen_tiny_opt, cfg2=lambda: gen_big("cfg2", synth.CFG2_SHAPE),
+                cfg5=lambda: gen_big("cfg5", synth.CFG5_SHAPE))
+    for name in (sys.argv[1:] or list(jobs)):          # no arguments: everything (cfg2 / cfg5 take minutes)
+        jobs[name]()

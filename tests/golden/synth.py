@@ -19,6 +19,13 @@ CFG1 = dict(input_dim=80, enc_hidden_dim=128, enc_n_layers=1, subsample=[2], dro
 CFG1_ILENS = [200, 180, 150, 120]
 CFG1_YLENS = [25, 22, 18, 15]
 
+CFG2 = dict(input_dim=80, enc_hidden_dim=512, enc_n_layers=3, subsample=[2, 2, 2], dropout_rate=0.0,
+            dec_hidden_dim=512, att_dim=512, conv_channels=10, conv_kernel_size=100, att_odim=512,
+            embedding_dim=128, output_dim=34, ls_weight=0.05)
+# (batch, frames, weight seed, batch seed, labeldist seed) of the large reference-held fixtures
+CFG2_SHAPE = dict(n_utt=32, t_max=800, wseed=99, bseed=1234, ldseed=5)
+CFG5_SHAPE = dict(n_utt=8, t_max=1600, wseed=99, bseed=1235, ldseed=5)
+
 TINY_LM = dict(output_dim=9, embedding_dim=16, hidden_dim=16, dropout_rate=0.0, n_layers=2,
                ls_weight=0.05)
 
@@ -108,3 +115,19 @@ def batch(input_dim, V, ilens, ylens, seed):
         xs[b, :l] = rs.normal(0, 1, size=(l, input_dim)).astype(np.float32)
     ys = [rs.randint(3, V, size=(n,)).astype(np.int64) for n in ylens]
     return xs, list(ilens), ys
+
+
+
+def ragged_batch(n_utt, t_max, input_dim, V, seed):
+    """Seeded synthetic batch in collate layout: N(0,1) features, ragged lengths U[0.6T, T] sorted
+    descending with the longest pinned to T, label length max(2, 0.125 T_i), ids in [3, V)."""
+    rs = np.random.RandomState(seed)
+    lens = sorted([int(v) for v in rs.randint(int(0.6 * t_max), t_max + 1, size=n_utt)], reverse=True)
+    lens[0] = t_max
+    xs = np.zeros((n_utt, t_max, input_dim), dtype=np.float32)
+    ys = []
+    for b, l in enumerate(lens):
+        xs[b, :l] = rs.normal(0, 1, size=(l, input_dim)).astype(np.float32)
+        ys.append(rs.randint(3, V, size=(max(2, int(0.125 * l)),)).astype(np.int64))
+    ys[0] = rs.randint(3, V, size=(int(0.125 * t_max),)).astype(np.int64)
+    return xs, lens, ys

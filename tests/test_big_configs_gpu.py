@@ -1,0 +1,94 @@
+"""The headline configurations at their own shapes, against fixtures the REFERENCE produced at those shapes
+(tests/golden/make_golden.py gen_big: reference model.py:408-456 + solver.py:375-383 run on CPU in the build
+container): cfg-2 = 3x512 encoder / 512 decoder, B=32, T=800 ragged; cfg-5 = same model, B=8, T=1600 (T'=200).
+Weights and inputs are regenerated from the synth seeds.  Tolerance: 1e-3 relative fp32 (BASELINE.json north_star).
+
+Both tests also assert, through hip_backend.LAUNCHES, that the persistent XCD-local kernels are what ran: a silent
+ASR_E_SHAPE fallback to the per-step kernels fails the test (hb.require_persistent)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def _gpu():
+    import __graft_entry__ as entry
+    entry.build()
+    assert torch.cuda.is_available()
+    return torch.device("cuda")
+
+
+def _rel(got, want):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = np.asarray(want)
+    return float(np.abs(got - want).max()) / max(1e-30, float(np.abs(want).max()))
+
+
+def _run_big(golden_dir, name, shape):
+    dev = _gpu()
+    import hip_backend as hb
+    import model as M
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False))
+    cfg = synth.CFG2
+    net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], shape["ldseed"]), **cfg).to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.e2e_weights(cfg, shape["wseed"]).items()})
+    net.train()
+    xs, ilens, ys = synth.ragged_batch(shape["n_utt"], shape["t_max"], cfg["input_dim"], cfg["output_dim"],
+                                       shape["bseed"])
+    assert ilens == g["ilens"].tolist() and [len(y) for y in ys] == g["ylens"].tolist()
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+    hb.LAUNCHES.clear()
+    with hb.require_persistent():
+        np.random.seed(5)
+        enc_h, enc_lens = net.encoder(xs_d, ilens)
+        logits, lp, pred, ws = net.decoder(enc_h, enc_lens, ys_d, tf_rate=1.0)
+        loss = -lp.mean()
+        net.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+    assert not hb.persist_aborted(dev), "abort code %d" % hb.persist_abort_code(dev)
+    n_layers = cfg["enc_n_layers"]
+    assert hb.LAUNCHES["lstm_fwd_persist"] == n_layers and hb.LAUNCHES["lstm_bwd_persist"] == n_layers, dict(hb.LAUNCHES)
+    assert hb.LAUNCHES["dec_fwd_persist"] == 1 and hb.LAUNCHES["dec_bwd_persist"] == 1, dict(hb.LAUNCHES)
+    assert not any(k.endswith("_step") for k in hb.LAUNCHES), dict(hb.LAUNCHES)
+    # ---- forward
+    assert enc_lens == g["enc_lens"].tolist()
+    assert _rel(enc_h[0], g["enc_h_b0"]) < RTOL and _rel(enc_h[-1], g["enc_h_blast"]) < RTOL
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    assert _rel(lp, g["lp"]) < RTOL
+    assert _rel(logits[:, :4], g["logits_head"]) < RTOL and _rel(logits[:, -2:], g["logits_tail"]) < RTOL
+    half = ws.size(1) // 2
+    for got, key in ((ws[:, 0], "ws_first"), (ws[:, half], "ws_mid"), (ws[:, -1], "ws_last")):
+        assert _rel(got, g[key]) < RTOL, key
+    agree = float((pred.cpu().numpy() == g["pred"]).mean())
+    assert agree > 0.999, "argmax agreement %.5f" % agree          # ties within fp32 noise may flip a handful
+    assert abs(float(net.mask_and_cal_loss(lp, ys_d)) - float(g["masked_loss"])) <= 1e-4 * abs(float(g["masked_loss"]))
+    # ---- every parameter gradient: norm, and head / tail elements relative to the gradient's own scale
+    worst = 0.0
+    for n, p in net.named_parameters():
+        flat = p.grad.detach().cpu().numpy().ravel()
+        norm = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        assert abs(norm - float(g["gnorm/" + n])) <= RTOL * float(g["gnorm/" + n]), (n, norm, float(g["gnorm/" + n]))
+        scale = float(np.abs(flat).max())
+        e = max(np.abs(flat[:16] - g["ghead/" + n]).max(), np.abs(flat[-16:] - g["gtail/" + n]).max()) / scale
+        worst = max(worst, float(e))
+        assert e <= RTOL, (n, float(e))
+    print("%s: loss %.6f (ref %.6f), worst gradient element error %.2e, launches %s" % (
+        name, float(loss), float(g["loss"]), worst, dict(hb.LAUNCHES)))
+
+
+def test_cfg2_against_golden(golden_dir):
+    """cfg-2 (BASELINE.json configs[1], the bench workload) end to end on the persistent kernels vs the reference."""
+    _run_big(golden_dir, "cfg2", synth.CFG2_SHAPE)
+
+
+def test_cfg5_against_golden(golden_dir):
+    """cfg-5 (configs[4]: 80x1600 frames, batch 8, T'=200, L+1=201) vs the reference: 4-row LSTM groups, the
+    T' <= 256 persistent decoder."""
+    _run_big(golden_dir, "cfg5", synth.CFG5_SHAPE)

@@ -234,6 +234,54 @@ def test_tiny_optimizer_steps(golden_dir):
                     _close(p, g["clip/" + n], rtol=1e-4, atol=2e-6, what="clip %s" % n)
 
 
+def _ref_adam_state(g):
+    """tiny_opt.npz -> the dict torch.optim.Adam.state_dict() returned in the reference run (what `.opt` files hold)."""
+    state = {}
+    for k, v in g.items():
+        if k.startswith("state/"):
+            _, i, name = k.split("/")
+            state.setdefault(int(i), {})[name] = torch.from_numpy(np.asarray(v))
+    grp = dict(lr=float(g["group/lr"]), betas=tuple(float(b) for b in g["group/betas"]), eps=float(g["group/eps"]),
+               weight_decay=float(g["group/weight_decay"]), amsgrad=bool(g["group/amsgrad"]),
+               params=[int(i) for i in g["group/params"]])
+    return dict(state=state, param_groups=[grp])
+
+
+def test_resume_from_reference_adam_state(golden_dir):
+    """a `.opt` written by the reference (torch.optim.Adam.state_dict() after step 1, solver.py:38-46)
+    loads into FlatAdam; steps 2-3 from there land on the reference's weights after 3 steps."""
+    dev = _gpu()
+    from parallel import FlatAdam
+    g = _load(golden_dir, "tiny_e2e.npz")
+    o = _load(golden_dir, "tiny_opt.npz")
+    after1 = {k[len("after1/"):]: v for k, v in o.items() if k.startswith("after1/")}
+    weights = dict(synth.e2e_weights(synth.TINY, 11))
+    for k in weights:                                  # incl. the duplicated attention keys
+        base = k[len("decoder."):] if k.startswith("decoder.attention.") else k
+        weights[k] = after1[base]
+    net = _product(synth.TINY, weights, g["labeldist"], dev)
+    assert [n for n, _ in net.named_parameters()] == [str(n) for n in o["param_order"]]
+    opt = FlatAdam(net, lr=1.0, weight_decay=0.5, amsgrad=True, max_grad_norm=5.0)       # wrong on purpose: the file wins
+    opt.load_state_dict(_ref_adam_state(o))
+    assert opt.t == 1 and opt.param_groups[0]["lr"] == 5e-4 and opt.param_groups[0]["weight_decay"] == 1e-6
+    xs, ilens, ys = synth.batch(8, 9, synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+    for step in (1, 2):
+        np.random.seed(100 + step)
+        _, lp, _, _ = net(xs_d, ilens, ys_d, tf_rate=1.0)
+        _close(-lp.mean(), g["opt_loss%d" % step], rtol=1e-4, what="loss of step %d" % step)
+        opt.zero_grad()
+        (-lp.mean()).backward()
+        opt.step()
+    for n, p in net.named_parameters():
+        _close(p, g["after3/" + n], rtol=1e-4, atol=2e-6, what="after3 %s" % n)
+    # and back out: the state FlatAdam saves has torch.optim.Adam's schema (one entry per parameter, same fields)
+    sd = opt.state_dict()
+    assert sorted(sd["state"].keys()) == list(range(len(list(net.parameters()))))
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
+    assert float(sd["state"][0]["step"]) == 3.0
+
+
 def test_cfg1_against_golden(golden_dir):
     dev = _gpu()
     g = _load(golden_dir, "cfg1.npz")
@@ -536,12 +584,17 @@ def test_lstm_persistent_path(ndir, B, T, lens, H):
     ref = torch.cat([O.lstm_direction(xc, lens, *cp[4 * d:4 * d + 4], reverse=(d == 1)) for d in range(ndir)], 2)
     gp = [p.to(dev).requires_grad_(True) for p in prm]
     xg = x.to(dev).requires_grad_(True)
-    got = ops.lstm_layer(xg.transpose(0, 1), torch.tensor(lens, dtype=torch.int32, device=dev), gp, ndir)
+    hb.LAUNCHES.clear()
+    with hb.require_persistent():          # an ASR_E_SHAPE fallback to the per-step kernels raises
+        got = ops.lstm_layer(xg.transpose(0, 1), torch.tensor(lens, dtype=torch.int32, device=dev), gp, ndir)
     assert not hb.persist_aborted(dev)
     _close(got.transpose(0, 1), ref, rtol=1e-4, atol=1e-5, what="y (persistent)")
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
-    got.backward(dy.transpose(0, 1).contiguous().to(dev))
+    with hb.require_persistent():
+        got.backward(dy.transpose(0, 1).contiguous().to(dev))
+    assert hb.LAUNCHES["lstm_fwd_persist"] == 1 and hb.LAUNCHES["lstm_bwd_persist"] == 1, dict(hb.LAUNCHES)
+    assert hb.LAUNCHES["lstm_fwd_step"] == 0 and hb.LAUNCHES["lstm_bwd_step"] == 0, dict(hb.LAUNCHES)
     _close(xg.grad, xc.grad, rtol=1e-3, atol=1e-5, what="dx")
     for i, (a, b) in enumerate(zip(gp, cp)):
         _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
@@ -586,11 +639,15 @@ def test_decoder_persistent_path(dim, B, Tp, L, drop):
         try:
             par = {k: v.clone().requires_grad_(True) for k, v in base.items()}
             opts = dict(L=L, tokens=tokens, tf_flags=None, smooth=False, sample=False, scaling=2.0, xmask=xmask, bos=1)
+            hb.LAUNCHES.clear()
             logits, ws, _pred = ops.decoder_sequence(par["P"], par["Q"], par["emb_w"], par["w_ih"], par["w_hh"],
                                                      par["b_ih"], par["b_hh"], par["wdec"], par["convw"], par["watt"],
                                                      par["gvec"], par["bo"], par["w_out"], par["b_out"], w0, opts)
             ((logits * dlog).sum() + (ws * dws).sum()).backward()
             torch.cuda.synchronize()
+            # the path that ran is the path that was asked for (a silent ASR_E_SHAPE fallback fails here)
+            want = {"dec_fwd_persist" if persist else "dec_fwd_step": 1, "dec_bwd_persist" if persist_bwd else "dec_bwd_step": 1}
+            assert dict(hb.LAUNCHES) == want, (dict(hb.LAUNCHES), want)
             return logits.detach(), ws.detach(), {k: par[k].grad.detach() for k in names}
         finally:
             hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = old
@@ -777,11 +834,15 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
             par = {k: v.clone().requires_grad_(True) for k, v in base.items()}
             opts = dict(L=L, tokens=tokens, tf_flags=flags, smooth=kind == "smooth", smooth_scaling=3.0, sample=False,
                         scaling=2.0, xmask=xmask, bos=1, pooled=True)
+            hb.LAUNCHES.clear()
             logits, ws, pred = ops.decoder_sequence(par["P"], par["Q"], par["emb_w"], par["w_ih"], par["w_hh"],
                                                     par["b_ih"], par["b_hh"], par["wdec"], par["convw"], par["watt"],
                                                     par["gvec"], par["bo"], par["w_out"], par["b_out"], w0, opts)
             ((logits * dlog).sum() + (ws * dws).sum()).backward()
             torch.cuda.synchronize()
+            if fused and kind != "mixed":
+                assert hb.LAUNCHES["dec_free_persist" if persist else "dec_free_step"] == 1, (persist, dict(hb.LAUNCHES))
+                assert hb.LAUNCHES["dec_free_step" if persist else "dec_free_persist"] == 0, (persist, dict(hb.LAUNCHES))
             return logits.detach(), ws.detach(), pred.clone(), {k: par[k].grad.detach() for k in names}
         finally:
             hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC = old

@@ -200,6 +200,34 @@ def test_cfg1_shape(golden_dir):
         np.testing.assert_allclose(flat[:16], g["ghead/" + n], rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("name,shape", [("cfg2", synth.CFG2_SHAPE), ("cfg5", synth.CFG5_SHAPE)])
+def test_big_shapes(golden_dir, name, shape):
+    """The oracle at the headline shapes (3x512 model; cfg-2: B=32, T=800; cfg-5: B=8, T=1600) against what the
+    reference produced there: forward outputs and every parameter gradient (norm, first / last 16 elements)."""
+    g = _load(golden_dir, name + ".npz")
+    cfg = dict(synth.CFG2, labeldist=synth.labeldist(34, shape["ldseed"]))
+    sd = O.make_leaf_state(synth.e2e_weights(synth.CFG2, shape["wseed"]))
+    xs, ilens, ys = synth.ragged_batch(shape["n_utt"], shape["t_max"], 80, 34, shape["bseed"])
+    assert ilens == g["ilens"].tolist()
+    np.random.seed(5)
+    logits, lp, pred, ws = O.e2e_forward(sd, cfg, torch.from_numpy(xs), ilens, [torch.from_numpy(y) for y in ys])
+    _close(-lp.mean(), g["loss"], rtol=1e-6)
+    _close(lp, g["lp"])
+    _close(logits[:, :4], g["logits_head"], atol=2e-5)
+    _close(logits[:, -2:], g["logits_tail"], atol=2e-5)
+    _close(ws[:, 0], g["ws_first"])
+    _close(ws[:, -1], g["ws_last"])
+    assert (pred.numpy() == g["pred"]).mean() > 0.999
+    names = O.unique_param_names(sd)
+    grads = torch.autograd.grad(-lp.mean(), [sd[n] for n in names])
+    for n, gr in zip(names, grads):
+        flat = gr.numpy().ravel()
+        np.testing.assert_allclose(np.sqrt((flat.astype(np.float64) ** 2).sum()), g["gnorm/" + n], rtol=2e-5)
+        scale = float(np.abs(flat).max())
+        assert np.abs(flat[:16] - g["ghead/" + n]).max() <= 2e-5 * scale + 1e-9, n
+        assert np.abs(flat[-16:] - g["gtail/" + n]).max() <= 2e-5 * scale + 1e-9, n
+
+
 def test_text_helpers(golden_dir):
     with open(os.path.join(golden_dir, "text.json")) as f:
         g = json.load(f)

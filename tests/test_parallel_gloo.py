@@ -1,7 +1,8 @@
 """Data-parallel logic on CPU: world_size-2 gloo ranks must reproduce the single-process gradients exactly
 (SURVEY 8e): strided shard, global padded extents, local loss = -sum/(B_global*olength), ONE all-reduce of
 the flat gradient buffer.  The compute is the CPU oracle; the sharding / flat-buffer / collective code is the
-product's parallel.py."""
+product's parallel.py: the three step kinds of the reference (supervised solver.py:375-378, semi-supervised
+generator step 460-483 with its globally normalised auxiliary loss, judge step 288-291)."""
 import os
 import socket
 import sys
@@ -55,6 +56,120 @@ def _grads_for(rank, world, tf_rate=1.0):
     loss.backward()
     buf.collect()                                        # gradients -> flat buffer (FlatAdam.step does this itself)
     return buf, names, float(loss.detach())
+
+
+def _model_fwd(sd, cfg):
+    """E2E.forward's signature (as parallel.py calls it) on the oracle."""
+    from oracle import asr_oracle as O
+
+    def fwd(xs, ilens, ys=None, olength=None, **kw):
+        xs_t = xs if torch.is_tensor(xs) else torch.from_numpy(np.ascontiguousarray(xs))
+        return O.e2e_forward(sd, cfg, xs_t, ilens, ys, olength_override=olength, **kw)
+    return fwd
+
+
+UILENS = [12, 10, 9, 7, 4]                               # 5 unlabeled utterances over 2 ranks: uneven shards
+
+
+def _ssl_for(rank, world):
+    """Generator step of the semi-supervised training through parallel.ssl_local_loss -> (flat grads, scalars)."""
+    from oracle import asr_oracle as O
+    import parallel
+    cfg = dict(CFG, labeldist=synth.labeldist(CFG["output_dim"], 12))
+    sd = O.make_leaf_state(synth.e2e_weights(CFG, 11))
+    jsd = {k: torch.from_numpy(v) for k, v in synth.lm_weights(synth.TINY_LM, 31).items()}
+    names = O.unique_param_names(sd)
+    buf = parallel.FlatBuffers([sd[n] for n in names])
+    xs, ilens, ys = synth.batch(CFG["input_dim"], CFG["output_dim"], ILENS, YLENS, 13)
+    uxs, uilens, _ = synth.batch(CFG["input_dim"], CFG["output_dim"], UILENS, [2] * len(UILENS), 41)
+
+    def judge_probs(hyp):
+        with torch.no_grad():
+            return O.lm_forward(jsd, hyp, discrete_input=False, n_layers=2)[1]
+
+    np.random.seed(9)
+    loss, (unsup, sup) = parallel.ssl_local_loss(
+        _model_fwd(sd, cfg), judge_probs, (xs, ilens, [torch.from_numpy(y) for y in ys]), (torch.from_numpy(uxs), uilens),
+        rank, world, eos=2, unsup_weight=0.5, proportion=0.5, smooth=True, scaling=3.0,
+        n_layers=CFG["enc_n_layers"], subsample=CFG["subsample"])
+    buf.zero_grad()
+    loss.backward()
+    buf.set_aux([unsup, sup, loss])
+    buf.allreduce_grads()                                # the step's single gradient collective (+ aux scalars)
+    return buf, buf.aux[:3].tolist()
+
+
+def _judge_for(rank, world):
+    from oracle import asr_oracle as O
+    import parallel
+    jsd = {k: torch.tensor(v, requires_grad=True) for k, v in synth.lm_weights(synth.TINY_LM, 31).items()}
+    buf = parallel.FlatBuffers(list(jsd.values()))
+    rs = np.random.RandomState(33)
+    ys = [torch.from_numpy(rs.randint(3, 9, size=(n,)).astype(np.int64)) for n in (6, 5, 4, 3, 3)]
+    ld = synth.labeldist(9, 32)
+    loss, avg = parallel.judge_local_loss(
+        lambda y: O.lm_forward(jsd, y, discrete_input=True, n_layers=2, ls_weight=0.05, labeldist=ld),
+        O.lm_masked_sum, ys, rank, world)
+    buf.zero_grad()
+    loss.backward()
+    buf.set_aux([loss, avg])
+    buf.allreduce_grads()
+    return buf, buf.aux[:2].tolist()
+
+
+def _worker_kind(rank, world, port, kind, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf, scalars = (_ssl_for if kind == "ssl" else _judge_for)(rank, world)
+    if rank == 0:
+        torch.save(dict(flat=buf.flat_g[:buf.total].clone(), scalars=scalars), os.path.join(out_dir, kind + ".pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["ssl", "judge"])
+def test_ssl_and_judge_steps_two_ranks_equal_one_rank(tmp_path, kind):
+    """The semi-supervised generator step (auxiliary loss normalised by the GLOBAL hypothesis-token count, uneven
+    shards) and the judge step (normalised by the global sum of len+5): 2 ranks == 1 process, losses and gradients."""
+    _setup_paths()
+    port = _free_port()
+    mp.spawn(_worker_kind, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(os.path.join(str(tmp_path), kind + ".pt"))
+    ref_buf, ref_scalars = (_ssl_for if kind == "ssl" else _judge_for)(0, 1)
+    for a, b in zip(got["scalars"], ref_scalars):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got["scalars"], ref_scalars)
+    ref = ref_buf.flat_g[:ref_buf.total]
+    err = (got["flat"] - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert scale > 0 and err <= 1e-6 * max(scale, 1.0) + 1e-7, (err, scale)
+    if kind == "ssl":
+        # and the one-process value of the helper is the reference's own loss assembly (oracle.ssl_losses)
+        from oracle import asr_oracle as O
+        cfg = dict(CFG, labeldist=synth.labeldist(CFG["output_dim"], 12))
+        sd = O.make_leaf_state(synth.e2e_weights(CFG, 11))
+        jsd = {k: torch.from_numpy(v) for k, v in synth.lm_weights(synth.TINY_LM, 31).items()}
+        xs, ilens, ys = synth.batch(CFG["input_dim"], CFG["output_dim"], ILENS, YLENS, 13)
+        uxs, uilens, _ = synth.batch(CFG["input_dim"], CFG["output_dim"], UILENS, [2] * len(UILENS), 41)
+        np.random.seed(9)
+        sup, unsup = O.ssl_losses(sd, jsd, cfg, dict(n_layers=2), torch.from_numpy(xs), ilens,
+                                  [torch.from_numpy(y) for y in ys], torch.from_numpy(uxs), uilens, 0.5)
+        assert abs(float(unsup) - ref_scalars[0]) < 1e-6 and abs(float(sup) - ref_scalars[1]) < 1e-6
+
+
+def test_empty_shard_keeps_rng_aligned():
+    """More ranks than utterances: the idle rank returns no loss but consumes the same teacher-forcing draws."""
+    _setup_paths()
+    import parallel
+    xs, ilens, ys = synth.batch(CFG["input_dim"], CFG["output_dim"], [7, 5], [3, 2], 13)
+    np.random.seed(3)
+    assert parallel.sup_local_loss(None, xs, ilens, [torch.from_numpy(y) for y in ys], 0.5, 2, 3, 2, [2, 2]) is None
+    after_idle = np.random.random_sample()
+    np.random.seed(3)
+    for _ in range(4):                                   # olength = max label length + 1
+        np.random.random_sample()
+    assert after_idle == np.random.random_sample()
 
 
 def _worker(rank, world, port, tf_rate, out_dir):
@@ -114,3 +229,8 @@ def test_flat_buffers_alias_params_and_grads():
     assert torch.equal(buf.flat_g[o:o + 7], torch.full((7,), 2.0))
     buf.flat_p[buf.offsets[1]:buf.offsets[1] + 3] = 5.0
     assert torch.equal(lin.bias.data, torch.full((3,), 5.0))
+    # aux slots ride behind the gradients and survive zero_grad / collect
+    buf.set_aux([torch.tensor(1.5), 2.0])
+    buf.zero_grad()
+    buf.collect()
+    assert buf.flat_g.numel() == buf.total + buf.NAUX and buf.aux.tolist() == [1.5, 2.0, 0.0, 0.0]
