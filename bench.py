@@ -1,16 +1,19 @@
 """bench.py — utterances/sec of a full train step (forward + loss + backward + gradient all-reduce + clip +
-Adam) of the seq2seq ASR hot path on N MI355X GPUs, plus the dominant kernel's roofline fraction and a CPU
-baseline (the oracle port) timed on the host cores of the same box.
+Adam) of the seq2seq ASR hot path on N MI355X GPUs, plus the dominant kernel's roofline fraction, the per-layer
+encoder gate-GEMM fractions and a CPU baseline (the oracle port) timed on the host cores of the same box.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 10 --warmup 3                                  # cfg-2, the headline line
+    python bench.py --config cfg5            |  --config cfg1  |  --frames 400       # the other BASELINE.json shapes
+    python bench.py --scaling strong --global-batch 256                              # fixed total work over N GPUs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1] ("cfg-2"): 3x512 pyramidal BiLSTM encoder, 512 LSTM decoder with
+Default workload = BASELINE.json configs[1] ("cfg-2"): 3x512 pyramidal BiLSTM encoder, 512 LSTM decoder with
 location-aware attention, V=34, batch 32 per GPU, 80-dim x 800-frame synthetic fbank (ragged lengths
 U[0.6T, T], longest pinned to T; label length 0.125 T_i), dropout 0.3 as in config.yaml, fp32.
-Weak scaling: 32 utterances per GPU; at N=8 the global batch is 256 (configs[2]'s shape).  Every rank
-pads its strided shard to the global T_max / olength (exact-parity mode).
+Weak scaling (default): 32 utterances per GPU; at N=8 the global batch is 256 (configs[2]'s shape).
+Strong scaling: --global-batch utterances in total, split over the ranks (N=1 runs all of them on one GPU).
+Every rank pads its strided shard to the global T_max / olength (exact-parity mode).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -27,32 +30,29 @@ for p in (ROOT, os.path.join(ROOT, "semi-supervised-asr_amd"), os.path.join(ROOT
 import numpy as np
 import torch
 
-CFG2 = dict(input_dim=80, enc_hidden_dim=512, enc_n_layers=3, subsample=[2, 2, 2], dropout_rate=0.3,
-            dec_hidden_dim=512, att_dim=512, conv_channels=10, conv_kernel_size=100, att_odim=512,
-            embedding_dim=128, output_dim=34, ls_weight=0.05)
-T_FRAMES = 800
-B_PER_GPU = 32
+import synth
+
+# BASELINE.json configs: (model dims, utterances per GPU, frames); dropout 0.3 = config.yaml
+CONFIGS = {
+    "cfg1": dict(model=dict(synth.CFG1, dropout_rate=0.3), batch=4, frames=200,
+                 name="cfg-1: config.yaml-shaped 1x128 pBiLSTM enc / 320 LSTM dec (BASELINE.json configs[0])"),
+    "cfg2": dict(model=dict(synth.CFG2, dropout_rate=0.3), batch=32, frames=800,
+                 name="cfg-2: 3x512 pBiLSTM enc / 1x512 LSTM dec + location attention (BASELINE.json configs[1])"),
+    "cfg5": dict(model=dict(synth.CFG2, dropout_rate=0.3), batch=8, frames=1600,
+                 name="cfg-5: cfg-2's model on long utterances (BASELINE.json configs[4])"),
+}
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TF = 157.3
+CFG2 = CONFIGS["cfg2"]["model"]                 # used by tools/
 
 
 def global_batch(n_utt, t_max, seed):
-    """Seeded synthetic batch in collate layout: N(0,1) features, ragged lengths, sorted desc."""
-    rs = np.random.RandomState(seed)
-    lens = sorted([int(v) for v in rs.randint(int(0.6 * t_max), t_max + 1, size=n_utt)], reverse=True)
-    lens[0] = t_max
-    xs = np.zeros((n_utt, t_max, CFG2["input_dim"]), dtype=np.float32)
-    ys = []
-    for b, l in enumerate(lens):
-        xs[b, :l] = rs.normal(0, 1, size=(l, CFG2["input_dim"])).astype(np.float32)
-        ys.append(rs.randint(3, CFG2["output_dim"], size=(max(2, int(0.125 * l)),)).astype(np.int64))
-    ys[0] = rs.randint(3, CFG2["output_dim"], size=(int(0.125 * t_max),)).astype(np.int64)
-    return xs, lens, ys
+    """The synthetic batch generator of the benchmark (tools/ use it too)."""
+    return synth.ragged_batch(n_utt, t_max, CFG2["input_dim"], CFG2["output_dim"], seed)
 
 
-def fwd_flops_per_utt(t_frames, l_plus_1):
-    """SURVEY 8d F_fwd (algorithmic, per utterance)."""
-    c = CFG2
+def fwd_flops_per_utt(c, t_frames, l_plus_1):
+    """SURVEY 8d F_fwd (algorithmic, per utterance) for model dims c."""
     H, I = c["enc_hidden_dim"], c["input_dim"]
     f, t = 0.0, t_frames
     for layer in range(c["enc_n_layers"]):
@@ -87,62 +87,166 @@ def note(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (CPU port of the reference path) on a bounded sample of the same workload."""
-    import synth
+def cpu_baseline(cfg, xs, lens, ys, label, min_steps):
+    """The oracle (CPU port of the reference path, oracle/asr_oracle.py) running the SAME train step on the SAME
+    synthetic batch the GPU was timed on (identical batches; 1 step at the cfg-2 / cfg-5 shapes, >= 3 at
+    cfg-1), on the host cores of this box."""
     from oracle import asr_oracle as O
     ncores = usable_cpus()
-    note("cpu baseline on %d threads" % ncores)
+    note("cpu baseline: %s on %d threads" % (label, ncores))
     torch.set_num_threads(ncores)
-    n_s = 2
-    xs, lens, ys = global_batch(B_PER_GPU, T_FRAMES, 1234)
-    xs, lens, ys = xs[:n_s], lens[:n_s], ys[:n_s]
-    cfg = dict(CFG2, labeldist=synth.labeldist(CFG2["output_dim"], 5))
-    sd = O.make_leaf_state(synth.e2e_weights(CFG2, 99))
-    names = O.unique_param_names(sd)
-    opt = O.AdamAmsgrad(names, lr=5e-4, weight_decay=1e-6)
+    mcfg = dict(cfg, labeldist=synth.labeldist(cfg["output_dim"], 5))
+    sd = O.make_leaf_state(synth.e2e_weights(cfg, 99))
+    opt = O.AdamAmsgrad(O.unique_param_names(sd), lr=5e-4, weight_decay=1e-6)
     xs_t, ys_t = torch.from_numpy(xs), [torch.from_numpy(y) for y in ys]
     t0 = time.perf_counter()
     steps = 0
     while True:
-        O.sup_train_step(sd, cfg, opt, xs_t, lens, ys_t, max_grad_norm=5.0)
+        O.sup_train_step(sd, mcfg, opt, xs_t, lens, ys_t, max_grad_norm=5.0)
         steps += 1
         el = time.perf_counter() - t0
-        if el * (steps + 1) / steps > seconds_budget or steps >= 3:
+        if steps >= min_steps and (el > 20.0 or steps >= 10):
             break
-    return dict(value=n_s * steps / el, unit="utterances/sec", cores=ncores, kind="port",
-                sample="%d train step(s) of oracle/asr_oracle.py on the first %d utterances of the cfg-2 batch "
-                       "(T=%d, dropout 0.3), %d torch CPU threads" % (steps, n_s, T_FRAMES, ncores))
+    return dict(value=len(lens) * steps / el, unit="utterances/sec", cores=ncores, kind="port", seconds=el,
+                sample="%d full train step(s) of oracle/asr_oracle.py on the whole %s batch the GPU ran (%d utterances, "
+                       "T=%d, dropout %.1f, clip 5 + Adam(amsgrad)), %d torch CPU threads"
+                       % (steps, label, len(lens), max(lens), cfg["dropout_rate"], ncores))
 
 
-def tn_gemm_shapes():
-    """The weight-gradient (transA) GEMM launches of ONE cfg-2 train step: (M, N, K, batch).  dW_hh is not among
-    them: the persistent LSTM backward kernel accumulates it."""
-    c = CFG2
-    H, I, B = c["enc_hidden_dim"], c["input_dim"], B_PER_GPU
-    D, O, E, A, V = c["dec_hidden_dim"], c["att_odim"], c["embedding_dim"], c["att_dim"], c["output_dim"]
-    shapes, t = [], T_FRAMES
+def encoder_layer_frames(c, t_frames):
+    out, t = [], t_frames
     for layer in range(c["enc_n_layers"]):
+        out.append(t)
+        t = (t + 1) // 2 if c["subsample"][layer] > 1 else t
+    return out, t
+
+
+def tn_gemm_shapes(c, B, t_frames, olength):
+    """The weight-gradient (transA) GEMM launches of ONE train step: (M, N, K, batch).  dW_hh is not among them: the
+    persistent LSTM backward kernel accumulates it."""
+    H, I = c["enc_hidden_dim"], c["input_dim"]
+    D, O, E, A, V = c["dec_hidden_dim"], c["att_odim"], c["embedding_dim"], c["att_dim"], c["output_dim"]
+    shapes = []
+    frames, tp = encoder_layer_frames(c, t_frames)
+    for layer, t in enumerate(frames):
         idim = I if layer == 0 else H
         shapes.append((8 * H, idim, t * B, 1))                       # dW_ih (both directions)
-        t2 = (t + 1) // 2
-        shapes.append((H, 4 * H, t2 * B, 1))                         # dW of the pyramid projection
-        t = t2
-    L = int(0.125 * T_FRAMES) + 1
-    shapes += [(A, H, t * B, 1), (O, H, t * B, 1)]                   # mlp_enc, mlp_o (hoisted)
+        sub = c["subsample"][layer] > 1
+        shapes.append((H, 4 * H if sub else 2 * H, ((t + 1) // 2 if sub else t) * B, 1))   # dW of the projection
+    L = olength
+    shapes += [(A, H, tp * B, 1), (O, H, tp * B, 1)]                 # mlp_enc, mlp_o (hoisted)
     shapes += [(V, D + O, L * B, 1), (4 * D, D + O + E, L * B, 1), (A, D, L * B, 1)]   # output layer, cell, mlp_dec
-    shapes.append((t, O, L, B))                                      # dQ, batched over utterances
+    shapes.append((tp, O, L, B))                                     # dQ, batched over utterances
     return shapes
 
 
-def kernel_roofline(dev):
-    """Roofline of the dominant kernel of the cfg-2 train step, timed live with HIP events on the launch stream.
+def _time_events(fn, reps):
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
 
-    Two kernels compete for "dominant by total time per step" (profiles/r01_bench_kernel_stats_*.csv), so both are
+
+def encoder_gate_gemms(dev, c, B, t_frames):
+    """north_star: ">= 40 % MFMA utilisation on the encoder gate GEMM".  Per encoder layer, on operands of the step's
+    shapes that were evicted from the caches before each launch (a 512 MB fill in between: the train step finds them in
+    HBM too): the input-gate projection [T*B, in] x [in, 8H] (forward), its two backward GEMMs (dX = dG W_ih,
+    dW_ih = dG^T X), and the recurrent products of the persistent kernels (h W_hh^T forward; dG W_hh + dG^T h backward)
+    timed as whole kernels.  Each entry: achieved TFLOP/s and fraction of the 157.3 TF f32-MFMA peak."""
+    import hip_backend as hb
+    lib = hb.load()
+    H, I = c["enc_hidden_dim"], c["input_dim"]
+    frames, _ = encoder_layer_frames(c, t_frames)
+    flush = torch.empty(128 * 1024 * 1024, device=dev)
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def cold(fn):
+        best = None
+        for _ in range(3):
+            flush.fill_(1.0)
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            dt = e0.elapsed_time(e1) * 1e-3
+            best = dt if best is None else min(best, dt)
+        return best
+
+    out = []
+    g = torch.Generator().manual_seed(7)
+    xch, ctrl = hb.persist_scratch(dev)
+    for layer, T in enumerate(frames):
+        idim = I if layer == 0 else H
+        M = T * B
+        x = torch.randn(M, idim, device=dev)
+        w = torch.randn(8 * H, idim, device=dev) / np.sqrt(idim)
+        dG = torch.randn(M, 8 * H, device=dev)
+        gates = torch.empty(M, 8 * H, device=dev)
+        bias = torch.zeros(8 * H, device=dev)
+        rows = []
+        for op, fn, flops in (
+                ("in-proj fwd  [T*B,%d]x[%d,8H]" % (idim, idim), lambda: hb.gemm(x, w, trans_b=True, bias=bias, out=gates),
+                 2.0 * M * idim * 8 * H),
+                ("dX = dG W_ih [T*B,8H]x[8H,%d]" % idim, lambda: hb.gemm(dG, w), 2.0 * M * idim * 8 * H),
+                ("dW_ih = dG^T X [8H,T*B]x[T*B,%d]" % idim, lambda: hb.gemm(dG, x, trans_a=True), 2.0 * M * idim * 8 * H)):
+            if layer == 0 and op.startswith("dX"):
+                continue                                  # the features need no gradient
+            dt = cold(fn)
+            rows.append(dict(layer=layer, op=op, us=dt * 1e6, tflops=flops / dt / 1e12,
+                             frac=flops / dt / 1e12 / MFMA_F32_PEAK_TF))
+        del x, w, dG, gates
+        # recurrent products: the persistent kernels of this layer (both directions)
+        lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        gts = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).to(dev)
+        whh = (torch.randn(2, 4 * H, H, generator=g) / np.sqrt(H)).to(dev)
+        y = torch.empty(T, B, 2 * H, device=dev)
+        cst = torch.empty(T, B, 2 * H, device=dev)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whh), hb.ptr(lens), hb.ptr(y), hb.ptr(cst),
+                                          hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), hb.stream())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        if rc == 0:
+            dt = e0.elapsed_time(e1) * 1e-3
+            fl = T * 2.0 * B * 4 * H * H * 2
+            rows.append(dict(layer=layer, op="recurrent fwd h W_hh^T (persistent kernel, T=%d)" % T, us=dt * 1e6,
+                             us_per_time_step=dt / T * 1e6, tflops=fl / dt / 1e12, frac=fl / dt / 1e12 / MFMA_F32_PEAK_TF))
+            dy = (torch.randn(T, B, 2 * H, generator=g) * 0.01).to(dev)
+            dw = torch.zeros(2, 4 * H, H, device=dev)
+            db = torch.zeros(2 * 4 * H, device=dev)
+            whT = whh.transpose(1, 2).contiguous()
+            torch.cuda.synchronize()
+            e0.record(stream)
+            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whT), hb.ptr(lens), hb.ptr(dy), hb.ptr(cst),
+                                              hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
+                                              hb.c_p(ctrl.data_ptr()), hb.stream())
+            e1.record(stream)
+            torch.cuda.synchronize()
+            hb.check(rc, "asr_lstm_seq_bwd_persist")
+            dt = e0.elapsed_time(e1) * 1e-3
+            rows.append(dict(layer=layer, op="recurrent bwd dG W_hh + dG^T h (persistent kernel, T=%d)" % T, us=dt * 1e6,
+                             us_per_time_step=dt / T * 1e6, tflops=2 * fl / dt / 1e12,
+                             frac=2 * fl / dt / 1e12 / MFMA_F32_PEAK_TF))
+        out += rows
+    return out
+
+
+def kernel_roofline(dev, c, B, t_frames, olength):
+    """Roofline of the dominant kernel of the train step, timed live with HIP events on the launch stream.
+
+    Two kernels compete for "dominant by total time per step" (profiles/*_bench_kernel_stats*.csv), so both are
     replayed on synthetic operands of the step's exact shapes and the one with the larger per-step total is reported
     as the roofline (the other goes to `also`):
-      * lstm_persist_bwd_kernel<512>: one launch per encoder layer (T = 800, 400, 200); algorithmic flops per time
-        step = 2*B*4H*H*ndir for dh_rec = dG W_hh plus the same again for the fused dW_hh += dG^T h.
+      * lstm_persist_bwd_kernel<H>: one launch per encoder layer and row block; algorithmic flops per time step =
+        2*B*4H*H*ndir for dh_rec = dG W_hh plus the same again for the fused dW_hh += dG^T h.
       * gemm_f32_kernel<false,false>: the transA f32-MFMA GEMMs that form the remaining weight gradients.
     `achieved` = algorithmic flops of those launches / their total time; us_per_launch is directly comparable with
     rocprofv3's average duration for that kernel name."""
@@ -152,7 +256,7 @@ def kernel_roofline(dev):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     # ---- transA GEMMs
-    shapes = tn_gemm_shapes()
+    shapes = tn_gemm_shapes(c, B, t_frames, olength)
     bufs = []
     for (M, N, K, batch) in shapes:
         bufs.append((torch.randn(batch * K, M, device=dev) if batch == 1 else torch.randn(K, batch, M, device=dev),
@@ -166,15 +270,7 @@ def kernel_roofline(dev):
             else:
                 hb.gemm_batched(a_, b_, o_, True, False, M, N, K, batch * M, batch * N, N, batch, M, N, M * N)
 
-    run_all()
-    torch.cuda.synchronize()
-    reps = 3
-    e0.record(stream)
-    for _ in range(reps):
-        run_all()
-    e1.record(stream)
-    torch.cuda.synchronize()
-    gemm_s = e0.elapsed_time(e1) * 1e-3 / reps
+    gemm_s = _time_events(run_all, 3)
     gemm_flops = sum(2.0 * M * N * K * batch for (M, N, K, batch) in shapes)
     del bufs
     gemm = dict(bound="mfma", kernel="gemm_f32_kernel<false,false> (transA weight-gradient GEMMs of one step)",
@@ -182,25 +278,23 @@ def kernel_roofline(dev):
                 frac=gemm_flops / gemm_s / 1e12 / MFMA_F32_PEAK_TF, traffic=None, launches_per_step=len(shapes),
                 us_per_launch=gemm_s / len(shapes) * 1e6, ms_per_step=gemm_s * 1e3)
 
-    # ---- persistent LSTM backward (with the fused recurrent weight gradient), the three encoder layers
-    H, B = CFG2["enc_hidden_dim"], B_PER_GPU
+    # ---- persistent LSTM backward (with the fused recurrent weight gradient), the encoder layers
+    H = c["enc_hidden_dim"]
     g = torch.Generator().manual_seed(3)
-    layers, t = [], T_FRAMES
-    for _ in range(CFG2["enc_n_layers"]):
-        layers.append(t)
-        t = (t + 1) // 2
+    layers, _ = encoder_layer_frames(c, t_frames)
     w = (torch.randn(2, H, 4 * H, generator=g) / np.sqrt(H)).to(dev)
-    lens = torch.full((B,), T_FRAMES, dtype=torch.int32, device=dev)
+    lens = torch.full((B,), t_frames, dtype=torch.int32, device=dev)
     T0 = layers[0]
     gates0 = (torch.rand(T0, B, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
     gates = torch.empty_like(gates0)
     dy = (torch.randn(T0, B, 2 * H, generator=g) * 0.01).to(dev)
-    c = torch.randn(T0, B, 2 * H, generator=g).to(dev)
+    cst = torch.randn(T0, B, 2 * H, generator=g).to(dev)
     y = torch.tanh(torch.randn(T0, B, 2 * H, generator=g)).to(dev)
     dw = torch.zeros(2, 4 * H, H, device=dev)
     xch, ctrl = hb.persist_scratch(dev)
-    lstm_s, lstm_flops = 0.0, 0.0
+    lstm_s, lstm_flops, launches = 0.0, 0.0, 0
     db = torch.zeros(2 * 4 * H, device=dev)
+    rows_per_launch = 16 if B <= 16 else 32
     for T in layers:
         lens.fill_(T)
         best = None
@@ -209,31 +303,40 @@ def kernel_roofline(dev):
             torch.cuda.synchronize()
             e0.record(stream)
             rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy),
-                                              hb.ptr(c), hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
+                                              hb.ptr(cst), hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
                                               hb.c_p(ctrl.data_ptr()), hb.stream())
             e1.record(stream)
             torch.cuda.synchronize()
+            if rc == -2:
+                return dict(gemm, note="persistent LSTM kernels do not cover H=%d" % H)
             hb.check(rc, "asr_lstm_seq_bwd_persist")
             if _rep > 0:
                 dt = e0.elapsed_time(e1) * 1e-3
                 best = dt if best is None else min(best, dt)
         lstm_s += best
         lstm_flops += T * 2.0 * (2.0 * B * 4 * H * H * 2)
-    lstm = dict(bound="mfma", kernel="lstm_persist_bwd_kernel<512> (dG recurrence + fused dW_hh, 3 encoder layers)",
+        launches += (B + rows_per_launch - 1) // rows_per_launch
+    lstm = dict(bound="mfma", kernel="lstm_persist_bwd_kernel<%d> (dG recurrence + fused dW_hh, %d encoder layers)"
+                                     % (H, len(layers)),
                 achieved=lstm_flops / lstm_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                frac=lstm_flops / lstm_s / 1e12 / MFMA_F32_PEAK_TF, traffic=None, launches_per_step=len(layers),
-                us_per_launch=lstm_s / len(layers) * 1e6, ms_per_step=lstm_s * 1e3,
-                us_per_time_step=lstm_s / sum(layers) * 1e6, aborted=bool(hb.persist_aborted(dev)))
-    # HBM-side traffic of that kernel from the committed PMC passes (profiles/r01_pmc_lstm_persist.json: separate
-    # --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc_probe.py, FETCH doubled as the gfx950 guide prescribes)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_lstm_persist.json")) as f:
-            pmc = json.load(f)["lstm_persist_bwd_kernel<512>"]
-        lstm["traffic"] = pmc["hbm_side_bytes_per_time_step"] * sum(layers) / len(layers)
-        lstm["traffic_unit"] = "bytes/launch (PMC bytes per time step x mean T of the 3 launches)"
-        lstm["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes_per_time_step"] * sum(layers) / len(layers)
-    except (OSError, KeyError, ValueError):
-        pass
+                frac=lstm_flops / lstm_s / 1e12 / MFMA_F32_PEAK_TF, traffic=None, launches_per_step=launches,
+                us_per_launch=lstm_s / launches * 1e6, ms_per_step=lstm_s * 1e3,
+                us_per_time_step=lstm_s / (sum(layers) * (launches // len(layers))) * 1e6,
+                aborted=bool(hb.persist_aborted(dev)))
+    # HBM-side traffic of that kernel from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    # tools/pmc_probe.py, FETCH doubled as the gfx950 guide prescribes); measured at H=512, 8-row groups
+    if H == 512 and B >= 32:
+        for name in ("r02_pmc_lstm_persist.json", "r01_pmc_lstm_persist.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)["lstm_persist_bwd_kernel<512>"]
+                scale = (B / 32.0) * sum(layers) / launches          # PMC bytes are per time step of a 32-row launch
+                lstm["traffic"] = pmc["hbm_side_bytes_per_time_step"] * scale
+                lstm["traffic_unit"] = "bytes/launch (PMC bytes per time step x mean T of the launches), " + name
+                lstm["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes_per_time_step"] * scale
+                break
+            except (OSError, KeyError, ValueError):
+                continue
     first, second = (lstm, gemm) if lstm_s >= gemm_s else (gemm, lstm)
     first["also"] = second
     return first
@@ -244,8 +347,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--frames", type=int, default=None, help="T of the synthetic 80 x T batches (200/400/800/1600)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--global-batch", type=int, default=256, help="total utterances with --scaling strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dropout", type=float, default=CFG2["dropout_rate"])
+    ap.add_argument("--no-layer-gemms", action="store_true")
+    ap.add_argument("--dropout", type=float, default=None)
     args = ap.parse_args()
 
     import __graft_entry__ as entry
@@ -253,26 +362,34 @@ def main():
     import parallel
     import model as M
     from parallel import FlatAdam
-    import synth
     import torch.distributed as dist
 
     rank, world, local = parallel.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = dict(CFG2, dropout_rate=args.dropout)
+    spec = CONFIGS[args.config]
+    cfg = dict(spec["model"])
+    if args.dropout is not None:
+        cfg["dropout_rate"] = args.dropout
+    t_frames = args.frames or spec["frames"]
+    if args.scaling == "strong":
+        n_global = args.global_batch
+        assert n_global % world == 0, "--global-batch must divide by the number of GPUs"
+    else:
+        n_global = (args.batch_per_gpu or spec["batch"]) * world
     torch.manual_seed(1000 + rank)                     # per-rank dropout streams; weights below are shared
     net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 5), **cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.e2e_weights(cfg, 99).items()})
     net = net.to(dev).train()
     opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0)
 
-    n_global = B_PER_GPU * world
-    xs, lens, ys = global_batch(n_global, T_FRAMES, 1234)
+    xs, lens, ys = synth.ragged_batch(n_global, t_frames, cfg["input_dim"], cfg["output_dim"], 1234)
     xs_r, lens_r, ys_r, info = parallel.shard_batch(xs, lens, ys, rank, world)
     xs_d = torch.from_numpy(np.ascontiguousarray(xs_r)).to(dev)       # inputs resident in HBM before timing
     ys_d = [torch.from_numpy(y).to(dev) for y in ys_r]
     tl = M.padded_lengths(info["t_max"], cfg["enc_n_layers"], cfg["subsample"])
+    b_local = len(lens_r)
 
     def step():
         _, lp, _, _ = net(xs_d, lens_r, ys_d, tf_rate=1.0, total_length=tl, olength=info["olength"])
@@ -288,7 +405,7 @@ def main():
         torch.cuda.synchronize()
 
     if rank == 0:
-        note("warmup")
+        note("%s, %d utterances per GPU x %d GPU(s), T=%d: warmup" % (args.config, b_local, world, t_frames))
     for _ in range(args.warmup):
         step()
     fence()
@@ -307,29 +424,7 @@ def main():
         for _ in range(max(1, args.warmup)):
             step()
         fence()
-    # launch-mode autotune (untimed): eager launches on the current stream vs hipGraph replay of the per-step chains.
-    # Replay costs ~0.8 us more per kernel on the GPU but frees the host; which wins depends on the host CPU.
-    mode_ms = {}
-    if os.environ.get("ASR_GRAPHS") is None:
-        for mode in (False, True):
-            hb.USE_GRAPHS = mode
-            for _ in range(3 if mode else 1):       # replay needs: first sighting, capture, then steady state
-                step()
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(2):
-                step()
-            fence()
-            mode_ms["graphs" if mode else "eager"] = (time.perf_counter() - t0) / 2 * 1e3
-        use = mode_ms["graphs"] < 0.97 * mode_ms["eager"]
-        if world > 1:                               # all ranks must agree
-            flag = torch.tensor([1.0 if use else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            use = bool(flag.item() > 0.5)
-        hb.USE_GRAPHS = use
-        step()
-        fence()
-    launch_mode = "hipgraph-replay" if hb.USE_GRAPHS else "eager"
+    hb.LAUNCHES.clear()
     if rank == 0:
         note("timing %d steps" % args.steps)
     t0 = time.perf_counter()
@@ -341,29 +436,36 @@ def main():
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    final_loss = float(loss.item()) * world
+    final_loss = float(loss.item()) * (world if world > 1 else 1)
+    paths = {k: v // max(1, args.steps) for k, v in sorted(hb.LAUNCHES.items())}
 
     if rank == 0:
         ms = el / args.steps * 1e3
         value = n_global * args.steps / el
-        f_train = 3.0 * sum(fwd_flops_per_utt(info["t_max"], info["olength"]) for _ in range(1))
+        f_train = 3.0 * sum(fwd_flops_per_utt(cfg, l, max(2, int(0.125 * l)) + 1) for l in lens) / len(lens)
+        f_train_padded = 3.0 * fwd_flops_per_utt(cfg, info["t_max"], info["olength"])
         out = {
             "metric": "utterances/sec (train step)", "value": value, "unit": "utterances/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg-2: 3x512 pBiLSTM enc / 1x512 LSTM dec + location attention, "
-                                   "batch 32 per GPU, 80x800 synthetic fbank (ragged 0.6T..T), V=34, L+1=%d, "
-                                   "dropout %.2f, Adam(amsgrad)+clip 5" % (info["olength"], args.dropout),
-                       "global_batch": n_global, "frames": T_FRAMES, "parallelism": "dp%d" % world,
-                       "pad_mode": "global-exact", "launch_mode": launch_mode, "launch_mode_probe_ms": mode_ms,
-                       "persistent_kernels": bool(hb.USE_PERSIST)},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, batch %d per GPU, 80x%d synthetic fbank (ragged 0.6T..T), V=%d, L+1=%d, "
+                                   "dropout %.2f, Adam(amsgrad)+clip 5" % (spec["name"], b_local, t_frames,
+                                                                           cfg["output_dim"], info["olength"],
+                                                                           cfg["dropout_rate"]),
+                       "config": args.config, "global_batch": n_global, "frames": t_frames,
+                       "parallelism": "dp%d" % world, "pad_mode": "global-exact", "launch_mode": "eager",
+                       "persistent_kernels": bool(hb.USE_PERSIST), "sequence_op_paths_per_step": paths},
             "loss": final_loss,
             "model_tflops": value * f_train / 1e12,
+            "model_tflops_incl_padded_frames": value * f_train_padded / 1e12,
         }
         note("%.1f utt/s, %.2f ms/step; measuring dominant kernel" % (value, ms))
-        out["roofline"] = kernel_roofline(dev)
+        out["roofline"] = kernel_roofline(dev, cfg, b_local, t_frames, info["olength"])
+        if not args.no_layer_gemms:
+            out["encoder_gate_gemm"] = encoder_gate_gemms(dev, cfg, b_local, t_frames)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cfg, xs, lens, ys, args.config + " T=%d" % t_frames,
+                                               3 if args.config == "cfg1" else 1)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

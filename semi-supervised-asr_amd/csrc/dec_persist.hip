@@ -1475,8 +1475,7 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
   const bool cfg1 = p->D == 320 && p->A == 320 && p->O == 320 && p->E == 128;
   if (!cfg1 && !cfg2) return ASR_E_SHAPE;
   const int TpP = (p->Tp + 3) & ~3;
-  if (p->Tp > DP_TPM || p->C <= 0 || p->C > 16 || p->K < 0 || p->K > DP_KMAX || 2 * p->C * TpP > 4 * DP_NT ||
-      p->nb > 128)
+  if (p->Tp > DP_TPM || p->C <= 0 || p->C > 16 || p->K < 0 || p->K > DP_KMAX || 2 * p->C * TpP > 4 * DP_NT)
     return ASR_E_SHAPE;
   if (!asr_persist_device_ok()) return ASR_E_SHAPE;
   const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;
@@ -1550,7 +1549,7 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
   if (!cfg1 && !cfg2) return ASR_E_SHAPE;
   const int TpP = (p->Tp + 3) & ~3;
   if (p->Tp > DP_TPM || p->C <= 0 || p->C > 16 || p->K < 0 || p->K > DP_KMAX || p->C * TpP > 2 * DP_NT ||
-      4 * p->C * TpP > 8 * DP_NT || p->nb > 128)
+      4 * p->C * TpP > 8 * DP_NT)
     return ASR_E_SHAPE;
   if (!asr_persist_device_ok()) return ASR_E_SHAPE;
   const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;

@@ -746,7 +746,8 @@ bool asr_persist_device_ok() {
 }
 
 // Returns ASR_E_SHAPE when the fast path does not apply (caller falls back to asr_lstm_seq_fwd).  Batches larger
-// than 8 * (8 / ndir) rows run as consecutive launches over row blocks (rows are independent).
+// than 8 * (8 / ndir) rows run as consecutive launches over row blocks (rows are independent; any batch size: a
+// single-GPU batch of 256 is 8 launches per layer).
 // xch: >= 1 MB, ctrl: >= 64 B; both are zeroed here on the stream before every launch.
 extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
                                         const int32_t* lens, float* y, float* c, void* xch, void* ctrl,
@@ -756,7 +757,6 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
   if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   const int nr = rows_per_group(nb, ndir);
   const int rows_per_launch = nr * (8 / ndir);
-  if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;          // large batches: the per-step kernels are the better fit
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
     hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * PRG * H * sizeof(u64), stream);
     if (e != hipSuccess) return (int)e;
@@ -781,7 +781,6 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
   if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   const int nr = rows_per_group(nb, ndir);
   const int rows_per_launch = nr * (8 / ndir);
-  if (nb > 4 * rows_per_launch) return ASR_E_SHAPE;
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
     hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * PRG * 4 * H * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;

@@ -601,7 +601,8 @@ def test_lstm_persistent_path(ndir, B, T, lens, H):
 
 
 @pytest.mark.parametrize("dim,B,Tp,L,drop", [(512, 32, 100, 6, True), (512, 7, 37, 4, False), (320, 32, 100, 5, True),
-                                             (512, 40, 100, 3, False), (512, 32, 128, 3, True), (320, 5, 9, 4, False)])
+                                             (512, 40, 100, 3, False), (512, 16, 96, 3, True), (320, 5, 9, 4, False),
+                                             (512, 70, 100, 2, True)])
 def test_decoder_persistent_path(dim, B, Tp, L, drop):
     """The persistent XCD-local decoder forward kernel (one launch for the whole teacher-forced sequence) against the
     per-step kernels on the same inputs: outputs and every gradient (the backward consumes the buffers it saved).
