@@ -35,6 +35,9 @@
                                      1 = single-stage LSB-tagged words read as 8-byte atomics (2.38-2.45),
                                      2 = the same words read with 16-byte sc1 buffer loads (2.05) */
 #endif
+#ifndef ASR_LSTM_BF3_DEFAULT   /* split-bf16 recurrent products: bit 0 forward, bit 1 backward (env ASR_LSTM_BF3 overrides) */
+#define ASR_LSTM_BF3_DEFAULT 3
+#endif
 #ifndef ASR_LSTM_TOUCH
 #define ASR_LSTM_TOUCH 1
 #endif
@@ -378,6 +381,211 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------- forward, split-bf16 products
+// Same organisation as lstm_persist_fwd_kernel (roles, exchange of LSB-tagged words laid out [unit][row], pointwise
+// ownership, deferred stores); the gate product runs on v_mfma_f32_16x16x32_bf16 with both operands split into two
+// bf16 terms, x = hi + lo (hi = the upper 16 bits of the fp32 word, lo = the upper 16 bits of x - hi: 16 significand
+// bits in all), and three products hi*hi + hi*lo + lo*hi accumulated in fp32.  The dropped lo*lo term and the
+// truncation are <= 2^-15 relative per operand pair (fp32 itself: 2^-24) - two orders of magnitude inside the 1e-3
+// parity gate, measured in tests/test_hip_parity.py::test_lstm_persistent_path - while the bf16 pipe runs 16x the rate
+// of the fp32 MFMA: the product leaves the serial chain of a time step (1 024 -> 384 MFMA cycles per wave at H = 512).
+//   A = W_hh: M tile mt = gate rows 16 mt .. 16 mt + 15 of this CU (4 units x 4 gates), lane l holds row l & 15,
+//       k = 32 ks + 8 (l >> 4) + j of the wave's K range, j = 0..7, as bf16x8: registers for the whole sequence;
+//   B = h_{t-1}: lane l holds batch row l & 15 (rows >= 8 alias row l & 7, their columns of D are never read),
+//       the same 8 k's, read from the wave's LDS tile as one 16-byte load per term;
+//   D: lane l holds gate rows 16 mt + 4 (l >> 4) + i = the four gates of unit 4 mt + (l >> 4) for batch row l & 15:
+//       exactly the float4 the pointwise thread of (unit, row) sums over the 8 waves.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf3_hi(float v) { return __float_as_uint(v) >> 16; }
+__device__ __forceinline__ unsigned bf3_lo(float v) {
+  return __float_as_uint(v - __uint_as_float(__float_as_uint(v) & 0xffff0000u)) >> 16;
+}
+__device__ __forceinline__ void bf3_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+  hi = (u32x4){bf3_hi(v[0]) | (bf3_hi(v[1]) << 16), bf3_hi(v[2]) | (bf3_hi(v[3]) << 16),
+               bf3_hi(v[4]) | (bf3_hi(v[5]) << 16), bf3_hi(v[6]) | (bf3_hi(v[7]) << 16)};
+  lo = (u32x4){bf3_lo(v[0]) | (bf3_lo(v[1]) << 16), bf3_lo(v[2]) | (bf3_lo(v[3]) << 16),
+               bf3_lo(v[4]) | (bf3_lo(v[5]) << 16), bf3_lo(v[6]) | (bf3_lo(v[7]) << 16)};
+}
+__device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int PH, int NR>
+__global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a) {
+  static_assert(NR == 4 || NR == PRG, "rows per group");
+  constexpr int PKW = PH / PW;           // K columns per wave
+  constexpr int KS = (PKW + 31) / 32;    // k-steps of 32 (the range is zero padded to KS * 32)
+  constexpr int KP = KS * 32;
+  constexpr int PUC = PH / 32;           // hidden units per CU
+  constexpr int MT = (PUC + 3) / 4;      // M tiles: 4 units (16 gate rows) each
+  constexpr int HST = KP + 8;            // LDS row stride in bf16: 16-byte multiple, rows 144 B apart at KP = 64 (the 8
+                                         // rows of a 16-byte operand read then cover 8 distinct bank groups)
+  __shared__ __attribute__((aligned(16))) unsigned short hhi[PW][PRG][HST];
+  __shared__ __attribute__((aligned(16))) unsigned short hlo[PW][PRG][HST];
+  __shared__ __attribute__((aligned(16))) float part[2][PW][4 * MT][PRG][4];   // K-partials [unit][row][gate], double buffered
+  __shared__ int role[2];
+  extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < PW * PRG * HST; i += PNT) { (&hhi[0][0][0])[i] = 0; (&hlo[0][0][0])[i] = 0; }   // K padding, unused rows
+  int g, slice;
+  take_role(a.ctrl, role, g, slice);
+  if (slice < 0) return;
+  const int T = a.T, B = a.B, ndir = a.ndir;
+  const int d = ndir == 2 ? (g & 1) : 0;
+  const int rowgroup = ndir == 2 ? (g >> 1) : g;
+  const int r0 = rowgroup * NR;
+  if (r0 >= a.nb) return;                      // this group has no rows (nobody waits for it)
+  const int64_t ldy = (int64_t)ndir * PH;
+  const int ml = lane & 15, kq = lane >> 4;
+  // recurrent weights of this CU -> split bf16 registers
+  u32x4 whi[MT][KS], wlo[MT][KS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int grow = 16 * mt + ml;                                  // gate-interleaved row within this CU's 4*PUC
+    const bool rok = grow < 4 * PUC;
+    const float* wr = a.w + ((int64_t)d * 4 * PH + 4 * PUC * slice + (rok ? grow : 0)) * PH + wave * PKW;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k0 = 32 * ks + 8 * kq;
+      float v[8];
+#pragma unroll
+      for (int j4 = 0; j4 < 2; ++j4) {
+        const bool kok = rok && k0 + 4 * j4 < PKW;                  // PKW % 4 == 0: a quad is all in or all out
+        const float4 q = *reinterpret_cast<const float4*>(wr + (kok ? k0 + 4 * j4 : 0));
+        v[4 * j4] = kok ? q.x : 0.f; v[4 * j4 + 1] = kok ? q.y : 0.f;
+        v[4 * j4 + 2] = kok ? q.z : 0.f; v[4 * j4 + 3] = kok ? q.w : 0.f;
+      }
+      bf3_split8(v, whi[mt][ks], wlo[mt][ks]);
+    }
+  }
+  // pointwise ownership: thread (pu, pj) for tid < PUC*PRG -> unit PUC*slice+pu, row r0+pj
+  const int pu = tid >> 3, pj = tid & 7;
+  const bool pw_thread = tid < PUC * PRG && pj < NR;
+  const int prow = r0 + pj;
+  const bool prow_ok = pw_thread && prow < a.nb;
+  const int punit = PUC * slice + pu;
+  const int plen = prow_ok ? a.lens[prow] : 0;
+  float c_prev = 0.f;
+  float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * PRG;   // [parity][unit][row]
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
+  bool aborted = false;
+  auto gx_ptr = [&](int sn) {
+    const int tt = d == 0 ? sn : T - 1 - sn;
+    return reinterpret_cast<const float4*>(a.gates + (((int64_t)tt * B + prow) * ndir + d) * 4 * PH + punit * 4);
+  };
+  float4 gx_n1 = make_float4(0.f, 0.f, 0.f, 0.f), gx_n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (prow_ok) {
+    gx_n1 = *gx_ptr(0);
+    if (T > 1) gx_n2 = *gx_ptr(1);
+  }
+  float4 st_g = make_float4(0.f, 0.f, 0.f, 0.f);
+  float st_c = 0.f, st_y = 0.f;
+  float4* st_gp = nullptr;
+  int64_t st_so = 0;
+  __syncthreads();                             // LDS zero fill
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? s : T - 1 - s;
+    const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;
+    const float4 gx = gx_n1;
+    gx_n1 = gx_n2;
+    float4* gp = nullptr;
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      // single-stage hand-off: lane (< PKW) owns one k of the wave's range and reads its NR rows as 16-byte quads
+      const bool gl = lane < PKW;
+      const unsigned boff = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
+                                       (wave * PKW + (gl ? lane : 0)) * PRG) * 4u;
+      const unsigned tb = tag_bit_of_step(s - 1);
+      u32x4 gw[NR / 4];
+      unsigned spins = 0;
+      while (true) {
+#pragma unroll
+        for (int j = 0; j < NR / 4; ++j) gw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff + 16u * j, 0, 16);
+        unsigned bits = 1u;
+#pragma unroll
+        for (int j = 0; j < NR / 4; ++j) bits &= ~(gw[j].x ^ tb) & ~(gw[j].y ^ tb) & ~(gw[j].z ^ tb) & ~(gw[j].w ^ tb);
+        if (__all(!gl || (bits & 1u))) break;
+        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
+          aborted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+      }
+      if (gl) {
+#pragma unroll
+        for (int j = 0; j < NR / 4; ++j) {
+          const float f[4] = {__uint_as_float(gw[j].x), __uint_as_float(gw[j].y), __uint_as_float(gw[j].z),
+                              __uint_as_float(gw[j].w)};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            hhi[wave][4 * j + i][lane] = (unsigned short)bf3_hi(f[i]);
+            hlo[wave][4 * j + i][lane] = (unsigned short)bf3_lo(f[i]);
+          }
+        }
+      }
+      if (st_gp) {                    // previous step's outputs (stores after the poll: vmcnt retires in order)
+        *st_gp = st_g;
+        a.c[st_so] = st_c;
+        a.y[st_so] = st_y;
+        st_gp = nullptr;
+      }
+      if (prow_ok && s + 2 < T) gx_n2 = *gx_ptr(s + 2);     // in flight for two steps
+      // (wave-private LDS tile: program order within the wave is enough)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(&hhi[wave][ml & 7][32 * ks + 8 * kq]);
+        const u32x4 bl = *reinterpret_cast<const u32x4*>(&hlo[wave][ml & 7][32 * ks + 8 * kq]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bh, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bl, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wlo[mt][ks], bh, acc[mt]);
+      }
+    }
+    if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
+    if (ml < NR) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<float4*>(&part[s & 1][wave][4 * mt + kq][ml][0]) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    }
+    __syncthreads();
+    if (pw_thread) {
+      float pre[4] = {gx.x, gx.y, gx.z, gx.w};
+#pragma unroll
+      for (int w2 = 0; w2 < PW; ++w2) {
+        const float4 v = *reinterpret_cast<const float4*>(&part[s & 1][w2][pu][pj][0]);
+        pre[0] += v.x; pre[1] += v.y; pre[2] += v.z; pre[3] += v.w;
+      }
+      const float gi = asr_fast_sigmoid(pre[0]), gf = asr_fast_sigmoid(pre[1]);
+      const float gg = asr_fast_tanh(pre[2]), go = asr_fast_sigmoid(pre[3]);
+      float cn = gf * c_prev + gi * gg;
+      float hn = go * asr_fast_tanh(cn);
+      if (t >= plen) { cn = 0.f; hn = 0.f; }
+      if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
+      c_prev = cn;
+      word_store(xw_g + (s & 1) * (PH * PRG) + (int64_t)punit * PRG + pj, hn, tag_bit_of_step(s));       // hand-off first
+      if (prow_ok) {
+        st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
+        st_gp = gp;
+        st_so = ((int64_t)t * B + prow) * ldy + d * PH + punit;
+      }
+    }
+  }
+  if (st_gp) {
+    *st_gp = st_g;
+    a.c[st_so] = st_c;
+    a.y[st_so] = st_y;
+  }
+}
+
 // --------------------------------------------------------------------------------------------------- backward
 // dh_rec = dG_{t_next} W_hh for this CU's 16 units, then the pointwise LSTM backward at time t (dG_t written in
 // place over the saved gates AND published to the group).  The exchange here is 4x larger than in the forward
@@ -684,6 +892,297 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------- backward, split-bf16 dh product
+// lstm_persist_bwd_kernel with the recurrent product dh_rec = dG_{t_next} W_hh on v_mfma_f32_16x16x32_bf16 (operands
+// split as in lstm_persist_fwd_bf3_kernel: three products, fp32 accumulation): A = this CU's 16 units of W_hh^T in
+// registers, B = the gathered dG tile, which the gathering lanes write to LDS twice - as fp32 for the fused dW_hh
+// product (unchanged, exact fp32, off the serial chain) and split in bf16 for this one.  D puts the 4 units 4 (l >> 4)
+// .. + 3 of batch row l & 15 in one lane: the 4 k-sub partials and their DPP reduction of the 4x4x1 mapping are gone.
+template <int PH, int NR>
+__global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a) {
+  static_assert(NR == 4 || NR == PRG, "rows per group (see the forward kernel)");
+  constexpr int PUC = PH / 32;       // hidden units per CU
+  constexpr int PKB = 4 * PH / PW;   // gate columns per wave
+  constexpr int PQ = PKB / 4;        // k's per (wave, k-sub)
+  constexpr int PQS = PQ + 4;        // padded LDS stride of a k-sub chunk
+  // this wave's K range of dG as [row][k-sub][64 + 4]: the 16 distinct (k-sub, row) addresses of one ds_read_b128
+  // differ by 68*ks + 272*row floats = 16 distinct 16-B bank slots (unpadded they are all 256-B multiples: 16-way)
+  __shared__ __attribute__((aligned(16))) float hs[PW][PRG][4 * PQS];    // fp32 copy of the dG tile: operand of dW_hh
+  constexpr int KSB = PKB / 32;      // k-steps of the split-bf16 dh product
+  constexpr int BST = PKB + 8;       // bf16 row stride (16-byte multiple, 8 rows of a read on distinct bank groups)
+  static_assert(PKB % 32 == 0 && PUC <= 16, "one 16-unit M tile, whole k-steps");
+  __shared__ __attribute__((aligned(16))) unsigned short bhi[PW][PRG][BST];   // dG tile split for the dh product
+  __shared__ __attribute__((aligned(16))) unsigned short blo[PW][PRG][BST];
+  __shared__ __attribute__((aligned(16))) float part[2][PW][PRG][16];         // partial dh_rec [row][unit], double buffered
+  __shared__ float ysl[2][PRG][16];                                       // this CU's slice of h at the current time
+  __shared__ int role[2];
+  constexpr int NKQ = (PKB + 63) / 64;                                    // 64-column chunks of the wave's K range
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 2 * PRG * 16) (&ysl[0][0][0])[tid] = 0.f;
+  for (int i = tid; i < PW * PRG * BST; i += PNT) { (&bhi[0][0][0])[i] = 0; (&blo[0][0][0])[i] = 0; }   // rows >= NR stay 0
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int g, slice;
+  take_role(a.ctrl, role, g, slice);
+  if (slice < 0) return;
+  const int T = a.T, B = a.B, ndir = a.ndir;
+  const int d = ndir == 2 ? (g & 1) : 0;
+  const int rowgroup = ndir == 2 ? (g >> 1) : g;
+  const int r0 = rowgroup * NR;
+  if (r0 >= a.nb) return;
+  const int64_t ldy = (int64_t)ndir * PH, ldg = (int64_t)ndir * 4 * PH;
+  // W_hhT slice -> registers: lane (ug = lane>>4, ks = (lane>>2)&3, i = lane&3) holds unit 16*slice+4ug+i,
+  // k = 256*wave + 64*ks + q, q = 0..63
+  // W_hhT slice -> split bf16 registers: A operand of the 16x16x32 product, lane l holds unit l & 15 of this CU,
+  // gate columns wave*PKB + 32 ks + 8 (l >> 4) + j
+  const int ml = lane & 15, kq = lane >> 4;
+  u32x4 whi[KSB], wlo[KSB];
+  {
+    const bool uok = ml < PUC;
+    const float* wr = a.w + ((int64_t)d * PH + PUC * slice + (uok ? ml : 0)) * (4 * PH) + wave * PKB + 8 * kq;
+#pragma unroll
+    for (int ks = 0; ks < KSB; ++ks) {
+      const float4 q0 = *reinterpret_cast<const float4*>(wr + 32 * ks), q1 = *reinterpret_cast<const float4*>(wr + 32 * ks + 4);
+      const float v[8] = {uok ? q0.x : 0.f, uok ? q0.y : 0.f, uok ? q0.z : 0.f, uok ? q0.w : 0.f,
+                          uok ? q1.x : 0.f, uok ? q1.y : 0.f, uok ? q1.z : 0.f, uok ? q1.w : 0.f};
+      bf3_split8(v, whi[ks], wlo[ks]);
+    }
+  }
+  // Waves 6-7 mirror the pointwise threads' (unit, row) mapping: they issue the SAME forward-data loads two steps
+  // further ahead and discard them, which pulls those HBM rows into this XCD's L2 before the pointwise threads ask
+  // (their own loads, one step ahead, were HBM first touches: ~0.3 us of every step with a cached row, see DESIGN).
+  const int mt = tid & 127;
+  const int pu = mt >> 3, pj = mt & 7;
+  const bool pw_lane = tid < PUC * PRG;                 // all 8 row lanes of a unit (bias-gradient reduction)
+  const bool pw_thread = pw_lane && pj < NR;
+  const int prow = r0 + pj;
+  const bool prow_ok = pw_thread && prow < a.nb;
+  const bool touch_ok = ASR_LSTM_TOUCH && tid >= 384 && mt < PUC * PRG && pj < NR && prow < a.nb;
+  const int punit = PUC * slice + pu;
+  const int plen = prow_ok ? a.lens[prow] : 0;
+  float dcarry = 0.f;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of this thread's (unit, row): sum of dG over time
+  float* xch_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * PRG * 4 * PH;   // + parity * 8*PRG*4H
+  const int64_t par_stride = (int64_t)8 * PRG * 4 * PH;
+#if ASR_LSTM_BWD_B128
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);   // raw dwords
+#endif
+  bool aborted = false;
+  // pointwise operands are fetched one step ahead (see the forward kernel)
+  float n_dy = 0.f, n_ct = 0.f, n_cp = 0.f, n_y = 0.f;
+  float4 n_av = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool fuse_dw = a.dw != nullptr && a.yfwd != nullptr;
+  // dW_hh accumulators: [64-column chunk][unit group] 4x4 blocks, kept in registers for the whole sequence
+  f32x4 dwacc[NKQ][4];
+#pragma unroll
+  for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) dwacc[kq][u4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto fetch_step = [&](int sn) {
+    const int tt = (ASR_LP_ABL & 8) ? 1 : (d == 0 ? T - 1 - sn : sn);      // bit 8 (measurement): always the same, cached row
+    const int ttp = d == 0 ? tt - 1 : tt + 1;
+    const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
+    const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
+    n_dy = a.dy[so];
+    n_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    n_ct = a.c[so];
+    n_cp = hp ? a.c[((int64_t)ttp * B + prow) * ldy + d * PH + punit] : 0.f;
+    if (fuse_dw) n_y = a.yfwd[so];
+  };
+  if (prow_ok) fetch_step(0);
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? T - 1 - s : s;
+    LP_MARK(0);
+    const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;     // see the forward kernel
+    const float dyv = n_dy, ct = n_ct, cp = n_cp;
+    const float4 av = n_av;
+    float4* gp = nullptr;
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (fuse_dw && pw_thread) ysl[s & 1][pj][pu] = prow_ok ? n_y : 0.f;     // h_t of this CU's units (read after the barrier)
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const unsigned want = (((unsigned)(s - 1) >> 1) & 1u) ^ 1u;      // tag bit of the data written at step s-1
+      const bool gl = 4 * lane < PKB;                   // lanes beyond the wave's K range re-read column 0
+      const float* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKB + (gl ? 4 * lane : 0);
+      float4 gr[NR];
+      unsigned spins = 0;
+      auto load_row = [&](int rr) {
+#if ASR_LSTM_BWD_B128
+        // L1-bypassing 16-byte read in ONE instruction: buffer load with the sc1 cache policy (the same policy the
+        // agent-scope atomic loads get, which exist only up to 8 bytes)
+        const u4v v = __builtin_amdgcn_raw_buffer_load_b128(
+            xrs, (unsigned)((src - reinterpret_cast<const float*>(a.xch)) + rr * 4 * PH) * 4u, 0, 16);
+        gr[rr].x = __uint_as_float(v.x); gr[rr].y = __uint_as_float(v.y);
+        gr[rr].z = __uint_as_float(v.z); gr[rr].w = __uint_as_float(v.w);
+#else
+        // L1-bypassing 16-byte read as two 8-byte agent-scope atomics
+        const u64 lo = granule_load(reinterpret_cast<const u64*>(src + (int64_t)rr * 4 * PH));
+        const u64 hi = granule_load(reinterpret_cast<const u64*>(src + (int64_t)rr * 4 * PH) + 1);
+        gr[rr].x = __uint_as_float((unsigned)lo); gr[rr].y = __uint_as_float((unsigned)(lo >> 32));
+        gr[rr].z = __uint_as_float((unsigned)hi); gr[rr].w = __uint_as_float((unsigned)(hi >> 32));
+#endif
+      };
+      auto row_bits = [&](int rr) -> unsigned {
+        const unsigned m = (__float_as_uint(gr[rr].x) & 1u) | ((__float_as_uint(gr[rr].y) & 1u) << 1) |
+                           ((__float_as_uint(gr[rr].z) & 1u) << 2) | ((__float_as_uint(gr[rr].w) & 1u) << 3);
+        return want ? m : (~m & 0xFu);
+      };
+      bool first = wave < ASR_LSTM_BWD_FULL_WAVES;
+      while (true) {
+        if (first) {
+          // the pointwise waves poll last: first attempt requests the whole tile at once (one L2 round trip); as a
+          // separate code path -- folded into the sentinel condition the compiler still waited for the sentinel
+          first = false;
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) load_row(rr);
+          unsigned bits = 0xFu;
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) bits &= row_bits(rr);
+          if (__all(!gl || bits == 0xFu)) break;
+        } else {
+          // cheap sentinel poll: the last row of this wave's K range (1 KB, touches all 4 producer CUs); a failed
+          // poll of the whole 64 KB per CU would saturate the XCD's L2 and delay the producers themselves
+          load_row(NR - 1);
+          bool ok = !gl || row_bits(NR - 1) == 0xFu;
+          if (__all(ok)) {
+#pragma unroll
+            for (int rr = 0; rr < NR - 1; ++rr) load_row(rr);
+            unsigned bits = row_bits(NR - 1);
+#pragma unroll
+            for (int rr = 0; rr < NR - 1; ++rr) bits &= row_bits(rr);
+            if (__all(!gl || bits == 0xFu)) break;
+          }
+        }
+#ifdef ASR_NO_POLL
+        break;
+#endif
+        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
+          aborted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+      }
+      LP_MARK(1);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr)
+        if (gl) {
+          *reinterpret_cast<float4*>(&hs[wave][rr][PQS * ((4 * lane) / PQ) + (4 * lane) % PQ]) = gr[rr];
+          *reinterpret_cast<uint2*>(&bhi[wave][rr][4 * lane]) =
+              make_uint2(bf3_hi(gr[rr].x) | (bf3_hi(gr[rr].y) << 16), bf3_hi(gr[rr].z) | (bf3_hi(gr[rr].w) << 16));
+          *reinterpret_cast<uint2*>(&blo[wave][rr][4 * lane]) =
+              make_uint2(bf3_lo(gr[rr].x) | (bf3_lo(gr[rr].y) << 16), bf3_lo(gr[rr].z) | (bf3_lo(gr[rr].w) << 16));
+        }
+      if (prow_ok && s + 1 < T) fetch_step(s + 1);
+      else if (touch_ok && s + ASR_LSTM_TOUCH_DIST < T) fetch_step(s + ASR_LSTM_TOUCH_DIST);   // L2 warm-up (results unused)
+      // dh partial [16 units x rows] of this wave's K range: three independent accumulators (one per split term)
+#pragma unroll
+      for (int ks = 0; ks < ((ASR_LP_ABL & 1) ? 1 : KSB); ++ks) {
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(&bhi[wave][ml & 7][32 * ks + 8 * kq]);
+        const u32x4 bl = *reinterpret_cast<const u32x4*>(&blo[wave][ml & 7][32 * ks + 8 * kq]);
+        acc0 = bf3_mfma(whi[ks], bh, acc0);
+        acc1 = bf3_mfma(whi[ks], bl, acc1);
+        acc2 = bf3_mfma(wlo[ks], bh, acc2);
+      }
+    }
+    if (s == 0 && prow_ok && T > 1) fetch_step(1);
+    LP_MARK(2);
+    // D: lane l holds units 4 (l >> 4) .. + 3 of batch row l & 15
+    if (ml < NR)
+      *reinterpret_cast<float4*>(&part[s & 1][wave][ml][4 * kq]) =
+          make_float4(acc0[0] + acc1[0] + acc2[0], acc0[1] + acc1[1] + acc2[1], acc0[2] + acc1[2] + acc2[2],
+                      acc0[3] + acc1[3] + acc2[3]);
+    LP_MARK(3);
+    __syncthreads();
+    LP_MARK(4);
+    if (pw_thread) {
+      // dh_rec[unit pu][row pj]: lanes 16*(pu>>2) + 4*ks + (pj&3), register 4*(pj>>2) + (pu&3), all ks, all waves
+      float dh = dyv;
+#pragma unroll
+      for (int w2 = 0; w2 < PW; ++w2) dh += part[s & 1][w2][pj][pu];
+      LP_MARK(9);
+      const float tc = asr_fast_tanh(ct);
+      const float dc = dcarry + dh * av.w * (1.f - tc * tc);
+      float4 da;
+      da.x = dc * av.z * av.x * (1.f - av.x);
+      da.y = dc * cp * av.y * (1.f - av.y);
+      da.z = dc * av.x * (1.f - av.z * av.z);
+      da.w = dh * tc * av.w * (1.f - av.w);
+      float dcn = dc * av.y;
+      if (t >= plen) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
+      if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
+      dcarry = dcn;
+      const unsigned bit = (((unsigned)s >> 1) & 1u) ^ 1u;
+      float4 tg;
+      tg.x = tag_word(da.x, bit); tg.y = tag_word(da.y, bit); tg.z = tag_word(da.z, bit); tg.w = tag_word(da.w, bit);
+      LP_MARK(10);
+      float* dst = xch_g + (s & 1) * par_stride + (int64_t)pj * 4 * PH + punit * 4;
+      // two 8-byte workgroup-scope (plain, L2-resident) stores; every word carries its own tag
+      __hip_atomic_store((gu64*)dst, ((u64)__float_as_uint(tg.y) << 32) | __float_as_uint(tg.x), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store((gu64*)dst + 1, ((u64)__float_as_uint(tg.w) << 32) | __float_as_uint(tg.z), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+      LP_MARK(11);
+      if (prow_ok) {     // after the hand-off: the bulk store and the bias-gradient sum are off the serial chain
+        if (!(ASR_LP_ABL & 16)) *gp = da;
+        dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
+      }
+    }
+    LP_MARK(5);
+    // Fused recurrent weight gradient: dW_hh[k][u] += sum_rows dG_{t_next}[row][k] * h_t[row][u].  The gathered dG
+    // tile is still in this wave's LDS region and h_t is the partner of dG_{t_next} in both directions.  Placed
+    // after the publish so that it fills the wait for the next hand-off.  Blocks = 16 groups of 4 gate columns,
+    // A = dG (4 columns), B = h (4 units), K = one batch row per instruction.
+    if (fuse_dw && s > 0 && !(ASR_LP_ABL & 2)) {
+      const int kb4 = lane;                      // column within the 64-column chunk (= 4*block + i)
+      const int jj = lane & 3;
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) {
+        float bv[4];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) bv[u4] = ysl[s & 1][rr][4 * u4 + jj];
+#pragma unroll
+        for (int kq = 0; kq < NKQ; ++kq) {
+          const int cidx = 64 * kq + kb4;
+          const float av2 = cidx < PKB ? hs[wave][rr][PQS * (cidx / PQ) + cidx % PQ] : 0.f;
+#pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4)
+            dwacc[kq][u4] = __builtin_amdgcn_mfma_f32_4x4x1f32(av2, bv[u4], dwacc[kq][u4], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (a.db != nullptr && pw_lane) {
+    // rows of a unit sit in 8 consecutive lanes (pj = tid & 7); the 4 row groups (XCDs) of a direction add up
+    float v[4] = {dbacc.x, dbacc.y, dbacc.z, dbacc.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] += __shfl_xor(v[k], 1, 64);
+      v[k] += __shfl_xor(v[k], 2, 64);
+      v[k] += __shfl_xor(v[k], 4, 64);
+    }
+    if (pj == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(a.db + (int64_t)d * 4 * PH + punit * 4 + k, v[k]);
+    }
+  }
+  if (fuse_dw) {
+    // D[i][j] of block kb: gate column 64*kq + 4*kb + i of this wave's range, unit 4*u4 + j of this CU; the 4 row
+    // groups (XCDs) of a direction add into the same dW_hh
+    const int kb = lane >> 2, jj = lane & 3;
+#pragma unroll
+    for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cidx = 64 * kq + 4 * kb + i, un = 4 * u4 + jj;
+          if (cidx < PKB && un < PUC)
+            atomicAdd(a.dw + ((int64_t)d * 4 * PH + wave * PKB + cidx) * PH + PUC * slice + un, dwacc[kq][u4][i]);
+        }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -699,6 +1198,25 @@ int launch_fwd(const PersistArgs& a, hipStream_t stream) {
   return 0;
 }
 
+// split-bf16 products: on by default (ASR_LSTM_BF3=0 selects the exact-fp32 4x4x1 products)
+// bit 0: forward gate product, bit 1: backward dh product
+int bf3_enabled() {
+  static const int on = [] { const char* e = getenv("ASR_LSTM_BF3"); return e ? atoi(e) : ASR_LSTM_BF3_DEFAULT; }();
+  return on;
+}
+
+template <int PH, int NR>
+int launch_fwd_bf3(const PersistArgs& a, hipStream_t stream) {
+  constexpr int KP = ((PH / PW + 31) / 32) * 32, MT = (PH / 32 + 3) / 4;
+  const size_t stat = (size_t)2 * PW * PRG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * PRG * 4 + 64;
+  const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_bf3_kernel<PH, NR>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
+  return 0;
+}
+
 template <int PH, int NR>
 int launch_bwd(const PersistArgs& a, hipStream_t stream) {
   const size_t stat = sizeof(float) * ((size_t)PW * PRG * 4 * (PH / 2 / 4 + 4) + 2 * PW * 64 * 9) + 64;
@@ -707,6 +1225,19 @@ int launch_bwd(const PersistArgs& a, hipStream_t stream) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((lstm_persist_bwd_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
+  return 0;
+}
+
+template <int PH, int NR>
+int launch_bwd_bf3(const PersistArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * ((size_t)PW * PRG * 4 * (PH / 2 / 4 + 4) + 2 * PW * PRG * 16 + 2 * PRG * 16) +
+                     (size_t)2 * PW * PRG * (PH / 2 + 8) * 2 + 64;
+  if (lds > 160 * 1024) return ASR_E_SHAPE;
+  const size_t pad = lds > 82 * 1024 ? 0 : 82 * 1024 - lds;
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_bf3_kernel<PH, NR>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((lstm_persist_bwd_bf3_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
@@ -721,11 +1252,17 @@ int rows_per_group(int nb, int ndir) {
 
 template <int NR>
 int dispatch_fwd(int H, const PersistArgs& a, hipStream_t stream) {
+  if (bf3_enabled() & 1)
+    return H == 512 ? launch_fwd_bf3<512, NR>(a, stream) : H == 320 ? launch_fwd_bf3<320, NR>(a, stream)
+         : H == 256 ? launch_fwd_bf3<256, NR>(a, stream) : launch_fwd_bf3<128, NR>(a, stream);
   return H == 512 ? launch_fwd<512, NR>(a, stream) : H == 320 ? launch_fwd<320, NR>(a, stream)
        : H == 256 ? launch_fwd<256, NR>(a, stream) : launch_fwd<128, NR>(a, stream);
 }
 template <int NR>
 int dispatch_bwd(int H, const PersistArgs& a, hipStream_t stream) {
+  if (bf3_enabled() & 2)
+    return H == 512 ? launch_bwd_bf3<512, NR>(a, stream) : H == 320 ? launch_bwd_bf3<320, NR>(a, stream)
+         : H == 256 ? launch_bwd_bf3<256, NR>(a, stream) : launch_bwd_bf3<128, NR>(a, stream);
   return H == 512 ? launch_bwd<512, NR>(a, stream) : H == 320 ? launch_bwd<320, NR>(a, stream)
        : H == 256 ? launch_bwd<256, NR>(a, stream) : launch_bwd<128, NR>(a, stream);
 }

@@ -20,7 +20,7 @@ db = torch.zeros(2 * 4 * H, device=dev)
 xch, ctrl = hb.persist_scratch(dev, trace=True)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = hb.stream()
-l = ctypes.CDLL(ROOT + '/scratchlibs/lib_lptrace.so')
+l = ctypes.CDLL(ROOT + '/scratchlibs/' + (sys.argv[1] if len(sys.argv) > 1 else 'lib_lptrace.so'))
 def report(name, n):
     t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)[:, :n]
     print(name, 'cycles/step %.0f' % (t[1:, 0] - t[:-1, 0]).mean(), ' deltas:', ' '.join('%d:%.0f' % (i + 1, x) for i, x in enumerate(np.diff(t, axis=1).mean(0))),
@@ -41,3 +41,8 @@ for _ in range(2):
     torch.cuda.synchronize(); report('bwd', 6)
     t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     print('   bwd pointwise split: partial sums %.0f | math+tags %.0f | publish %.0f | bulk store+db %.0f' % ((t[:, 9] - t[:, 4]).mean(), (t[:, 10] - t[:, 9]).mean(), (t[:, 11] - t[:, 10]).mean(), (t[:, 5] - t[:, 11]).mean()))
+    t7 = ctrl[16 + 256:16 + 256 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    names = {0: 'top', 1: 'gathered', 2: 'dh MFMA done', 3: 'partials written', 4: 'barrier passed', 9: 'partials summed', 10: 'math+tags', 11: 'published', 5: 'stores done (dW starts)'}
+    for wname, tt in (('wave 0', t), ('wave 7', t7)):
+        print('   %s, cycles after wave 0 top of the same step: ' % wname + ' | '.join('%s %.0f' % (names[k], (tt[:, k] - t[:, 0]).mean()) for k in (0, 1, 2, 3, 4, 9, 10, 11, 5) if tt[:, k].min() > 0) +
+              ' | next top %.0f' % (tt[1:, 0] - t[:-1, 0]).mean())
