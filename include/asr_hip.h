@@ -136,7 +136,10 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
                      const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
                      asr_stream_t stream);
 /* Persistent fast path of asr_lstm_seq_bwd (same conditions / abort convention as asr_lstm_seq_fwd_persist;
- * xch >= 1 MB).  The exchanged copy of dG carries a 1-bit tag in each mantissa LSB; the in-place dG is exact.
+ * xch >= 8 MB: at H in {128, 256, 512} the CUs of a group exchange partial sums of dh_rec, laid out
+ * [8 groups][2][32 dest][32 src][8 rows][H/32] floats).  Exchanged words carry a 1-bit tag in the mantissa LSB; the
+ * in-place dG is what the pointwise update produced.  The recurrent products run on the bf16 MFMA with both operands
+ * split in two bf16 terms (3 products, fp32 accumulation, ~2^-15 relative; env ASR_LSTM_BF3=0: exact-fp32 products).
  * If y (forward hidden states) and dw_hh ([ndir][4H][H], gate-interleaved, zero-filled or holding a running sum)
  * are given, the recurrent weight gradient sum_t dG_t^T h_{t-1} is accumulated into dw_hh inside the kernel
  * (fp32 atomics across the row groups) and the caller skips that GEMM.  If db ([ndir][4H], gate-interleaved,

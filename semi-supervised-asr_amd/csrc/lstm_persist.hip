@@ -35,8 +35,8 @@
                                      1 = single-stage LSB-tagged words read as 8-byte atomics (2.38-2.45),
                                      2 = the same words read with 16-byte sc1 buffer loads (2.05) */
 #endif
-#ifndef ASR_LSTM_BF3_DEFAULT   /* split-bf16 recurrent products: bit 0 forward, bit 1 backward (env ASR_LSTM_BF3 overrides) */
-#define ASR_LSTM_BF3_DEFAULT 3
+#ifndef ASR_LSTM_BF3_DEFAULT   /* split-bf16 recurrent products, see bf3_enabled() (env ASR_LSTM_BF3 overrides) */
+#define ASR_LSTM_BF3_DEFAULT 7
 #endif
 #ifndef ASR_LSTM_TOUCH
 #define ASR_LSTM_TOUCH 1
@@ -1183,6 +1183,408 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
   }
 }
 
+// ------------------------------------------------------------- backward, exchanged dh partials ("reduce-scatter")
+// The kernels above hand the step's dG (8 rows x 4H) to all 32 CUs of the group: every CU gathers 64 KB per time step
+// (2 MB through the XCD's L2), which is what a backward step waits for (tools/lstm_trace.py: 1 600 cycles from the top
+// of a step to its tile, another 2 500 to stage, convert and multiply it).  dG is the wide side of the product
+// dh_rec[row][unit] = sum_col dG[row][col] W_hh[col][unit]; this kernel exchanges the narrow one:
+//   * CU j keeps the dG columns of its OWN units (it produces them in the pointwise phase: 8 rows x 64 columns that
+//     never leave the CU) and the matching 64 rows of W_hh for ALL units (split bf16, registers);
+//   * per step it forms the partial dh of all H units from those columns (K = 64: two k-steps of
+//     v_mfma_f32_16x16x32_bf16 per 16-unit tile, 3 split products) and publishes it as LSB-tagged fp32 quads, laid out
+//     [dest CU][source CU][row][unit]: 16 KB written, and each CU then gathers the 16 KB addressed to it
+//     (32 sources x 8 rows x 16 units) - a quarter of the old gather, no operand conversion on the consumer side - and
+//     sums the 32 sources with DPP adds inside half waves;
+//   * dW_hh[col][unit] += sum_rows dG_t[row][col] h_{t_prev}[row][unit] for the CU's 64 columns x all H units: dG is
+//     local, h_{t_prev} is forward data (8 rows x H, prefetched a step ahead); the product runs on
+//     v_mfma_f32_16x16x16_bf16 (K = 8 batch rows, zero padded to 16), split in three like the others: 768 MFMA cycles
+//     per SIMD and step instead of 2 048 on the fp32 pipe, and it sits between the publish and the next gather.
+// H in {128, 256, 512} (units per CU a multiple of 4); other sizes keep lstm_persist_bwd_bf3_kernel.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 bf3_mfma16(const uint2& a, const uint2& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
+template <int PH>
+struct RsDims {
+  static constexpr int PUC = PH / 32;            // units per CU
+  static constexpr int NC = 4 * PUC;             // local gate columns
+  static constexpr int KS = (NC + 31) / 32;      // k-steps of the dh-partial product
+  static constexpr int KP = KS * 32;
+  static constexpr int MTW = (PH / 16) / PW;     // 16-unit tiles per wave (dh partial M tiles = dW unit tiles)
+  static constexpr int CT = (NC + 15) / 16;      // 16-column tiles of dW
+  static constexpr int UPW = PH / PW;            // units per wave
+  static constexpr int CPW = PUC / 4;            // (row, unit-quad) combos gathered per wave
+  static constexpr int QPU = PUC / 4;            // unit quads per (source, row)
+  static constexpr int GST = KP + 8;             // bf16 row stride of the row-major local dG
+  static constexpr size_t group_floats = (size_t)2 * 32 * 32 * PRG * PUC;     // exchange per group (both parities)
+  static_assert(PH % 128 == 0 && PUC % 4 == 0 && PUC <= 16, "H in {128, 256, 384, 512}");
+};
+
+template <int PH, int NR>
+__global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a) {
+  using RD = RsDims<PH>;
+  constexpr int PUC = RD::PUC, NC = RD::NC, KS = RD::KS, MTW = RD::MTW, CT = RD::CT, UPW = RD::UPW, CPW = RD::CPW;
+  constexpr int QPU = RD::QPU, GST = RD::GST;
+  constexpr int NE = (CPW + 1) / 2;               // quads per lane in the gather
+  __shared__ __attribute__((aligned(16))) unsigned short dgr_hi[PRG][GST], dgr_lo[PRG][GST];   // local dG, [row][col]
+  // operands of the dW_hh product, four time-step slots of 8 rows each = K = 32 of one v_mfma_f32_16x16x32_bf16:
+  // local dG [col][slot][row] and h_{t_prev} [unit][slot][row]; step s lives in slot s & 3 (see the dW_hh block)
+  __shared__ __attribute__((aligned(16))) unsigned short dgc_hi[16 * CT][4][PRG], dgc_lo[16 * CT][4][PRG];
+  __shared__ __attribute__((aligned(16))) unsigned short ht_hi[PH][4][PRG], ht_lo[PH][4][PRG];
+  __shared__ __attribute__((aligned(16))) float dhs[PRG][16];                                 // reduced dh_rec [row][unit]
+  __shared__ int role[2];
+  extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < PRG * GST; i += PNT) { (&dgr_hi[0][0])[i] = 0; (&dgr_lo[0][0])[i] = 0; }
+  for (int i = tid; i < 16 * CT * 4 * PRG; i += PNT) { (&dgc_hi[0][0][0])[i] = 0; (&dgc_lo[0][0][0])[i] = 0; }
+  for (int i = tid; i < PH * 4 * PRG; i += PNT) { (&ht_hi[0][0][0])[i] = 0; (&ht_lo[0][0][0])[i] = 0; }
+  if (tid < PRG * 16) (&dhs[0][0])[tid] = 0.f;
+  int g, slice;
+  take_role(a.ctrl, role, g, slice);
+  if (slice < 0) return;
+  const int T = a.T, B = a.B, ndir = a.ndir;
+  const int d = ndir == 2 ? (g & 1) : 0;
+  const int rowgroup = ndir == 2 ? (g >> 1) : g;
+  const int r0 = rowgroup * NR;
+  if (r0 >= a.nb) return;
+  const int64_t ldy = (int64_t)ndir * PH, ldg = (int64_t)ndir * 4 * PH;
+  const int ml = lane & 15, kq = lane >> 4;
+  // W_hh rows of this CU's columns, all units -> split bf16: A operand of the dh-partial product.  a.w is W_hh^T
+  // [unit][4H]: lane l holds unit 16 (MTW wave + mt) + (l & 15), columns NC slice + 32 ks + 8 (l >> 4) + j
+  u32x4 whi[MTW][KS], wlo[MTW][KS];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    const float* wr = a.w + ((int64_t)d * PH + 16 * (MTW * wave + mt) + ml) * (4 * PH) + NC * slice;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k0 = 32 * ks + 8 * kq;
+      float v[8];
+#pragma unroll
+      for (int j4 = 0; j4 < 2; ++j4) {
+        const bool kok = k0 + 4 * j4 < NC;
+        const float4 q = *reinterpret_cast<const float4*>(wr + (kok ? k0 + 4 * j4 : 0));
+        v[4 * j4] = kok ? q.x : 0.f; v[4 * j4 + 1] = kok ? q.y : 0.f;
+        v[4 * j4 + 2] = kok ? q.z : 0.f; v[4 * j4 + 3] = kok ? q.w : 0.f;
+      }
+      bf3_split8(v, whi[mt][ks], wlo[mt][ks]);
+    }
+  }
+  // pointwise ownership as in the other kernels: thread (pu, pj), tid < PUC*PRG
+  const int pu = tid >> 3, pj = tid & 7;
+  const bool pw_lane = tid < PUC * PRG;
+  const bool pw_thread = pw_lane && pj < NR;
+  const int prow = r0 + pj;
+  const bool prow_ok = pw_thread && prow < a.nb;
+  const int punit = PUC * slice + pu;
+  const int plen = prow_ok ? a.lens[prow] : 0;
+  float dcarry = 0.f;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* xg = reinterpret_cast<float*>(a.xch) + (int64_t)g * RD::group_floats;
+  constexpr int PARSZ = 32 * 32 * PRG * PUC;      // floats per parity
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
+  bool aborted = false;
+  const bool fuse_dw = a.dw != nullptr && a.yfwd != nullptr;
+  // gather role: half wave hf sums the 32 sources (lane & 31) of combo CPW wave + hf + 2 e = (row, unit quad)
+  const int hf = lane >> 5, src = lane & 31;
+  // h_{t_prev} loader: lane l < UPW of wave w owns unit UPW w + l (this wave's own dW unit tiles: wave-private LDS rows)
+  const bool h_lane = fuse_dw && lane < UPW;
+  const int hunit = UPW * wave + (lane < UPW ? lane : 0);
+  // Forward data of the pointwise threads (dy, saved gates, c) is fetched TWO steps ahead and always right after a
+  // poll has completed: these are HBM first touches (~2 us), vmcnt retires in order, and a load issued shortly before
+  // a poll makes that poll wait for it.  c_{t_prev} of step s is c_t of step s + 1: no load of its own.
+  float n1_dy = 0.f, n1_ct = 0.f, n2_dy = 0.f, n2_ct = 0.f;
+  float4 n1_av = make_float4(0.f, 0.f, 0.f, 0.f), n2_av = make_float4(0.f, 0.f, 0.f, 0.f);
+  float n_h[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) n_h[r] = 0.f;
+  auto time_of = [&](int sn) { return d == 0 ? T - 1 - sn : sn; };
+  auto fetch_step = [&](int sn, float& o_dy, float& o_ct, float4& o_av) {
+    const int tt = time_of(sn);
+    const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
+    o_dy = a.dy[so];
+    o_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    o_ct = a.c[so];
+  };
+  // forward hidden state at the time that fed step sn's time.  Bare loads from clamped addresses: nothing may touch a
+  // loaded value here (a select right after the load makes hipcc wait for it on the spot: an HBM round trip on the
+  // serial chain); rows / times that do not exist are zeroed when the registers are staged (stage_h).
+  auto fetch_h = [&](int sn) {
+    const int tt = time_of(sn);
+    const int ttp = d == 0 ? tt - 1 : tt + 1;
+    const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int row = r0 + r < a.nb ? r0 + r : r0;
+      n_h[r] = a.yfwd[((int64_t)(hp ? ttp : tt) * B + row) * ldy + d * PH + hunit];
+    }
+  };
+  auto stage_h = [&](int buf, int sn) {  // n_h (fetched for step sn) -> this lane's unit, slot buf of ht_hi / ht_lo
+    const int tt = time_of(sn);
+    const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
+    unsigned hi[NR / 2], lo[NR / 2];
+#pragma unroll
+    for (int r = 0; r < NR / 2; ++r) {
+      const float v0 = (hp && r0 + 2 * r < a.nb) ? n_h[2 * r] : 0.f;
+      const float v1 = (hp && r0 + 2 * r + 1 < a.nb) ? n_h[2 * r + 1] : 0.f;
+      hi[r] = bf3_hi(v0) | (bf3_hi(v1) << 16);
+      lo[r] = bf3_lo(v0) | (bf3_lo(v1) << 16);
+    }
+    if (NR == 8) {
+      *reinterpret_cast<u32x4*>(&ht_hi[hunit][buf][0]) = (u32x4){hi[0], hi[1], hi[NR / 2 - 2], hi[NR / 2 - 1]};
+      *reinterpret_cast<u32x4*>(&ht_lo[hunit][buf][0]) = (u32x4){lo[0], lo[1], lo[NR / 2 - 2], lo[NR / 2 - 1]};
+    } else {
+      *reinterpret_cast<uint2*>(&ht_hi[hunit][buf][0]) = make_uint2(hi[0], hi[1]);
+      *reinterpret_cast<uint2*>(&ht_lo[hunit][buf][0]) = make_uint2(lo[0], lo[1]);
+    }
+  };
+  // gather descriptors (loop invariant): byte offset of this lane's quads in parity 0, and whether they exist
+  unsigned goff[NE];
+  bool use[NE];
+  int grow[NE], guq[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int kk = hf + 2 * e;
+    const int c = CPW * wave + (kk < CPW ? kk : 0);
+    grow[e] = c / QPU; guq[e] = c - grow[e] * QPU;
+    use[e] = kk < CPW && grow[e] < NR && r0 + grow[e] < a.nb;
+    goff[e] = (unsigned)((xg - reinterpret_cast<float*>(a.xch)) + ((slice * 32 + src) * PRG + grow[e]) * PUC + 4 * guq[e]) * 4u;
+  }
+  u32x4 q[NE];
+  bool q_inflight = false;            // q holds an attempt issued in the middle of the previous step's dW_hh block
+  if (prow_ok) {
+    fetch_step(0, n1_dy, n1_ct, n1_av);
+    if (T > 1) fetch_step(1, n2_dy, n2_ct, n2_av);
+  }
+  if (h_lane) fetch_h(0);
+  // dW_hh accumulators: D[m = local column 16 ct + 4 (l >> 4) + i][n = unit 16 (MTW wave + ut) + (l & 15)]
+  f32x4 dwacc[CT][MTW];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int ut = 0; ut < MTW; ++ut) dwacc[ct][ut] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 st_da = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* st_gp = nullptr;
+  __syncthreads();                             // LDS zero fill
+  if (h_lane) stage_h(0, 0);
+  if (h_lane && T > 1) fetch_h(1);
+  for (int s = 0; s < T; ++s) {
+    const int t = time_of(s);
+    LP_MARK(0);
+    const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;
+    const float dyv = n1_dy, ct_ = n1_ct;
+    const float4 av = n1_av;
+    // rotate: n1 <- n2 (step s + 1's).  Opaque moves: left to itself hipcc renames the rotation away and instead copies
+    // each prefetched value out of a temporary right after its load - a wait for an HBM round trip on the serial chain.
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_dy) : "v"(n2_dy));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_ct) : "v"(n2_ct));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.x) : "v"(n2_av.x));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.y) : "v"(n2_av.y));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.z) : "v"(n2_av.z));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.w) : "v"(n2_av.w));
+    const float cp = s + 1 < T ? n1_ct : 0.f;                     // c at the time that feeds this one
+    // h tile of the NEXT step (fetched after the previous poll, a whole step ago) -> the other LDS buffer, while this
+    // step's partials are still in flight
+    if (h_lane && s + 1 < T) stage_h((s + 1) & 3, s + 1);
+    float4* gp = nullptr;
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    // ---------------------------------------------------------------- (1) gather the partials addressed to this CU
+    if (s > 0) {
+      const unsigned tb = tag_bit_of_step(s - 1);
+      unsigned spins = 0;
+      while (true) {
+        bool ok = true;
+        if (!q_inflight) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[e] + (unsigned)(((s - 1) & 1) * PARSZ) * 4u, 0, 16);
+        }
+        q_inflight = false;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ok = ok && (!use[e] || quad_ok(q[e], tb));
+        if (__all(ok)) break;
+        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
+          aborted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+      }
+      LP_MARK(1);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        float v[4] = {__uint_as_float(q[e].x), __uint_as_float(q[e].y), __uint_as_float(q[e].z), __uint_as_float(q[e].w)};
+        if (!use[e]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+        row16_sum4(v);                               // every lane of a 16-lane row holds the row's total
+        float tot[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int vi = __builtin_bit_cast(int, v[i]);
+          const float lo16 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+          const float hi16 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+          tot[i] = v[i] + (hf ? hi16 : lo16);
+        }
+        if (src == 0 && hf + 2 * e < CPW) *reinterpret_cast<float4*>(&dhs[grow[e]][4 * guq[e]]) = make_float4(tot[0], tot[1], tot[2], tot[3]);
+      }
+    }
+    if (st_gp) {                         // previous step's dG (bulk store after the poll: vmcnt retires in order)
+      *st_gp = st_da;
+      st_gp = nullptr;
+    }
+    // prefetches: right after the poll, i.e. as far ahead of the next one as possible
+    if (prow_ok && s + 2 < T) fetch_step(s + 2, n2_dy, n2_ct, n2_av);
+    if (h_lane && s + 2 < T) fetch_h(s + 2);
+    LP_MARK(2);
+    __syncthreads();                                                                                     // A
+    LP_MARK(3);
+    // ---------------------------------------------------------------- (2) pointwise LSTM backward of this CU's units
+    if (pw_lane) {
+      float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pw_thread) {
+        const float dh = dyv + (s > 0 ? dhs[pj][pu] : 0.f);
+        const float tc = asr_fast_tanh(ct_);
+        const float dc = dcarry + dh * av.w * (1.f - tc * tc);
+        da.x = dc * av.z * av.x * (1.f - av.x);
+        da.y = dc * cp * av.y * (1.f - av.y);
+        da.z = dc * av.x * (1.f - av.z * av.z);
+        da.w = dh * tc * av.w * (1.f - av.w);
+        float dcn = dc * av.y;
+        if (t >= plen) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
+        if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
+        dcarry = dcn;
+        *reinterpret_cast<uint2*>(&dgr_hi[pj][4 * pu]) = make_uint2(bf3_hi(da.x) | (bf3_hi(da.y) << 16), bf3_hi(da.z) | (bf3_hi(da.w) << 16));
+        *reinterpret_cast<uint2*>(&dgr_lo[pj][4 * pu]) = make_uint2(bf3_lo(da.x) | (bf3_lo(da.y) << 16), bf3_lo(da.z) | (bf3_lo(da.w) << 16));
+        if (fuse_dw) {
+          const int sl = s & 3, zs = (s + 1) & 3;          // this step's slot; the slot the NEXT step's h is staged into
+          const float dv[4] = {da.x, da.y, da.z, da.w};    // must read as zero in the flush that does not cover it
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dgc_hi[4 * pu + i][sl][pj] = (unsigned short)bf3_hi(dv[i]);
+            dgc_lo[4 * pu + i][sl][pj] = (unsigned short)bf3_lo(dv[i]);
+            dgc_hi[4 * pu + i][zs][pj] = 0;
+            dgc_lo[4 * pu + i][zs][pj] = 0;
+          }
+        }
+        if (prow_ok) {
+          st_da = da;
+          st_gp = gp;
+          dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
+        }
+      }
+    }
+    LP_MARK(4);
+    __syncthreads();                                                                                     // B
+    LP_MARK(5);
+    // ---------------------------------------------------------------- (3) partial dh of all units, publish
+    {
+      f32x4 acc[MTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(&dgr_hi[ml & 7][32 * ks + 8 * kq]);
+        const u32x4 bl = *reinterpret_cast<const u32x4*>(&dgr_lo[ml & 7][32 * ks + 8 * kq]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bh, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bl, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wlo[mt][ks], bh, acc[mt]);
+      }
+      LP_MARK(6);
+      // D: lane l holds units 16 tile + 4 (l >> 4) .. + 3 of batch row l & 15 -> one tagged quad to their owner's slot
+      if (ml < NR && s + 1 < T) {
+        const unsigned bit = tag_bit_of_step(s);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int ug = 16 * (MTW * wave + mt) + 4 * kq;
+          const int dest = ug / PUC, uo = ug - dest * PUC;
+          const unsigned doff = (unsigned)((xg - reinterpret_cast<float*>(a.xch)) + (s & 1) * PARSZ +
+                                           ((dest * 32 + slice) * PRG + ml) * PUC + uo) * 4u;
+          // one 16-byte store (plain: it stays in this XCD's L2); every word carries its own tag, tearing is harmless
+          const u32x4 tq = {__float_as_uint(tag_word(acc[mt][0], bit)), __float_as_uint(tag_word(acc[mt][1], bit)),
+                            __float_as_uint(tag_word(acc[mt][2], bit)), __float_as_uint(tag_word(acc[mt][3], bit))};
+          __builtin_amdgcn_raw_buffer_store_b128(tq, xrs, doff, 0, 0);
+        }
+      }
+    }
+    LP_MARK(7);
+    // ---------------------------------------------------------------- (4) off the serial chain
+    // dW_hh += dG_t^T h_{t_prev} (A = local dG [col][k], B = h [unit][k], k = (slot, row)): once every THREE steps for the
+    // three steps just done.  A single step only fills 8 of the K = 32 of the bf16 MFMA and every shape costs the same
+    // 16 cycles, so a per-step product was 1 536 MFMA cycles per SIMD and step; the fourth slot is the one the next
+    // step's h is being staged into (its dG slot is kept zero), which lets the staging stay where the prefetch needs it.
+    if (fuse_dw && (s % 3 == 2 || s == T - 1)) {
+      if (s % 3 != 2) {
+        // tail of the sequence (1 or 2 pending steps): slots of steps that were flushed already must read as zero
+        __syncthreads();
+        if (pw_thread) {
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) {
+            const bool pending = sl == (s & 3) || (s % 3 == 1 && sl == ((s - 1) & 3));
+            if (!pending) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { dgc_hi[4 * pu + i][sl][pj] = 0; dgc_lo[4 * pu + i][sl][pj] = 0; }
+            }
+          }
+        }
+        __syncthreads();
+      }
+      u32x4 ah[CT], al[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        ah[ct] = *reinterpret_cast<const u32x4*>(&dgc_hi[16 * ct + ml][kq][0]);
+        al[ct] = *reinterpret_cast<const u32x4*>(&dgc_lo[16 * ct + ml][kq][0]);
+      }
+#pragma unroll
+      for (int ut = 0; ut < MTW; ++ut) {
+        if (ut == (MTW + 1) / 2 && s + 1 < T) {
+          // first attempt at the next step's partials, issued half way through this block: the round trip runs under
+          // the remaining MFMAs, and the poll at the top of the next step starts by looking at what came back
+#pragma unroll
+          for (int e = 0; e < NE; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[e] + (unsigned)((s & 1) * PARSZ) * 4u, 0, 16);
+          q_inflight = true;
+        }
+        const int un = 16 * (MTW * wave + ut) + ml;
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(&ht_hi[un][kq][0]);
+        const u32x4 bl = *reinterpret_cast<const u32x4*>(&ht_lo[un][kq][0]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(ah[ct], bh, dwacc[ct][ut]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(ah[ct], bl, dwacc[ct][ut]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(al[ct], bh, dwacc[ct][ut]);
+      }
+      LP_MARK(8);
+    }
+  }
+  if (st_gp) *st_gp = st_da;
+  if (a.db != nullptr && pw_lane) {
+    float v[4] = {dbacc.x, dbacc.y, dbacc.z, dbacc.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] += __shfl_xor(v[k], 1, 64);
+      v[k] += __shfl_xor(v[k], 2, 64);
+      v[k] += __shfl_xor(v[k], 4, 64);
+    }
+    if (pj == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(a.db + (int64_t)d * 4 * PH + punit * 4 + k, v[k]);
+    }
+  }
+  if (fuse_dw) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int ut = 0; ut < MTW; ++ut)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = 16 * ct + 4 * kq + i, un = 16 * (MTW * wave + ut) + ml;
+          if (col < NC) atomicAdd(a.dw + ((int64_t)d * 4 * PH + NC * slice + col) * PH + un, dwacc[ct][ut][i]);
+        }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -1199,7 +1601,8 @@ int launch_fwd(const PersistArgs& a, hipStream_t stream) {
 }
 
 // split-bf16 products: on by default (ASR_LSTM_BF3=0 selects the exact-fp32 4x4x1 products)
-// bit 0: forward gate product, bit 1: backward dh product
+// bit 0: forward gate product, bit 1: backward dh product (gathered-dG kernel), bit 2: backward with exchanged dh
+// partials (lstm_persist_bwd_rs_kernel; H in {128, 256, 512}, takes precedence over bit 1)
 int bf3_enabled() {
   static const int on = [] { const char* e = getenv("ASR_LSTM_BF3"); return e ? atoi(e) : ASR_LSTM_BF3_DEFAULT; }();
   return on;
@@ -1241,6 +1644,19 @@ int launch_bwd_bf3(const PersistArgs& a, hipStream_t stream) {
   return 0;
 }
 
+template <int PH, int NR>
+int launch_bwd_rs(const PersistArgs& a, hipStream_t stream) {
+  using RD = RsDims<PH>;
+  const size_t stat = (size_t)2 * PRG * RD::GST * 2 + (size_t)2 * 16 * RD::CT * 4 * PRG * 2 + (size_t)2 * PH * 4 * PRG * 2 +
+                      PRG * 16 * sizeof(float) + 64;
+  const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_rs_kernel<PH, NR>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((lstm_persist_bwd_rs_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
+  return 0;
+}
+
 bool persist_supported(int H) { return H == 128 || H == 256 || H == 320 || H == 512; }
 
 // rows per XCD group: 4 when the whole batch fits 4-row groups (half the MFMA work and gather per step), else 8
@@ -1260,6 +1676,9 @@ int dispatch_fwd(int H, const PersistArgs& a, hipStream_t stream) {
 }
 template <int NR>
 int dispatch_bwd(int H, const PersistArgs& a, hipStream_t stream) {
+  if ((bf3_enabled() & 4) && (H == 512 || H == 256 || H == 128))
+    return H == 512 ? launch_bwd_rs<512, NR>(a, stream) : H == 256 ? launch_bwd_rs<256, NR>(a, stream)
+                                                        : launch_bwd_rs<128, NR>(a, stream);
   if (bf3_enabled() & 2)
     return H == 512 ? launch_bwd_bf3<512, NR>(a, stream) : H == 320 ? launch_bwd_bf3<320, NR>(a, stream)
          : H == 256 ? launch_bwd_bf3<256, NR>(a, stream) : launch_bwd_bf3<128, NR>(a, stream);
@@ -1285,7 +1704,7 @@ bool asr_persist_device_ok() {
 // Returns ASR_E_SHAPE when the fast path does not apply (caller falls back to asr_lstm_seq_fwd).  Batches larger
 // than 8 * (8 / ndir) rows run as consecutive launches over row blocks (rows are independent; any batch size: a
 // single-GPU batch of 256 is 8 launches per layer).
-// xch: >= 1 MB, ctrl: >= 64 B; both are zeroed here on the stream before every launch.
+// xch: >= 8 MB (the backward's exchanged partials at H = 512), ctrl: >= 64 B; zeroed here on the stream before every launch.
 extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
                                         const int32_t* lens, float* y, float* c, void* xch, void* ctrl,
                                         asr_stream_t stream_) {
@@ -1319,7 +1738,11 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
   const int nr = rows_per_group(nb, ndir);
   const int rows_per_launch = nr * (8 / ndir);
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
-    hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * PRG * 4 * H * sizeof(float), stream);
+    const bool rs = (bf3_enabled() & 4) && (H == 512 || H == 256 || H == 128);
+    // exchanged-partials kernel: [8 groups][2 parities][32 dest][32 src][8 rows][H/32 units] floats (8 MB at H = 512)
+    const size_t xbytes = rs ? (size_t)8 * 2 * 32 * 32 * PRG * (H / 32) * sizeof(float)
+                             : (size_t)2 * 8 * PRG * 4 * H * sizeof(float);
+    hipError_t e = persist_reset(xch, ctrl, xbytes, stream);
     if (e != hipSuccess) return (int)e;
     PersistArgs a;
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;

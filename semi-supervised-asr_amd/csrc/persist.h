@@ -62,8 +62,10 @@ __device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g,
     if (tk >= 32u) { flag_store(ctrl + 9, 2u); flag_store(ctrl + 8, 1u); }   // unexpected placement
   }
   __syncthreads();
-  g = lds_role[0];
-  slice = lds_role[1];
+  // workgroup-uniform: in SGPRs, so that everything derived from the role (direction, rows, slices of the weights,
+  // exchange addresses) is scalar arithmetic instead of per-lane 64-bit VALU math
+  g = __builtin_amdgcn_readfirstlane(lds_role[0]);
+  slice = __builtin_amdgcn_readfirstlane(lds_role[1]);
 }
 
 // Poll N 8-byte slots, each holding two LSB-tagged fp32 words, until every word carries tag bit `want`.  The last

@@ -424,6 +424,9 @@ USE_FEEDBACK_KERNEL = os.environ.get("ASR_FEEDBACK_KERNEL", "1") != "0"
 # first <EOS> is stripped by the CER path; the predictions of the skipped steps read <EOS>)
 DECODE_EARLY_STOP = os.environ.get("ASR_DECODE_EARLY_STOP", "1") != "0"
 _persist_scratch = {}
+# exchange area of the persistent kernels: the largest user is the LSTM backward with exchanged dh partials,
+# [8 groups][2 parities][32 dest][32 src][8 rows][H/32 units] floats = 8 MB at H = 512 (each launcher zeroes what it uses)
+XCH_BYTES = 8 * 2 * 32 * 32 * 8 * 16 * 4
 
 # Which path every sequence operator actually took, per process: "<op>_persist" counts launches of the persistent
 # XCD-local kernels, "<op>_step" counts sequences that ran on the per-step kernels instead (persistent path switched off,
@@ -460,14 +463,14 @@ def persist_scratch(device, trace=False):
     if trace:
         tkey = str(device) + "/trace"
         if tkey not in _persist_scratch:
-            _persist_scratch[tkey] = (torch.zeros(2 * 8 * 8 * 2048, dtype=torch.int64, device=device),
+            _persist_scratch[tkey] = (torch.zeros(XCH_BYTES // 8, dtype=torch.int64, device=device),
                                       torch.zeros(1024, dtype=torch.int32, device=device))
         return _persist_scratch[tkey]
     key = str(device)
     if key not in _persist_scratch:
-        # one allocation: [64-byte control block | 2 MB exchange] so that the pre-launch reset is a single fill
+        # one allocation: [64-byte control block | 8 MB exchange] so that the pre-launch reset is a single fill
         # (persist.h: persist_reset), plus a separate trace area used only by the measurement builds
-        base = torch.zeros(8 + 2 * 8 * 8 * 2048, dtype=torch.int64, device=device)
+        base = torch.zeros(8 + XCH_BYTES // 8, dtype=torch.int64, device=device)
         _persist_scratch[key] = (base[8:], base[:8].view(torch.int32), base)
     return _persist_scratch[key][:2]
 

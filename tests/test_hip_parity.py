@@ -559,7 +559,9 @@ def test_edge_shapes(B, T):
 @pytest.mark.parametrize("ndir,B,T,lens,H", [(2, 32, 9, None, 512), (2, 20, 6, None, 512), (1, 40, 5, None, 512),
                                               (2, 3, 4, [4, 2, 1], 512), (2, 48, 5, None, 320), (2, 7, 6, None, 128),
                                               (1, 70, 4, None, 256), (2, 16, 5, None, 512), (2, 12, 7, None, 320),
-                                              (2, 17, 4, None, 256), (1, 30, 5, None, 128), (2, 8, 40, None, 512)])
+                                              (2, 17, 4, None, 256), (1, 30, 5, None, 128), (2, 8, 40, None, 512),
+                                              (2, 32, 1, None, 512), (2, 9, 2, None, 512), (2, 32, 3, None, 256),
+                                              (2, 32, 41, None, 512), (1, 64, 13, None, 128), (2, 33, 8, None, 512)])
 def test_lstm_persistent_path(ndir, B, T, lens, H):
     """H in {128,256,320,512} takes the persistent XCD-local kernels (forward and backward); parity vs the oracle
     incl. ragged lengths, batches spanning several row blocks, and both group shapes (4 rows per XCD group up to

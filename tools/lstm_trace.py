@@ -46,3 +46,10 @@ for _ in range(2):
     for wname, tt in (('wave 0', t), ('wave 7', t7)):
         print('   %s, cycles after wave 0 top of the same step: ' % wname + ' | '.join('%s %.0f' % (names[k], (tt[:, k] - t[:, 0]).mean()) for k in (0, 1, 2, 3, 4, 9, 10, 11, 5) if tt[:, k].min() > 0) +
               ' | next top %.0f' % (tt[1:, 0] - t[:-1, 0]).mean())
+
+# exchanged-partials backward (lstm_persist_bwd_rs_kernel): its own marks
+if len(sys.argv) > 2 and sys.argv[2] == 'rs':
+    names = ['top', 'gathered', 'reduced+prefetch issued', 'barrier A', 'pointwise done', 'barrier B', 'dh MFMA done', 'published', 'dW done']
+    for wname, tt in (('wave 0', t), ('wave 7', t7)):
+        print('   rs %s, cycles after wave 0 top of the same step: ' % wname + ' | '.join('%s %.0f' % (names[k], (tt[:, k] - t[:, 0]).mean()) for k in range(9)) +
+              ' | next top %.0f' % (tt[1:, 0] - t[:-1, 0]).mean())
