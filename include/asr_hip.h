@@ -41,6 +41,16 @@ typedef void* asr_stream_t; /* hipStream_t */
 
 int asr_abi_version(void);
 
+/* Product arithmetic of the MFMA kernels.  All operands, accumulators and results are fp32; by default the products of
+ * asr_gemm_f32 and of the persistent LSTM recurrences run on the bf16 MFMA with each fp32 operand split in two bf16
+ * terms (hi + lo, 16 significand bits) and three products hi*hi + hi*lo + lo*hi (<= 2^-15 relative per product,
+ * fp32 accumulation): 16x the MAC rate of the fp32-input MFMA for a result that stays ~30x inside the 1e-3 parity
+ * gate (measured against the reference at cfg-2: worst gradient element 9e-5).  asr_set_split_bf16 selects per
+ * kernel family; it returns the previous mask.  Bits: 1 LSTM forward, 2 LSTM backward (gathered-dG kernel),
+ * 4 LSTM backward with exchanged partials, 8 asr_gemm_f32.  mask < 0: query only.  Environment overrides at load time:
+ * ASR_LSTM_BF3 (bits 1|2|4), ASR_GEMM_BF3 (0/1).  Not thread safe against concurrent launches. */
+int asr_set_split_bf16(int mask);
+
 /* ---------------------------------------------------------------------------------------
  * Graph memo for the per-time-step launch chains (asr_lstm_seq_*, asr_dec_seq_*).  The `graphs`
  * argument of those calls may be NULL (eager launches) or a handle from asr_graphs_create(): the

@@ -5,8 +5,12 @@
 //   asr_colsum_f32      bias gradients.
 // Replaces the torch mm/addmm/bmm calls behind nn.Linear / nn.LSTM input projections on the
 // reference path (model.py:67-68,80,93-94,144,163,293 and their autograd backward).
+#include <cstdlib>
 #include "common.h"
 
+#ifndef ASR_GEMM_BF3_DEFAULT
+#define ASR_GEMM_BF3_DEFAULT 1
+#endif
 #ifndef ASR_GEMM_SETPRIO
 #define ASR_GEMM_SETPRIO 1
 #endif
@@ -275,6 +279,257 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ split-bf16 product
+// Same tiling, operand fetch, split-K and epilogue as gemm_f32_kernel; the product runs on v_mfma_f32_32x32x16_bf16
+// with both fp32 operands split in two bf16 terms while they are staged into LDS (x = hi + lo, hi = the upper 16 bits
+// of the fp32 word, lo = bf16(x - hi) rounded to nearest: 16 significand bits) and three products hi*hi + hi*lo + lo*hi
+// accumulated in fp32.  Dropped: lo*lo and the rounding of lo, <= 2^-16 relative per product (fp32: 2^-24), far inside
+// the 1e-3 parity gate (tests/test_hip_parity.py::test_gemm_variants, test_cfg2_against_golden).  The bf16 pipe does
+// 16x the MACs per cycle of the fp32 MFMA, so a K tile of 32 costs 24 MFMAs of 32 cycles per wave instead of 64 of 64.
+// LDS images: per operand hi and lo, [128 rows][32 k] bf16 with 80-byte rows; a fragment (row l & 31, 8 consecutive k)
+// is one ds_read_b128.  Operands stored k-contiguous ([rows][K]) are staged as before (a thread's float4 = 4 k of one
+// row); operands stored row-contiguous ([K][rows]) use a 4 (k) x 4 (rows) register block per thread, read as four
+// float4 at consecutive k, so that both kinds end up as 8-byte LDS writes of 4 consecutive k.
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+constexpr int BS = 40;                       // LDS row stride in bf16 (80 bytes)
+
+__device__ __forceinline__ unsigned bf3g_hi2(float a, float b) {      // {hi(a), hi(b)}: upper halves of the two words
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ unsigned bf3g_lo2(float a, float b) {      // {lo(a), lo(b)}, rounded to nearest
+  const float la = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u);
+  const float lb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+  const gbf16x2 p = {(__bf16)la, (__bf16)lb};
+  return __builtin_bit_cast(unsigned, p);
+}
+
+// this thread's 4 float4 pieces of a 128 (rows) x 32 (k) operand tile; MC mapping: k block t & 7, rows 4 (t >> 3) .. + 3
+template <bool KC>
+__device__ __forceinline__ void tile_fetch_bf3(const MatView& m, int64_t row0, int64_t k0, float4 (&v)[4]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (KC) {
+      const int f = t + 256 * i;
+      v[i] = load4_guard(m, row0 + (f >> 3), k0 + 4 * (f & 7));
+    } else {
+      v[i] = load4_guard(m, k0 + 4 * (t & 7) + i, row0 + 4 * (t >> 3));
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void tile_store_bf3(unsigned short* hi, unsigned short* lo, const float4 (&v)[4]) {
+  const int t = threadIdx.x;
+  if (KC) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = t + 256 * i;
+      const int o = (f >> 3) * BS + 4 * (f & 7);
+      *reinterpret_cast<uint2*>(hi + o) = make_uint2(bf3g_hi2(v[i].x, v[i].y), bf3g_hi2(v[i].z, v[i].w));
+      *reinterpret_cast<uint2*>(lo + o) = make_uint2(bf3g_lo2(v[i].x, v[i].y), bf3g_lo2(v[i].z, v[i].w));
+    }
+  } else {
+    const int o = 4 * (t >> 3) * BS + 4 * (t & 7);
+    const float r[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
+                           {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<uint2*>(hi + o + j * BS) = make_uint2(bf3g_hi2(r[j][0], r[j][1]), bf3g_hi2(r[j][2], r[j][3]));
+      *reinterpret_cast<uint2*>(lo + o + j * BS) = make_uint2(bf3g_lo2(r[j][0], r[j][1]), bf3g_lo2(r[j][2], r[j][3]));
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[4 * BM * BS];
+  unsigned short* Ah = smem;
+  unsigned short* Al = smem + BM * BS;
+  unsigned short* Bh = smem + 2 * BM * BS;
+  unsigned short* Bl = smem + 3 * BM * BS;
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  int tid = blockIdx.x;
+  {
+    const int q = ntile >> 3, rmd = ntile & 7, xcd = tid & 7, idx = tid >> 3;
+    tid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
+  }
+  const int tm = tid / g.tiles_n, tn = tid % g.tiles_n;
+  const int z = blockIdx.y;
+  const int bz = z / g.split_k, kz = z % g.split_k;
+
+  MatView A = g.A, B = g.B;
+  A.p += bz * g.sA;
+  B.p += bz * g.sB;
+  float* C = g.C + bz * g.sC;
+
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t ktiles = (g.K + BK - 1) / BK;
+  const int64_t per = (ktiles + g.split_k - 1) / g.split_k;
+  const int64_t kt_begin = kz * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // interior tiles and full K tiles: uniform base + 32-bit per-thread offsets (see gemm_f32_kernel)
+  const bool fast_a = A.vec && (AKC ? (m0 + BM <= A.R) : (m0 + BM <= A.Cn)) && A.R * A.ld < (int64_t)1 << 30;
+  const bool fast_b = B.vec && (BKC ? (n0 + BN <= B.R) : (n0 + BN <= B.Cn)) && B.R * B.ld < (int64_t)1 << 30;
+  const bool fast = fast_a && fast_b;
+  unsigned offa[4], offb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = threadIdx.x + 256 * i;
+    const int t = threadIdx.x;
+    offa[i] = AKC ? (unsigned)((f >> 3) * A.ld + 4 * (f & 7)) : (unsigned)((4 * (t & 7) + i) * A.ld + 4 * (t >> 3));
+    offb[i] = BKC ? (unsigned)((f >> 3) * B.ld + 4 * (f & 7)) : (unsigned)((4 * (t & 7) + i) * B.ld + 4 * (t >> 3));
+  }
+  const float* basea = AKC ? A.p + m0 * A.ld : A.p + m0;     // + k0 (KC) or + k0*ld (MC)
+  const float* baseb = BKC ? B.p + n0 * B.ld : B.p + n0;
+  float4 ra[4], rb[4];
+  auto fetch = [&](int64_t kt2) {
+    const int64_t k0 = kt2 * BK;
+    if (fast && k0 + BK <= g.K) {
+      const float* pa = basea + (AKC ? k0 : k0 * A.ld);
+      const float* pb = baseb + (BKC ? k0 : k0 * B.ld);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + offa[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + offb[i]);
+    } else {
+      tile_fetch_bf3<AKC>(A, m0, k0, ra);
+      tile_fetch_bf3<BKC>(B, n0, k0, rb);
+    }
+  };
+  if (kt_begin < kt_end) fetch(kt_begin);
+  const int tt = threadIdx.x & 127;
+  const bool touch_a = threadIdx.x < 128;
+  float touched = 0.f;
+  const bool do_touch = kt_end - kt_begin > 16;
+  auto touch_tile = [&](int64_t ktt) {
+    const MatView& m = touch_a ? A : B;
+    const bool kc = touch_a ? AKC : BKC;
+    const int64_t r0t = touch_a ? m0 : n0;
+    int64_t rr, cc;
+    if (kc) { rr = r0t + tt; cc = ktt * BK; }
+    else { rr = ktt * BK + (tt >> 2); cc = r0t + 32 * (tt & 3); }
+    rr = rr < m.R ? rr : m.R - 1;
+    cc = cc < m.Cn ? cc : m.Cn - 1;
+    touched = m.p[rr * m.ld + cc];
+  };
+  for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+    tile_store_bf3<AKC>(Ah, Al, ra);
+    tile_store_bf3<BKC>(Bh, Bl, rb);
+    __syncthreads();
+    if (kt + 1 < kt_end) fetch(kt + 1);
+#if ASR_GEMM_TOUCH
+    asm volatile("" ::"v"(touched));
+    if (do_touch && kt + ASR_GEMM_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_TOUCH);
+#endif
+    // fragment of row tile i at k-step ks: row wm*64 + 32 i + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7
+    const int ao = (wm * 64 + l31) * BS + 8 * kh, bo = (wn * 64 + l31) * BS + 8 * kh;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      gu32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const gu32x4*>(Ah + ao + 32 * i * BS + 16 * ks);
+        al[i] = *reinterpret_cast<const gu32x4*>(Al + ao + 32 * i * BS + 16 * ks);
+        bh[i] = *reinterpret_cast<const gu32x4*>(Bh + bo + 32 * i * BS + 16 * ks);
+        bl[i] = *reinterpret_cast<const gu32x4*>(Bl + bo + 32 * i * BS + 16 * ks);
+      }
+#define BF3G(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a_), __builtin_bit_cast(gbf16x8, b_), c_, 0, 0, 0)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) BF3G(ah[i], bh[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) BF3G(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) BF3G(al[i], bh[j], acc[i][j]);
+#undef BF3G
+    }
+    __syncthreads();
+  }
+
+  // epilogue (as gemm_f32_kernel: the C/D lane map of the 32x32 MFMAs does not depend on the input type)
+  if (m0 + BM <= g.M && n0 + BN <= g.N) {
+    const unsigned ldc = (unsigned)g.ldc;
+    const bool split = g.split_k > 1, accum = g.accumulate != 0, relu = g.relu != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 32 + l31;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* base = C + (m0 + wm * 64 + i * 32 + 4 * kh) * g.ldc + n;
+        if (split) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) atomicAdd(base + (unsigned)((e & 3) + 8 * (e >> 2)) * ldc, acc[i][j][e]);
+        } else if (accum) {
+          float old[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) old[e] = base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv + old[e];
+            if (relu) v = fmaxf(v, 0.f);
+            base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= g.N) continue;
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (m >= g.M) continue;
+        float v = acc[i][j][e];
+        float* dst = C + m * g.ldc + n;
+        if (g.split_k > 1) {
+          atomicAdd(dst, v);
+        } else {
+          v += bv;
+          if (g.accumulate) v += *dst;
+          if (g.relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
 // bias (+ReLU) pass after a split-K product (the atomics cannot carry an epilogue)
 __global__ void bias_act_kernel(float* C, int64_t ldc, int64_t M, int64_t N, int64_t sC, const float* __restrict__ bias,
                                 int relu) {
@@ -387,6 +642,24 @@ __global__ __launch_bounds__(256) void colsum4_kernel(int64_t M, int64_t N, cons
 
 extern "C" int asr_abi_version(void) { return ASR_ABI_VERSION; }
 
+#ifndef ASR_LSTM_BF3_DEFAULT
+#define ASR_LSTM_BF3_DEFAULT 7
+#endif
+static int& split_bf16_state() {
+  static int mask = [] {
+    const char* l = getenv("ASR_LSTM_BF3");
+    const char* g = getenv("ASR_GEMM_BF3");
+    return ((l ? atoi(l) : ASR_LSTM_BF3_DEFAULT) & 7) | ((g ? atoi(g) : ASR_GEMM_BF3_DEFAULT) ? 8 : 0);
+  }();
+  return mask;
+}
+int asr_split_bf16_mask() { return split_bf16_state(); }
+extern "C" int asr_set_split_bf16(int mask) {
+  const int old = split_bf16_state();
+  if (mask >= 0) split_bf16_state() = mask & 15;
+  return old;
+}
+
 extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                             const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
                             int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC, int split_k,
@@ -420,7 +693,13 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
     hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
   }
   dim3 grid(g.tiles_m * g.tiles_n, batch * split_k, 1), block(256);
-  if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
+  // split-bf16 products by default; asr_set_split_bf16 / ASR_GEMM_BF3=0 select the exact-fp32 MFMA kernel
+  if (asr_split_bf16_mask() & 8) {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, true>), grid, block, 0, stream, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, false>), grid, block, 0, stream, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<false, true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm_bf3_kernel<false, false>), grid, block, 0, stream, g);
+  } else if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
   else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
   else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
   else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);

@@ -1602,11 +1602,9 @@ int launch_fwd(const PersistArgs& a, hipStream_t stream) {
 
 // split-bf16 products: on by default (ASR_LSTM_BF3=0 selects the exact-fp32 4x4x1 products)
 // bit 0: forward gate product, bit 1: backward dh product (gathered-dG kernel), bit 2: backward with exchanged dh
-// partials (lstm_persist_bwd_rs_kernel; H in {128, 256, 512}, takes precedence over bit 1)
-int bf3_enabled() {
-  static const int on = [] { const char* e = getenv("ASR_LSTM_BF3"); return e ? atoi(e) : ASR_LSTM_BF3_DEFAULT; }();
-  return on;
-}
+// partials (lstm_persist_bwd_rs_kernel; H in {128, 256, 512}, takes precedence over bit 1); bit 3 belongs to gemm.hip.
+// Shared, process-wide switch (asr_set_split_bf16).
+int bf3_enabled() { return asr_split_bf16_mask(); }
 
 template <int PH, int NR>
 int launch_fwd_bf3(const PersistArgs& a, hipStream_t stream) {

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libasr_hip.so")
 ABI_VERSION = 1
 
 EXPORTS = (
-    "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
+    "asr_abi_version", "asr_set_split_bf16", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
@@ -61,6 +61,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     for name in EXPORTS:
         getattr(lib, name).restype = c_i
+    lib.asr_set_split_bf16.argtypes = [c_i]
     lib.asr_graphs_create.restype = c_p
     lib.asr_graphs_create.argtypes = [c_i]
     lib.asr_graphs_destroy.restype = None
@@ -108,6 +109,30 @@ def load():
         raise RuntimeError("libasr_hip.so ABI %d != expected %d" % (lib.asr_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+SPLIT_LSTM_FWD, SPLIT_LSTM_BWD, SPLIT_LSTM_BWD_RS, SPLIT_GEMM = 1, 2, 4, 8
+
+
+def set_split_bf16(mask):
+    """Select split-bf16 (hi + lo, three products) or exact-fp32 MFMA products per kernel family (asr_set_split_bf16);
+    returns the previous mask.  mask < 0 only queries."""
+    return int(load().asr_set_split_bf16(int(mask)))
+
+
+class split_bf16(object):
+    """Context manager: run with the given product-arithmetic mask (0 = every product on the fp32-input MFMA)."""
+
+    def __init__(self, mask):
+        self.mask = mask
+
+    def __enter__(self):
+        self.old = set_split_bf16(self.mask)
+        return self
+
+    def __exit__(self, *exc):
+        set_split_bf16(self.old)
+        return False
 
 
 def _dev(t, name="tensor"):

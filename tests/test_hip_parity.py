@@ -34,25 +34,50 @@ def _load(golden_dir, name):
 
 
 # ----------------------------------------------------------------------------------------- GEMMs
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 130, 70), (33, 34, 9), (1000, 96, 513)])
-def test_gemm_variants(ta, tb, M, N, K):
+def test_gemm_variants(ta, tb, M, N, K, split):
+    """asr_gemm_f32 in its four operand layouts, with epilogue / split-K / accumulate, in both product arithmetics:
+    split-bf16 (default: hi + lo terms, three bf16 MFMA products, <= 2^-16 relative per product) and the exact
+    fp32-input MFMA.  Tolerances relative to the largest output: 1e-5 (fp32), 3e-5 (split) - the parity gate is 1e-3."""
     dev = _gpu()
     import hip_backend as hb
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
     B = torch.randn((N, K) if tb else (K, N), generator=g)
     bias = torch.randn(N, generator=g)
-    ref = (A.t() if ta else A) @ (B.t() if tb else B)
-    out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
-    _close(out, ref, rtol=1e-5, atol=1e-4, what="plain")
-    out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, bias=bias.to(dev), relu=True)
-    _close(out, torch.relu(ref + bias), rtol=1e-5, atol=1e-4, what="bias+relu")
-    out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, split_k=3)
-    _close(out, ref, rtol=1e-5, atol=1e-4, what="split-k")
-    base = torch.randn(M, N, generator=g)
-    out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, out=base.to(dev), accumulate=True)
-    _close(out, ref + base, rtol=1e-5, atol=1e-4, what="accumulate")
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    tol = dict(rtol=3e-5 if split else 1e-5, atol=1e-4)
+    with hb.split_bf16(hb.SPLIT_GEMM if split else 0):
+        out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
+        _close(out, ref.float(), what="plain", **tol)
+        out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, bias=bias.to(dev), relu=True)
+        _close(out, torch.relu(ref + bias).float(), what="bias+relu", **tol)
+        out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, split_k=3)
+        _close(out, ref.float(), what="split-k", **tol)
+        base = torch.randn(M, N, generator=g)
+        out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, out=base.to(dev), accumulate=True)
+        _close(out, (ref + base).float(), what="accumulate", **tol)
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("ta,tb,M,N,K", [(False, True, 25600, 4096, 80),      # layer-0 input-gate projection [T*B,80]x[80,8H]
+                                         (True, False, 4096, 80, 25600),     # layer-0 dW_ih = dG^T X
+                                         (False, False, 6400, 512, 4096),    # dX = dG W_ih (layer 2)
+                                         (True, False, 512, 2048, 12800)])   # projection weight gradient
+def test_gemm_step_shapes(ta, tb, M, N, K, split):
+    """The shapes of the cfg-2 train step with a thin dimension (K = 80, N = 80) or a long contraction (K = T*B), against a
+    float64 product of the same fp32 inputs."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = ((A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())).float()
+    with hb.split_bf16(hb.SPLIT_GEMM if split else 0):
+        out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
+    _close(out, ref, rtol=3e-5 if split else 1e-5, atol=1e-4, what="%dx%dx%d" % (M, N, K))
 
 
 def test_gemm_strided_views_and_batched():
@@ -63,7 +88,7 @@ def test_gemm_strided_views_and_batched():
     W = torch.randn(48, 40, generator=g).to(dev)
     out = torch.zeros(64, 80, device=dev)
     hb.gemm(big[:, 20:60], W, trans_b=True, out=out[:, 16:64])
-    _close(out[:, 16:64], big[:, 20:60].cpu() @ W.cpu().t(), rtol=1e-5, atol=1e-4)
+    _close(out[:, 16:64], big[:, 20:60].cpu() @ W.cpu().t(), rtol=3e-5, atol=1e-4)      # split-bf16 products (default)
     assert float(out[:, :16].abs().max()) == 0.0
     # batched: C[b] = A[:, b, :]^T B[:, b, :]
     L, Bn, Tp, Od = 7, 3, 10, 12
@@ -71,7 +96,7 @@ def test_gemm_strided_views_and_batched():
     Bm = torch.randn(L, Bn, Od, generator=g).to(dev)
     C = torch.empty(Bn, Tp, Od, device=dev)
     hb.gemm_batched(A, Bm, C, True, False, Tp, Od, L, Bn * Tp, Bn * Od, Od, Bn, Tp, Od, Tp * Od)
-    _close(C, torch.einsum("lbt,lbo->bto", A.cpu(), Bm.cpu()), rtol=1e-5, atol=1e-4)
+    _close(C, torch.einsum("lbt,lbo->bto", A.cpu(), Bm.cpu()), rtol=3e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("M,N,K", [(32, 2048, 512), (3, 9, 32), (20, 34, 1024), (40, 100, 64)])
@@ -209,29 +234,37 @@ def test_tiny_e2e_free_running_modes(golden_dir):
     _close(lp_eval, g["eval_lp"], what="eval lp")
 
 
-def test_tiny_optimizer_steps(golden_dir):
+@pytest.mark.parametrize("split", [True, False])
+def test_tiny_optimizer_steps(golden_dir, split):
+    """Weights after 1 and 3 clip + Adam(amsgrad) steps vs the reference (solver.py:152-153,382-385), clip active and
+    inactive.  Adam divides by sqrt(v): after the first steps an update is ~lr * sign(g), so tiny gradient differences
+    show up amplified; the exact-fp32 products are held to 1e-4 of each tensor's scale, the default split-bf16 products
+    to 5e-4 (gate: 1e-3)."""
     dev = _gpu()
+    import hip_backend as hb
     from parallel import FlatAdam
     g = _load(golden_dir, "tiny_e2e.npz")
     xs, ilens, ys = synth.batch(8, 9, synth.TINY_ILENS, synth.TINY_YLENS, 13)
     xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
-    for clip, prefix, steps in ((5.0, "after", 3), (0.05, "clip", 1)):
-        net = _product(synth.TINY, synth.e2e_weights(synth.TINY, 11), g["labeldist"], dev)
-        opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=clip)
-        for step in range(steps):
-            np.random.seed(100 + step)
-            _, lp, _, _ = net(xs_d, ilens, ys_d, tf_rate=1.0)
-            opt.zero_grad()
-            (-lp.mean()).backward()
-            gsq = opt.step()
-            if prefix == "after":
-                _close(gsq.sqrt(), g["opt_gnorm%d" % step], rtol=1e-3)
-                if step in (0, 2):
+    rtol = 5e-4 if split else 1e-4
+    with hb.split_bf16(hb.set_split_bf16(-1) if split else 0):
+        for clip, prefix, steps in ((5.0, "after", 3), (0.05, "clip", 1)):
+            net = _product(synth.TINY, synth.e2e_weights(synth.TINY, 11), g["labeldist"], dev)
+            opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=clip)
+            for step in range(steps):
+                np.random.seed(100 + step)
+                _, lp, _, _ = net(xs_d, ilens, ys_d, tf_rate=1.0)
+                opt.zero_grad()
+                (-lp.mean()).backward()
+                gsq = opt.step()
+                if prefix == "after":
+                    _close(gsq.sqrt(), g["opt_gnorm%d" % step], rtol=1e-3)
+                    if step in (0, 2):
+                        for n, p in net.named_parameters():
+                            _close(p, g["after%d/%s" % (step + 1, n)], rtol=rtol, atol=2e-6, what="after %s" % n)
+                else:
                     for n, p in net.named_parameters():
-                        _close(p, g["after%d/%s" % (step + 1, n)], rtol=1e-4, atol=2e-6, what="after %s" % n)
-            else:
-                for n, p in net.named_parameters():
-                    _close(p, g["clip/" + n], rtol=1e-4, atol=2e-6, what="clip %s" % n)
+                        _close(p, g["clip/" + n], rtol=rtol, atol=2e-6, what="clip %s" % n)
 
 
 def _ref_adam_state(g):
@@ -274,7 +307,7 @@ def test_resume_from_reference_adam_state(golden_dir):
         (-lp.mean()).backward()
         opt.step()
     for n, p in net.named_parameters():
-        _close(p, g["after3/" + n], rtol=1e-4, atol=2e-6, what="after3 %s" % n)
+        _close(p, g["after3/" + n], rtol=5e-4, atol=2e-6, what="after3 %s" % n)
     # and back out: the state FlatAdam saves has torch.optim.Adam's schema (one entry per parameter, same fields)
     sd = opt.state_dict()
     assert sorted(sd["state"].keys()) == list(range(len(list(net.parameters()))))
