@@ -11,6 +11,9 @@
 #ifndef ASR_GEMM_BF3_DEFAULT
 #define ASR_GEMM_BF3_DEFAULT 1
 #endif
+#ifndef ASR_GEMM_BF3_TOUCH      /* L2 warm-up distance of the split-bf16 kernel in K tiles (2, 4, 6, 10 measured within 5 %: tools/gemm_cold_sweep.py; the kernel is bound by operand traffic at 32 flop/byte per 128x128 tile, not by latency) */
+#define ASR_GEMM_BF3_TOUCH 2
+#endif
 #ifndef ASR_GEMM_SETPRIO
 #define ASR_GEMM_SETPRIO 1
 #endif
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   const int tt = threadIdx.x & 127;
   const bool touch_a = threadIdx.x < 128;
   float touched = 0.f;
-  const bool do_touch = kt_end - kt_begin > 16;
+  const bool do_touch = kt_end - kt_begin > 2 * ASR_GEMM_BF3_TOUCH;
   auto touch_tile = [&](int64_t ktt) {
     const MatView& m = touch_a ? A : B;
     const bool kc = touch_a ? AKC : BKC;
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
     if (kt + 1 < kt_end) fetch(kt + 1);
 #if ASR_GEMM_TOUCH
     asm volatile("" ::"v"(touched));
-    if (do_touch && kt + ASR_GEMM_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_TOUCH);
+    if (do_touch && kt + ASR_GEMM_BF3_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_BF3_TOUCH);
 #endif
     // fragment of row tile i at k-step ks: row wm*64 + 32 i + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7
     const int ao = (wm * 64 + l31) * BS + 8 * kh, bo = (wn * 64 + l31) * BS + 8 * kh;
