@@ -497,20 +497,31 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // single-stage hand-off: lane (< PKW) owns one k of the wave's range and reads its NR rows as 16-byte quads
-      const bool gl = lane < PKW;
-      const unsigned boff = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
-                                       (wave * PKW + (gl ? lane : 0)) * PRG) * 4u;
+      // single-stage hand-off: a lane owns k = lane (+ 64 for H > 512) of the wave's range and reads its NR rows as
+      // 16-byte quads
+      constexpr int NKC = (PKW + 63) / 64;
+      bool gl[NKC];
+      unsigned boff[NKC];
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        gl[kc] = lane + 64 * kc < PKW;
+        boff[kc] = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
+                              (wave * PKW + (gl[kc] ? lane + 64 * kc : 0)) * PRG) * 4u;
+      }
       const unsigned tb = tag_bit_of_step(s - 1);
-      u32x4 gw[NR / 4];
+      u32x4 gw[NKC][NR / 4];
       unsigned spins = 0;
       while (true) {
 #pragma unroll
-        for (int j = 0; j < NR / 4; ++j) gw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff + 16u * j, 0, 16);
-        unsigned bits = 1u;
+        for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
-        for (int j = 0; j < NR / 4; ++j) bits &= ~(gw[j].x ^ tb) & ~(gw[j].y ^ tb) & ~(gw[j].z ^ tb) & ~(gw[j].w ^ tb);
-        if (__all(!gl || (bits & 1u))) break;
+          for (int j = 0; j < NR / 4; ++j) gw[kc][j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff[kc] + 16u * j, 0, 16);
+        bool ok = true;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+          for (int j = 0; j < NR / 4; ++j) ok = ok && (!gl[kc] || quad_ok(gw[kc][j], tb));
+        if (__all(ok)) break;
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
           if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
           aborted = true;
@@ -518,18 +529,20 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
         }
         __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
-      if (gl) {
 #pragma unroll
-        for (int j = 0; j < NR / 4; ++j) {
-          const float f[4] = {__uint_as_float(gw[j].x), __uint_as_float(gw[j].y), __uint_as_float(gw[j].z),
-                              __uint_as_float(gw[j].w)};
+      for (int kc = 0; kc < NKC; ++kc)
+        if (gl[kc]) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            hhi[wave][4 * j + i][lane] = (unsigned short)bf3_hi(f[i]);
-            hlo[wave][4 * j + i][lane] = (unsigned short)bf3_lo(f[i]);
+          for (int j = 0; j < NR / 4; ++j) {
+            const float f[4] = {__uint_as_float(gw[kc][j].x), __uint_as_float(gw[kc][j].y), __uint_as_float(gw[kc][j].z),
+                                __uint_as_float(gw[kc][j].w)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              hhi[wave][4 * j + i][lane + 64 * kc] = (unsigned short)bf3_hi(f[i]);
+              hlo[wave][4 * j + i][lane + 64 * kc] = (unsigned short)bf3_lo(f[i]);
+            }
           }
         }
-      }
       if (st_gp) {                    // previous step's outputs (stores after the poll: vmcnt retires in order)
         *st_gp = st_g;
         a.c[st_so] = st_c;
@@ -1666,6 +1679,7 @@ int rows_per_group(int nb, int ndir) {
 
 template <int NR>
 int dispatch_fwd(int H, const PersistArgs& a, hipStream_t stream) {
+  if (H == 640) return launch_fwd_bf3<640, NR>(a, stream);          // the judge's width: split-bf16 kernel only
   if (bf3_enabled() & 1)
     return H == 512 ? launch_fwd_bf3<512, NR>(a, stream) : H == 320 ? launch_fwd_bf3<320, NR>(a, stream)
          : H == 256 ? launch_fwd_bf3<256, NR>(a, stream) : launch_fwd_bf3<128, NR>(a, stream);
@@ -1708,7 +1722,8 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
                                         asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
-  if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
+  // H = 640 (the judge LM, config.yaml dis_hidden_dim): forward only - 20 units per CU = 5 M tiles of the bf16 MFMA
+  if (!(persist_supported(H) || H == 640) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   const int nr = rows_per_group(nb, ndir);
   const int rows_per_launch = nr * (8 / ndir);
   for (int rb = 0; rb < nb; rb += rows_per_launch) {

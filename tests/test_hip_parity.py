@@ -635,6 +635,42 @@ def test_lstm_persistent_path(ndir, B, T, lens, H):
         _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
 
 
+@pytest.mark.parametrize("B,T,ndir", [(32, 12, 1), (20, 7, 1), (8, 5, 2), (40, 3, 1)])
+def test_lstm_judge_width_h640(B, T, ndir):
+    """H = 640 (the judge LM: config.yaml dis_hidden_dim, reference model.py:466-467): the forward recurrence runs on the
+    persistent split-bf16 kernel (20 units per CU = 5 M tiles), the backward on the per-step kernels; both against the
+    oracle, and the counters say which kernels ran."""
+    dev = _gpu()
+    import ops
+    import hip_backend as hb
+    H, I = 640, 256
+    g = torch.Generator().manual_seed(B * 10 + T)
+    lens = sorted([int(v) for v in torch.randint(1, T + 1, (B,), generator=g)], reverse=True)
+    lens[0] = T
+    x = torch.randn(B, T, I, generator=g)
+    k = 1.0 / np.sqrt(H)
+    prm = []
+    for d in range(ndir):
+        prm += [torch.empty(4 * H, I).uniform_(-k, k, generator=g), torch.empty(4 * H, H).uniform_(-k, k, generator=g),
+                torch.empty(4 * H).uniform_(-k, k, generator=g), torch.empty(4 * H).uniform_(-k, k, generator=g)]
+    cp = [p.clone().requires_grad_(True) for p in prm]
+    xc = x.clone().requires_grad_(True)
+    ref = torch.cat([O.lstm_direction(xc, lens, *cp[4 * d:4 * d + 4], reverse=(d == 1)) for d in range(ndir)], 2)
+    gp = [p.to(dev).requires_grad_(True) for p in prm]
+    xg = x.to(dev).requires_grad_(True)
+    hb.LAUNCHES.clear()
+    got = ops.lstm_layer(xg.transpose(0, 1), torch.tensor(lens, dtype=torch.int32, device=dev), gp, ndir)
+    assert not hb.persist_aborted(dev)
+    _close(got.transpose(0, 1), ref, rtol=1e-4, atol=1e-5, what="y (H=640)")
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    got.backward(dy.transpose(0, 1).contiguous().to(dev))
+    assert hb.LAUNCHES["lstm_fwd_persist"] == 1 and hb.LAUNCHES["lstm_bwd_step"] == 1, dict(hb.LAUNCHES)
+    _close(xg.grad, xc.grad, rtol=1e-3, atol=1e-5, what="dx")
+    for i, (a, b) in enumerate(zip(gp, cp)):
+        _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
+
+
 @pytest.mark.parametrize("dim,B,Tp,L,drop", [(512, 32, 100, 6, True), (512, 7, 37, 4, False), (320, 32, 100, 5, True),
                                              (512, 40, 100, 3, False), (512, 16, 96, 3, True), (320, 5, 9, 4, False),
                                              (512, 70, 100, 2, True)])
