@@ -39,21 +39,37 @@
 namespace {
 
 constexpr int DP_NT = 512;          // 8 waves
-constexpr int DP_TPM = 128;         // max encoder frames T'
+constexpr int DP_TPM = 128;         // max encoder frames T' of the 4-rows-per-group geometry (and of the backward kernel)
 constexpr int DP_FPC = 16;          // conv frames per CU (8 CUs per row)
 constexpr int DP_KMAX = 100;        // max conv half width
 constexpr int DP_TAPS4 = 208;       // LDS row length of the filter image (>= 2*KMAX+1 rounded to 4)
-constexpr int DP_WLEN = DP_TPM + 2 * DP_KMAX + 8;
-constexpr int DP_NP = DP_TPM / 8;   // (row, frame) pairs per score thread
-// exchange layout per group, in floats
-constexpr int DX_Z = 0;                            // [2][4][512]
-constexpr int DX_C = DX_Z + 2 * 4 * 512;           // [2][4][512]
-constexpr int DX_F = DX_C + 2 * 4 * 512;           // [2][4][16][TPM]
-constexpr int DX_E = DX_F + 2 * 4 * 16 * DP_TPM;   // [2][32][4][TPM]
-constexpr int DX_U = DX_E + 2 * 32 * 4 * DP_TPM;  // [2][4][512]  free-running only: ctx before the dropout mask
-constexpr int DX_M = DX_U + 2 * 4 * 512;           // [2][4][128]  free-running only: embedding input of the step
-constexpr int DX_S = DX_M + 2 * 4 * 128;           // [2][2]       free-running only: "every row of the group has emitted <EOS>"
-constexpr int DX_GROUP = DX_S + 2 * 2 + 4;
+// Geometry of a group (= XCD).  RG utterances per group, each served by PPR = 32 / RG CUs ("parts"): a part owns 16 conv
+// frames, O / PPR context outputs and (like every CU) D/32 cell units and A/32 attention columns of all RG rows.
+//   RG = 4, TPM = 128: a batch of 32 fills the chip (T' <= 102 with 10 conv channels: cfg-2, cfg-1);
+//   RG = 2, TPM = 256: 16 CUs per utterance, so the T'-sized LDS images (P slice, Q slice, conv features) keep their
+//                      size at twice the frames (T' <= 256: cfg-5's T' = 200); 16 utterances per launch.
+// The row axis of the exchange and LDS layouts keeps 4 slots in both geometries (rows >= RG are never published to
+// other CUs and never read from them).
+template <int RG_, int TPM_>
+struct DecGeo {
+  static constexpr int RG = RG_, TPM = TPM_;
+  static constexpr int PPR = 32 / RG;                 // parts (CUs) per row
+  static constexpr int LR = RG == 4 ? 3 : 4;          // log2(PPR)
+  static constexpr int FPT = 16 / RG;                 // frames per score tile (16 (row, frame) pairs)
+  static constexpr int NFQ = RG == 4 ? 2 : 3;         // conv-feature quads per thread in the z / f poll
+  static constexpr int FROWS = RG == 4 ? 16 : 12;     // rows of the conv filter image (channels, zero padded)
+  static constexpr int WLEN = TPM + 2 * DP_KMAX + 8;
+  // exchange layout per group, in floats
+  static constexpr int X_Z = 0;                            // [2][4][512]
+  static constexpr int X_C = X_Z + 2 * 4 * 512;            // [2][4][512]
+  static constexpr int X_F = X_C + 2 * 4 * 512;            // [2][4][16][TPM]
+  static constexpr int X_E = X_F + 2 * 4 * 16 * TPM;       // [2][32][4][TPM]
+  static constexpr int X_U = X_E + 2 * 32 * 4 * TPM;       // [2][4][512]  free-running only: ctx before the dropout mask
+  static constexpr int X_M = X_U + 2 * 4 * 512;            // [2][4][128]  free-running only: embedding input of the step
+  static constexpr int X_S = X_M + 2 * 4 * 128;            // [2][2]       free-running only: all rows of the group at <EOS>
+  static constexpr int X_GROUP = X_S + 2 * 2 + 4;
+  static_assert(PPR * DP_FPC == TPM && 32 * FPT == TPM, "16 conv frames per part, 32 score tiles");
+};
 
 struct DecPersistArgs {
   int B, nb, Tp, C, K, L;
@@ -74,21 +90,22 @@ __device__ __forceinline__ float dp_tanh(float x) {   // same formula as decoder
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
 }
 
-template <int DD, int AA, int OO, int EE>
+template <int DD, int AA, int OO, int EE, int RG = 4, int TPM = DP_TPM>
 struct DecDims {
+  using GEO = DecGeo<RG, TPM>;
   static constexpr int KX = DD + OO + EE;
   static constexpr int KXW = KX / 8;       // K columns of the cell product per wave
   static constexpr int DU = DD / 32;       // cell units per CU
   static constexpr int AU = AA / 32;       // attention columns per CU
-  static constexpr int OQ = OO / 8;        // context outputs per CU
+  static constexpr int OQ = OO / GEO::PPR; // context outputs per CU
   static constexpr int DKW = DD / 8;       // W_dec product: k's per wave
   static constexpr int DKQ = DD / 32;      // ... per (wave, k-sub)
   static constexpr int XS = KX + 4;        // padded LDS row of the cell operand
   static constexpr int NZ = (2 * DD + DP_NT - 1) / DP_NT;     // 8-byte pairs per thread when gathering z
   static constexpr int NC = (2 * OO + DP_NT - 1) / DP_NT;
   static constexpr int NE = (4 * EE + DP_NT - 1) / DP_NT;     // embedding values per thread
-  static constexpr size_t lds_floats = 4 * XS + 8 * 64 * 5 + 64 + 4 * 16 * DP_TPM + DP_TPM * OQ + 16 * DP_TAPS4 +
-                                       DP_WLEN + 8 * 16 * 17 + 8 * DP_TPM + DP_TPM + 8 * 64 + 32 * 4 * 64 + 8;
+  static constexpr size_t lds_floats = 4 * XS + 8 * 64 * 5 + 64 + RG * 16 * TPM + TPM * OQ + GEO::FROWS * DP_TAPS4 +
+                                       GEO::WLEN + 8 * 16 * 17 + 8 * TPM + TPM + 8 * 64 + 32 * 4 * 64 + 8;
   static_assert(KX % 32 == 0 && DD % 32 == 0 && AA % 32 == 0 && OO % 8 == 0 && (EE & (EE - 1)) == 0, "slice sizes");
   static_assert(DU <= 16 && AU <= 16 && OQ <= 64 && DD <= 512 && OO <= 512, "per-CU slices must fit the mappings");
 };
@@ -99,23 +116,28 @@ struct DecDims {
 // W_out [z, ctx] + b (W_out streamed from L2, one wave per output), argmax / softmax(scale * logits), embedding row or
 // p @ E, dropout mask, -> X/Xd, logits, pred, fed, probs in global memory and one more exchange (DX_M) from which all
 // 32 CUs take the 4 x 128 embedding values.  The logits of the last step are left to the caller.
-template <int DD, int AA, int OO, int EE, bool FB>
+template <int DD, int AA, int OO, int EE, bool FB, int RG = 4, int TPM = DP_TPM>
 __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a) {
-  using DM = DecDims<DD, AA, OO, EE>;
+  using DM = DecDims<DD, AA, OO, EE, RG, TPM>;
+  using GEO = DecGeo<RG, TPM>;
+  constexpr int PPR = GEO::PPR, LR = GEO::LR, FPT = GEO::FPT, NFQ = GEO::NFQ, FROWS = GEO::FROWS, DP_WLEN = GEO::WLEN;
+  constexpr int DX_Z = GEO::X_Z, DX_C = GEO::X_C, DX_F = GEO::X_F, DX_E = GEO::X_E, DX_U = GEO::X_U, DX_M = GEO::X_M;
+  constexpr int DX_S = GEO::X_S, DX_GROUP = GEO::X_GROUP;
+  static_assert(!FB || RG == 4, "the free-running feedback is written for 4 rows per group");
   constexpr int KX = DM::KX, KXW = DM::KXW, DU = DM::DU, AU = DM::AU, OQ = DM::OQ, DKW = DM::DKW, DKQ = DM::DKQ;
   constexpr int XS = DM::XS, NZ = DM::NZ, NC = DM::NC, NE = DM::NE;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* xs = sm;                            // [4][XS]      cell operand [z | ctx(masked) | emb(masked)] per row
   float* part = xs + 4 * XS;                 // [8][64][5]   K-partials (cell product, then W_dec product)
   float* dps = part + 8 * 64 * 5;            // [4][16]      W_dec z slice
-  float* fs = dps + 64;                      // [4][16][TPM] conv features of all rows
-  float* Qs = fs + 4 * 16 * DP_TPM;          // [TPM][OQ]    Q slice of this CU's row
-  float* Fs = Qs + DP_TPM * OQ;              // [16][TAPS4]  conv filters, zero padded
-  float* wp = Fs + 16 * DP_TAPS4;            // [WLEN]       previous attention weights of this CU's row, zero halo
+  float* fs = dps + 64;                      // [RG][16][TPM] conv features of all rows
+  float* Qs = fs + RG * 16 * TPM;            // [TPM][OQ]    Q slice of this CU's row
+  float* Fs = Qs + TPM * OQ;                 // [FROWS][TAPS4] conv filters, zero padded
+  float* wp = Fs + FROWS * DP_TAPS4;         // [WLEN]       previous attention weights of this CU's row, zero halo
   float* cred = wp + DP_WLEN;                // [8][16][17]  conv partial tiles
   float* epart = cred + 8 * 16 * 17;         // [8][TPM]     partial energy sums
-  float* wsm = epart + 8 * DP_TPM;           // [TPM]        attention weights of this step
-  float* cpart = wsm + DP_TPM;               // [8][64]      context partials
+  float* wsm = epart + 8 * TPM;              // [TPM]        attention weights of this step
+  float* cpart = wsm + TPM;                  // [8][64]      context partials
   float* Ps = cpart + 8 * 64;                // [32 tiles][4 rows][64 lanes]  P slice in the score-lane layout
   int* role = reinterpret_cast<int*>(Ps + 32 * 4 * 64);
 
@@ -124,7 +146,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
-  const int r0 = 4 * g;
+  const int r0 = RG * g;
   if (r0 >= a.nb) return;                    // this group has no rows (nobody waits for it)
   const int Tp = a.Tp, C = a.C, K = a.K, B = a.B, L = a.L, nb = a.nb;
   const int TpP = (Tp + 3) & ~3;
@@ -137,7 +159,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
 
   // ---------------------------------------------------------------- per-role constants
   // attention row / part of this CU
-  const int ar = slice >> 3, aq = slice & 7;
+  const int ar = slice >> LR, aq = slice & (PPR - 1);
   const int ab = r0 + ar;
   const bool ab_ok = ab < nb;
   const int abc = ab_ok ? ab : r0;
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
   const bool pw_thread = tid < 4 * DU;
   const int punit = DU * slice + (pw_thread ? (tid >> 2) : 0);
   const int pb = r0 + (tid & 3);
-  const bool pb_ok = pw_thread && pb < nb;
+  const bool pb_ok = pw_thread && (tid & 3) < RG && pb < nb;
   float4 pbias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pw_thread) pbias = *reinterpret_cast<const float4*>(a.bcat + punit * 4);
   float c_prev = 0.f;
@@ -189,12 +211,12 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
 
   // ---------------------------------------------------------------- LDS images
   for (int i = tid; i < 4 * XS; i += DP_NT) xs[i] = 0.f;                 // z_{-1} = 0, ctx_{-1} = 0
-  for (int i = tid; i < 4 * 16 * DP_TPM; i += DP_NT) fs[i] = 0.f;        // channels >= C stay zero
+  for (int i = tid; i < RG * 16 * TPM; i += DP_NT) fs[i] = 0.f;          // channels >= C stay zero
   for (int i = tid; i < Tp * OQ; i += DP_NT) {
     const int t = i / OQ, o = i - t * OQ;
     Qs[i] = a.Q[((int64_t)abc * Tp + t) * OO + OQ * aq + o];
   }
-  for (int i = tid; i < 16 * DP_TAPS4; i += DP_NT) {
+  for (int i = tid; i < FROWS * DP_TAPS4; i += DP_NT) {
     const int ch = i / DP_TAPS4, j = i - ch * DP_TAPS4;
     Fs[i] = (ch < C && j < taps) ? a.convw[ch * taps + j] : 0.f;
   }
@@ -203,11 +225,12 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     wp[i] = (fr >= 0 && fr < Tp) ? a.w0[(int64_t)abc * Tp + fr] : 0.f;
   }
   // P slice (constant over the sequence) in the layout the score lanes read: tile = wave + 8*it, row i, lane
+  // (pair 4 sq + i of a tile = row (4 sq + i) % RG, frame FPT tile + (4 sq + i) / RG: the D layout of the score MFMA)
 #pragma unroll
   for (int it = 0; it < 4; ++it)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int tile = wave + 8 * it, t = 4 * tile + sq, b = r0 + i;
+      const int tile = wave + 8 * it, t = FPT * tile + (4 * sq + i) / RG, b = r0 + (4 * sq + i) % RG;
       Ps[(tile * 4 + i) * 64 + lane] = a.P[((int64_t)(b < nb ? b : r0) * Tp + (t < Tp ? t : Tp - 1)) * AA + acol];
     }
   // embedding part of the first step's operand (already masked in Xd)
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     const bool pw_thread_ = tid_ < 4 * DU;
     const int punit_ = DU * slice + (pw_thread_ ? (tid_ >> 2) : 0);
     const int pb_ = r0 + (tid_ & 3);
-    const bool pb_ok_ = pw_thread_ && pb_ < nb;
+    const bool pb_ok_ = pw_thread_ && (tid_ & 3) < RG && pb_ < nb;
     const int a_l_ = lane_ & 15, sq_ = lane_ >> 4;
     const bool sc_ok_ = a_l_ < AU;
     const int acol_ = AU * slice + (sc_ok_ ? a_l_ : 0);
@@ -254,14 +277,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       for (int i = 0; i < NQ; ++i) {
         const int id = tid_ + DP_NT * i;                 // quad id over [4][OO/4]
         const int row = (4 * id) / OO, o = 4 * id - row * OO;
-        off[i] = cbase + (unsigned)((4 * id < 4 * OO) ? row * 512 + o : 0) * 4u;
+        off[i] = cbase + (unsigned)((4 * id < RG * OO) ? row * 512 + o : 0) * 4u;      // rows >= RG are never published
       }
       poll_quads<NQ, true>(xrs, off, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 11u);
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const int id = tid_ + DP_NT * i;
         const int row = (4 * id) / OO, o = 4 * id - row * OO;
-        if (4 * id < 4 * OO)
+        if (4 * id < RG * OO)
           *reinterpret_cast<float4*>(xs + row * XS + DD + o) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
                                                                           __uint_as_float(v[i].z), __uint_as_float(v[i].w));
       }
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int r = lane_ & 15, q = lane_ >> 4;
       const float* ap = wp + aq * DP_FPC + r + q;
-      const float* bp = Fs + r * DP_TAPS4 + q;
+      const float* bp = Fs + (r < FROWS ? r : FROWS - 1) * DP_TAPS4 + q;      // rows >= C are zero
       for (int j = 4 * wave; j < ((ASR_DP_ABL & 8) ? 4 : taps4); j += 32) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[j], bp[j], acc, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) cred[(wave * 16 + 4 * q + i) * 17 + r] = acc[i];
@@ -498,7 +521,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       if (ch < C && t < TpP) {
         if (t >= Tp) v = 0.f;
         if (ab_ok && t < Tp) a.fconv[(((int64_t)s * B + ab) * C + ch) * Tp + t] = v;
-        word_store(xg + DX_F + ((par * 4 + ar) * 16 + ch) * DP_TPM + t, v, bit);
+        word_store(xg + DX_F + ((par * 4 + ar) * 16 + ch) * TPM + t, v, bit);
       }
     }
     DP_MARK(4);
@@ -508,30 +531,30 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       // [4 rows][C][TpP/4], id = tid + 512 i; small-integer divisions via exact float reciprocals
       constexpr int NZQ = (DD + DP_NT - 1) / DP_NT;
       const unsigned zbase = (unsigned)((xg - a.xch) + DX_Z + par * 4 * 512) * 4u;
-      const unsigned fbase = (unsigned)((xg - a.xch) + DX_F + par * 4 * 16 * DP_TPM) * 4u;
+      const unsigned fbase = (unsigned)((xg - a.xch) + DX_F + par * 4 * 16 * TPM) * 4u;
       const int hq = TpP >> 2;
       const float rhq = 1.0f / (float)hq, rC = 1.0f / (float)C;
-      int foff[2];
-      unsigned off[NZQ + 2];
-      u4v v[NZQ + 2];
+      int foff[NFQ];
+      unsigned off[NZQ + NFQ];
+      u4v v[NZQ + NFQ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NFQ; ++i) {
         const int id = tid_ + DP_NT * i;
         const int rc = (int)(((float)id + 0.5f) * rhq), t4 = id - rc * hq;
         const int row = (int)(((float)rc + 0.5f) * rC), c = rc - row * C;
-        foff[i] = rc < 4 * C ? (row * 16 + c) * DP_TPM + 4 * t4 : -1;
+        foff[i] = rc < RG * C ? (row * 16 + c) * TPM + 4 * t4 : -1;
         off[i] = fbase + (unsigned)(foff[i] < 0 ? 0 : foff[i]) * 4u;
       }
 #pragma unroll
       for (int i = 0; i < NZQ; ++i) {
         const int id = tid_ + DP_NT * i;
         const int row = (4 * id) / DD, d = 4 * id - row * DD;
-        off[2 + i] = zbase + (unsigned)((4 * id < 4 * DD) ? row * 512 + d : 0) * 4u;
+        off[NFQ + i] = zbase + (unsigned)((4 * id < 4 * DD) ? row * 512 + d : 0) * 4u;
       }
-      poll_quads<NZQ + 2, true>(xrs, off, bit, v, a.ctrl, aborted, 12u);
+      poll_quads<NZQ + NFQ, true>(xrs, off, bit, v, a.ctrl, aborted, 12u);
       DP_MARK(5);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NFQ; ++i)
         if (foff[i] >= 0)
           *reinterpret_cast<float4*>(fs + foff[i]) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
                                                                  __uint_as_float(v[i].z), __uint_as_float(v[i].w));
@@ -540,8 +563,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         const int id = tid_ + DP_NT * i;
         const int row = (4 * id) / DD, d = 4 * id - row * DD;
         if (4 * id < 4 * DD)
-          *reinterpret_cast<float4*>(xs + row * XS + d) = make_float4(__uint_as_float(v[2 + i].x), __uint_as_float(v[2 + i].y),
-                                                                     __uint_as_float(v[2 + i].z), __uint_as_float(v[2 + i].w));
+          *reinterpret_cast<float4*>(xs + row * XS + d) = make_float4(__uint_as_float(v[NFQ + i].x), __uint_as_float(v[NFQ + i].y),
+                                                                     __uint_as_float(v[NFQ + i].z), __uint_as_float(v[NFQ + i].w));
       }
     }
     __syncthreads();
@@ -574,36 +597,37 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     DP_MARK(6);
     // ------------------------------------------------------------ (6) energies: partial sums over this CU's columns
     {
-      const int m = lane_ & 15;                       // A operand: pair m of the tile = (row m&3, frame 4*tile + (m>>2))
+      // A operand: pair m of the tile = (row m % RG, frame FPT tile + m / RG); D: lane (q, col) holds pairs 4 q + i
+      const int m = lane_ & 15;
       const int nkk = (C + 3) >> 2;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int tile = wave + 8 * it;
-        if (4 * tile < TpP && !(ASR_DP_ABL & 4)) {                        // wave-uniform
+        if (FPT * tile < TpP && !(ASR_DP_ABL & 4)) {                      // wave-uniform
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const float* fa = fs + ((m & 3) * 16 + sq_) * DP_TPM + 4 * tile + (m >> 2);
+          const float* fa = fs + ((m % RG) * 16 + sq_) * TPM + FPT * tile + m / RG;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
-            if (kk < nkk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * kk * DP_TPM], ub[kk], acc, 0, 0, 0);
-          const int t = 4 * tile + sq_;
-          // uniform row bases + one 32-bit lane offset per tile (no 64-bit index math per element)
-          const int soff = t * AA + acol_;
-          const bool sst = sc_ok_ && t < Tp && !(ASR_DP_ABL & 16);
+            if (kk < nkk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * kk * TPM], ub[kk], acc, 0, 0, 0);
           float pe[4], sv[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            sv[i] = dp_tanh(acc[i] + Ps[(tile * 4 + i) * 64 + lane_] + dps[i * 16 + a_l_]);
+            sv[i] = dp_tanh(acc[i] + Ps[(tile * 4 + i) * 64 + lane_] + dps[((4 * sq_ + i) % RG) * 16 + a_l_]);
             pe[i] = sc_ok_ ? gv * sv[i] : 0.f;
           }
-          if (sst) {                                   // one lane predicate per tile; the row test is wave-uniform
+          // uniform row bases + one 32-bit lane offset per pair (no 64-bit index math per element)
+          if (sc_ok_ && !(ASR_DP_ABL & 16)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (r0 + i < nb) (a.S + ((int64_t)s * B + r0 + i) * Tp * AA)[soff] = sv[i];
+            for (int i = 0; i < 4; ++i) {
+              const int ri = (4 * sq_ + i) % RG, ti = FPT * tile + (4 * sq_ + i) / RG;
+              if (ti < Tp && r0 + ri < nb) (a.S + ((int64_t)s * B + r0 + ri) * Tp * AA)[ti * AA + acol_] = sv[i];
+            }
           }
           row16_sum4(pe);
-          if (a_l_ < 4) {      // lane i of each 16-lane group publishes row i (every lane of the group holds all four sums)
+          if (a_l_ < 4) {      // lane i of each 16-lane group publishes pair i (every lane of the group holds all four sums)
             const float pv_ = a_l_ == 0 ? pe[0] : a_l_ == 1 ? pe[1] : a_l_ == 2 ? pe[2] : pe[3];
-            word_store(xg + DX_E + ((par * 32 + slice) * 4 + a_l_) * DP_TPM + t, t < Tp ? pv_ : 0.f, bit);
+            const int ri = (4 * sq_ + a_l_) % RG, ti = FPT * tile + (4 * sq_ + a_l_) / RG;
+            word_store(xg + DX_E + ((par * 32 + slice) * 4 + ri) * TPM + ti, ti < Tp ? pv_ : 0.f, bit);
           }
         }
       }
@@ -611,33 +635,37 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
     DP_MARK(7);
     // ------------------------------------------------------------ (7) full energies of this CU's row -> softmax
     {
-      const float* ex = xg + DX_E + par * 32 * 4 * DP_TPM + ar * DP_TPM;
-      const int t2 = lane_;                           // pair (2*t2, 2*t2+1); producers 4*wave .. 4*wave+3
-      const bool ok = 2 * t2 < TpP;
-      const u64* p[4];
-      u64 v[4];
+      const float* ex = xg + DX_E + par * 32 * 4 * TPM + ar * TPM;
+      // pair (2 t2, 2 t2 + 1) of frames per lane and pass; producers 4*wave .. 4*wave+3
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        p[i] = reinterpret_cast<const u64*>(ex + (4 * wave + i) * 4 * DP_TPM + (ok ? 2 * t2 : 0));
-      poll_pairs<4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 14u);
+      for (int pp = 0; pp < TPM / 128; ++pp) {
+        const int t2 = lane_ + 64 * pp;
+        const bool ok = 2 * t2 < TpP;
+        const u64* p[4];
+        u64 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          p[i] = reinterpret_cast<const u64*>(ex + (4 * wave + i) * 4 * TPM + (ok ? 2 * t2 : 0));
+        poll_pairs<4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 14u);
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { e0 += pair_lo(v[i]); e1 += pair_hi(v[i]); }
+        if (ok) { epart[wave * TPM + 2 * t2] = e0; epart[wave * TPM + 2 * t2 + 1] = e1; }
+      }
       DP_MARK(8);
-      float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { e0 += pair_lo(v[i]); e1 += pair_hi(v[i]); }
-      if (ok) { epart[wave * DP_TPM + 2 * t2] = e0; epart[wave * DP_TPM + 2 * t2 + 1] = e1; }
     }
     __syncthreads();
     {
       // every wave runs the (tiny) softmax redundantly; wave 0 keeps the results
-      float ev[2], wv[2];
+      float ev[TPM / 64], wv[TPM / 64];
       float mx = -INFINITY;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < TPM / 64; ++k) {
         const int t = lane_ + 64 * k;
         float e = 0.f;
         if (t < Tp) {
 #pragma unroll
-          for (int w2 = 0; w2 < 8; ++w2) e += epart[w2 * DP_TPM + t];
+          for (int w2 = 0; w2 < 8; ++w2) e += epart[w2 * TPM + t];
         }
         ev[k] = e;
         if (t < Tp) mx = fmaxf(mx, a.scaling * e);
@@ -645,7 +673,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       mx = wave_max_dpp(mx);
       float sum = 0.f;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < TPM / 64; ++k) {
         const int t = lane_ + 64 * k;
         wv[k] = t < Tp ? __expf(a.scaling * ev[k] - mx) : 0.f;
         sum += wv[k];
@@ -654,7 +682,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
       const float inv = 1.0f / sum;
       if (wave == 0) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < TPM / 64; ++k) {
           const int t = lane_ + 64 * k;
           if (t < Tp) {
             const float w = wv[k] * inv;
@@ -708,16 +736,16 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
   }
 }
 
-template <int DD, int AA, int OO, int EE, bool FB>
+template <int DD, int AA, int OO, int EE, bool FB, int RG = 4, int TPM = DP_TPM>
 int launch_dec_fwd(const DecPersistArgs& a, hipStream_t stream) {
-  using DM = DecDims<DD, AA, OO, EE>;
+  using DM = DecDims<DD, AA, OO, EE, RG, TPM>;
   const size_t lds = DM::lds_floats * sizeof(float);     // > 80 KB: one workgroup per CU
   static_assert(DM::lds_floats * sizeof(float) > 82 * 1024 && DM::lds_floats * sizeof(float) <= 160 * 1024, "LDS budget");
   static_assert(!FB || (EE == 128 && DD % 64 == 0 && OO % 64 == 0), "free-running feedback mapping");
-  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_fwd_kernel<DD, AA, OO, EE, FB>,
+  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_fwd_kernel<DD, AA, OO, EE, FB, RG, TPM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((dec_persist_fwd_kernel<DD, AA, OO, EE, FB>), dim3(256), dim3(DP_NT), lds, stream, a);
+  hipLaunchKernelGGL((dec_persist_fwd_kernel<DD, AA, OO, EE, FB, RG, TPM>), dim3(256), dim3(DP_NT), lds, stream, a);
   return 0;
 }
 
@@ -1475,15 +1503,22 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
   const bool cfg1 = p->D == 320 && p->A == 320 && p->O == 320 && p->E == 128;
   if (!cfg1 && !cfg2) return ASR_E_SHAPE;
   const int TpP = (p->Tp + 3) & ~3;
-  if (p->Tp > DP_TPM || p->C <= 0 || p->C > 16 || p->K < 0 || p->K > DP_KMAX || 2 * p->C * TpP > 4 * DP_NT)
-    return ASR_E_SHAPE;
+  if (p->Tp <= 0 || p->C <= 0 || p->C > 12 || p->K < 0 || p->K > DP_KMAX) return ASR_E_SHAPE;
+  // geometry: 4 utterances per group while the conv features of 4 rows fit the z / f poll (2 quads per thread: T' <= 102
+  // at 10 channels), else 2 utterances per group on 16 CUs each (T' <= 256; teacher-forced only)
+  using G4 = DecGeo<4, DP_TPM>;
+  using G2 = DecGeo<2, 256>;
+  const bool geo4 = p->Tp <= G4::TPM && 4 * p->C * (TpP / 4) <= G4::NFQ * DP_NT;
+  const bool geo2 = !geo4 && !f && p->Tp <= G2::TPM && 2 * p->C * (TpP / 4) <= G2::NFQ * DP_NT;
+  if (!geo4 && !geo2) return ASR_E_SHAPE;
   if (!asr_persist_device_ok()) return ASR_E_SHAPE;
   const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;
-  for (int rb = 0; rb < p->nb; rb += 32) {
-    hipError_t e = persist_reset(xch, ctrl, (size_t)8 * DX_GROUP * sizeof(float), stream);
+  const int rows_per_launch = geo4 ? 32 : 16;
+  for (int rb = 0; rb < p->nb; rb += rows_per_launch) {
+    hipError_t e = persist_reset(xch, ctrl, (size_t)8 * (geo4 ? G4::X_GROUP : G2::X_GROUP) * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
     DecPersistArgs a;
-    a.B = B; a.nb = p->nb - rb < 32 ? p->nb - rb : 32; a.Tp = Tp; a.C = C; a.K = p->K; a.L = p->L;
+    a.B = B; a.nb = p->nb - rb < rows_per_launch ? p->nb - rb : rows_per_launch; a.Tp = Tp; a.C = C; a.K = p->K; a.L = p->L;
     a.scaling = p->scaling;
     a.P = p->P + (int64_t)rb * Tp * A; a.Q = p->Q + (int64_t)rb * Tp * O; a.bo = p->bo; a.wcat = p->wcat;
     a.bcat = p->bcat; a.wdec = p->wdec; a.convw = p->convw; a.watt = p->watt; a.gvec = p->gvec;
@@ -1501,8 +1536,11 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
       a.logits = f->logits + (int64_t)rb * f->V; a.probs = f->probs ? f->probs + (int64_t)rb * f->V : nullptr;
       a.pred = (long long*)f->pred + rb; a.fed = (long long*)f->fed + rb;
       rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true>(a, stream) : launch_dec_fwd<320, 320, 320, 128, true>(a, stream);
-    } else {
+    } else if (geo4) {
       rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, false>(a, stream) : launch_dec_fwd<320, 320, 320, 128, false>(a, stream);
+    } else {
+      rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, false, 2, 256>(a, stream)
+                : launch_dec_fwd<320, 320, 320, 128, false, 2, 256>(a, stream);
     }
     if (rc) return rc;
   }
