@@ -42,7 +42,12 @@ CONFIGS = {
                  name="cfg-5: cfg-2's model on long utterances (BASELINE.json configs[4])"),
 }
 HBM_PEAK_GBS = 8000.0
-MFMA_F32_PEAK_TF = 157.3
+MFMA_F32_PEAK_TF = 157.3                       # fp32-input MFMA, dense (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0                     # bf16 MFMA, dense
+# The recurrent products and the GEMMs run on the bf16 MFMA with each fp32 operand split in two bf16 terms and three
+# products per algorithmic product (include/asr_hip.h: asr_set_split_bf16).  `achieved` counts ALGORITHMIC flops, so the
+# roof those kernels are priced against is a third of the bf16 peak; the fp32-MFMA peak (round 1's roof) is quoted too.
+MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 CFG2 = CONFIGS["cfg2"]["model"]                 # used by tools/
 
 
@@ -158,7 +163,9 @@ def encoder_gate_gemms(dev, c, B, t_frames):
     shapes that were evicted from the caches before each launch (a 512 MB fill in between: the train step finds them in
     HBM too): the input-gate projection [T*B, in] x [in, 8H] (forward), its two backward GEMMs (dX = dG W_ih,
     dW_ih = dG^T X), and the recurrent products of the persistent kernels (h W_hh^T forward; dG W_hh + dG^T h backward)
-    timed as whole kernels.  Each entry: achieved TFLOP/s and fraction of the 157.3 TF f32-MFMA peak."""
+    timed as whole kernels.  Each entry: achieved algorithmic TFLOP/s, `frac` = fraction of the 157.3 TF fp32-MFMA peak
+    (the target's reference point; it can exceed 1 now that the products run as split bf16) and `frac_split_bf16_peak` =
+    fraction of 2 500 / 3 TF, the roof of the pipe they actually run on."""
     import hip_backend as hb
     lib = hb.load()
     H, I = c["enc_hidden_dim"], c["input_dim"]
@@ -200,7 +207,7 @@ def encoder_gate_gemms(dev, c, B, t_frames):
                 continue                                  # the features need no gradient
             dt = cold(fn)
             rows.append(dict(layer=layer, op=op, us=dt * 1e6, tflops=flops / dt / 1e12,
-                             frac=flops / dt / 1e12 / MFMA_F32_PEAK_TF))
+                             frac=flops / dt / 1e12 / MFMA_F32_PEAK_TF, frac_split_bf16_peak=flops / dt / 1e12 / MFMA_SPLIT_PEAK_TF))
         del x, w, dG, gates
         # recurrent products: the persistent kernels of this layer (both directions)
         lens = torch.full((B,), T, dtype=torch.int32, device=dev)
@@ -218,7 +225,8 @@ def encoder_gate_gemms(dev, c, B, t_frames):
             dt = e0.elapsed_time(e1) * 1e-3
             fl = T * 2.0 * B * 4 * H * H * 2
             rows.append(dict(layer=layer, op="recurrent fwd h W_hh^T (persistent kernel, T=%d)" % T, us=dt * 1e6,
-                             us_per_time_step=dt / T * 1e6, tflops=fl / dt / 1e12, frac=fl / dt / 1e12 / MFMA_F32_PEAK_TF))
+                             us_per_time_step=dt / T * 1e6, tflops=fl / dt / 1e12, frac=fl / dt / 1e12 / MFMA_F32_PEAK_TF,
+                             frac_split_bf16_peak=fl / dt / 1e12 / MFMA_SPLIT_PEAK_TF))
             dy = (torch.randn(T, B, 2 * H, generator=g) * 0.01).to(dev)
             dw = torch.zeros(2, 4 * H, H, device=dev)
             db = torch.zeros(2 * 4 * H, device=dev)
@@ -234,7 +242,8 @@ def encoder_gate_gemms(dev, c, B, t_frames):
             dt = e0.elapsed_time(e1) * 1e-3
             rows.append(dict(layer=layer, op="recurrent bwd dG W_hh + dG^T h (persistent kernel, T=%d)" % T, us=dt * 1e6,
                              us_per_time_step=dt / T * 1e6, tflops=2 * fl / dt / 1e12,
-                             frac=2 * fl / dt / 1e12 / MFMA_F32_PEAK_TF))
+                             frac=2 * fl / dt / 1e12 / MFMA_F32_PEAK_TF,
+                             frac_split_bf16_peak=2 * fl / dt / 1e12 / MFMA_SPLIT_PEAK_TF))
         out += rows
     return out
 
@@ -273,9 +282,13 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     gemm_s = _time_events(run_all, 3)
     gemm_flops = sum(2.0 * M * N * K * batch for (M, N, K, batch) in shapes)
     del bufs
-    gemm = dict(bound="mfma", kernel="gemm_f32_kernel<false,false> (transA weight-gradient GEMMs of one step)",
-                achieved=gemm_flops / gemm_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                frac=gemm_flops / gemm_s / 1e12 / MFMA_F32_PEAK_TF, traffic=None, launches_per_step=len(shapes),
+    split = hb.set_split_bf16(-1)
+    gpeak = MFMA_SPLIT_PEAK_TF if split & hb.SPLIT_GEMM else MFMA_F32_PEAK_TF
+    gemm = dict(bound="mfma", kernel="gemm_%s_kernel<false,false> (transA weight-gradient GEMMs of one step)"
+                                     % ("bf3" if split & hb.SPLIT_GEMM else "f32"),
+                achieved=gemm_flops / gemm_s / 1e12, peak=gpeak, unit="TFLOP/s",
+                frac=gemm_flops / gemm_s / 1e12 / gpeak, frac_f32_mfma_peak=gemm_flops / gemm_s / 1e12 / MFMA_F32_PEAK_TF,
+                traffic=None, launches_per_step=len(shapes),
                 us_per_launch=gemm_s / len(shapes) * 1e6, ms_per_step=gemm_s * 1e3)
 
     # ---- persistent LSTM backward (with the fused recurrent weight gradient), the encoder layers
@@ -316,10 +329,15 @@ def kernel_roofline(dev, c, B, t_frames, olength):
         lstm_s += best
         lstm_flops += T * 2.0 * (2.0 * B * 4 * H * H * 2)
         launches += (B + rows_per_launch - 1) // rows_per_launch
-    lstm = dict(bound="mfma", kernel="lstm_persist_bwd_kernel<%d> (dG recurrence + fused dW_hh, %d encoder layers)"
-                                     % (H, len(layers)),
-                achieved=lstm_flops / lstm_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                frac=lstm_flops / lstm_s / 1e12 / MFMA_F32_PEAK_TF, traffic=None, launches_per_step=launches,
+    rs = bool(split & hb.SPLIT_LSTM_BWD_RS) and H in (128, 256, 512)
+    lpeak = MFMA_SPLIT_PEAK_TF if (rs or split & hb.SPLIT_LSTM_BWD) else MFMA_F32_PEAK_TF
+    lstm = dict(bound="mfma", kernel="%s<%d> (dG recurrence + fused dW_hh, %d encoder layers)"
+                                     % ("lstm_persist_bwd_rs_kernel" if rs else "lstm_persist_bwd_kernel", H, len(layers)),
+                limiter="dependent chain: per time step two barriers and one L2 hand-off of partial sums between the 32 CUs "
+                        "of an XCD; the MFMA floor of the step is ~0.3 us",
+                achieved=lstm_flops / lstm_s / 1e12, peak=lpeak, unit="TFLOP/s",
+                frac=lstm_flops / lstm_s / 1e12 / lpeak, frac_f32_mfma_peak=lstm_flops / lstm_s / 1e12 / MFMA_F32_PEAK_TF,
+                traffic=None, launches_per_step=launches,
                 us_per_launch=lstm_s / launches * 1e6, ms_per_step=lstm_s * 1e3,
                 us_per_time_step=lstm_s / (sum(layers) * (launches // len(layers))) * 1e6,
                 aborted=bool(hb.persist_aborted(dev)))
@@ -447,7 +465,12 @@ def main():
         out = {
             "metric": "utterances/sec (train step)", "value": value, "unit": "utterances/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (split-bf16 x3 products)" if hb.set_split_bf16(-1) else "f32", "data": "synthetic",
+            "arithmetic": "fp32 operands, accumulators and results; MFMA products %s" % (
+                "on the bf16 pipe with every operand split hi + lo (16 significand bits) and three products per product, "
+                "<= 2^-15 relative each: parity vs the reference at this shape 8e-5 of the 1e-3 gate "
+                "(tests/test_big_configs_gpu.py); ASR_LSTM_BF3=0 ASR_GEMM_BF3=0 select the fp32-input MFMA"
+                if hb.set_split_bf16(-1) else "on the fp32-input MFMA"),
             "config": {"workload": "%s, batch %d per GPU, 80x%d synthetic fbank (ragged 0.6T..T), V=%d, L+1=%d, "
                                    "dropout %.2f, Adam(amsgrad)+clip 5" % (spec["name"], b_local, t_frames,
                                                                            cfg["output_dim"], info["olength"],

@@ -1,0 +1,13 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r2f
+mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; rc=$?; tail -3 $O/tests.log
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
+timeout -k 10 300 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err && tail -1 $O/bench_cfg2.err &&
+for T in 200 400 1600; do timeout -k 10 300 python bench.py --frames $T --no-cpu-baseline --no-layer-gemms > $O/bench_cfg2_T$T.json 2> $O/bench_T$T.err && tail -1 $O/bench_T$T.err || exit 1; done &&
+timeout -k 10 300 python bench.py --config cfg1 > $O/bench_cfg1.json 2> $O/bench_cfg1.err && tail -1 $O/bench_cfg1.err &&
+timeout -k 10 300 python bench.py --config cfg5 > $O/bench_cfg5.json 2> $O/bench_cfg5.err && tail -1 $O/bench_cfg5.err &&
+timeout -k 10 300 python bench.py --scaling strong --global-batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-layer-gemms > $O/bench_strong_n1.json 2> $O/bench_strong.err && tail -1 $O/bench_strong.err &&
+(cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o r2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-layer-gemms > $O/prof.log 2>&1; python3 tools/db_to_stats.py $O/prof/r2_results.db $O/kernel_stats.csv) &&
+(cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o f -- python3 tools/pmc_probe.py > $O/pmc_f.log 2>&1; timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o w -- python3 tools/pmc_probe.py > $O/pmc_w.log 2>&1; ls $O/pmc_f $O/pmc_w)
