@@ -353,11 +353,9 @@ class LM(torch.nn.Module):
         if labeldist is not None:
             self.vlabeldist = cc(torch.from_numpy(np.array(labeldist, dtype=np.float32)))
 
-    def _run_lstm(self, x_tm, lens_dev, state=None):
+    def _run_lstm(self, x_tm, lens_dev):
         """x_tm [T,B,E] -> [T,B,H] through all layers; inter-layer dropout like nn.LSTM(dropout=p)."""
-        new_state = []
         for l in range(self.n_layers):
-            st = None if state is None else state[l]
             x_tm = ops.lstm_layer(x_tm, lens_dev, self.LSTM.direction_params(l), 1)
             if l + 1 < self.n_layers and self.training and self.dropout_rate > 0:
                 x_tm = F.dropout(x_tm, self.dropout_rate, True)
