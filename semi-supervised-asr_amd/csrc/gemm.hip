@@ -14,6 +14,9 @@
 #ifndef ASR_GEMM_BF3_TOUCH      /* L2 warm-up distance of the split-bf16 kernel in K tiles (2, 4, 6, 10 measured within 5 %: tools/gemm_cold_sweep.py; the kernel is bound by operand traffic at 32 flop/byte per 128x128 tile, not by latency) */
 #define ASR_GEMM_BF3_TOUCH 2
 #endif
+#ifndef ASR_GB_ABL               /* measurement only: 1 no products, 2 no operand loads after the first tile, 4 no LDS staging */
+#define ASR_GB_ABL 0
+#endif
 #ifndef ASR_GEMM_SETPRIO
 #define ASR_GEMM_SETPRIO 1
 #endif
@@ -402,21 +405,24 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   const float* basea = AKC ? A.p + m0 * A.ld : A.p + m0;     // + k0 (KC) or + k0*ld (MC)
   const float* baseb = BKC ? B.p + n0 * B.ld : B.p + n0;
   float4 ra[4], rb[4];
-  auto fetch = [&](int64_t kt2) {
+  // Two copies of the K loop, chosen once per workgroup.  With the bare loads and the guarded loads as two branches of
+  // one fetch, hipcc loads into temporaries and copies them into (ra, rb) at the end of the branch - an s_waitcnt vmcnt
+  // right behind the loads, i.e. a full memory round trip exposed on every K tile (the kernel ran at 150 TF-equivalent
+  // on every large shape, and removing EITHER the loads, the staging or the products made the rest free).
+  auto fetch_fast = [&](int64_t kt2) {
     const int64_t k0 = kt2 * BK;
-    if (fast && k0 + BK <= g.K) {
-      const float* pa = basea + (AKC ? k0 : k0 * A.ld);
-      const float* pb = baseb + (BKC ? k0 : k0 * B.ld);
+    const float* pa = basea + (AKC ? k0 : k0 * A.ld);
+    const float* pb = baseb + (BKC ? k0 : k0 * B.ld);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + offa[i]);
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + offa[i]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + offb[i]);
-    } else {
-      tile_fetch_bf3<AKC>(A, m0, k0, ra);
-      tile_fetch_bf3<BKC>(B, n0, k0, rb);
-    }
+    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + offb[i]);
   };
-  if (kt_begin < kt_end) fetch(kt_begin);
+  auto fetch_guard = [&](int64_t kt2) {
+    const int64_t k0 = kt2 * BK;
+    tile_fetch_bf3<AKC>(A, m0, k0, ra);
+    tile_fetch_bf3<BKC>(B, n0, k0, rb);
+  };
   const int tt = threadIdx.x & 127;
   const bool touch_a = threadIdx.x < 128;
   float touched = 0.f;
@@ -432,19 +438,11 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
     cc = cc < m.Cn ? cc : m.Cn - 1;
     touched = m.p[rr * m.ld + cc];
   };
-  for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
-    tile_store_bf3<AKC>(Ah, Al, ra);
-    tile_store_bf3<BKC>(Bh, Bl, rb);
-    __syncthreads();
-    if (kt + 1 < kt_end) fetch(kt + 1);
-#if ASR_GEMM_TOUCH
-    asm volatile("" ::"v"(touched));
-    if (do_touch && kt + ASR_GEMM_BF3_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_BF3_TOUCH);
-#endif
-    // fragment of row tile i at k-step ks: row wm*64 + 32 i + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7
-    const int ao = (wm * 64 + l31) * BS + 8 * kh, bo = (wn * 64 + l31) * BS + 8 * kh;
+  // fragment of row tile i at k-step ks: row wm*64 + 32 i + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7
+  const int ao = (wm * 64 + l31) * BS + 8 * kh, bo = (wn * 64 + l31) * BS + 8 * kh;
+  auto multiply = [&]() {
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < ((ASR_GB_ABL & 1) ? 0 : BK / 16); ++ks) {
       gu32x4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -468,7 +466,35 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) BF3G(al[i], bh[j], acc[i][j]);
 #undef BF3G
     }
-    __syncthreads();
+  };
+  if (fast && kt_end * BK <= g.K) {
+    if (kt_begin < kt_end) fetch_fast(kt_begin);
+    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+      tile_store_bf3<AKC>(Ah, Al, ra);
+      tile_store_bf3<BKC>(Bh, Bl, rb);
+      __syncthreads();
+      if (kt + 1 < kt_end) fetch_fast(kt + 1);
+#if ASR_GEMM_TOUCH
+      asm volatile("" ::"v"(touched));
+      if (do_touch && kt + ASR_GEMM_BF3_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_BF3_TOUCH);
+#endif
+      multiply();
+      __syncthreads();
+    }
+  } else {
+    if (kt_begin < kt_end) fetch_guard(kt_begin);
+    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+      tile_store_bf3<AKC>(Ah, Al, ra);
+      tile_store_bf3<BKC>(Bh, Bl, rb);
+      __syncthreads();
+      if (kt + 1 < kt_end) fetch_guard(kt + 1);
+#if ASR_GEMM_TOUCH
+      asm volatile("" ::"v"(touched));
+      if (do_touch && kt + ASR_GEMM_BF3_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_BF3_TOUCH);
+#endif
+      multiply();
+      __syncthreads();
+    }
   }
 
   // epilogue (as gemm_f32_kernel: the C/D lane map of the 32x32 MFMAs does not depend on the input type)
