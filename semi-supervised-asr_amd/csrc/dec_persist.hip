@@ -766,11 +766,15 @@ int launch_dec_fwd(const DecPersistArgs& a, hipStream_t stream) {
 //   (g) dX = dgates W_cat for the CU's z and ctx columns (W_cat^T slice in registers, 4x4x1 MFMA); the z part
 //       stays in the CU, the (masked) ctx part + G_out is the total d(ctx_{s-1})                           -> XC
 // The embedding part of dX is not recurrent: one GEMM after the kernel (asr_dec_seq_bwd_persist).
-constexpr int BX_C = 0;                      // [2][4][512]
-constexpr int BX_W = BX_C + 2 * 4 * 512;     // [2][4][TPM]
-constexpr int BX_D = BX_W + 2 * 4 * DP_TPM;  // [2][4][512]
-constexpr int BX_G = BX_D + 2 * 4 * 512;     // [2][4][2048]
-constexpr int BX_GROUP = BX_G + 2 * 4 * 2048;
+// exchange layout per group (floats); the row axis keeps 4 slots in both geometries (see DecGeo)
+template <int TPM>
+struct BwdX {
+  static constexpr int C_ = 0;                      // [2][4][512]
+  static constexpr int W_ = C_ + 2 * 4 * 512;       // [2][4][TPM]
+  static constexpr int D_ = W_ + 2 * 4 * TPM;       // [2][4][512]
+  static constexpr int G_ = D_ + 2 * 4 * 512;       // [2][4][2048]
+  static constexpr int GROUP = G_ + 2 * 4 * 2048;
+};
 
 struct DecPersistBwdArgs {
   int B, nb, Tp, C, K, L;
@@ -778,6 +782,7 @@ struct DecPersistBwdArgs {
   const float *Q, *wcatT, *wdecT, *convw, *watt, *gvec, *w0, *xmask;
   const float *gates, *cstate, *S, *fconv, *ws, *Mf, *dws;
   float *G, *dgates, *dD, *dP, *dgvec_part, *dwatt_part, *dconv_part;
+  float* dbg;          // measurement builds only (ASR_DP_DEBUG): d(conv features) of the last step, [B][C][Tp]
   float* xch;
   unsigned* ctrl;
 };
@@ -800,7 +805,7 @@ struct BwdLds {
   int dgs, part, qs, dcx, fs, dps, Fs, dfh, wph, des, dwr, wsl, dds, ddp, dwext, ugs, total;
   int dfs_stride, taps4;
 };
-template <int DD, int AA, int OO>
+template <int DD, int AA, int OO, int RG = 4, int TPM = DP_TPM>
 __host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K) {
   using BM = DecBwdDims<DD, AA, OO>;
   const int TpP = (Tp + 3) & ~3;
@@ -811,19 +816,19 @@ __host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K) {
   // wave instruction; a stride that is a multiple of 16 puts every second channel on the same LDS bank (5-way conflict)
   l.dfs_stride = TpP + 2 * K + 4;
   l.dfs_stride += (13 - (l.dfs_stride & 31) + 32) & 31;
-  l.dgs = o; o += 4 * BM::GS;
+  l.dgs = o; o += RG * BM::GS;
   l.part = o; o += 8 * 64 * 5;
   l.qs = o; o += 16 * OO;
   l.dcx = o; o += OO;
-  l.fs = o; o += 4 * C * TpP;
-  l.dps = o; o += TpP * 64;
+  l.fs = o; o += RG * C * TpP;
+  l.dps = o; o += ((TpP + 16 / RG - 1) / (16 / RG)) * 4 * 64;       // [tiles of 16 / RG frames][4 pairs][64 lanes]
   l.Fs = o; o += C * (l.taps4 + 8);     // rows zero padded by 8: the Toeplitz products read up to 6 taps past the end
   l.dfh = o; o += C * l.dfs_stride;
   l.wph = o; o += l.dfs_stride;
-  l.des = o; o += 4 * DP_TPM;
-  l.dwr = o; o += 4 * DP_TPM;
-  l.wsl = o; o += 4 * DP_TPM;
-  l.dds = o; o += 4 * BM::DS;
+  l.des = o; o += RG * TPM;
+  l.dwr = o; o += RG * TPM;
+  l.wsl = o; o += RG * TPM;
+  l.dds = o; o += RG * BM::DS;
   l.ddp = o; o += 8 * 4 * 16;
   l.dwext = o; o += 16;
   l.ugs = o; o += 16;
@@ -831,16 +836,24 @@ __host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K) {
   return l;
 }
 
-template <int DD, int AA, int OO, int EE>
+template <int DD, int AA, int OO, int EE, int RG = 4, int TPM = DP_TPM>
 __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArgs a) {
   using BM = DecBwdDims<DD, AA, OO>;
+  using GEO = DecGeo<RG, TPM>;
+  using BX = BwdX<TPM>;
+  constexpr int PPR = GEO::PPR, LR = GEO::LR, FPT = GEO::FPT;
+  constexpr int BX_C = BX::C_, BX_W = BX::W_, BX_D = BX::D_, BX_G = BX::G_, BX_GROUP = BX::GROUP;
+  constexpr int NFR = RG == 4 ? 8 : 10;      // conv features of the RG rows per thread (ids over [RG][C][TpP])
+  constexpr int NMR = RG == 4 ? 2 : 5;       // M values per thread (ids over [C][TpP])
+  constexpr int LT = RG == 4 ? 7 : 8;        // log2(TPM)
+  static_assert((1 << LT) == TPM && RG * TPM == DP_NT, "one thread per (row, frame) of the attention weights");
   constexpr int KX = DD + OO + EE;
   constexpr int GK = BM::GK, GKW = BM::GKW, GKS = BM::GKS, GS = BM::GS, DU = BM::DU, AU = BM::AU, OU = BM::OU;
   constexpr int AKW = BM::AKW, AQ = BM::AQ, DS = BM::DS;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Tp = a.Tp, C = a.C, K = a.K, B = a.B, L = a.L, nb = a.nb;
   const int TpP = (Tp + 3) & ~3;
-  const BwdLds ld = bwd_lds_plan<DD, AA, OO>(Tp, C, K);
+  const BwdLds ld = bwd_lds_plan<DD, AA, OO, RG, TPM>(Tp, C, K);
   float* dgs = sm + ld.dgs;      // [4][GS]          gathered dgates of the 4 rows
   float* part = sm + ld.part;    // [8][64][5]       K-partials of both MFMA products
   float* Qs = sm + ld.qs;        // [16][OO]         Q rows of this CU's 16 frames
@@ -864,14 +877,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
-  const int r0 = 4 * g;
+  const int r0 = RG * g;
   if (r0 >= nb) return;
   const int taps = 2 * K + 1, taps4 = ld.taps4, DFS = ld.dfs_stride;
   const bool drop = a.xmask != nullptr;
   float* xg = a.xch + (int64_t)g * BX_GROUP;
   const __amdgpu_buffer_rsrc_t xrs = make_xch_rsrc(a.xch);
   bool aborted = false;
-  const int ar = slice >> 3, aq = slice & 7;
+  const int ar = slice >> LR, aq = slice & (PPR - 1);
   const int ab = r0 + ar;
   const bool ab_ok = ab < nb;
   const int abc = ab_ok ? ab : r0;
@@ -933,16 +946,16 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
   const bool pw_thread = tid < 4 * DU;
   const int punit = DU * slice + (pw_thread ? (tid >> 2) : 0);
   const int pb = r0 + (tid & 3);
-  const bool pb_ok = pw_thread && pb < nb;
-  const int pbc = pb < nb ? pb : r0;
+  const bool pb_ok = pw_thread && (tid & 3) < RG && pb < nb;
+  const int pbc = ((tid & 3) < RG && pb < nb) ? pb : r0;
   // ctx-column threads of the dX result (64 <= tid < 64 + 4*OU): column OU*slice + ((tid-64)>>2), row tid&3
   const bool cx_thread = tid >= 64 && tid < 64 + 4 * OU;
   const int cxcol = OU * slice + (cx_thread ? ((tid - 64) >> 2) : 0);
 
   // ---------------------------------------------------------------- prefetch registers (data of iteration n)
-  float sreg[16];      // S[s][row i][frame 4*tile+q4][acol], tile = wave + 8*it
-  float freg[8];       // conv features of the 4 rows (ids tid + 512 k over [4][C][TpP])
-  float mreg[2];       // M[s][row ar][c][t] (ids tid + 512 k over [C][TpP])
+  float sreg[16];      // S[s][pair 4 q4 + i of tile wave + 8 it][acol]: row (4 q4 + i) % RG, frame FPT tile + (4 q4 + i) / RG
+  float freg[NFR];     // conv features of the RG rows (ids tid + 512 k over [RG][C][TpP])
+  float mreg[NMR];     // M[s][row ar][c][t] (ids tid + 512 k over [C][TpP])
   float wsreg = 0.f, wpreg = 0.f, dwsreg = 0.f;
   float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
   float ct = 0.f, cp = 0.f, gz = 0.f, gc = 0.f, xm = 1.f;
@@ -955,37 +968,36 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     const int acolq = AU * slice + (alq < AU ? alq : 0);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int t = 32 * it + 4 * wave + q4q;
-      const int voff = (t < Tp ? t : Tp - 1) * AA + acolq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int b = r0 + i;
+        const int t = FPT * (wave + 8 * it) + (4 * q4q + i) / RG;
+        const int b = r0 + (4 * q4q + i) % RG;
         const float* sb = a.S + ((int64_t)s * B + (b < nb ? b : r0)) * Tp * AA;
-        sreg[it * 4 + i] = sb[voff];
+        sreg[it * 4 + i] = sb[(t < Tp ? t : Tp - 1) * AA + acolq];
       }
     }
     const float rct = 1.0f / (float)(C * TpP), rtp = 1.0f / (float)TpP;
     const float* fb = a.fconv + (int64_t)s * B * C * Tp;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NFR; ++k) {
       const int id = tidq + DP_NT * k;
       const int row = (int)(((float)id + 0.5f) * rct), rem = id - row * C * TpP;
       const int c = (int)(((float)rem + 0.5f) * rtp), t = rem - c * TpP;
-      const int b = r0 + (row < 4 ? row : 0);
-      freg[k] = fb[((b < nb ? b : r0) * C + (row < 4 ? c : 0)) * Tp + (t < Tp ? t : Tp - 1)];
+      const int b = r0 + (row < RG ? row : 0);
+      freg[k] = fb[((b < nb ? b : r0) * C + (row < RG ? c : 0)) * Tp + (t < Tp ? t : Tp - 1)];
     }
     const float* mb = a.Mf + ((int64_t)s * B + abc) * C * Tp;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NMR; ++k) {
       const int id = tidq + DP_NT * k;
       const int c = (int)(((float)id + 0.5f) * rtp), t = id - c * TpP;
-      mreg[k] = mb[(c < C ? c : 0) * Tp + (t < Tp ? t : Tp - 1)];
+      mreg[k] = mb[(c < C ? c : 0) * Tp + (t < Tp && c < C ? t : Tp - 1)];
     }
     {
-      const int row = tidq >> 7, t = tidq & 127, b = r0 + row;      // w_s of the 4 rows: 4 x 128 threads
+      const int row = tidq >> LT, t = tidq & (TPM - 1), b = r0 + row;      // w_s of the RG rows: RG x TPM threads
       wsreg = a.ws[((int64_t)s * B + (b < nb ? b : r0)) * Tp + (t < Tp ? t : Tp - 1)];
       const float* wprev = s > 0 ? a.ws + ((int64_t)(s - 1) * B + abc) * Tp : a.w0 + (int64_t)abc * Tp;
-      wpreg = wprev[t < Tp ? t : Tp - 1];                            // (threads tid < 128 use it)
+      wpreg = wprev[t < Tp ? t : Tp - 1];                            // (threads tid < TPM use it)
       const int tq = 16 * aq + (tidq >> 5);
       dwsreg = a.dws ? a.dws[((int64_t)s * B + abc) * Tp + (tq < Tp ? tq : Tp - 1)] : 0.f;
     }
@@ -1036,17 +1048,17 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     {
       const float rct = 1.0f / (float)(C * TpP), rtp = 1.0f / (float)TpP;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < NFR; ++k) {
         const int id = tid_ + DP_NT * k;
-        if (id < 4 * C * TpP) {
+        if (id < RG * C * TpP) {
           const int row = (int)(((float)id + 0.5f) * rct), rem = id - row * C * TpP;
           const int c = (int)(((float)rem + 0.5f) * rtp), t = rem - c * TpP;
           fs[id] = t < Tp ? freg[k] : 0.f;
         }
       }
-      const int t = tid_ & 127;
-      wsl[tid_] = t < Tp ? wsreg : 0.f;                           // [row = tid>>7][t]
-      if (tid_ < 128 && t < Tp) wph[K + t] = wpreg;
+      const int t = tid_ & (TPM - 1);
+      wsl[tid_] = t < Tp ? wsreg : 0.f;                           // [row = tid >> log2(TPM)][t]
+      if (tid_ < TPM && t < Tp) wph[K + t] = wpreg;
     }
     DP_MARK(1);
     // ------------------------------------------------------------ (a) total d(ctx_s) of my row -> dw_raw of my frames
@@ -1067,34 +1079,37 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       acc = row16_sum(acc);
       acc += __shfl_xor(acc, 16, 64);
       const int t = 16 * aq + tl;
-      if (op == 0 && t < TpP) word_store(xg + BX_W + (slot * 4 + ar) * DP_TPM + t, t < Tp ? acc + dwext[tl] + dwsreg : 0.f, bit);
+      if (op == 0 && t < TpP) word_store(xg + BX_W + (slot * 4 + ar) * TPM + t, t < Tp ? acc + dwext[tl] + dwsreg : 0.f, bit);
+#ifdef ASR_DP_DEBUG
+      if (op == 0 && t < Tp && n == 1 && ab_ok) a.dbg[(int64_t)3 * B * C * Tp + (int64_t)ab * Tp + t] = dwext[tl];
+#endif
     }
     DP_MARK(2);
     // ------------------------------------------------------------ (c) dw_raw of the 4 rows -> softmax backward
     {
       const int hp = TpP >> 1;
       const int row = (int)(((float)tid_ + 0.5f) * (1.0f / (float)hp)), t2 = tid_ - row * hp;
-      const bool ok = row < 4;
+      const bool ok = row < RG;                     // rows >= RG are never published
       const u64* p[1];
       u64 v[1];
-      p[0] = reinterpret_cast<const u64*>(xg + BX_W + slot * 4 * DP_TPM + (ok ? row * DP_TPM + 2 * t2 : 0));
+      p[0] = reinterpret_cast<const u64*>(xg + BX_W + slot * 4 * TPM + (ok ? row * TPM + 2 * t2 : 0));
       poll_pairs<1, true>(p, bit, v, a.ctrl, aborted, 22u);
-      if (ok) { dwr[row * DP_TPM + 2 * t2] = pair_lo(v[0]); dwr[row * DP_TPM + 2 * t2 + 1] = pair_hi(v[0]); }
+      if (ok) { dwr[row * TPM + 2 * t2] = pair_lo(v[0]); dwr[row * TPM + 2 * t2 + 1] = pair_hi(v[0]); }
     }
     __syncthreads();
-    if (wave < 4) {
-      float w[2], dv[2], dot = 0.f;
+    if (wave < RG) {
+      float w[TPM / 64], dv[TPM / 64], dot = 0.f;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < TPM / 64; ++k) {
         const int t = lane_ + 64 * k;
-        w[k] = t < Tp ? wsl[wave * DP_TPM + t] : 0.f;
-        dv[k] = t < Tp ? dwr[wave * DP_TPM + t] : 0.f;
+        w[k] = t < Tp ? wsl[wave * TPM + t] : 0.f;
+        dv[k] = t < Tp ? dwr[wave * TPM + t] : 0.f;
         dot += w[k] * dv[k];
       }
       dot = wave_sum_dpp(dot);
 #pragma unroll
-      for (int k = 0; k < 2; ++k)     // rows beyond the batch contribute nothing to the sequence-long accumulators
-        des[wave * DP_TPM + lane_ + 64 * k] = r0 + wave < nb ? a.scaling * w[k] * (dv[k] - dot) : 0.f;
+      for (int k = 0; k < TPM / 64; ++k)     // rows beyond the batch contribute nothing to the sequence-long accumulators
+        des[wave * TPM + lane_ + 64 * k] = r0 + wave < nb ? a.scaling * w[k] * (dv[k] - dot) : 0.f;
     }
     __syncthreads();
     DP_MARK(3);
@@ -1104,18 +1119,19 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int tile = wave + 8 * it;
-        if (4 * tile < TpP) {
-          const int t = 4 * tile + q4_;
+        if (FPT * tile < TpP) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+            // pair 4 q4 + i of the tile: row ri (a compile-time constant: 4 q4 is a multiple of RG), frame t
+            const int ri = i % RG, t = FPT * tile + (4 * q4_ + i) / RG;
             const float sv = sreg[it * 4 + i];
-            const float det = des[i * DP_TPM + t];
+            const float det = des[ri * TPM + t];          // des is defined (0 beyond T') for every t < TPM
             const float duv = sc_ok_ ? det * gv * (1.f - sv * sv) : 0.f;
             dPs[(tile * 4 + i) * 64 + lane_] += duv;
-            dDl[i] += duv;
+            dDl[ri] += duv;
             dgl += sc_ok_ ? det * sv : 0.f;
-            // dW_att[a][c] += sum over this k-group of 4 frames: A[m = a][k = q4] = du, B[k = q4][n = c] = f[i][c][4 tile + q4]
-            const float fb = fs[(i * C + (a_l_ < C ? a_l_ : 0)) * TpP + t];
+            // dW_att[a][c] += sum over the k-group of this MFMA: A[m = a][k = q4] = du, B[k = q4][n = c] = f[row][c][frame]
+            const float fb = fs[(ri * C + (a_l_ < C ? a_l_ : 0)) * TpP + ((RG == 4 || t < TpP) ? t : 0)];
             acc_watt = __builtin_amdgcn_mfma_f32_16x16x4f32(duv, a_l_ < C ? fb : 0.f, acc_watt, 0, 0, 0);
           }
         }
@@ -1136,7 +1152,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       for (int w2 = 0; w2 < 8; ++w2) v += dDp[(w2 * 4 + row) * 16 + al];
       const int b = r0 + row;
       if (al < AU) {
-        if (b < nb) a.dD[((int64_t)s * B + b) * AA + AU * slice + al] = v;
+        if (row < RG && b < nb) a.dD[((int64_t)s * B + b) * AA + AU * slice + al] = v;
         word_store(xg + BX_D + (slot * 4 + row) * 512 + AU * slice + al, v, bit);
       }
     }
@@ -1145,11 +1161,18 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     {
       const float rtp = 1.0f / (float)TpP;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < NMR; ++k) {
         const int id = tid_ + DP_NT * k;
         if (id < C * TpP) {
           const int c = (int)(((float)id + 0.5f) * rtp), t = id - c * TpP;
-          if (t < Tp) dfh[c * DFS + K + t] = des[ar * DP_TPM + t] * (ugs[c] - mreg[k]);
+          if (t < Tp) dfh[c * DFS + K + t] = des[ar * TPM + t] * (ugs[c] - mreg[k]);
+#ifdef ASR_DP_DEBUG
+          if (t < Tp && n == 0 && aq == 0 && ab_ok) {
+            a.dbg[((int64_t)ab * C + c) * Tp + t] = des[ar * TPM + t] * (ugs[c] - mreg[k]);
+            a.dbg[(int64_t)B * C * Tp + ((int64_t)ab * C + c) * Tp + t] = mreg[k];
+            a.dbg[(int64_t)2 * B * C * Tp + ((int64_t)ab * C + c) * Tp + t] = des[ar * TPM + t];
+          }
+#endif
         }
       }
     }
@@ -1165,9 +1188,12 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       const int cc = cok ? cb : 0;
       {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};   // alternating partials
-        const float* ap = dfh + cc * DFS + 16 * aq + 4 * li + 2 * K;
-        const float* bp = Fs + cc * FSS + li;
-        const int jend = taps + 3;
+        // The summation index runs from -3: output jj needs the taps j + jj >= 0, i.e. j >= -jj (their operands are d(conv
+        // features) of frames beyond t0 + 4i + K, which are zero only while T' <= K + 1 - the case of every test of
+        // round 1).  js = j + 4 >= 0 is the loop variable; taps with j + jj < 0 are masked.
+        const float* ap = dfh + cc * DFS + 16 * aq + 4 * li + 2 * K + 4;
+        const float* bp = Fs + cc * FSS + li - 4;
+        const int jend = taps + 3 + 4;
         for (int j = wave; j < jend; j += 32) {      // 4 taps per trip: 8 LDS reads in flight, then 4 MFMAs
           float av[4], bv[4];
 #pragma unroll
@@ -1178,8 +1204,9 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
           }
 #pragma unroll
           for (int u = 0; u < 4; u += 2) {
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32((cok && j + 8 * u < jend) ? av[u] : 0.f, bv[u], acc, 0, 0, 0);
-            accb = __builtin_amdgcn_mfma_f32_4x4x1f32((cok && j + 8 * (u + 1) < jend) ? av[u + 1] : 0.f, bv[u + 1], accb, 0, 0, 0);
+            const int j0 = j + 8 * u, j1 = j + 8 * (u + 1);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32((cok && j0 < jend) ? av[u] : 0.f, j0 - 4 + li >= 0 ? bv[u] : 0.f, acc, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_4x4x1f32((cok && j1 < jend) ? av[u + 1] : 0.f, j1 - 4 + li >= 0 ? bv[u + 1] : 0.f, accb, 0, 0, 0);
           }
         }
         float* pp = part + (wave * 64 + lane_) * 5;
@@ -1187,11 +1214,11 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
         for (int i = 0; i < 4; ++i) pp[i] = acc[i] + accb[i];
       }
       // (2) dconv[c][j0 + 4i + jj] += sum_u w_{s-1}[u + j0 + 4i - K] df[c][u - jj]: A = wph[u + j0 + 4i], B = dfh[c][K + u - jj];
-      //     this CU owns the 16-tap tiles aq and aq + 8 of its row; accumulators live in registers for the whole sequence
+      //     this CU owns the 16-tap tiles aq and aq + PPR of its row; accumulators live in registers for the whole sequence
       {
         const float* bq = dfh + cc * DFS + K - li;
         const float* a0 = wph + 16 * aq + 4 * li;
-        const bool two = 16 * (aq + 8) < taps;
+        const bool two = 16 * (aq + PPR) < taps;
         const int uend = Tp + 3;
         for (int u = wave; u < uend; u += 32) {
           float bv[4], a0v[4], a1v[4];
@@ -1200,7 +1227,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
             const int uc = u + 8 * k < uend ? u + 8 * k : u;
             bv[k] = bq[uc];
             a0v[k] = a0[uc];
-            a1v[k] = a0[uc + 128];
+            a1v[k] = a0[two ? uc + 16 * PPR : uc];
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -1247,7 +1274,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       for (int i = 0; i < ND; ++i) {
         const int id = tid_ + DP_NT * i;
         const int row = (4 * id) / AA, c4 = 4 * id - row * AA;
-        if (4 * id < 4 * AA)
+        if (4 * id < RG * AA)
           *reinterpret_cast<float4*>(dDs + row * DS + c4) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
                                                                        __uint_as_float(v[i].z), __uint_as_float(v[i].w));
       }
@@ -1255,7 +1282,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     __syncthreads();
     {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};   // even / odd k partials
-      const float* dr = dDs + (lane_ & 3) * DS + wave * AKW + (lane_ >> 4) * AQ;
+      const float* dr = dDs + ((lane_ & 3) % RG) * DS + wave * AKW + (lane_ >> 4) * AQ;      // rows >= RG alias (results unused)
 #pragma unroll
       for (int q = 0; q < AQ; q += 2) {
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[q], dr[q], acc, 0, 0, 0);
@@ -1285,7 +1312,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       dcarry = dc * ga.y;
       if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
       const int un = DU * slice + ul, b = r0 + row;
-      if (b < nb) *reinterpret_cast<float4*>(a.dgates + ((int64_t)s * B + b) * GK + un * 4) = da;
+      if (row < RG && b < nb) *reinterpret_cast<float4*>(a.dgates + ((int64_t)s * B + b) * GK + un * 4) = da;
       float* dst = xg + BX_G + (slot * 4 + row) * 2048 + un * 4;
       word_store(dst, da.x, bit); word_store(dst + 1, da.y, bit);
       word_store(dst + 2, da.z, bit); word_store(dst + 3, da.w, bit);
@@ -1310,7 +1337,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       for (int i = 0; i < NG; ++i) {
         const int id = tid_ + DP_NT * i;
         const int row = (4 * id) / GK, c4 = 4 * id - row * GK;
-        if (4 * id < 4 * GK)
+        if (4 * id < RG * GK)
           *reinterpret_cast<float4*>(dgs + row * GS + c4) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
                                                                        __uint_as_float(v[i].z), __uint_as_float(v[i].w));
       }
@@ -1323,7 +1350,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};   // even / odd k partials
       DP_MARK(8);
-      const float* gr = dgs + (lane_ & 3) * GS + wave * GKW + ((lane_ >> 2) & 1) * GKS;
+      const float* gr = dgs + ((lane_ & 3) % RG) * GS + wave * GKW + ((lane_ >> 2) & 1) * GKS;   // rows >= RG alias
 #pragma unroll
       for (int q4 = 0; q4 < GKS / 4; ++q4) {
         const float4 b = *reinterpret_cast<const float4*>(gr + 4 * q4);
@@ -1352,7 +1379,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       } else if (ci - 16 < OU) {
         const int col = OU * slice + ci - 16, b = r0 + row;
         const float tot = gc + v * xm;                        // total d(ctx_{s-1}) = output layer + masked cell input
-        if (b < nb) a.G[((int64_t)s * B + b) * KX + DD + col] = tot;
+        if (row < RG && b < nb) a.G[((int64_t)s * B + b) * KX + DD + col] = tot;
         word_store(xg + BX_C + (((n + 1) & 1) * 4 + row) * 512 + col, tot, tag_bit_of_step(n + 1));
       }
     }
@@ -1370,11 +1397,10 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int tile = wave + 8 * it;
-    if (4 * tile < TpP) {
-      const int t = 4 * tile + q4e;
+    if (FPT * tile < TpP) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int b = r0 + i;
+        const int b = r0 + (4 * q4e + i) % RG, t = FPT * tile + (4 * q4e + i) / RG;
         if (sc_oke && b < nb && t < Tp) a.dP[((int64_t)b * Tp + t) * AA + acole] = dPs[(tile * 4 + i) * 64 + lane_e];
       }
     }
@@ -1395,7 +1421,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     if (c < C && ab_ok) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int j0 = 16 * aq + 4 * i + jj, j1 = j0 + 128;
+        const int j0 = 16 * aq + 4 * i + jj, j1 = j0 + 16 * PPR;
         if (j0 < taps) atomicAdd(a.dconv_part + ((int64_t)ab * C + c) * taps + j0, acc_cv0[i]);
         if (j1 < taps) atomicAdd(a.dconv_part + ((int64_t)ab * C + c) * taps + j1, acc_cv1[i]);
       }
@@ -1469,15 +1495,16 @@ __global__ void mask_emb_kernel(int L, int B, int nb, int D, int O, int E, const
   G[((int64_t)s * B + b) * (D + O + E) + D + O + e] *= xmask[((int64_t)s * B + b) * (O + E) + O + e];
 }
 
-template <int DD, int AA, int OO, int EE>
+template <int DD, int AA, int OO, int EE, int RG = 4, int TPM = DP_TPM>
 int launch_dec_bwd(const DecPersistBwdArgs& a, hipStream_t stream) {
-  const BwdLds ld = bwd_lds_plan<DD, AA, OO>(a.Tp, a.C, a.K);
-  const size_t lds = (size_t)ld.total * sizeof(float);
-  if (lds > 160 * 1024 || lds <= 82 * 1024) return ASR_E_SHAPE;     // must fit, and must force one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_bwd_kernel<DD, AA, OO, EE>,
+  const BwdLds ld = bwd_lds_plan<DD, AA, OO, RG, TPM>(a.Tp, a.C, a.K);
+  size_t lds = (size_t)ld.total * sizeof(float);
+  if (lds > 160 * 1024) return ASR_E_SHAPE;                          // must fit ...
+  if (lds <= 82 * 1024) lds = 82 * 1024 + 64;                        // ... and must force one workgroup per CU
+  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_bwd_kernel<DD, AA, OO, EE, RG, TPM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((dec_persist_bwd_kernel<DD, AA, OO, EE>), dim3(256), dim3(DP_NT), lds, stream, a);
+  hipLaunchKernelGGL((dec_persist_bwd_kernel<DD, AA, OO, EE, RG, TPM>), dim3(256), dim3(DP_NT), lds, stream, a);
   return 0;
 }
 
@@ -1586,15 +1613,19 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
   const bool cfg1 = p->D == 320 && p->A == 320 && p->O == 320 && p->E == 128;
   if (!cfg1 && !cfg2) return ASR_E_SHAPE;
   const int TpP = (p->Tp + 3) & ~3;
-  if (p->Tp > DP_TPM || p->C <= 0 || p->C > 16 || p->K < 0 || p->K > DP_KMAX || p->C * TpP > 2 * DP_NT ||
-      4 * p->C * TpP > 8 * DP_NT)
-    return ASR_E_SHAPE;
+  if (p->C <= 0 || p->C > 16 || p->K < 0 || p->K > DP_KMAX) return ASR_E_SHAPE;
+  // geometry as in the forward: 4 utterances per group while the per-thread prefetch registers cover the conv features
+  // and M of 4 rows (T' <= 102 at 10 channels), else 2 utterances per group on 16 CUs each (T' <= 256)
+  const bool geo4 = p->Tp <= DP_TPM && p->C * TpP <= 2 * DP_NT && 4 * p->C * TpP <= 8 * DP_NT;
+  const bool geo2 = !geo4 && p->Tp <= 256 && p->C * TpP <= 5 * DP_NT && 2 * p->C * TpP <= 10 * DP_NT;
+  if (!geo4 && !geo2) return ASR_E_SHAPE;
   if (!asr_persist_device_ok()) return ASR_E_SHAPE;
   const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;
   const int taps = 2 * p->K + 1;
-  for (int rb = 0; rb < p->nb; rb += 32) {
-    const int nbb = p->nb - rb < 32 ? p->nb - rb : 32;
-    hipError_t e = persist_reset(xch, ctrl, (size_t)8 * BX_GROUP * sizeof(float), stream);
+  const int rows_per_launch = geo4 ? 32 : 16;
+  for (int rb = 0; rb < p->nb; rb += rows_per_launch) {
+    const int nbb = p->nb - rb < rows_per_launch ? p->nb - rb : rows_per_launch;
+    hipError_t e = persist_reset(xch, ctrl, (size_t)8 * (geo4 ? BwdX<DP_TPM>::GROUP : BwdX<256>::GROUP) * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
     if (cfg2)
       hipLaunchKernelGGL((att_m_kernel<512>), dim3(nbb * p->L < 2048 ? nbb * p->L : 2048), dim3(256), 0, stream, B, nbb, p->L, Tp, C,
@@ -1609,11 +1640,14 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
     a.gates = p->gates + (int64_t)rb * 4 * D; a.cstate = p->cstate + (int64_t)rb * D;
     a.S = p->S + (int64_t)rb * Tp * A; a.fconv = p->fconv + (int64_t)rb * C * Tp; a.ws = p->ws + (int64_t)rb * Tp;
     a.Mf = mbuf + (int64_t)rb * C * Tp; a.dws = q->dws ? q->dws + (int64_t)rb * Tp : nullptr;
+    a.dbg = q->dfpart;
     a.G = q->G + (int64_t)rb * KX; a.dgates = q->dgates + (int64_t)rb * 4 * D; a.dD = q->dD + (int64_t)rb * A;
     a.dP = q->dP + (int64_t)rb * Tp * A; a.dgvec_part = q->dgvec_part + (int64_t)rb * A;
     a.dwatt_part = q->dwatt_part + (int64_t)rb * A * C; a.dconv_part = q->dconv_part + (int64_t)rb * C * taps;
     a.xch = (float*)xch; a.ctrl = (unsigned*)ctrl;
-    const int rc = cfg2 ? launch_dec_bwd<512, 512, 512, 128>(a, stream) : launch_dec_bwd<320, 320, 320, 128>(a, stream);
+    const int rc = geo4 ? (cfg2 ? launch_dec_bwd<512, 512, 512, 128>(a, stream) : launch_dec_bwd<320, 320, 320, 128>(a, stream))
+                        : (cfg2 ? launch_dec_bwd<512, 512, 512, 128, 2, 256>(a, stream)
+                                : launch_dec_bwd<320, 320, 320, 128, 2, 256>(a, stream));
     if (rc) return rc;
   }
   ASR_CHECK_LAUNCH();

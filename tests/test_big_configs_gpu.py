@@ -93,7 +93,6 @@ def test_cfg2_against_golden(golden_dir):
 
 
 def test_cfg5_against_golden(golden_dir):
-    """cfg-5 (configs[4]: 80x1600 frames, batch 8, T'=200, L+1=201) vs the reference: 4-row LSTM groups, the decoder
-    forward in the T' <= 256 geometry (2 utterances per XCD group); the decoder backward at T' > 102 is the one operator
-    that still runs on the per-step kernels, and the test says so."""
-    _run_big(golden_dir, "cfg5", synth.CFG5_SHAPE, dec_bwd_persistent=False)
+    """cfg-5 (configs[4]: 80x1600 frames, batch 8, T'=200, L+1=201) vs the reference: 4-row LSTM groups, both decoder
+    kernels in the T' <= 256 geometry (2 utterances per XCD group)."""
+    _run_big(golden_dir, "cfg5", synth.CFG5_SHAPE)

@@ -675,7 +675,7 @@ def test_lstm_judge_width_h640(B, T, ndir):
                                              (512, 40, 100, 3, False), (512, 16, 96, 3, True), (320, 5, 9, 4, False),
                                              (512, 70, 100, 2, True), (512, 8, 200, 4, True), (512, 32, 128, 3, True),
                                              (512, 19, 256, 3, False), (320, 6, 150, 5, True)])
-def test_decoder_persistent_path(dim, B, Tp, L, drop):
+def test_decoder_persistent_path(dim, B, Tp, L, drop, K=100):
     """The persistent XCD-local decoder forward kernel (one launch for the whole teacher-forced sequence) against the
     per-step kernels on the same inputs: outputs and every gradient (the backward consumes the buffers it saved).
     The tiny/cfg-1 end-to-end tests hold the per-step kernels to the oracle; cfg-2 end to end covers this path."""
@@ -684,7 +684,7 @@ def test_decoder_persistent_path(dim, B, Tp, L, drop):
     import hip_backend as hb
     g = torch.Generator().manual_seed(13 + B + Tp)
     D = A = O = dim
-    E, C, K, V = 128, 10, 100, 34
+    E, C, V = 128, 10, 34
     sc0 = 1.0 / np.sqrt(D)
 
     def rnd(*sh, sc=1.0):
@@ -726,10 +726,8 @@ def test_decoder_persistent_path(dim, B, Tp, L, drop):
             hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = old
 
     lr, wr, gr = run(False)
-    # T' > 102 (at 10 conv channels): the forward runs in the 2-utterances-per-group geometry (T' <= 256), the backward
-    # of such sequences on the per-step kernels
-    wide = Tp > 102
-    for mode in (((True, False),) if wide else ((True, False), (False, True), (True, True))):   # persistent fwd / bwd / both
+    # (T' > 102 at 10 conv channels: both persistent kernels run in the 2-utterances-per-group geometry, T' <= 256)
+    for mode in ((True, False), (False, True), (True, True)):      # persistent forward / backward / both
         lp, wpp, gp = run(*mode)
         assert not hb.persist_aborted(dev), mode
         assert torch.isfinite(lp).all()
@@ -739,6 +737,15 @@ def test_decoder_persistent_path(dim, B, Tp, L, drop):
             scale = float(gr[k].abs().max()) + 1e-12
             err = float((gp[k] - gr[k]).abs().max()) / scale
             assert err < 2e-4, (mode, k, err)
+
+
+@pytest.mark.parametrize("B,Tp,K", [(8, 96, 2), (12, 60, 7), (8, 130, 30), (6, 104, 2)])
+def test_decoder_persistent_conv_wider_than_reach(B, Tp, K):
+    """T' > K + 1: frames further apart than the location conv reaches.  The conv-backward Toeplitz product of the
+    persistent backward dropped the first taps of three of every four output frames - invisible while T' <= K + 1 (their
+    operands are zero then), which was the case of every persistent-path test of round 1 (K = 100, T' <= 100); found when
+    the T' <= 256 geometry arrived.  Same comparison as test_decoder_persistent_path, short conv kernels."""
+    test_decoder_persistent_path(512, B, Tp, 3, True, K=K)
 
 
 @pytest.mark.parametrize("V,ls", [(34, 0.05), (34, 0.0), (100, 0.1), (7, 0.3)])
