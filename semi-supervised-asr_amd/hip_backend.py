@@ -164,31 +164,18 @@ def _rowmajor(t):
 
 def auto_split_k(M, N, K, batch=1, epilogue=False):
     """Split-K factor (partials are added with f32 atomics; a bias/ReLU epilogue then needs a second pass over C).
-    For K >= 2048 it minimises a wave-quantisation model fitted on MI355X with cold operands
-    (tools/gemm_cold_split_sweep.py): 256 CUs hold two 128x128 workgroups each, so tiles*s workgroups run as
-    full passes of 512 plus a remainder that costs a whole pass if it exceeds 256 (two workgroups share a CU) and
-    0.56 of one otherwise; each K slice adds ~1 % (zero fill + atomics), an epilogue pass ~8 %.  That picks 5 for
-    200 / 400 tiles (1 000 / 2 000 workgroups), 4 for 128, 7 for 144 and 8 for 64 tiles - within 2 % of the best
-    measured factor for every large GEMM of the cfg-2 step.  Below K = 2048 the earlier measured rule stands: even
-    K = 512 is worth splitting under ~128 tiles (a workgroup's K loop is a serial chain)."""
+    256 CUs hold two 128x128 workgroups each, so the target is ~512 workgroups: floor(512 / tiles), at most 8 (16 for <= 32 tiles), every
+    K slice at least 256 long.  Measured on MI355X with cold operands and the split-bf16 kernel
+    (tools/gemm_cold_split_sweep.py, round 2): 400 tiles -> 1 (120 us vs 171 at the 5 the round-1 model picked: the
+    product got 2x cheaper, the atomics, the zero fill and the late epilogue did not), 200 -> 2, 144 -> 3, 128 -> 4,
+    64 -> 8; within 5 % of the best factor for every large GEMM of the cfg-2 step."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    if tiles >= 1024 or K < 512:
+    if tiles >= 512 or K < 512:
         return 1
-    if K < 2048:
-        if tiles > 128 or (epilogue and tiles > 64):
-            return 1
-        return int(max(1, min(8 if tiles <= 32 else 4, K // 128)))
-    best, best_cost = 1, None
-    for sk in range(1, 17):
-        if sk > 1 and K // sk < 256:
-            break
-        wgs = tiles * sk
-        rem = wgs % 512
-        passes = wgs // 512 + (0.0 if rem == 0 else (0.56 if rem <= 256 else 1.0))
-        cost = passes / sk * (1.0 + 0.01 * sk) * (1.08 if (epilogue and sk > 1) else 1.0)
-        if best_cost is None or cost < best_cost - 1e-9:
-            best, best_cost = sk, cost
-    return best
+    sk = max(1, min(16 if tiles <= 32 else 8, 512 // tiles, K // 256))
+    if epilogue and sk > 1 and tiles > 64:
+        return 1
+    return int(sk)
 
 
 def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, split_k=None):
