@@ -635,6 +635,17 @@ def test_lstm_persistent_path(ndir, B, T, lens, H):
         _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
 
 
+@pytest.mark.parametrize("mask,name", [(0, "fp32-input MFMA products"), (3, "split-bf16, gathered-dG backward")])
+@pytest.mark.parametrize("ndir,B,T,H", [(2, 32, 9, 512), (2, 7, 6, 128), (1, 40, 5, 256), (2, 12, 7, 320)])
+def test_lstm_persistent_other_arithmetics(ndir, B, T, H, mask, name):
+    """The persistent LSTM kernels that are not the default any more stay selectable (asr_set_split_bf16) and correct:
+    the exact-fp32 4x4x1 products of round 1 and the gathered-dG backward with split-bf16 dh products."""
+    _gpu()
+    import hip_backend as hb
+    with hb.split_bf16((hb.set_split_bf16(-1) & hb.SPLIT_GEMM) | mask):
+        test_lstm_persistent_path(ndir, B, T, None, H)
+
+
 @pytest.mark.parametrize("B,T,ndir", [(32, 12, 1), (20, 7, 1), (8, 5, 2), (40, 3, 1)])
 def test_lstm_judge_width_h640(B, T, ndir):
     """H = 640 (the judge LM: config.yaml dis_hidden_dim, reference model.py:466-467): the forward recurrence runs on the
