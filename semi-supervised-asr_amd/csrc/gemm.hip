@@ -467,13 +467,17 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
 #undef BF3G
     }
   };
-  if (fast && kt_end * BK <= g.K) {
-    if (kt_begin < kt_end) fetch_fast(kt_begin);
-    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+  // full K tiles of interior workgroups run the bare-load loop; a K tail (K % 32 != 0, e.g. the 80-dim features) and edge
+  // workgroups take the guarded loop, which does not overlap its loads (one tile in the K = 80 case)
+  const int64_t kt_full = g.K / BK < kt_end ? g.K / BK : kt_end;
+  const int64_t kt_fast_end = (fast && kt_full > kt_begin) ? kt_full : kt_begin;
+  if (kt_begin < kt_fast_end) {
+    fetch_fast(kt_begin);
+    for (int64_t kt = kt_begin; kt < kt_fast_end; ++kt) {
       tile_store_bf3<AKC>(Ah, Al, ra);
       tile_store_bf3<BKC>(Bh, Bl, rb);
       __syncthreads();
-      if (kt + 1 < kt_end) fetch_fast(kt + 1);
+      if (kt + 1 < kt_fast_end) fetch_fast(kt + 1);
 #if ASR_GEMM_TOUCH
       asm volatile("" ::"v"(touched));
       if (do_touch && kt + ASR_GEMM_BF3_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_BF3_TOUCH);
@@ -481,9 +485,10 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
       multiply();
       __syncthreads();
     }
-  } else {
-    if (kt_begin < kt_end) fetch_guard(kt_begin);
-    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+  }
+  if (kt_fast_end < kt_end) {
+    fetch_guard(kt_fast_end);
+    for (int64_t kt = kt_fast_end; kt < kt_end; ++kt) {
       tile_store_bf3<AKC>(Ah, Al, ra);
       tile_store_bf3<BKC>(Bh, Bl, rb);
       __syncthreads();
