@@ -47,8 +47,10 @@ int asr_abi_version(void);
  * fp32 accumulation): 16x the MAC rate of the fp32-input MFMA for a result that stays ~30x inside the 1e-3 parity
  * gate (measured against the reference at cfg-2: worst gradient element 9e-5).  asr_set_split_bf16 selects per
  * kernel family; it returns the previous mask.  Bits: 1 LSTM forward, 2 LSTM backward (gathered-dG kernel),
- * 4 LSTM backward with exchanged partials, 8 asr_gemm_f32.  mask < 0: query only.  Environment overrides at load time:
- * ASR_LSTM_BF3 (bits 1|2|4), ASR_GEMM_BF3 (0/1).  Not thread safe against concurrent launches. */
+ * 4 LSTM backward with exchanged partials, 8 asr_gemm_f32, 16 (with 8) the 256 x 128 LDS-DMA GEMM kernel for the
+ * shapes it pays on (weight gradients, long-K projections; M % 256 == 0, N % 128 == 0, K % 32 == 0), 32 that kernel for
+ * every conforming shape (tests, measurements).  mask < 0: query only.  Environment overrides at load time:
+ * ASR_LSTM_BF3 (bits 1|2|4), ASR_GEMM_BF3 (0/1), ASR_GEMM_WIDE (0/1/2).  Not thread safe against concurrent launches. */
 int asr_set_split_bf16(int mask);
 
 /* ---------------------------------------------------------------------------------------

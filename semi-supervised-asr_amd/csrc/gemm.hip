@@ -6,6 +6,7 @@
 // Replaces the torch mm/addmm/bmm calls behind nn.Linear / nn.LSTM input projections on the
 // reference path (model.py:67-68,80,93-94,144,163,293 and their autograd backward).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 #ifndef ASR_GEMM_BF3_DEFAULT
@@ -474,10 +475,20 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   if (kt_begin < kt_fast_end) {
     fetch_fast(kt_begin);
     for (int64_t kt = kt_begin; kt < kt_fast_end; ++kt) {
+#if ASR_GB_ABL & 4
+      if (kt == kt_begin) {
+        tile_store_bf3<AKC>(Ah, Al, ra);
+        tile_store_bf3<BKC>(Bh, Bl, rb);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w), "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+      }
+#else
       tile_store_bf3<AKC>(Ah, Al, ra);
       tile_store_bf3<BKC>(Bh, Bl, rb);
+#endif
       __syncthreads();
-      if (kt + 1 < kt_fast_end) fetch_fast(kt + 1);
+      if (kt + 1 < kt_fast_end && !(ASR_GB_ABL & 2)) fetch_fast(kt + 1);
 #if ASR_GEMM_TOUCH
       asm volatile("" ::"v"(touched));
       if (do_touch && kt + ASR_GEMM_BF3_TOUCH < kt_end) touch_tile(kt + ASR_GEMM_BF3_TOUCH);
@@ -562,6 +573,329 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------ split-bf16, wide tile
+// gemm_bf3w_kernel: the same arithmetic on a 256 x 128 output tile per workgroup of 8 waves, operands brought in by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of three fp32 stages of
+// 32 k (48 KB each, 96 KB in flight per CU while the third is multiplied), one raw s_barrier per stage and counted
+// s_waitcnt vmcnt.  The bf16 split happens on the fragments, after the LDS read (2.5 VALU per element in the shadow of
+// the MFMAs).  Waves: 2 (M) x 2 (N) x 2 (K halves of a stage); a wave owns a 128 x 64 accumulator (4 x 2 blocks of
+// 32 x 32) over its 16 k of every stage, and the two K halves are summed through LDS once, each half then writing 64
+// of the 128 rows.  Per stage and wave: 12 ds_read_b128 (or 48 ds_read_b32), 120 VALU, 24 MFMAs of 32 cycles.
+//   k-contiguous operands ([rows][K]): a 1 KB piece = 8 rows x 128 B; the 16-byte granule q of row r sits at slot
+//     q ^ ((r >> 1) & 7) of its row (the swizzle is applied to the SOURCE address of the DMA lane: the LDS side of a
+//     DMA is lane-linear), which makes the fragment's two ds_read_b128 conflict-free over the instruction's lane groups;
+//   row-contiguous operands ([K][rows]): a piece = one k (A) or two (B), image [k][rows], fragments by ds_read_b32.
+// Shapes: M % 256 == 0, N % 128 == 0, K % 32 == 0, 16-byte aligned rows; everything else stays on gemm_bf3_kernel.
+constexpr int WM = 256, WN = 128, WK = 32;
+constexpr int W_A_FLOATS = WM * WK, W_B_FLOATS = WN * WK, W_STAGE_FLOATS = W_A_FLOATS + W_B_FLOATS, W_STAGES = 3;
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + 16 * lane.  Issued as inline asm
+// on purpose: for the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the next ds_read of the same array (it cannot
+// tell the stages of the ring apart), which drains the two stages in flight every iteration.  The kernel counts vmcnt
+// itself; no other VMEM load is outstanding while DMAs are.
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
+  const unsigned dst = (unsigned)(uintptr_t)(lds_vptr)lds_dst;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+}
+
+#ifndef ASR_GW_ABL      /* measurement only: 1 no DMA inside the stage loop, 2 no split arithmetic (raw bits as hi / lo), 4 no fragment reads after the prologue */
+#define ASR_GW_ABL 0
+#endif
+__device__ __forceinline__ void bf3w_split(const float (&v)[8], gu32x4& hi, gu32x4& lo) {
+#if ASR_GW_ABL & 2
+#pragma unroll
+  for (int p = 0; p < 4; ++p) { hi[p] = __float_as_uint(v[p]); lo[p] = __float_as_uint(v[4 + p]); }
+  return;
+#endif
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    hi[p] = bf3g_hi2(v[2 * p], v[2 * p + 1]);
+    lo[p] = bf3g_lo2(v[2 * p], v[2 * p + 1]);
+  }
+}
+
+// the 8 consecutive k of this lane for one 32-row block of an operand stage
+template <bool KC, int ROWS>
+__device__ __forceinline__ void bf3w_frag(const float* st, int row, int kq0s, int kq1s, int k0, gu32x4& hi, gu32x4& lo) {
+  float v[8];
+  if (KC) {
+    const float4 x = *reinterpret_cast<const float4*>(st + row * WK + kq0s);
+    const float4 y = *reinterpret_cast<const float4*>(st + row * WK + kq1s);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = st[(k0 + e) * ROWS + row];
+  }
+  bf3w_split(v, hi, lo);
+}
+
+template <int I0>
+__device__ __forceinline__ void bf3w_send(float* xs, const f32x16 (&acc)[4][2], int lane) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xs[((b * 2 + j) * 16 + e) * 64 + lane] = acc[I0 + b][j][e];
+}
+
+template <int I0>
+__device__ __forceinline__ void bf3w_finish(const float* xr, f32x16 (&acc)[4][2], const GemmArgs& g, float* C, int64_t mrow0,
+                                            int64_t ncol0, int lane) {
+  const int l31 = lane & 31, kh = lane >> 5;
+  const unsigned ldc = (unsigned)g.ldc;
+  const bool split = g.split_k > 1, accum = g.accumulate != 0, relu = g.relu != 0;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = ncol0 + j * 32 + l31;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+      float* base = C + (mrow0 + (I0 + b) * 32 + 4 * kh) * g.ldc + n;
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = acc[I0 + b][j][e] + xr[((b * 2 + j) * 16 + e) * 64 + lane];
+      if (split) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) atomicAdd(base + (unsigned)((e & 3) + 8 * (e >> 2)) * ldc, v[e]);
+      } else {
+        if (accum) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float o = v[e] + bv;
+          if (relu) o = fmaxf(o, 0.f);
+          base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = o;
+        }
+      }
+    }
+}
+
+#ifdef ASR_GW_TRACE   /* measurement builds only (tools/gemm_wide_trace.py): shader-clock stamps of waves 0 and 4 of workgroup 0 */
+__device__ unsigned long long asr_gw_trace_buf[2 * 64 * 8];
+#define GW_MARK(m) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0 && st < 63) \
+    asr_gw_trace_buf[((wave >> 2) * 64 + st) * 8 + (m)] = clock64(); } while (0)
+#define GW_COARSE(m) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) asr_gw_trace_buf[63 * 8 + (m)] = clock64(); } while (0)
+#else
+#define GW_MARK(m) do {} while (0)
+#define GW_COARSE(m) do {} while (0)
+#endif
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512) void gemm_bf3w_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) float smem[W_STAGES * W_STAGE_FLOATS];
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  int tid = blockIdx.x;
+  {
+    const int q = ntile >> 3, rmd = ntile & 7, xcd = tid & 7, idx = tid >> 3;
+    tid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
+  }
+  const int tm = tid / g.tiles_n, tn = tid % g.tiles_n;
+  const int z = blockIdx.y;
+  const int bz = z / g.split_k, kz = z % g.split_k;
+  const float* Ap = g.A.p + bz * g.sA;
+  const float* Bp = g.B.p + bz * g.sB;
+  float* C = g.C + bz * g.sC;
+  const int64_t m0 = (int64_t)tm * WM, n0 = (int64_t)tn * WN;
+  const int64_t ktiles = g.K / WK;
+  const int64_t per = (ktiles + g.split_k - 1) / g.split_k;
+  const int64_t kt_begin = kz * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int S = (int)(kt_end - kt_begin);
+  if (S <= 0) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  // ---- DMA source offsets of this lane (floats, relative to the tile's first row / column at the stage's first k)
+  const int64_t lda = g.A.ld, ldb = g.B.ld;
+  unsigned offa[4], offb[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = 4 * wave + q;
+    if (AKC) {
+      const int r = 8 * p + (lane >> 3);
+      offa[q] = (unsigned)(r * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
+    } else {
+      offa[q] = (unsigned)(p * lda + 4 * lane);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int p = 2 * wave + q;
+    if (BKC) {
+      const int r = 8 * p + (lane >> 3);
+      offb[q] = (unsigned)(r * ldb + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
+    } else {
+      offb[q] = (unsigned)((2 * p + (lane >> 5)) * ldb + 4 * (lane & 31));
+    }
+  }
+  const float* basea = AKC ? Ap + m0 * lda + kt_begin * WK : Ap + kt_begin * WK * lda + m0;
+  const float* baseb = BKC ? Bp + n0 * ldb + kt_begin * WK : Bp + kt_begin * WK * ldb + n0;
+  const int64_t stepa = AKC ? WK : WK * lda, stepb = BKC ? WK : WK * ldb;
+  auto issue = [&](int st, int buf) {
+    float* sb = smem + buf * W_STAGE_FLOATS;
+    const float* pa = basea + st * stepa;
+    const float* pb = baseb + st * stepb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16(pa + offa[q], sb + (4 * wave + q) * 256);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) glds16(pb + offb[q], sb + W_A_FLOATS + (2 * wave + q) * 256);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addressing: granules (4 kg + 2 kh, + 1) of the lane's row, swizzled by (row >> 1) & 7 = (l31 >> 1) & 7
+  const int sw = (l31 >> 1) & 7;
+  const int kq0s = 4 * ((4 * kg + 2 * kh) ^ sw), kq1s = kq0s ^ 4;
+  const int kfirst = 16 * kg + 8 * kh;
+  const int arow = wm * 128 + l31, brow = wn * 64 + l31;
+
+  // Software pipeline inside every wave (all 8 waves in step, one barrier per stage, in its middle):
+  //   H1(s): 12 MFMAs  A rows 0-63 x B of stage s          || read + split A rows 64-127 of stage s
+  //   mid(s): this wave's DMAs of stage s + 1 have landed (counted vmcnt, stage s + 2 stays in flight), barrier
+  //   H2(s): 12 MFMAs  A rows 64-127 x B of stage s        || read + split B and A rows 0-63 of stage s + 1,
+  //                                                            issue the six DMAs of stage s + 3 into stage s's buffer
+  // (stage s's buffer is last read in H1(s), before the barrier).  Measured before this: with the fragment reads, the
+  // split and the MFMAs of a stage back to back (first version) a stage took 3 800 cycles per SIMD for 1 536 cycles of
+  // matrix pipe, and with the two K halves running in opposite phases (second version) 5 250: tools/gemm_wide_trace.py
+  // showed 1 040-1 550 cycles per fragment phase (three exposed LDS round trips + 120 VALU) and 125 cycles per DMA issue.
+  gu32x4 bh[2][2], bl[2][2], a0h[2], a0l[2], a1h[2], a1l[2];
+#define BF3W(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a_), __builtin_bit_cast(gbf16x8, b_), c_, 0, 0, 0)
+  auto stage = [&](int st, int buf, auto ptag, auto ftag) {
+    constexpr int P = decltype(ptag)::value;
+    constexpr bool FULL = decltype(ftag)::value;       // stages st + 1 and st + 3 exist: no conditionals in the body
+    const float* sa = smem + buf * W_STAGE_FLOATS;
+    const int buf1 = buf == 2 ? 0 : buf + 1;
+    const float* sa1 = smem + buf1 * W_STAGE_FLOATS;
+    // ---- H1
+    GW_MARK(0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) BF3W(a0h[a], bh[P][j], acc[a][j]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) if (!(ASR_GW_ABL & 4) || st == 0) bf3w_frag<AKC, WM>(sa, arow + 32 * (2 + a), kq0s, kq1s, kfirst, a1h[a], a1l[a]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) BF3W(a0h[a], bl[P][j], acc[a][j]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) BF3W(a0l[a], bh[P][j], acc[a][j]);
+    // ---- mid
+    const bool next = FULL || st + 1 < S;
+    GW_MARK(1);
+    if (next) {
+      if (FULL || st + 2 < S) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      GW_MARK(2);
+      __builtin_amdgcn_s_barrier();
+    }
+    GW_MARK(3);
+    // ---- H2
+    const bool dma = (FULL || st + 3 < S) && !(ASR_GW_ABL & 1);
+    float* sb = smem + buf * W_STAGE_FLOATS;           // stage st + 3 goes where stage st was
+    const float* pa = basea + (st + 3) * stepa;
+    const float* pb = baseb + (st + 3) * stepb;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) BF3W(a1h[a], bh[P][j], acc[2 + a][j]);
+    if (dma) {
+      glds16(pa + offa[0], sb + (4 * wave + 0) * 256);
+      glds16(pa + offa[1], sb + (4 * wave + 1) * 256);
+    }
+    if (next && (!(ASR_GW_ABL & 4) || st < 2)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf3w_frag<BKC, WN>(sa1 + W_A_FLOATS, brow + 32 * j, kq0s, kq1s, kfirst, bh[1 - P][j], bl[1 - P][j]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) BF3W(a1h[a], bl[P][j], acc[2 + a][j]);
+    if (dma) {
+      glds16(pa + offa[2], sb + (4 * wave + 2) * 256);
+      glds16(pa + offa[3], sb + (4 * wave + 3) * 256);
+    }
+    if (next && (!(ASR_GW_ABL & 4) || st < 2)) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) bf3w_frag<AKC, WM>(sa1, arow + 32 * a, kq0s, kq1s, kfirst, a0h[a], a0l[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) BF3W(a1l[a], bh[P][j], acc[2 + a][j]);
+    if (dma) {
+      glds16(pb + offb[0], sb + W_A_FLOATS + (2 * wave + 0) * 256);
+      glds16(pb + offb[1], sb + W_A_FLOATS + (2 * wave + 1) * 256);
+    }
+    GW_MARK(4);
+  };
+#undef BF3W
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+  typedef std::integral_constant<bool, true> Full;
+  typedef std::integral_constant<bool, false> Tail;
+
+  GW_COARSE(0);
+  issue(0, 0);
+  if (S > 1) issue(1, 1);
+  if (S > 2) issue(2, 2);
+  if (S > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (S > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bf3w_frag<BKC, WN>(smem + W_A_FLOATS, brow + 32 * j, kq0s, kq1s, kfirst, bh[0][j], bl[0][j]);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) bf3w_frag<AKC, WM>(smem, arow + 32 * a, kq0s, kq1s, kfirst, a0h[a], a0l[a]);
+  int st = 0, buf = 0;
+  GW_COARSE(1);
+  for (; st + 4 < S; st += 2) {                  // both stages of the pair have st + 3 < S
+    stage(st, buf, P0(), Full());
+    buf = buf == 2 ? 0 : buf + 1;
+    stage(st + 1, buf, P1(), Full());
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  for (; st < S; st += 2) {                      // st stays even: the parity of the B registers is a compile-time tag
+    stage(st, buf, P0(), Tail());
+    buf = buf == 2 ? 0 : buf + 1;
+    if (st + 1 < S) {
+      stage(st + 1, buf, P1(), Tail());
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+  }
+
+  // ---- sum the two K halves: each wave hands the 64 rows it does not write to its partner (same wm, wn)
+  GW_COARSE(2);
+  __syncthreads();
+  const int w4 = wave & 3;
+  float* xs = smem + ((w4 * 2 + (1 - kg)) * 64) * 64;       // read by the partner
+  const float* xr = smem + ((w4 * 2 + kg) * 64) * 64;       // written by the partner
+  if (kg == 0) bf3w_send<2>(xs, acc, lane); else bf3w_send<0>(xs, acc, lane);
+  __syncthreads();
+  const int64_t mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
+  GW_COARSE(3);
+  if (kg == 0) bf3w_finish<0>(xr, acc, g, C, mrow0, ncol0, lane);
+  else bf3w_finish<2>(xr, acc, g, C, mrow0, ncol0, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GW_COARSE(4);
 }
 
 // bias (+ReLU) pass after a split-K product (the atomics cannot carry an epilogue)
@@ -679,20 +1013,31 @@ extern "C" int asr_abi_version(void) { return ASR_ABI_VERSION; }
 #ifndef ASR_LSTM_BF3_DEFAULT
 #define ASR_LSTM_BF3_DEFAULT 7
 #endif
+#ifndef ASR_GEMM_WIDE_DEFAULT
+#define ASR_GEMM_WIDE_DEFAULT 1
+#endif
 static int& split_bf16_state() {
   static int mask = [] {
     const char* l = getenv("ASR_LSTM_BF3");
     const char* g = getenv("ASR_GEMM_BF3");
-    return ((l ? atoi(l) : ASR_LSTM_BF3_DEFAULT) & 7) | ((g ? atoi(g) : ASR_GEMM_BF3_DEFAULT) ? 8 : 0);
+    const char* w = getenv("ASR_GEMM_WIDE");
+    return ((l ? atoi(l) : ASR_LSTM_BF3_DEFAULT) & 7) | ((g ? atoi(g) : ASR_GEMM_BF3_DEFAULT) ? 8 : 0) |
+           ((w ? atoi(w) : ASR_GEMM_WIDE_DEFAULT) ? 16 : 0) | ((w && atoi(w) == 2) ? 32 : 0);
   }();
   return mask;
 }
 int asr_split_bf16_mask() { return split_bf16_state(); }
 extern "C" int asr_set_split_bf16(int mask) {
   const int old = split_bf16_state();
-  if (mask >= 0) split_bf16_state() = mask & 15;
+  if (mask >= 0) split_bf16_state() = mask & 63;
   return old;
 }
+
+#ifdef ASR_GW_TRACE
+extern "C" int asr_gw_trace_read(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(asr_gw_trace_buf), sizeof(unsigned long long) * 2 * 64 * 8);
+}
+#endif
 
 extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                             const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
@@ -718,6 +1063,50 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.bias = bias; g.relu = relu; g.accumulate = accumulate; g.split_k = split_k;
   g.sA = sA; g.sB = sB; g.sC = sC;
+  // wide-tile LDS-DMA kernel for conforming shapes (see gemm_bf3w_kernel); it picks its own K split: 256 workgroup
+  // slots (one 8-wave workgroup per CU), cost = rounds x (stages per slice + a fixed prologue / epilogue share)
+  // Where it is used (tools/gemm_shapes.py, cold operands, one cfg-2 step): the weight-gradient products (both operands
+  // row-contiguous, long K: 192 vs 258 us, 120 vs 153, 119 vs 156, 89 vs 111) and long-K projections with enough tiles
+  // for 256 CUs (109 vs 127 us); K = 512 projections and dX products time the same on both kernels (one 8-wave workgroup
+  // per CU cannot hide its prologue and its 128 KB of output behind another workgroup) and stay on the 128 x 128 one.
+  // Mask bit 32 (tests, measurements; ASR_GEMM_WIDE=2) sends every conforming shape here.
+  const bool wide_shape = M % WM == 0 && N % WN == 0 && K % WK == 0 && g.A.vec && g.B.vec && lda < (1 << 22) && ldb < (1 << 22);
+  const bool wide_all = (asr_split_bf16_mask() & 32) != 0;
+  const bool wide_pays = (!akc && !bkc && K >= 1024) || (akc && bkc && K >= 2048 && (M / WM) * (N / WN) * batch >= 192) || wide_all;
+  const bool wide = (asr_split_bf16_mask() & 24) == 24 && wide_shape && wide_pays;
+  if (wide) {
+    const int64_t tiles = (M / WM) * (N / WN) * batch, stages = K / WK;
+    int best = 1;
+    if (split_k > 1 || !(bias || relu)) {
+      double best_cost = 1e30;
+      for (int sk = 1; sk <= 16 && stages / sk >= 8; ++sk) {
+        const int64_t wgs = tiles * sk, rounds = (wgs + 255) / 256;
+        const double cost = (double)rounds * ((double)((stages + sk - 1) / sk) + 6.0) * (1.0 + 0.01 * (sk - 1));
+        if (cost < best_cost) { best_cost = cost; best = sk; }
+      }
+    }
+    const bool late = best > 1 && (bias_late || relu_late);
+    if (late && accumulate) return ASR_E_SHAPE;
+    if (late) { g.bias = nullptr; g.relu = 0; } else { g.bias = bias_late; g.relu = relu_late; }
+    g.split_k = best;
+    g.tiles_m = (int)(M / WM);
+    g.tiles_n = (int)(N / WN);
+    if (best > 1 && !accumulate) {
+      dim3 zg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
+      hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
+    }
+    dim3 grid(g.tiles_m * g.tiles_n, batch * best, 1), block(512);
+    if (akc && bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<true, true>), grid, block, 0, stream, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<true, false>), grid, block, 0, stream, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<false, true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm_bf3w_kernel<false, false>), grid, block, 0, stream, g);
+    if (late) {
+      dim3 eg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
+      hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, bias_late, relu_late);
+    }
+    ASR_CHECK_LAUNCH();
+    return 0;
+  }
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
   const int64_t ktiles = (K + BK - 1) / BK;

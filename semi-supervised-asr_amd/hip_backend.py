@@ -112,6 +112,8 @@ def load():
 
 
 SPLIT_LSTM_FWD, SPLIT_LSTM_BWD, SPLIT_LSTM_BWD_RS, SPLIT_GEMM = 1, 2, 4, 8
+SPLIT_GEMM_WIDE = 16      # with SPLIT_GEMM: the 256 x 128 LDS-DMA kernel (gemm_bf3w_kernel) for the shapes it pays on
+SPLIT_GEMM_WIDE_ALL = 32  # ... for every conforming shape (tests, measurements)
 
 
 def set_split_bf16(mask):

@@ -80,6 +80,42 @@ def test_gemm_step_shapes(ta, tb, M, N, K, split):
     _close(out, ref, rtol=3e-5 if split else 1e-5, atol=1e-4, what="%dx%dx%d" % (M, N, K))
 
 
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (256, 128, 64), (512, 256, 96), (256, 384, 4096), (1024, 128, 1024)])
+def test_gemm_wide_tile(ta, tb, M, N, K):
+    """The 256 x 128 LDS-DMA kernel (gemm_bf3w_kernel: conforming shapes of the split-bf16 arithmetic) in the four
+    operand layouts: 1, 2, 3 and many ring stages, its own K split (K = 4096 on few tiles), epilogue, accumulate, and
+    the same call with the kernel switched off (SPLIT_GEMM without SPLIT_GEMM_WIDE) giving the same numbers to 3e-5."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(M * 5 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    base = torch.randn(M, N, generator=g)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    tol = dict(rtol=3e-5, atol=1e-4)
+    for mode in (hb.SPLIT_GEMM | hb.SPLIT_GEMM_WIDE | hb.SPLIT_GEMM_WIDE_ALL, hb.SPLIT_GEMM | hb.SPLIT_GEMM_WIDE, hb.SPLIT_GEMM):
+        with hb.split_bf16(mode):
+            out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
+            _close(out, ref.float(), what="plain/%d" % mode, **tol)
+            out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, bias=bias.to(dev), relu=True)
+            _close(out, torch.relu(ref + bias).float(), what="bias+relu/%d" % mode, **tol)
+            out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, bias=bias.to(dev), relu=True, split_k=1)
+            _close(out, torch.relu(ref + bias).float(), what="bias+relu unsplit/%d" % mode, **tol)
+            out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb, out=base.to(dev), accumulate=True)
+            _close(out, (ref + base).float(), what="accumulate/%d" % mode, **tol)
+    # row-strided operands and output (views of wider buffers)
+    wideA = torch.randn((K, M + 64) if ta else (M, K + 64), generator=g).to(dev)
+    Av = wideA[:, 32:32 + M] if ta else wideA[:, 32:32 + K]
+    outw = torch.zeros(M, N + 32, device=dev)
+    with hb.split_bf16(hb.SPLIT_GEMM | hb.SPLIT_GEMM_WIDE | hb.SPLIT_GEMM_WIDE_ALL):
+        hb.gemm(Av, B.to(dev), trans_a=ta, trans_b=tb, out=outw[:, 16:16 + N])
+    refv = (Av.cpu().double().t() if ta else Av.cpu().double()) @ (B.double().t() if tb else B.double())
+    _close(outw[:, 16:16 + N], refv.float(), what="strided", **tol)
+    assert float(outw[:, :16].abs().max()) == 0.0 and float(outw[:, 16 + N:].abs().max()) == 0.0
+
+
 def test_gemm_strided_views_and_batched():
     dev = _gpu()
     import hip_backend as hb

@@ -19,7 +19,7 @@ def run(name,ta,tb,M,N,K,split):
     for _ in range(n): hb.gemm(A,B,trans_a=bool(ta),trans_b=bool(tb),out=out,split_k=sk)
     e1.record(); torch.cuda.synchronize(); ms=e0.elapsed_time(e1)/n
     print('%-16s M%6d N%5d K%6d split %2d  %8.1f us  %6.1f TF'%(name,M,N,K,sk,ms*1e3,2.0*M*N*K/ms/1e9),flush=True)
-for mode, name in ((8, 'split-bf16 products'), (0, 'fp32-input MFMA')):
+for mode, name in ((24, 'split-bf16 products, 256x128 LDS-DMA kernel where the shape conforms'), (8, 'split-bf16 products, 128x128 register-staged kernel'), (0, 'fp32-input MFMA')):
     hb.set_split_bf16((hb.set_split_bf16(-1) & 7) | mode)
     print('---', name)
     for s in shapes: run(*s)
