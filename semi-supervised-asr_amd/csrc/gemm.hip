@@ -587,7 +587,8 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
 //     q ^ ((r >> 1) & 7) of its row (the swizzle is applied to the SOURCE address of the DMA lane: the LDS side of a
 //     DMA is lane-linear), which makes the fragment's two ds_read_b128 conflict-free over the instruction's lane groups;
 //   row-contiguous operands ([K][rows]): a piece = one k (A) or two (B), image [k][rows], fragments by ds_read_b32.
-// Shapes: M % 256 == 0, N % 128 == 0, K % 32 == 0, 16-byte aligned rows; everything else stays on gemm_bf3_kernel.
+// Shapes: K % 32 == 0, 16-byte aligned rows, M and N free (edge tiles clamp their DMA sources and guard their stores);
+// everything else stays on gemm_bf3_kernel.
 constexpr int WM = 256, WN = 128, WK = 32;
 constexpr int W_A_FLOATS = WM * WK, W_B_FLOATS = WN * WK, W_STAGE_FLOATS = W_A_FLOATS + W_B_FLOATS, W_STAGES = 3;
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -642,7 +643,7 @@ __device__ __forceinline__ void bf3w_send(float* xs, const f32x16 (&acc)[4][2], 
       for (int e = 0; e < 16; ++e) xs[((b * 2 + j) * 16 + e) * 64 + lane] = acc[I0 + b][j][e];
 }
 
-template <int I0>
+template <int I0, bool EDGE>
 __device__ __forceinline__ void bf3w_finish(const float* xr, f32x16 (&acc)[4][2], const GemmArgs& g, float* C, int64_t mrow0,
                                             int64_t ncol0, int lane) {
   const int l31 = lane & 31, kh = lane >> 5;
@@ -653,24 +654,25 @@ __device__ __forceinline__ void bf3w_finish(const float* xr, f32x16 (&acc)[4][2]
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t n = ncol0 + j * 32 + l31;
-      const float bv = g.bias ? g.bias[n] : 0.f;
-      float* base = C + (mrow0 + (I0 + b) * 32 + 4 * kh) * g.ldc + n;
+      const int64_t mb = mrow0 + (I0 + b) * 32 + 4 * kh;
+      const bool nok = !EDGE || n < g.N;
+      const float bv = (g.bias && nok) ? g.bias[n] : 0.f;
+      float* base = C + mb * g.ldc + n;
       float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = acc[I0 + b][j][e] + xr[((b * 2 + j) * 16 + e) * 64 + lane];
-      if (split) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) atomicAdd(base + (unsigned)((e & 3) + 8 * (e >> 2)) * ldc, v[e]);
-      } else {
-        if (accum) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc];
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2);
+        if (EDGE && !(nok && mb + r < g.M)) continue;
+        float* dst = base + (unsigned)r * ldc;
+        if (split) {
+          atomicAdd(dst, v[e]);
+        } else {
           float o = v[e] + bv;
+          if (accum) o += *dst;
           if (relu) o = fmaxf(o, 0.f);
-          base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = o;
+          *dst = o;
         }
       }
     }
@@ -715,7 +717,9 @@ __global__ __launch_bounds__(512) void gemm_bf3w_kernel(GemmArgs g) {
   const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   const int l31 = lane & 31, kh = lane >> 5;
 
-  // ---- DMA source offsets of this lane (floats, relative to the tile's first row / column at the stage's first k)
+  // ---- DMA source offsets of this lane (floats, relative to the operand's first element at the stage's first k).  Rows
+  // and columns past the matrix edge are clamped to the last valid ones: what they deliver only reaches accumulator
+  // rows / columns that the guarded epilogue does not store.
   const int64_t lda = g.A.ld, ldb = g.B.ld;
   unsigned offa[4], offb[2];
 #pragma unroll
@@ -723,9 +727,11 @@ __global__ __launch_bounds__(512) void gemm_bf3w_kernel(GemmArgs g) {
     const int p = 4 * wave + q;
     if (AKC) {
       const int r = 8 * p + (lane >> 3);
-      offa[q] = (unsigned)(r * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
+      const int64_t row = m0 + r < g.M ? m0 + r : g.M - 1;
+      offa[q] = (unsigned)(row * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
     } else {
-      offa[q] = (unsigned)(p * lda + 4 * lane);
+      const int64_t col = m0 + 4 * lane + 4 <= g.M ? m0 + 4 * lane : g.M - 4;
+      offa[q] = (unsigned)(p * lda + col);
     }
   }
 #pragma unroll
@@ -733,13 +739,15 @@ __global__ __launch_bounds__(512) void gemm_bf3w_kernel(GemmArgs g) {
     const int p = 2 * wave + q;
     if (BKC) {
       const int r = 8 * p + (lane >> 3);
-      offb[q] = (unsigned)(r * ldb + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
+      const int64_t row = n0 + r < g.N ? n0 + r : g.N - 1;
+      offb[q] = (unsigned)(row * ldb + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
     } else {
-      offb[q] = (unsigned)((2 * p + (lane >> 5)) * ldb + 4 * (lane & 31));
+      const int64_t col = n0 + 4 * (lane & 31) + 4 <= g.N ? n0 + 4 * (lane & 31) : g.N - 4;
+      offb[q] = (unsigned)((2 * p + (lane >> 5)) * ldb + col);
     }
   }
-  const float* basea = AKC ? Ap + m0 * lda + kt_begin * WK : Ap + kt_begin * WK * lda + m0;
-  const float* baseb = BKC ? Bp + n0 * ldb + kt_begin * WK : Bp + kt_begin * WK * ldb + n0;
+  const float* basea = AKC ? Ap + kt_begin * WK : Ap + kt_begin * WK * lda;
+  const float* baseb = BKC ? Bp + kt_begin * WK : Bp + kt_begin * WK * ldb;
   const int64_t stepa = AKC ? WK : WK * lda, stepb = BKC ? WK : WK * ldb;
   auto issue = [&](int st, int buf) {
     float* sb = smem + buf * W_STAGE_FLOATS;
@@ -892,8 +900,13 @@ __global__ __launch_bounds__(512) void gemm_bf3w_kernel(GemmArgs g) {
   __syncthreads();
   const int64_t mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
   GW_COARSE(3);
-  if (kg == 0) bf3w_finish<0>(xr, acc, g, C, mrow0, ncol0, lane);
-  else bf3w_finish<2>(xr, acc, g, C, mrow0, ncol0, lane);
+  if (m0 + WM <= g.M && n0 + WN <= g.N) {
+    if (kg == 0) bf3w_finish<0, false>(xr, acc, g, C, mrow0, ncol0, lane);
+    else bf3w_finish<2, false>(xr, acc, g, C, mrow0, ncol0, lane);
+  } else {
+    if (kg == 0) bf3w_finish<0, true>(xr, acc, g, C, mrow0, ncol0, lane);
+    else bf3w_finish<2, true>(xr, acc, g, C, mrow0, ncol0, lane);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   GW_COARSE(4);
 }
@@ -1066,31 +1079,45 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   // wide-tile LDS-DMA kernel for conforming shapes (see gemm_bf3w_kernel); it picks its own K split: 256 workgroup
   // slots (one 8-wave workgroup per CU), cost = rounds x (stages per slice + a fixed prologue / epilogue share)
   // Where it is used (tools/gemm_shapes.py, cold operands, one cfg-2 step): the weight-gradient products (both operands
-  // row-contiguous, long K: 192 vs 258 us, 120 vs 153, 119 vs 156, 89 vs 111) and long-K projections with enough tiles
-  // for 256 CUs (109 vs 127 us); K = 512 projections and dX products time the same on both kernels (one 8-wave workgroup
-  // per CU cannot hide its prologue and its 128 KB of output behind another workgroup) and stay on the 128 x 128 one.
+  // row-contiguous, long K: 188 vs 263 us, 153 vs 227 (N = 80), 117 vs 154, 119 vs 158, 90 vs 112) and every K >= 2048
+  // product (dX = dG W_ih 215 vs 263 us unsplit, projections 114 vs 132); K = 512 projections time the same on both
+  // kernels or worse on this one (one 8-wave workgroup per CU cannot hide its prologue and its 128 KB of output behind
+  // another workgroup) and stay on the 128 x 128 kernel.
   // Mask bit 32 (tests, measurements; ASR_GEMM_WIDE=2) sends every conforming shape here.
-  const bool wide_shape = M % WM == 0 && N % WN == 0 && K % WK == 0 && g.A.vec && g.B.vec && lda < (1 << 22) && ldb < (1 << 22);
+  // any M, N (edge tiles clamp their DMA rows / columns and guard the stores); K % 32 == 0; row-contiguous operands need
+  // a multiple of 4 rows; per-lane offsets are 32-bit
+  const bool wide_shape = K % WK == 0 && g.A.vec && g.B.vec && (akc ? M : K) * lda < ((int64_t)1 << 31) &&
+                          (bkc ? N : K) * ldb < ((int64_t)1 << 31) && (akc || (M % 4 == 0 && M >= 4)) &&
+                          (bkc || (N % 4 == 0 && N >= 4)) && M >= 64 && N >= 64;
   const bool wide_all = (asr_split_bf16_mask() & 32) != 0;
-  const bool wide_pays = (!akc && !bkc && K >= 1024) || (akc && bkc && K >= 2048 && (M / WM) * (N / WN) * batch >= 192) || wide_all;
+  const int64_t wtiles = ((M + WM - 1) / WM) * ((N + WN - 1) / WN) * batch;
+  const bool may_split = split_k > 1 || !(bias || relu);
+  const bool wide_pays = (!akc && !bkc && K >= 1024) || (K >= 2048 && (may_split || wtiles >= 150)) || wide_all;
   const bool wide = (asr_split_bf16_mask() & 24) == 24 && wide_shape && wide_pays;
   if (wide) {
-    const int64_t tiles = (M / WM) * (N / WN) * batch, stages = K / WK;
+    const int64_t tiles = wtiles, stages = K / WK;
     int best = 1;
-    if (split_k > 1 || !(bias || relu)) {
+    if (may_split) {
       double best_cost = 1e30;
       for (int sk = 1; sk <= 16 && stages / sk >= 8; ++sk) {
         const int64_t wgs = tiles * sk, rounds = (wgs + 255) / 256;
-        const double cost = (double)rounds * ((double)((stages + sk - 1) / sk) + 6.0) * (1.0 + 0.01 * (sk - 1));
+        // in units of one stage (~1.7 us): rounds x (stages + prologue / epilogue share) + what the atomics and the zero pass
+        // of a split cost per MB of output (tools/gemm_wide_split.py: 12800 x 512 x 4096 takes 215 us unsplit on 200 of
+        // the 256 CUs, 256 us split in two)
+        const double out_mb = (double)M * N * batch * 4.0 / 1048576.0;
+        const double cost = (double)rounds * ((double)((stages + sk - 1) / sk) + 6.0) + (sk > 1 ? 0.47 * sk * out_mb : 0.0);
         if (cost < best_cost) { best_cost = cost; best = sk; }
       }
+    }
+    if (const char* f = getenv("ASR_GEMM_WIDE_SK")) {   // measurement: force the split
+      if (atoi(f) >= 1 && atoi(f) <= stages) best = atoi(f);
     }
     const bool late = best > 1 && (bias_late || relu_late);
     if (late && accumulate) return ASR_E_SHAPE;
     if (late) { g.bias = nullptr; g.relu = 0; } else { g.bias = bias_late; g.relu = relu_late; }
     g.split_k = best;
-    g.tiles_m = (int)(M / WM);
-    g.tiles_n = (int)(N / WN);
+    g.tiles_m = (int)((M + WM - 1) / WM);
+    g.tiles_n = (int)((N + WN - 1) / WN);
     if (best > 1 && !accumulate) {
       dim3 zg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
       hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);

@@ -51,6 +51,12 @@
 #define ASR_LSTM_FULL_WAVES 2      /* waves 0..1 hold the pointwise threads (PUC*PRG <= 128) */
 #endif
 // measurement only: shader-clock stamps of workgroup (group 0, slice 0), time steps 8..15, into ctrl[16..]
+#ifndef ASR_LA      /* measurement only: forward (bf3) chain ablation: 1 no products, 2 no h staging, 4 no stores / prefetch, 8 no transcendental math */
+#define ASR_LA 0
+#endif
+#ifndef ASR_RA      /* measurement only: backward (exchanged partials) chain ablation: 1 no reduction, 2 no stores / prefetch, 4 no dh products, 8 no tanh, 16 no h prefetch, 32 no dy / gates / c prefetch, 64 no dG store */
+#define ASR_RA 0
+#endif
 #ifdef ASR_LP_TRACE
 #define LP_MARK(k) do { if ((tid == 0 || tid == 448) && g == 0 && slice == 0 && s >= 8 && s < 16) \
     ((unsigned long long*)(a.ctrl + 16))[(tid ? 128 : 0) + (s - 8) * 16 + (k)] = clock64(); } while (0)
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       }
 #pragma unroll
       for (int kc = 0; kc < NKC; ++kc)
-        if (gl[kc]) {
+        if (gl[kc] && !(ASR_LA & 2)) {
 #pragma unroll
           for (int j = 0; j < NR / 4; ++j) {
             const float f[4] = {__uint_as_float(gw[kc][j].x), __uint_as_float(gw[kc][j].y), __uint_as_float(gw[kc][j].z),
@@ -543,16 +549,16 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
             }
           }
         }
-      if (st_gp) {                    // previous step's outputs (stores after the poll: vmcnt retires in order)
+      if (st_gp && !(ASR_LA & 4)) {   // previous step's outputs (stores after the poll: vmcnt retires in order)
         *st_gp = st_g;
         a.c[st_so] = st_c;
         a.y[st_so] = st_y;
         st_gp = nullptr;
       }
-      if (prow_ok && s + 2 < T) gx_n2 = *gx_ptr(s + 2);     // in flight for two steps
+      if (prow_ok && s + 2 < T && !(ASR_LA & 4)) gx_n2 = *gx_ptr(s + 2);     // in flight for two steps
       // (wave-private LDS tile: program order within the wave is enough)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < ((ASR_LA & 1) ? 0 : KS); ++ks) {
         const u32x4 bh = *reinterpret_cast<const u32x4*>(&hhi[wave][ml & 7][32 * ks + 8 * kq]);
         const u32x4 bl = *reinterpret_cast<const u32x4*>(&hlo[wave][ml & 7][32 * ks + 8 * kq]);
 #pragma unroll
@@ -1239,7 +1245,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   using RD = RsDims<PH>;
   constexpr int PUC = RD::PUC, NC = RD::NC, KS = RD::KS, MTW = RD::MTW, CT = RD::CT, UPW = RD::UPW, CPW = RD::CPW;
   constexpr int QPU = RD::QPU, GST = RD::GST;
-  constexpr int NE = (CPW + 1) / 2;               // quads per lane in the gather
+  constexpr int NE = 2;                           // quads per lane in the gather: two sources of one (row, unit quad)
   __shared__ __attribute__((aligned(16))) unsigned short dgr_hi[PRG][GST], dgr_lo[PRG][GST];   // local dG, [row][col]
   // operands of the dW_hh product, four time-step slots of 8 rows each = K = 32 of one v_mfma_f32_16x16x32_bf16:
   // local dG [col][slot][row] and h_{t_prev} [unit][slot][row]; step s lives in slot s & 3 (see the dW_hh block)
@@ -1299,8 +1305,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
   bool aborted = false;
   const bool fuse_dw = a.dw != nullptr && a.yfwd != nullptr;
-  // gather role: half wave hf sums the 32 sources (lane & 31) of combo CPW wave + hf + 2 e = (row, unit quad)
-  const int hf = lane >> 5, src = lane & 31;
+  // gather role: the 16 lanes of DPP row rr = lane >> 4 sum the 32 sources of combo CPW wave + rr = (row, unit quad), two
+  // sources (2 sp, 2 sp + 1) per lane: one add and a 16-lane DPP reduction per value.  (With one source per lane and 32
+  // lanes per combo the two DPP rows had to be joined through v_readlane: 0.29 us of the 2.52 us step, tools/persist_bench.py
+  // with -DASR_RA=1.)
+  const int rr = lane >> 4, sp = lane & 15;
   // h_{t_prev} loader: lane l < UPW of wave w owns unit UPW w + l (this wave's own dW unit tiles: wave-private LDS rows)
   const bool h_lane = fuse_dw && lane < UPW;
   const int hunit = UPW * wave + (lane < UPW ? lane : 0);
@@ -1323,14 +1332,20 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   // forward hidden state at the time that fed step sn's time.  Bare loads from clamped addresses: nothing may touch a
   // loaded value here (a select right after the load makes hipcc wait for it on the spot: an HBM round trip on the
   // serial chain); rows / times that do not exist are zeroed when the registers are staged (stage_h).
+  // Addressing: one per-lane byte offset (its unit) + a scalar offset per row and step through a buffer resource whose base
+  // is the time slab - eight bare buffer loads.  With per-lane 64-bit pointers hipcc spent ~10 VALU instructions (64-bit
+  // multiply-adds) in front of every load: 0.23 us of the 2.30 us step (tools/persist_bench.py, -DASR_RA=16).
+  const unsigned h_voff = (unsigned)(d * PH + hunit) * 4u;
   auto fetch_h = [&](int sn) {
     const int tt = time_of(sn);
     const int ttp = d == 0 ? tt - 1 : tt + 1;
     const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
+    const float* slab = a.yfwd + (int64_t)(hp ? ttp : tt) * B * ldy;
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(slab), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int row = r0 + r < a.nb ? r0 + r : r0;
-      n_h[r] = a.yfwd[((int64_t)(hp ? ttp : tt) * B + row) * ldy + d * PH + hunit];
+      n_h[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hrs, h_voff, (unsigned)(row * ldy) * 4u, 0));
     }
   };
   auto stage_h = [&](int buf, int sn) {  // n_h (fetched for step sn) -> this lane's unit, slot buf of ht_hi / ht_lo
@@ -1354,16 +1369,12 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   };
   // gather descriptors (loop invariant): byte offset of this lane's quads in parity 0, and whether they exist
   unsigned goff[NE];
-  bool use[NE];
-  int grow[NE], guq[NE];
+  const int gcombo = CPW * wave + (rr < CPW ? rr : 0);
+  const int grow = gcombo / QPU, guq = gcombo - grow * QPU;
+  const bool guse = rr < CPW && grow < NR && r0 + grow < a.nb;
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int kk = hf + 2 * e;
-    const int c = CPW * wave + (kk < CPW ? kk : 0);
-    grow[e] = c / QPU; guq[e] = c - grow[e] * QPU;
-    use[e] = kk < CPW && grow[e] < NR && r0 + grow[e] < a.nb;
-    goff[e] = (unsigned)((xg - reinterpret_cast<float*>(a.xch)) + ((slice * 32 + src) * PRG + grow[e]) * PUC + 4 * guq[e]) * 4u;
-  }
+  for (int e = 0; e < NE; ++e)
+    goff[e] = (unsigned)((xg - reinterpret_cast<float*>(a.xch)) + ((slice * 32 + 2 * sp + e) * PRG + grow) * PUC + 4 * guq) * 4u;
   u32x4 q[NE];
   bool q_inflight = false;            // q holds an attempt issued in the middle of the previous step's dW_hh block
   if (prow_ok) {
@@ -1414,7 +1425,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         }
         q_inflight = false;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) ok = ok && (!use[e] || quad_ok(q[e], tb));
+        for (int e = 0; e < NE; ++e) ok = ok && (!guse || quad_ok(q[e], tb));
         if (__all(ok)) break;
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
           if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
@@ -1424,29 +1435,20 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
       LP_MARK(1);
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        float v[4] = {__uint_as_float(q[e].x), __uint_as_float(q[e].y), __uint_as_float(q[e].z), __uint_as_float(q[e].w)};
-        if (!use[e]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+      if (!(ASR_RA & 1)) {
+        float v[4] = {__uint_as_float(q[0].x) + __uint_as_float(q[1].x), __uint_as_float(q[0].y) + __uint_as_float(q[1].y),
+                      __uint_as_float(q[0].z) + __uint_as_float(q[1].z), __uint_as_float(q[0].w) + __uint_as_float(q[1].w)};
         row16_sum4(v);                               // every lane of a 16-lane row holds the row's total
-        float tot[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int vi = __builtin_bit_cast(int, v[i]);
-          const float lo16 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
-          const float hi16 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
-          tot[i] = v[i] + (hf ? hi16 : lo16);
-        }
-        if (src == 0 && hf + 2 * e < CPW) *reinterpret_cast<float4*>(&dhs[grow[e]][4 * guq[e]]) = make_float4(tot[0], tot[1], tot[2], tot[3]);
+        if (sp == 0 && guse) *reinterpret_cast<float4*>(&dhs[grow][4 * guq]) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    if (st_gp) {                         // previous step's dG (bulk store after the poll: vmcnt retires in order)
+    if (st_gp && !(ASR_RA & (2 | 64))) { // previous step's dG (bulk store after the poll: vmcnt retires in order)
       *st_gp = st_da;
       st_gp = nullptr;
     }
     // prefetches: right after the poll, i.e. as far ahead of the next one as possible
-    if (prow_ok && s + 2 < T) fetch_step(s + 2, n2_dy, n2_ct, n2_av);
-    if (h_lane && s + 2 < T) fetch_h(s + 2);
+    if (prow_ok && s + 2 < T && !(ASR_RA & (2 | 32))) fetch_step(s + 2, n2_dy, n2_ct, n2_av);
+    if (h_lane && s + 2 < T && !(ASR_RA & (2 | 16))) fetch_h(s + 2);
     LP_MARK(2);
     __syncthreads();                                                                                     // A
     LP_MARK(3);
@@ -1455,7 +1457,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pw_thread) {
         const float dh = dyv + (s > 0 ? dhs[pj][pu] : 0.f);
-        const float tc = asr_fast_tanh(ct_);
+        const float tc = (ASR_RA & 8) ? ct_ * 0.1f : asr_fast_tanh(ct_);
         const float dc = dcarry + dh * av.w * (1.f - tc * tc);
         da.x = dc * av.z * av.x * (1.f - av.x);
         da.y = dc * cp * av.y * (1.f - av.y);
@@ -1494,7 +1496,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < ((ASR_RA & 4) ? 0 : KS); ++ks) {
         const u32x4 bh = *reinterpret_cast<const u32x4*>(&dgr_hi[ml & 7][32 * ks + 8 * kq]);
         const u32x4 bl = *reinterpret_cast<const u32x4*>(&dgr_lo[ml & 7][32 * ks + 8 * kq]);
 #pragma unroll

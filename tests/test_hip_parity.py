@@ -81,11 +81,13 @@ def test_gemm_step_shapes(ta, tb, M, N, K, split):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (256, 128, 64), (512, 256, 96), (256, 384, 4096), (1024, 128, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (256, 128, 64), (512, 256, 96), (256, 384, 4096), (1024, 128, 1024),
+                                   (300, 80, 64), (1000, 200, 512), (64, 64, 32), (4096, 80, 3200), (3232, 1152, 2048)])
 def test_gemm_wide_tile(ta, tb, M, N, K):
-    """The 256 x 128 LDS-DMA kernel (gemm_bf3w_kernel: conforming shapes of the split-bf16 arithmetic) in the four
-    operand layouts: 1, 2, 3 and many ring stages, its own K split (K = 4096 on few tiles), epilogue, accumulate, and
-    the same call with the kernel switched off (SPLIT_GEMM without SPLIT_GEMM_WIDE) giving the same numbers to 3e-5."""
+    """The 256 x 128 LDS-DMA kernel (gemm_bf3w_kernel: K % 32 == 0 shapes of the split-bf16 arithmetic) in the four
+    operand layouts: 1, 2, 3 and many ring stages, its own K split (long K on few tiles), edge tiles in M and N (clamped
+    DMA sources, guarded stores; the thin N = 80 weight gradient and the decoder's M = 3232), epilogue, accumulate, and
+    the same call under the shipping policy and with the kernel off giving the same numbers to 3e-5."""
     dev = _gpu()
     import hip_backend as hb
     g = torch.Generator().manual_seed(M * 5 + N * 3 + K)
