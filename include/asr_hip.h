@@ -333,6 +333,18 @@ int asr_lstm_pack_f32(int H, int I, int ndir, const float* const* w_ih, const fl
                       float* bias, asr_stream_t stream);
 int asr_lstm_unpack_f32(int H, int I, int ndir, const float* dw_ih_cat, const float* dw_hh_il, const float* db_il,
                         float* const* dw_ih, float* const* dw_hh, float* const* db, asr_stream_t stream);
+/* as asr_lstm_unpack_f32, with an optional second set of bias-gradient outputs (db2[d], may be NULL): nn.LSTM has two
+ * bias vectors per direction that receive the same gradient, and autograd would otherwise copy the shared tensor. */
+int asr_lstm_unpack2_f32(int H, int I, int ndir, const float* dw_ih_cat, const float* dw_hh_il, const float* db_il,
+                         float* const* dw_ih, float* const* dw_hh, float* const* db, float* const* db2,
+                         asr_stream_t stream);
+
+/* Teacher-forced decoder input in one launch (model.py:301-306,337: pad_list + embedding + dropout of the decoder input):
+ * X [L+1][B][D+O+E] = [0 | 0 | emb_w[tokens[b][s]]] (slab L all zero), Xd (nullable) the same with xmask
+ * [L][B][O+E] applied to the embedding part, fed [L][B] = tokens[b][s].  tokens: int64, element (b, s) at
+ * tokens[b * tok_row_stride + s].  (D+O) % 4 == 0, E % 4 == 0, 16-byte aligned buffers. */
+int asr_dec_prepare_f32(int L, int B, int D, int O, int E, const long long* tokens, int64_t tok_row_stride,
+                        const float* emb_w, const float* xmask, float* X, float* Xd, long long* fed, asr_stream_t stream);
 int asr_cell_pack_f32(int D, int O, int E, const float* w_ih, const float* w_hh, const float* b_ih,
                       const float* b_hh, float* wcat, float* bcat, asr_stream_t stream);
 int asr_cell_unpack_f32(int D, int O, int E, const float* dwcat, const float* db_il, float* dw_ih, float* dw_hh,

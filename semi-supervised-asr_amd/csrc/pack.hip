@@ -39,6 +39,7 @@ struct LstmUnpackArgs {
   float* dw_ih[2];
   float* dw_hh[2];
   float* db[2];
+  float* db2[2];            // optional second copy of the bias gradient (b_ih and b_hh receive the same values)
 };
 
 // grid = ndir*4H (one torch-layout row each)
@@ -52,7 +53,11 @@ __global__ void lstm_unpack_kernel(LstmUnpackArgs a) {
   const float* sh = a.dw_hh_il + ((int64_t)d * 4 * H + ri) * H;
   float* oh = a.dw_hh[d] + (int64_t)rt * H;
   for (int k = threadIdx.x; k < H; k += blockDim.x) oh[k] = sh[k];
-  if (threadIdx.x == 0) a.db[d][rt] = a.db_il[d * 4 * H + ri];
+  if (threadIdx.x == 0) {
+    const float v = a.db_il[d * 4 * H + ri];
+    a.db[d][rt] = v;
+    if (a.db2[d]) a.db2[d][rt] = v;
+  }
 }
 
 // decoder cell: wcat[u*4+g] = [w_hh[src][0:D] | w_ih[src][E:E+O] | w_ih[src][0:E]], bcat = b_ih + b_hh
@@ -103,9 +108,9 @@ extern "C" int asr_lstm_pack_f32(int H, int I, int ndir, const float* const* w_i
   return 0;
 }
 
-extern "C" int asr_lstm_unpack_f32(int H, int I, int ndir, const float* dw_ih_cat, const float* dw_hh_il,
-                                   const float* db_il, float* const* dw_ih, float* const* dw_hh, float* const* db,
-                                   asr_stream_t stream) {
+extern "C" int asr_lstm_unpack2_f32(int H, int I, int ndir, const float* dw_ih_cat, const float* dw_hh_il,
+                                    const float* db_il, float* const* dw_ih, float* const* dw_hh, float* const* db,
+                                    float* const* db2, asr_stream_t stream) {
   if (H <= 0 || I <= 0 || (ndir != 1 && ndir != 2) || !dw_ih_cat || !dw_hh_il || !db_il || !dw_ih || !dw_hh || !db)
     return ASR_E_ARG;
   LstmUnpackArgs a;
@@ -114,8 +119,59 @@ extern "C" int asr_lstm_unpack_f32(int H, int I, int ndir, const float* dw_ih_ca
     const int s = d < ndir ? d : 0;
     if (!dw_ih[s] || !dw_hh[s] || !db[s]) return ASR_E_ARG;
     a.dw_ih[d] = dw_ih[s]; a.dw_hh[d] = dw_hh[s]; a.db[d] = db[s];
+    a.db2[d] = db2 ? db2[s] : nullptr;
   }
   hipLaunchKernelGGL(lstm_unpack_kernel, dim3(ndir * 4 * H), dim3(128), 0, (hipStream_t)stream, a);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int asr_lstm_unpack_f32(int H, int I, int ndir, const float* dw_ih_cat, const float* dw_hh_il,
+                                   const float* db_il, float* const* dw_ih, float* const* dw_hh, float* const* db,
+                                   asr_stream_t stream) {
+  return asr_lstm_unpack2_f32(H, I, ndir, dw_ih_cat, dw_hh_il, db_il, dw_ih, dw_hh, db, nullptr, stream);
+}
+
+// teacher-forced decoder input: X[s][b] = [0 (z_{s-1}, ctx_{s-1}: written by the recurrence) | emb[tok[b][s]]], Xd = X with
+// the dropout mask on the embedding part, fed[s][b] = tok[b][s]; slab L (the recurrence's last z / ctx) all zero.
+// One launch for what was two fills, a transpose copy, a gather, a multiply and two strided copies (model.py:301-306, 337).
+__global__ void dec_prepare_kernel(int L, int B, int DO4, int E4, const long long* __restrict__ tok, int64_t tok_rs,
+                                   const float4* __restrict__ emb, const float* __restrict__ xmask, int OE,
+                                   float4* __restrict__ X, float4* __restrict__ Xd, long long* __restrict__ fed) {
+  const int KX4 = DO4 + E4;
+  const int64_t n = (int64_t)(L + 1) * B * KX4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % KX4);
+    const int64_t sb = i / KX4;
+    const int b = (int)(sb % B), s = (int)(sb / B);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), vd = v;
+    if (c4 >= DO4 && s < L) {
+      const long long t = tok[(int64_t)b * tok_rs + s];
+      const int e4 = c4 - DO4;
+      v = emb[t * E4 + e4];
+      vd = v;
+      if (xmask) {
+        const float4 m = *reinterpret_cast<const float4*>(xmask + sb * OE + (OE - 4 * E4) + 4 * e4);
+        vd = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+      }
+      if (e4 == 0) fed[sb] = t;
+    }
+    X[i] = v;
+    if (Xd) Xd[i] = vd;
+  }
+}
+
+extern "C" int asr_dec_prepare_f32(int L, int B, int D, int O, int E, const long long* tokens, int64_t tok_row_stride,
+                                   const float* emb_w, const float* xmask, float* X, float* Xd, long long* fed,
+                                   asr_stream_t stream) {
+  if (L <= 0 || B <= 0 || D <= 0 || O < 0 || E <= 0 || !tokens || !emb_w || !X || !fed) return ASR_E_ARG;
+  if ((D + O) % 4 || E % 4 || (xmask && (O + E) % 4)) return ASR_E_SHAPE;
+  if (!asr_aligned16(emb_w) || !asr_aligned16(X) || (Xd && !asr_aligned16(Xd)) || (xmask && !asr_aligned16(xmask))) return ASR_E_ALIGN;
+  const int64_t n = (int64_t)(L + 1) * B * ((D + O + E) / 4);
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(dec_prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, B, (D + O) / 4, E / 4, tokens,
+                     tok_row_stride, reinterpret_cast<const float4*>(emb_w), xmask, O + E, reinterpret_cast<float4*>(X),
+                     reinterpret_cast<float4*>(Xd), fed);
   ASR_CHECK_LAUNCH();
   return 0;
 }

@@ -19,7 +19,7 @@ EXPORTS = (
     "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
-    "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
+    "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
@@ -103,6 +103,8 @@ def load():
     pp = ctypes.POINTER(c_p)
     lib.asr_lstm_pack_f32.argtypes = [c_i, c_i, c_i, pp, pp, pp, pp, c_p, c_p, c_p, c_p]
     lib.asr_lstm_unpack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, pp, pp, pp, c_p]
+    lib.asr_lstm_unpack2_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, pp, pp, pp, pp, c_p]
+    lib.asr_dec_prepare_f32.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_cell_pack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_cell_unpack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]
     if lib.asr_abi_version() != ABI_VERSION:
@@ -400,16 +402,29 @@ def lstm_pack(params, ndir, w_ih_cat, w_hh_il, bias):
           "asr_lstm_pack_f32")
 
 
-def lstm_unpack(H, I, ndir, dw_ih_cat, dw_hh_il, db_il):
-    """Interleaved gradients -> [dw_ih, dw_hh, db] per direction in torch layout (one launch)."""
+def lstm_unpack(H, I, ndir, dw_ih_cat, dw_hh_il, db_il, two_biases=False):
+    """Interleaved gradients -> [dw_ih, dw_hh, db] per direction in torch layout (one launch).  two_biases: also a second,
+    independent copy of every bias gradient (for b_hh: autograd clones a tensor returned for two parameters)."""
     dev = dw_ih_cat.device
     f32 = dict(device=dev, dtype=torch.float32)
     dw_ih = [torch.empty(4 * H, I, **f32) for _ in range(ndir)]
     dw_hh = [torch.empty(4 * H, H, **f32) for _ in range(ndir)]
     db = [torch.empty(4 * H, **f32) for _ in range(ndir)]
-    check(load().asr_lstm_unpack_f32(H, I, ndir, ptr(dw_ih_cat), ptr(dw_hh_il), ptr(db_il), _ptr_array(dw_ih),
-                                     _ptr_array(dw_hh), _ptr_array(db), stream()), "asr_lstm_unpack_f32")
-    return dw_ih, dw_hh, db
+    db2 = [torch.empty(4 * H, **f32) for _ in range(ndir)] if two_biases else None
+    check(load().asr_lstm_unpack2_f32(H, I, ndir, ptr(dw_ih_cat), ptr(dw_hh_il), ptr(db_il), _ptr_array(dw_ih),
+                                      _ptr_array(dw_hh), _ptr_array(db), _ptr_array(db2) if two_biases else None, stream()),
+          "asr_lstm_unpack2_f32")
+    return (dw_ih, dw_hh, db, db2) if two_biases else (dw_ih, dw_hh, db)
+
+
+def dec_prepare(tokens, emb_w, xmask, X, Xd, fed, L, B, D, O, E):
+    """Teacher-forced decoder input (embedding gather into X / Xd, zero recurrent slots, fed = tokens^T) in one launch.
+    tokens [B, >= L] int64 on the device (row stride free)."""
+    assert tokens.dtype == torch.long and tokens.is_cuda and tokens.stride(1) == 1 and tokens.shape[1] >= L
+    assert X.is_contiguous() and (Xd is None or Xd.is_contiguous()) and fed.is_contiguous() and emb_w.is_contiguous()
+    check(load().asr_dec_prepare_f32(L, B, D, O, E, c_p(tokens.data_ptr()), tokens.stride(0), ptr(emb_w),
+                                     ptr(xmask) if xmask is not None else None, ptr(X), ptr(Xd) if Xd is not None else None,
+                                     c_p(fed.data_ptr()), stream()), "asr_dec_prepare_f32")
 
 
 def cell_pack(w_ih, w_hh, b_ih, b_hh, D, O, E, wcat, bcat):

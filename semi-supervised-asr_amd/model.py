@@ -110,7 +110,10 @@ class pBLSTM(torch.nn.Module):
         drop = self.training and self.dropout_rate > 0
         for i, (layer, proj) in enumerate(zip(self.layers, self.project_layers)):
             steps = max(lens) if total_length is None else int(total_length[i])
-            x = x[:steps].contiguous()
+            if steps != x.shape[0]:                                 # (a no-op slice still records a SliceBackward:
+                x = x[:steps]                                      #  a zero fill + a copy per layer in the backward)
+            if not x.is_contiguous():
+                x = x.contiguous()
             lens_dev = lens_all[i]
             y = ops.lstm_layer(x, lens_dev, layer.direction_params(0), 2)      # [T,B,2H]
             mask = _drop_mask(y.shape, self.dropout_rate, dev) if drop else None

@@ -179,10 +179,10 @@ class _LstmLayer(torch.autograd.Function):
                 else:
                     ws["dw_hh"][d].zero_()
         # gate-interleaved gradients -> torch layout, one launch
-        g_ih, g_hh, g_b = hb.lstm_unpack(H, I, ndir, dw_ih, ws["dw_hh"], db)
+        g_ih, g_hh, g_b, g_b2 = hb.lstm_unpack(H, I, ndir, dw_ih, ws["dw_hh"], db, two_biases=True)
         grads = []
         for d in range(ndir):
-            grads += [g_ih[d], g_hh[d], g_b[d], g_b[d]]
+            grads += [g_ih[d], g_hh[d], g_b[d], g_b2[d]]
         lease.release()
         return (dx, None, None, None) + tuple(grads)
 
@@ -320,9 +320,6 @@ class _DecoderSeq(torch.autograd.Function):
         if drop:
             ws["xmask"] = xmask_in.contiguous()
         X, Xd, xmask = ws["X"], ws["Xd"], ws["xmask"]
-        X.zero_()
-        if drop:
-            Xd.zero_()
         wdec_c, watt_c, bo_c, w_out_c = wdec.contiguous(), watt.contiguous(), bo.contiguous(), w_out.contiguous()
         d = dict(B=B, Tp=Tp, A=A, D=D, O=O, E=E, C=C, K=K, L=L, KX=KX, scaling=float(opts.get("scaling", 2.0)),
                  bo=bo_c, wdec=wdec_c, watt=watt_c)
@@ -334,13 +331,23 @@ class _DecoderSeq(torch.autograd.Function):
         smooth = bool(opts.get("smooth", False))
         sample = bool(opts.get("sample", False))
         all_teacher = tokens is not None and (tf_flags is None or all(tf_flags)) and not sample
-        fed = torch.zeros(L, B, dtype=torch.long, device=dev)       # token whose embedding fed step s (-1: smooth)
+        fused_prep = (all_teacher and (D + O) % 4 == 0 and E % 4 == 0 and (O + E) % 4 == 0 and X.shape[0] == L + 1 and
+                      X.is_contiguous() and tokens.stride(1) == 1)
         probs_saved = []
-        if all_teacher:
-            fed.copy_(tokens.t())
-            X[:L, :, D + O:] = emb_w[fed]
+        if fused_prep:                           # zero fills, embedding gather, input dropout, fed: one launch
+            fed = torch.empty(L, B, dtype=torch.long, device=dev)
+            hb.dec_prepare(tokens, emb_w.contiguous(), xmask if drop else None, X, Xd if drop else None, fed, L, B, D, O, E)
+        else:
+            fed = torch.zeros(L, B, dtype=torch.long, device=dev)   # token whose embedding fed step s (-1: smooth)
+            X.zero_()
             if drop:
-                Xd[:L, :, D + O:] = X[:L, :, D + O:] * xmask[:, :, O:]
+                Xd.zero_()
+        if all_teacher:
+            if not fused_prep:
+                fed.copy_(tokens.t())
+                X[:L, :, D + O:] = emb_w[fed]
+                if drop:
+                    Xd[:L, :, D + O:] = X[:L, :, D + O:] * xmask[:, :, O:]
             groups = hb.row_groups(B)
             done = False
             if hb.USE_PERSIST_DEC and len(groups) == 1:          # one launch for the whole sequence

@@ -64,7 +64,7 @@ def _run_big(golden_dir, name, shape, dec_bwd_persistent=True):
     # ---- forward
     assert enc_lens == g["enc_lens"].tolist()
     assert _rel(enc_h[0], g["enc_h_b0"]) < RTOL and _rel(enc_h[-1], g["enc_h_blast"]) < RTOL
-    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])), (float(loss.detach()), float(g["loss"]))
     assert _rel(lp, g["lp"]) < RTOL
     assert _rel(logits[:, :4], g["logits_head"]) < RTOL and _rel(logits[:, -2:], g["logits_tail"]) < RTOL
     half = ws.size(1) // 2

@@ -822,6 +822,31 @@ def test_label_logprob_kernels(V, ls):
     _close(g_got, ref_in.grad, rtol=1e-5, atol=1e-6, what="d(logits)")
 
 
+@pytest.mark.parametrize("drop", [False, True])
+def test_dec_prepare_matches_torch(drop):
+    """asr_dec_prepare_f32 (teacher-forced decoder input in one launch) against the torch ops it replaces: embedding
+    gather of the transposed tokens, dropout mask on the embedding part, zero recurrent slots, zero last slab."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(11)
+    L, B, D, O, E, V = 7, 5, 16, 12, 8, 11
+    KX = D + O + E
+    tokens = torch.randint(0, V, (B, L + 3), generator=g)[:, :L].to(dev)          # row-strided view
+    emb = torch.randn(V, E, generator=g).to(dev)
+    xmask = ((torch.rand(L, B, O + E, generator=g) > 0.3).float() / 0.7).to(dev) if drop else None
+    X = torch.full((L + 1, B, KX), 7.0, device=dev)
+    Xd = torch.full((L + 1, B, KX), 7.0, device=dev) if drop else None
+    fed = torch.empty(L, B, dtype=torch.long, device=dev)
+    hb.dec_prepare(tokens, emb, xmask, X, Xd, fed, L, B, D, O, E)
+    want = torch.zeros(L + 1, B, KX, device=dev)
+    want[:L, :, D + O:] = emb[tokens.t()]
+    assert torch.equal(fed, tokens.t()) and torch.equal(X, want)
+    if drop:
+        wd = want.clone()
+        wd[:L, :, D + O:] *= xmask[:, :, O:]
+        assert torch.equal(Xd, wd)
+
+
 @pytest.mark.parametrize("H,I,ndir", [(16, 12, 2), (128, 80, 2), (32, 32, 1)])
 def test_lstm_pack_unpack_roundtrip(H, I, ndir):
     """asr_lstm_pack_f32 produces the gate-interleaved layout (row = unit*4 + gate) and asr_lstm_unpack_f32 inverts it."""
