@@ -254,9 +254,11 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     Two kernels compete for "dominant by total time per step" (profiles/*_bench_kernel_stats*.csv), so both are
     replayed on synthetic operands of the step's exact shapes and the one with the larger per-step total is reported
     as the roofline (the other goes to `also`):
-      * lstm_persist_bwd_kernel<H>: one launch per encoder layer and row block; algorithmic flops per time step =
+      * lstm_persist_bwd_rs_kernel<H> (lstm_persist_bwd_kernel<H> where the exchanged-partials form does not apply): one
+        launch per encoder layer and row block; algorithmic flops per time step =
         2*B*4H*H*ndir for dh_rec = dG W_hh plus the same again for the fused dW_hh += dG^T h.
-      * gemm_f32_kernel<false,false>: the transA f32-MFMA GEMMs that form the remaining weight gradients.
+      * gemm_bf3w_kernel<false,false> (gemm_bf3_kernel / gemm_f32_kernel with the wide tile or the split products switched
+        off): the transA GEMMs that form the remaining weight gradients.
     `achieved` = algorithmic flops of those launches / their total time; us_per_launch is directly comparable with
     rocprofv3's average duration for that kernel name."""
     import hip_backend as hb
@@ -284,8 +286,8 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     del bufs
     split = hb.set_split_bf16(-1)
     gpeak = MFMA_SPLIT_PEAK_TF if split & hb.SPLIT_GEMM else MFMA_F32_PEAK_TF
-    gemm = dict(bound="mfma", kernel="gemm_%s_kernel<false,false> (transA weight-gradient GEMMs of one step)"
-                                     % ("bf3" if split & hb.SPLIT_GEMM else "f32"),
+    gname = "gemm_f32_kernel" if not split & hb.SPLIT_GEMM else ("gemm_bf3w_kernel" if split & hb.SPLIT_GEMM_WIDE else "gemm_bf3_kernel")
+    gemm = dict(bound="mfma", kernel="%s<false,false> (transA weight-gradient GEMMs of one step)" % gname,
                 achieved=gemm_flops / gemm_s / 1e12, peak=gpeak, unit="TFLOP/s",
                 frac=gemm_flops / gemm_s / 1e12 / gpeak, frac_f32_mfma_peak=gemm_flops / gemm_s / 1e12 / MFMA_F32_PEAK_TF,
                 traffic=None, launches_per_step=len(shapes),

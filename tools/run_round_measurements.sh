@@ -10,4 +10,5 @@ timeout -k 10 300 python bench.py --config cfg1 > $O/bench_cfg1.json 2> $O/bench
 timeout -k 10 300 python bench.py --config cfg5 > $O/bench_cfg5.json 2> $O/bench_cfg5.err && tail -1 $O/bench_cfg5.err &&
 timeout -k 10 300 python bench.py --scaling strong --global-batch 256 --steps 5 --warmup 2 --no-cpu-baseline --no-layer-gemms > $O/bench_strong_n1.json 2> $O/bench_strong.err && tail -1 $O/bench_strong.err &&
 (cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o r2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-layer-gemms > $O/prof.log 2>&1; python3 tools/db_to_stats.py $O/prof/r2_results.db $O/kernel_stats.csv) &&
-(cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o f -- python3 tools/pmc_probe.py > $O/pmc_f.log 2>&1; timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o w -- python3 tools/pmc_probe.py > $O/pmc_w.log 2>&1; ls $O/pmc_f $O/pmc_w)
+(cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o f -- python3 tools/pmc_probe.py > $O/pmc_f.log 2>&1; timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o w -- python3 tools/pmc_probe.py > $O/pmc_w.log 2>&1; python3 tools/pmc_summary.py $O/pmc_f/f_counter_collection.csv $O/pmc_w/w_counter_collection.csv $O/r02_pmc_lstm_persist.json > $O/pmc_summary.log 2>&1; tail -3 $O/pmc_summary.log) &&
+(python3 tools/timeline.py $O/prof/r2_results.db > $O/timeline.txt 2>&1; tail -1 $O/timeline.txt; timeout -k 10 300 python3 tools/gemm_shapes.py > $O/gemm_shapes.txt 2>&1; tail -1 $O/gemm_shapes.txt; timeout -k 10 200 python3 tools/persist_bench.py 400 > $O/persist_bench.txt 2>&1; tail -1 $O/persist_bench.txt; timeout -k 10 300 python3 tools/workload_times.py > $O/workload_times.log 2>&1; tail -3 $O/workload_times.log)
