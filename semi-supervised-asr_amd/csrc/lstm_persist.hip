@@ -54,7 +54,17 @@
 #ifndef ASR_LA      /* measurement only: forward (bf3) chain ablation: 1 no products, 2 no h staging, 4 no stores / prefetch, 8 no transcendental math */
 #define ASR_LA 0
 #endif
-#ifndef ASR_RA      /* measurement only: backward (exchanged partials) chain ablation: 1 no reduction, 2 no stores / prefetch, 4 no dh products, 8 no tanh, 16 no h prefetch, 32 no dy / gates / c prefetch, 64 no dG store */
+#ifndef ASR_ABORT_PERIOD_MASK /* the abort word is polled when (step & mask) == 0; 0 = every step (first version) */
+#define ASR_ABORT_PERIOD_MASK 15
+#endif
+#ifndef ASR_POLL_FIRST        /* 1 (measurement): first poll attempt issued before the h staging: 2.22 vs 2.14 us - an attempt that
+                                 arrives before the data costs a second L2 round trip */
+#define ASR_POLL_FIRST 0
+#endif
+#ifndef ASR_STAGE_H_TOP       /* 0 (measurement): h staging behind the poll instead of at the top of the step: 2.27 vs 2.16 us */
+#define ASR_STAGE_H_TOP 1
+#endif
+#ifndef ASR_RA      /* measurement only: backward (exchanged partials) chain ablation: 1 no reduction, 2 no stores / prefetch, 4 no dh products, 8 no tanh, 16 no h prefetch, 32 no dy / gates / c prefetch, 64 no dG store, 128 no column-major dG copy (dW_hh operand), 256 no h staging */
 #define ASR_RA 0
 #endif
 #ifdef ASR_LP_TRACE
@@ -492,9 +502,12 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   float4* st_gp = nullptr;
   int64_t st_so = 0;
   __syncthreads();                             // LDS zero fill
+  unsigned abort_seen = 0u;
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
-    const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;
+    if (ASR_ABORT_PERIOD_MASK == 0 || (s & ASR_ABORT_PERIOD_MASK) == 0) {      // see lstm_persist_bwd_rs_kernel
+      if (pw_thread && flag_load(a.ctrl + 8) != 0u) abort_seen = 1u;
+    }
     const float4 gx = gx_n1;
     gx_n1 = gx_n2;
     float4* gp = nullptr;
@@ -1393,10 +1406,15 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   __syncthreads();                             // LDS zero fill
   if (h_lane) stage_h(0, 0);
   if (h_lane && T > 1) fetch_h(1);
+  unsigned abort_seen = 0u;
   for (int s = 0; s < T; ++s) {
     const int t = time_of(s);
     LP_MARK(0);
-    const unsigned abort_seen = pw_thread ? flag_load(a.ctrl + 8) : 0u;
+    // another workgroup's abort: looked at every 16th step only (an agent-scope load and its wait on every step of the
+    // chain is not needed: a CU whose producers stopped publishing finds the flag in its spin loop)
+    if (ASR_ABORT_PERIOD_MASK == 0 || (s & ASR_ABORT_PERIOD_MASK) == 0) {
+      if (pw_thread && flag_load(a.ctrl + 8) != 0u) abort_seen = 1u;
+    }
     const float dyv = n1_dy, ct_ = n1_ct;
     const float4 av = n1_av;
     // rotate: n1 <- n2 (step s + 1's).  Opaque moves: left to itself hipcc renames the rotation away and instead copies
@@ -1408,9 +1426,18 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.z) : "v"(n2_av.z));
     asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.w) : "v"(n2_av.w));
     const float cp = s + 1 < T ? n1_ct : 0.f;                     // c at the time that feeds this one
-    // h tile of the NEXT step (fetched after the previous poll, a whole step ago) -> the other LDS buffer, while this
-    // step's partials are still in flight
-    if (h_lane && s + 1 < T) stage_h((s + 1) & 3, s + 1);
+#if ASR_POLL_FIRST
+    if (s > 0 && !q_inflight) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[e] + (unsigned)(((s - 1) & 1) * PARSZ) * 4u, 0, 16);
+      q_inflight = true;
+    }
+#endif
+    // h tile of the NEXT step (fetched after the previous poll, a whole step ago) -> the other LDS slot, while this step's
+    // partials are still in flight
+#if ASR_STAGE_H_TOP
+    if (h_lane && s + 1 < T && !(ASR_RA & 256)) stage_h((s + 1) & 3, s + 1);
+#endif
     float4* gp = nullptr;
     if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
     // ---------------------------------------------------------------- (1) gather the partials addressed to this CU
@@ -1446,6 +1473,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       *st_gp = st_da;
       st_gp = nullptr;
     }
+#if !ASR_STAGE_H_TOP
+    if (h_lane && s + 1 < T && !(ASR_RA & 256)) stage_h((s + 1) & 3, s + 1);
+#endif
     // prefetches: right after the poll, i.e. as far ahead of the next one as possible
     if (prow_ok && s + 2 < T && !(ASR_RA & (2 | 32))) fetch_step(s + 2, n2_dy, n2_ct, n2_av);
     if (h_lane && s + 2 < T && !(ASR_RA & (2 | 16))) fetch_h(s + 2);
@@ -1469,7 +1499,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         dcarry = dcn;
         *reinterpret_cast<uint2*>(&dgr_hi[pj][4 * pu]) = make_uint2(bf3_hi(da.x) | (bf3_hi(da.y) << 16), bf3_hi(da.z) | (bf3_hi(da.w) << 16));
         *reinterpret_cast<uint2*>(&dgr_lo[pj][4 * pu]) = make_uint2(bf3_lo(da.x) | (bf3_lo(da.y) << 16), bf3_lo(da.z) | (bf3_lo(da.w) << 16));
-        if (fuse_dw) {
+        if (fuse_dw && !(ASR_RA & 128)) {
           const int sl = s & 3, zs = (s + 1) & 3;          // this step's slot; the slot the NEXT step's h is staged into
           const float dv[4] = {da.x, da.y, da.z, da.w};    // must read as zero in the flush that does not cover it
 #pragma unroll
