@@ -159,6 +159,13 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
 int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                              const int32_t* lens, const float* dy, const float* c, const float* y,
                              float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream);
+/* asr_lstm_seq_bwd_persist with W_hh in the FORWARD layout (w_hh_il [ndir][4H][H], gate-interleaved: the array
+ * asr_lstm_seq_fwd_persist consumed) instead of its transpose: the exchanged-partials kernel (H in {128, 256, 512},
+ * split-bf16 bit 4 set) reads its slice once per launch.  Returns ASR_E_SHAPE where that kernel does not apply; the caller
+ * then forms w_hhT and calls asr_lstm_seq_bwd_persist / asr_lstm_seq_bwd. */
+int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh_il,
+                               const int32_t* lens, const float* dy, const float* c, const float* y, float* dw_hh,
+                               float* db, void* xch, void* ctrl, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pyramidal pair-concat (model.py:85-92), time-major:

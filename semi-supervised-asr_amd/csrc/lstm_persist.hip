@@ -90,6 +90,7 @@ struct PersistArgs {
   int T, B, nb, ndir;
   float* gates;         // [T][B][ndir][4H]
   const float* w;       // fwd: w_hh [ndir][4H][H];  bwd: w_hhT [ndir][H][4H]
+  const float* w_il;    // bwd, exchanged-partials kernel only: w_hh in the forward layout instead of w (saves the caller a transpose), or NULL
   const int32_t* lens;
   float* y;             // fwd: out y;  bwd: unused
   float* c;             // [T][B][ndir*H]
@@ -1288,17 +1289,27 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   u32x4 whi[MTW][KS], wlo[MTW][KS];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
-    const float* wr = a.w + ((int64_t)d * PH + 16 * (MTW * wave + mt) + ml) * (4 * PH) + NC * slice;
+    const int wunit = 16 * (MTW * wave + mt) + ml;
+    const float* wr = a.w + ((int64_t)d * PH + wunit) * (4 * PH) + NC * slice;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k0 = 32 * ks + 8 * kq;
       float v[8];
+      if (a.w_il != nullptr) {      // forward layout [4H columns][H units]: the same elements, one at a time (once per launch)
 #pragma unroll
-      for (int j4 = 0; j4 < 2; ++j4) {
-        const bool kok = k0 + 4 * j4 < NC;
-        const float4 q = *reinterpret_cast<const float4*>(wr + (kok ? k0 + 4 * j4 : 0));
-        v[4 * j4] = kok ? q.x : 0.f; v[4 * j4 + 1] = kok ? q.y : 0.f;
-        v[4 * j4 + 2] = kok ? q.z : 0.f; v[4 * j4 + 3] = kok ? q.w : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const bool kok = k0 + j < NC;
+          const float q = a.w_il[((int64_t)d * 4 * PH + NC * slice + (kok ? k0 + j : 0)) * PH + wunit];
+          v[j] = kok ? q : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int j4 = 0; j4 < 2; ++j4) {
+          const bool kok = k0 + 4 * j4 < NC;
+          const float4 q = *reinterpret_cast<const float4*>(wr + (kok ? k0 + 4 * j4 : 0));
+          v[4 * j4] = kok ? q.x : 0.f; v[4 * j4 + 1] = kok ? q.y : 0.f;
+          v[4 * j4 + 2] = kok ? q.z : 0.f; v[4 * j4 + 3] = kok ? q.w : 0.f;
+        }
       }
       bf3_split8(v, whi[mt][ks], wlo[mt][ks]);
     }
@@ -1761,7 +1772,7 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
     hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * PRG * H * sizeof(u64), stream);
     if (e != hipSuccess) return (int)e;
-    PersistArgs a;
+    PersistArgs a = {};
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
     a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
     a.y = y + (int64_t)rb * ndir * H; a.c = c + (int64_t)rb * ndir * H;
@@ -1774,12 +1785,14 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
 }
 
 // Persistent fast path of asr_lstm_seq_bwd (same arguments and results except that no dcarry scratch is needed).
-extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
-                                        const int32_t* lens, const float* dy, const float* c, const float* y,
-                                        float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream_) {
+static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT, const float* w_hh_il,
+                                     const int32_t* lens, const float* dy, const float* c, const float* y,
+                                     float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!gates || !w_hhT || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
+  if (!gates || (!w_hhT && !w_hh_il) || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
   if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
+  // the forward-layout weights are only read by the exchanged-partials kernel
+  if (!w_hhT && !((bf3_enabled() & 4) && (H == 512 || H == 256 || H == 128))) return ASR_E_SHAPE;
   const int nr = rows_per_group(nb, ndir);
   const int rows_per_launch = nr * (8 / ndir);
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
@@ -1789,9 +1802,9 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
                              : (size_t)2 * 8 * PRG * 4 * H * sizeof(float);
     hipError_t e = persist_reset(xch, ctrl, xbytes, stream);
     if (e != hipSuccess) return (int)e;
-    PersistArgs a;
+    PersistArgs a = {};
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
-    a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hhT; a.lens = lens + rb; a.y = nullptr;
+    a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hhT; a.w_il = w_hhT ? nullptr : w_hh_il; a.lens = lens + rb; a.y = nullptr;
     a.c = const_cast<float*>(c) + (int64_t)rb * ndir * H; a.dy = dy + (int64_t)rb * ndir * H;
     a.yfwd = (y && dw_hh) ? y + (int64_t)rb * ndir * H : nullptr; a.dw = (y && dw_hh) ? dw_hh : nullptr;
     a.db = db;
@@ -1801,4 +1814,21 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
   }
   ASR_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
+                                        const int32_t* lens, const float* dy, const float* c, const float* y,
+                                        float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream) {
+  if (!w_hhT) return ASR_E_ARG;
+  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, w_hhT, nullptr, lens, dy, c, y, dw_hh, db, xch, ctrl, stream);
+}
+
+// Same, taking W_hh in the FORWARD layout ([ndir][4H][H], what asr_lstm_seq_fwd_persist consumed): the exchanged-partials
+// kernel reads its slice of it once per launch, so the caller needs no transposed copy.  ASR_E_SHAPE when that kernel
+// does not apply (H not in {128, 256, 512}, or switched off): the caller then transposes and uses asr_lstm_seq_bwd_persist.
+extern "C" int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh_il,
+                                          const int32_t* lens, const float* dy, const float* c, const float* y,
+                                          float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream) {
+  if (!w_hh_il) return ASR_E_ARG;
+  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, nullptr, w_hh_il, lens, dy, c, y, dw_hh, db, xch, ctrl, stream);
 }

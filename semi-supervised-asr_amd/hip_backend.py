@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 EXPORTS = (
     "asr_abi_version", "asr_set_split_bf16", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
-    "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
+    "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_lstm_seq_bwd_persist_w", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
@@ -75,6 +75,7 @@ def load():
     lib.asr_lstm_seq_fwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_lstm_seq_fwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_bwd_persist_w.argtypes = lib.asr_lstm_seq_bwd_persist.argtypes
     lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -550,11 +551,25 @@ def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
     run_grouped(groups, one)
 
 
-def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None):
-    """Returns True when dW_hh (and the bias gradient `db`, if given) were accumulated by the persistent kernel itself."""
+def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None, w_hh=None):
+    """Returns True when dW_hh (and the bias gradient `db`, if given) were accumulated by the persistent kernel itself.
+    w_hhT: the transposed recurrent weights [ndir][H][4H], or a callable producing them on demand; w_hh: the forward
+    layout [ndir][4H][H] - when given, the kernel that can read it directly is tried first and the transpose is only
+    formed if that kernel does not apply."""
     T, B, ndir, H4 = gates.shape
     H = H4 // 4
     lib = load()
+    if USE_PERSIST and w_hh is not None:
+        xch, ctrl = persist_scratch(gates.device)
+        rc = lib.asr_lstm_seq_bwd_persist_w(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(dy), ptr(c),
+                                            ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
+        if rc == 0:
+            count_path("lstm_bwd", True)
+            return y is not None and dw_hh is not None
+        if rc != -2:
+            check(rc, "asr_lstm_seq_bwd_persist_w")
+    if callable(w_hhT):
+        w_hhT = w_hhT()
     if USE_PERSIST:
         xch, ctrl = persist_scratch(gates.device)
         rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hhT), ptr(lens), ptr(dy), ptr(c),

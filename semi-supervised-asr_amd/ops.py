@@ -156,11 +156,11 @@ class _LstmLayer(torch.autograd.Function):
         ws = lease.ws
         dev = dy.device
         dyc = dy if dy.is_contiguous() else ws["dy"].copy_(dy)
-        ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2))
         ws["zbuf"].zero_()                     # dcarry, dw_hh, db
         gates, y = ws["gates"], ws["y"]
-        fused_dw = hb.lstm_seq_bwd(gates, ws["w_hhT"], ws["lens"], dyc, ws["c"], ws["dcarry"], y=y,
-                                   dw_hh=ws["dw_hh"], db=ws["db"])                        # gates <- dG in place
+        # the transposed recurrent weights are only formed if the kernel that reads the forward layout does not apply
+        fused_dw = hb.lstm_seq_bwd(gates, lambda: ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2)), ws["lens"], dyc, ws["c"],
+                                   ws["dcarry"], y=y, dw_hh=ws["dw_hh"], db=ws["db"], w_hh=ws["w_hh"])   # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = hb.gemm(dG, x2, trans_a=True)                     # [ndir*4H, I]

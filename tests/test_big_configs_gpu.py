@@ -72,7 +72,7 @@ def _run_big(golden_dir, name, shape, dec_bwd_persistent=True):
         assert _rel(got, g[key]) < RTOL, key
     agree = float((pred.cpu().numpy() == g["pred"]).mean())
     assert agree > 0.999, "argmax agreement %.5f" % agree          # ties within fp32 noise may flip a handful
-    assert abs(float(net.mask_and_cal_loss(lp, ys_d)) - float(g["masked_loss"])) <= 1e-4 * abs(float(g["masked_loss"]))
+    assert abs(float(net.mask_and_cal_loss(lp, ys_d).detach()) - float(g["masked_loss"])) <= 1e-4 * abs(float(g["masked_loss"]))
     # ---- every parameter gradient: norm, and head / tail elements relative to the gradient's own scale
     worst = 0.0
     for n, p in net.named_parameters():

@@ -684,6 +684,44 @@ def test_lstm_persistent_other_arithmetics(ndir, B, T, H, mask, name):
         test_lstm_persistent_path(ndir, B, T, None, H)
 
 
+@pytest.mark.parametrize("H,B,T,ndir", [(512, 32, 7, 2), (256, 9, 5, 2), (128, 40, 4, 1)])
+def test_lstm_bwd_persist_forward_layout_weights(H, B, T, ndir):
+    """asr_lstm_seq_bwd_persist_w (W_hh in the forward layout, no transposed copy) gives bit-identical dG, dW_hh and db
+    to asr_lstm_seq_bwd_persist fed the transpose; with the exchanged-partials kernel off it declines (ASR_E_SHAPE)."""
+    dev = _gpu()
+    import hip_backend as hb
+    lib = hb.load()
+    g = torch.Generator().manual_seed(H + B + T)
+    gact = (torch.rand(T, B, ndir, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
+    w = (torch.randn(ndir, 4 * H, H, generator=g) / np.sqrt(H)).to(dev)
+    wT = w.transpose(1, 2).contiguous()
+    lens = torch.tensor(sorted([int(v) for v in torch.randint(1, T + 1, (B,), generator=g)], reverse=True), dtype=torch.int32, device=dev)
+    dy = (torch.randn(T, B, ndir * H, generator=g) * 0.1).to(dev)
+    c = torch.randn(T, B, ndir * H, generator=g).to(dev)
+    y = torch.tanh(torch.randn(T, B, ndir * H, generator=g)).to(dev)
+    xch, ctrl = hb.persist_scratch(dev)
+    outs = []
+    for fn, wt in ((lib.asr_lstm_seq_bwd_persist, wT), (lib.asr_lstm_seq_bwd_persist_w, w)):
+        gb = gact.clone()
+        dw = torch.zeros(ndir, 4 * H, H, device=dev)
+        db = torch.zeros(ndir * 4 * H, device=dev)
+        rc = fn(T, B, B, H, ndir, hb.ptr(gb), hb.ptr(wt), hb.ptr(lens), hb.ptr(dy), hb.ptr(c), hb.ptr(y), hb.ptr(dw), hb.ptr(db),
+                hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), hb.stream())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert not hb.persist_aborted(dev)
+        outs.append((gb, dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]), "dG differs"
+    # dW_hh / db are sums of float atomics over the row groups: equal up to the order of those additions
+    _close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-6, what="dW_hh")
+    _close(outs[1][2], outs[0][2], rtol=1e-5, atol=1e-6, what="db")
+    with hb.split_bf16(hb.set_split_bf16(-1) & ~hb.SPLIT_LSTM_BWD_RS):
+        gb = gact.clone()
+        rc = lib.asr_lstm_seq_bwd_persist_w(T, B, B, H, ndir, hb.ptr(gb), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c), None, None,
+                                            None, hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), hb.stream())
+        assert rc == -2, rc
+
+
 @pytest.mark.parametrize("B,T,ndir", [(32, 12, 1), (20, 7, 1), (8, 5, 2), (40, 3, 1)])
 def test_lstm_judge_width_h640(B, T, ndir):
     """H = 640 (the judge LM: config.yaml dis_hidden_dim, reference model.py:466-467): the forward recurrence runs on the
