@@ -61,6 +61,9 @@
                                  arrives before the data costs a second L2 round trip */
 #define ASR_POLL_FIRST 0
 #endif
+#ifndef ASR_POLL_FIRST_SLEEP
+#define ASR_POLL_FIRST_SLEEP 0
+#endif
 #ifndef ASR_STAGE_H_TOP       /* 0 (measurement): h staging behind the poll instead of at the top of the step: 2.27 vs 2.16 us */
 #define ASR_STAGE_H_TOP 1
 #endif
@@ -1439,6 +1442,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     const float cp = s + 1 < T ? n1_ct : 0.f;                     // c at the time that feeds this one
 #if ASR_POLL_FIRST
     if (s > 0 && !q_inflight) {
+#if ASR_POLL_FIRST_SLEEP
+      __builtin_amdgcn_s_sleep(ASR_POLL_FIRST_SLEEP);
+#endif
 #pragma unroll
       for (int e = 0; e < NE; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[e] + (unsigned)(((s - 1) & 1) * PARSZ) * 4u, 0, 16);
       q_inflight = true;
