@@ -509,6 +509,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   unsigned abort_seen = 0u;
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
+    LP_MARK(0);
     if (ASR_ABORT_PERIOD_MASK == 0 || (s & ASR_ABORT_PERIOD_MASK) == 0) {      // see lstm_persist_bwd_rs_kernel
       if (pw_thread && flag_load(a.ctrl + 8) != 0u) abort_seen = 1u;
     }
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
         }
         __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
+      LP_MARK(7);
 #pragma unroll
       for (int kc = 0; kc < NKC; ++kc)
         if (gl[kc] && !(ASR_LA & 2)) {
@@ -566,6 +568,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
             }
           }
         }
+      LP_MARK(1);
       if (st_gp && !(ASR_LA & 4)) {   // previous step's outputs (stores after the poll: vmcnt retires in order)
         *st_gp = st_g;
         a.c[st_so] = st_c;
@@ -586,13 +589,16 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
         for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wlo[mt][ks], bh, acc[mt]);
       }
     }
+    LP_MARK(2);
     if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
     if (ml < NR) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         *reinterpret_cast<float4*>(&part[s & 1][wave][4 * mt + kq][ml][0]) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
     }
+    LP_MARK(3);
     __syncthreads();
+    LP_MARK(4);
     if (pw_thread) {
       float pre[4] = {gx.x, gx.y, gx.z, gx.w};
 #pragma unroll
@@ -607,7 +613,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       if (t >= plen) { cn = 0.f; hn = 0.f; }
       if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
+      LP_MARK(5);
       word_store(xw_g + (s & 1) * (PH * PRG) + (int64_t)punit * PRG + pj, hn, tag_bit_of_step(s));       // hand-off first
+      LP_MARK(6);
       if (prow_ok) {
         st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
         st_gp = gp;

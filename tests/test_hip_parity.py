@@ -118,6 +118,23 @@ def test_gemm_wide_tile(ta, tb, M, N, K):
     assert float(outw[:, :16].abs().max()) == 0.0 and float(outw[:, 16 + N:].abs().max()) == 0.0
 
 
+def test_gemm_wide_tile_batched():
+    """The batched form (pointer + strides, one launch) through the 256 x 128 kernel: C[b] = A[:, b, :]^T B[:, b, :] with
+    K % 32 == 0, edge tiles in M and N, batch folded into grid.y next to the kernel's own K split."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(2)
+    L, Bn, Tp, Od = 2048, 3, 40, 72
+    A = torch.randn(L, Bn, Tp, generator=g).to(dev)
+    Bm = torch.randn(L, Bn, Od, generator=g).to(dev)
+    want = torch.einsum("lbt,lbo->bto", A.cpu().double(), Bm.cpu().double()).float()
+    for mode in (hb.SPLIT_GEMM | hb.SPLIT_GEMM_WIDE | hb.SPLIT_GEMM_WIDE_ALL, hb.SPLIT_GEMM):
+        C = torch.full((Bn, Tp, Od), 3.0, device=dev)
+        with hb.split_bf16(mode):
+            hb.gemm_batched(A, Bm, C, True, False, Tp, Od, L, Bn * Tp, Bn * Od, Od, Bn, Tp, Od, Tp * Od)
+        _close(C, want, rtol=3e-5, atol=1e-4, what="batched/%d" % mode)
+
+
 def test_gemm_strided_views_and_batched():
     dev = _gpu()
     import hip_backend as hb
