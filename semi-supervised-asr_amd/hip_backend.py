@@ -361,33 +361,49 @@ def run_grouped(groups, fn):
 
 
 _pinned_ring = {}
+_upload_streams = {}
+
+
+def _to_device(arr, torch_dtype, device):
+    """Host array -> device tensor without blocking the host and without a place in the compute stream: staged through a
+    small ring of pinned buffers and copied on a side stream (the compute stream only waits for the copy's event - the
+    host runs ahead of the GPU, so the copy has long finished when the stream gets there; as an in-stream copy each of
+    these small uploads cost ~10 us of the step)."""
+    key = (str(device), str(torch_dtype), arr.size)
+    ring = _pinned_ring.setdefault(key, dict(bufs=[torch.empty(arr.size, dtype=torch_dtype).pin_memory() for _ in range(8)], i=0))
+    buf = ring["bufs"][ring["i"] % 8]
+    ring["i"] += 1
+    buf.copy_(torch.from_numpy(arr.reshape(-1)))
+    dev = torch.device(device)
+    if dev.type != "cuda" or os.environ.get("ASR_UPLOAD_STREAM", "1") == "0":
+        return buf.to(device, non_blocking=True).view(arr.shape)
+    side = _upload_streams.get(str(dev))
+    if side is None:
+        side = _upload_streams.setdefault(str(dev), torch.cuda.Stream(device=dev))
+    main = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        out = buf.to(dev, non_blocking=True)
+    main.wait_stream(side)
+    out.record_stream(main)
+    return out.view(arr.shape)
 
 
 def to_device_i32(values, device):
-    """Host ints -> int32 device tensor without blocking the host: staged through a small ring of pinned buffers
-    and copied with non_blocking=True (a pageable-memory copy would stall the host until the stream drains)."""
+    """Host ints -> int32 device tensor (see _to_device)."""
     import numpy as np
-    arr = np.asarray(values, dtype=np.int32)
-    key = (str(device), arr.size)
-    ring = _pinned_ring.setdefault(key, dict(bufs=[torch.empty(arr.size, dtype=torch.int32).pin_memory()
-                                                   for _ in range(8)], i=0))
-    buf = ring["bufs"][ring["i"] % 8]
-    ring["i"] += 1
-    buf.copy_(torch.from_numpy(arr.reshape(-1)))
-    return buf.to(device, non_blocking=True).view(arr.shape)
+    return _to_device(np.asarray(values, dtype=np.int32), torch.int32, device)
+
+
+def to_device_i64(values, device):
+    """Host ints -> int64 device tensor (index tensors: no conversion kernel on the device)."""
+    import numpy as np
+    return _to_device(np.asarray(values, dtype=np.int64), torch.int64, device)
 
 
 def to_device_f32(array, device):
-    """Host float32 array -> device tensor through the pinned ring (see to_device_i32)."""
+    """Host float32 array -> device tensor (see _to_device)."""
     import numpy as np
-    arr = np.ascontiguousarray(array, dtype=np.float32)
-    key = (str(device), "f32", arr.size)
-    ring = _pinned_ring.setdefault(key, dict(bufs=[torch.empty(arr.size, dtype=torch.float32).pin_memory()
-                                                   for _ in range(8)], i=0))
-    buf = ring["bufs"][ring["i"] % 8]
-    ring["i"] += 1
-    buf.copy_(torch.from_numpy(arr.reshape(-1)))
-    return buf.to(device, non_blocking=True).view(arr.shape)
+    return _to_device(np.ascontiguousarray(array, dtype=np.float32), torch.float32, device)
 
 
 def _ptr_array(tensors):

@@ -248,7 +248,7 @@ class Decoder(torch.nn.Module):
             idx[1, b, :ln] = np.arange(off, off + ln)
             off += ln
         if dev.type == "cuda":
-            didx = hb_to_device(idx, dev).to(torch.long)
+            didx = hb.to_device_i64(idx, dev)
         else:
             didx = torch.from_numpy(idx).to(torch.long)
         both = flat[didx]
