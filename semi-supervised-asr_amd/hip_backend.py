@@ -362,6 +362,16 @@ def run_grouped(groups, fn):
 
 _pinned_ring = {}
 _upload_streams = {}
+# The side stream costs the host ~25 us per upload (stream switch, event record / wait): worth it when the GPU is the
+# bottleneck (the copy leaves the compute stream), a loss when the host is (cfg-1: 2.01 -> 2.32 ms per step).  E2E.forward
+# switches it on for batches of at least UPLOAD_SIDE_MIN_FRAMES padded frames (B * T); ASR_UPLOAD_STREAM=0/1 forces it.
+UPLOAD_SIDE_STREAM = [os.environ.get("ASR_UPLOAD_STREAM", "0") == "1"]
+UPLOAD_SIDE_MIN_FRAMES = 4096
+
+
+def upload_side_stream_for(n_frames):
+    if "ASR_UPLOAD_STREAM" not in os.environ:
+        UPLOAD_SIDE_STREAM[0] = int(n_frames) >= UPLOAD_SIDE_MIN_FRAMES
 
 
 def _to_device(arr, torch_dtype, device):
@@ -375,7 +385,7 @@ def _to_device(arr, torch_dtype, device):
     ring["i"] += 1
     buf.copy_(torch.from_numpy(arr.reshape(-1)))
     dev = torch.device(device)
-    if dev.type != "cuda" or os.environ.get("ASR_UPLOAD_STREAM", "1") == "0":
+    if dev.type != "cuda" or not UPLOAD_SIDE_STREAM[0]:
         return buf.to(device, non_blocking=True).view(arr.shape)
     side = _upload_streams.get(str(dev))
     if side is None:

@@ -319,6 +319,8 @@ class E2E(torch.nn.Module):
 
     def forward(self, data, ilens, ys=None, tf_rate=1.0, max_dec_timesteps=200, sample=False, smooth=False,
                 scaling=1.0, label_smoothing=True, total_length=None, olength=None):
+        if data.is_cuda:
+            hb.upload_side_stream_for(data.shape[0] * data.shape[1])       # small uploads leave the compute stream when the GPU is the bottleneck
         enc_h, enc_lens = self.encoder(data, ilens, total_length)
         return self.decoder(enc_h, enc_lens, ys, tf_rate=tf_rate, max_dec_timesteps=max_dec_timesteps, sample=sample,
                             smooth=smooth, scaling=scaling, label_smoothing=label_smoothing, olength=olength)
