@@ -18,6 +18,9 @@
 #ifndef ASR_GB_ABL               /* measurement only: 1 no products, 2 no operand loads after the first tile, 4 no LDS staging */
 #define ASR_GB_ABL 0
 #endif
+#ifndef ASR_GLDS_CLOBBER_M0
+#define ASR_GLDS_CLOBBER_M0 0
+#endif
 #ifndef ASR_GEMM_SETPRIO
 #define ASR_GEMM_SETPRIO 1
 #endif
@@ -599,7 +602,13 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 // itself; no other VMEM load is outstanding while DMAs are.
 __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
   const unsigned dst = (unsigned)(uintptr_t)(lds_vptr)lds_dst;
+#if ASR_GLDS_CLOBBER_M0     /* measurement: m0 on the clobber list instead (hipcc warns: reserved register) */
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+#else
+  unsigned keep;                                   // m0 is saved and restored: it may not appear in a clobber list
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+#endif
 }
 
 #ifndef ASR_GW_ABL      /* measurement only: 1 no DMA inside the stage loop, 2 no split arithmetic (raw bits as hi / lo), 4 no fragment reads after the prologue */
@@ -1109,9 +1118,8 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
         if (cost < best_cost) { best_cost = cost; best = sk; }
       }
     }
-    if (const char* f = getenv("ASR_GEMM_WIDE_SK")) {   // measurement: force the split
-      if (atoi(f) >= 1 && atoi(f) <= stages) best = atoi(f);
-    }
+    static const int forced_sk = [] { const char* f = getenv("ASR_GEMM_WIDE_SK"); return f ? atoi(f) : 0; }();   // measurement
+    if (forced_sk >= 1 && forced_sk <= stages) best = forced_sk;
     const bool late = best > 1 && (bias_late || relu_late);
     if (late && accumulate) return ASR_E_SHAPE;
     if (late) { g.bias = nullptr; g.relu = 0; } else { g.bias = bias_late; g.relu = relu_late; }
