@@ -67,7 +67,7 @@
 #ifndef ASR_STAGE_H_TOP       /* 0 (measurement): h staging behind the poll instead of at the top of the step: 2.27 vs 2.16 us */
 #define ASR_STAGE_H_TOP 1
 #endif
-#ifndef ASR_RA      /* measurement only: backward (exchanged partials) chain ablation: 1 no reduction, 2 no stores / prefetch, 4 no dh products, 8 no tanh, 16 no h prefetch, 32 no dy / gates / c prefetch, 64 no dG store, 128 no column-major dG copy (dW_hh operand), 256 no h staging */
+#ifndef ASR_RA      /* measurement only: backward (exchanged partials) chain ablation: 1 no reduction, 2 no stores / prefetch, 4 no dh products, 8 no tanh, 16 no h prefetch, 32 no dy / gates / c prefetch, 64 no dG store, 128 no column-major dG copy (dW_hh operand), 256 no h staging, 512 h staging without its LDS stores, 1024 without its split arithmetic */
 #define ASR_RA 0
 #endif
 #ifdef ASR_LP_TRACE
@@ -1245,6 +1245,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
 //     per SIMD and step instead of 2 048 on the fp32 pipe, and it sits between the publish and the next gather.
 // H in {128, 256, 512} (units per CU a multiple of 4); other sizes keep lstm_persist_bwd_bf3_kernel.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ f32x4 bf3_mfma16(const uint2& a, const uint2& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
 }
@@ -1271,18 +1272,20 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   constexpr int PUC = RD::PUC, NC = RD::NC, KS = RD::KS, MTW = RD::MTW, CT = RD::CT, UPW = RD::UPW, CPW = RD::CPW;
   constexpr int QPU = RD::QPU, GST = RD::GST;
   constexpr int NE = 2;                           // quads per lane in the gather: two sources of one (row, unit quad)
-  __shared__ __attribute__((aligned(16))) unsigned short dgr_hi[PRG][GST], dgr_lo[PRG][GST];   // local dG, [row][col]
-  // operands of the dW_hh product, four time-step slots of 8 rows each = K = 32 of one v_mfma_f32_16x16x32_bf16:
-  // local dG [col][slot][row] and h_{t_prev} [unit][slot][row]; step s lives in slot s & 3 (see the dW_hh block)
-  __shared__ __attribute__((aligned(16))) unsigned short dgc_hi[16 * CT][4][PRG], dgc_lo[16 * CT][4][PRG];
+  // local dG of the last four steps, row-major [slot s & 3][row][col] (split bf16).  One image serves both products:
+  //   dh partial (this step):  B operand = 8 consecutive columns of a row            -> ds_read_b128
+  //   dW_hh (every third step): A operand = 8 rows (k = slot * 8 + row) of a column  -> two ds_read_b64_tr_b16 (the
+  //     hardware transpose read, tools/micro/tr_read_check.hip)
+  // The first version kept a second, column-major copy for dW_hh that the pointwise threads filled with 24 two-byte LDS
+  // stores per step: 0.13 us of the serial chain (-DASR_RA=128).  h_{t_prev} stays [unit][slot][row].
+  __shared__ __attribute__((aligned(16))) unsigned short dgs_hi[4][PRG][GST], dgs_lo[4][PRG][GST];
   __shared__ __attribute__((aligned(16))) unsigned short ht_hi[PH][4][PRG], ht_lo[PH][4][PRG];
   __shared__ __attribute__((aligned(16))) float dhs[PRG][16];                                 // reduced dh_rec [row][unit]
   __shared__ int role[2];
   extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < PRG * GST; i += PNT) { (&dgr_hi[0][0])[i] = 0; (&dgr_lo[0][0])[i] = 0; }
-  for (int i = tid; i < 16 * CT * 4 * PRG; i += PNT) { (&dgc_hi[0][0][0])[i] = 0; (&dgc_lo[0][0][0])[i] = 0; }
+  for (int i = tid; i < 4 * PRG * GST; i += PNT) { (&dgs_hi[0][0][0])[i] = 0; (&dgs_lo[0][0][0])[i] = 0; }
   for (int i = tid; i < PH * 4 * PRG; i += PNT) { (&ht_hi[0][0][0])[i] = 0; (&ht_lo[0][0][0])[i] = 0; }
   if (tid < PRG * 16) (&dhs[0][0])[tid] = 0.f;
   int g, slice;
@@ -1389,12 +1392,19 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     unsigned hi[NR / 2], lo[NR / 2];
 #pragma unroll
     for (int r = 0; r < NR / 2; ++r) {
+#if ASR_RA & 1024
+      const float v0 = n_h[2 * r], v1 = n_h[2 * r + 1];
+      hi[r] = __float_as_uint(v0); lo[r] = __float_as_uint(v1);
+#else
       const float v0 = (hp && r0 + 2 * r < a.nb) ? n_h[2 * r] : 0.f;
       const float v1 = (hp && r0 + 2 * r + 1 < a.nb) ? n_h[2 * r + 1] : 0.f;
       hi[r] = bf3_hi(v0) | (bf3_hi(v1) << 16);
       lo[r] = bf3_lo(v0) | (bf3_lo(v1) << 16);
+#endif
     }
-    if (NR == 8) {
+    if (ASR_RA & 512) {
+      asm volatile("" ::"v"(hi[0]), "v"(hi[1]), "v"(lo[0]), "v"(lo[1]), "v"(hi[NR / 2 - 1]), "v"(lo[NR / 2 - 1]));
+    } else if (NR == 8) {
       *reinterpret_cast<u32x4*>(&ht_hi[hunit][buf][0]) = (u32x4){hi[0], hi[1], hi[NR / 2 - 2], hi[NR / 2 - 1]};
       *reinterpret_cast<u32x4*>(&ht_lo[hunit][buf][0]) = (u32x4){lo[0], lo[1], lo[NR / 2 - 2], lo[NR / 2 - 1]};
     } else {
@@ -1522,17 +1532,13 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         if (t >= plen) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
         if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
         dcarry = dcn;
-        *reinterpret_cast<uint2*>(&dgr_hi[pj][4 * pu]) = make_uint2(bf3_hi(da.x) | (bf3_hi(da.y) << 16), bf3_hi(da.z) | (bf3_hi(da.w) << 16));
-        *reinterpret_cast<uint2*>(&dgr_lo[pj][4 * pu]) = make_uint2(bf3_lo(da.x) | (bf3_lo(da.y) << 16), bf3_lo(da.z) | (bf3_lo(da.w) << 16));
-        if (fuse_dw && !(ASR_RA & 128)) {
+        {
           const int sl = s & 3, zs = (s + 1) & 3;          // this step's slot; the slot the NEXT step's h is staged into
-          const float dv[4] = {da.x, da.y, da.z, da.w};    // must read as zero in the flush that does not cover it
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            dgc_hi[4 * pu + i][sl][pj] = (unsigned short)bf3_hi(dv[i]);
-            dgc_lo[4 * pu + i][sl][pj] = (unsigned short)bf3_lo(dv[i]);
-            dgc_hi[4 * pu + i][zs][pj] = 0;
-            dgc_lo[4 * pu + i][zs][pj] = 0;
+          *reinterpret_cast<uint2*>(&dgs_hi[sl][pj][4 * pu]) = make_uint2(bf3_hi(da.x) | (bf3_hi(da.y) << 16), bf3_hi(da.z) | (bf3_hi(da.w) << 16));
+          *reinterpret_cast<uint2*>(&dgs_lo[sl][pj][4 * pu]) = make_uint2(bf3_lo(da.x) | (bf3_lo(da.y) << 16), bf3_lo(da.z) | (bf3_lo(da.w) << 16));
+          if (fuse_dw && !(ASR_RA & 128)) {                // must read as zero in the flush that does not cover it
+            *reinterpret_cast<uint2*>(&dgs_hi[zs][pj][4 * pu]) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(&dgs_lo[zs][pj][4 * pu]) = make_uint2(0u, 0u);
           }
         }
         if (prow_ok) {
@@ -1552,8 +1558,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < ((ASR_RA & 4) ? 0 : KS); ++ks) {
-        const u32x4 bh = *reinterpret_cast<const u32x4*>(&dgr_hi[ml & 7][32 * ks + 8 * kq]);
-        const u32x4 bl = *reinterpret_cast<const u32x4*>(&dgr_lo[ml & 7][32 * ks + 8 * kq]);
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(&dgs_hi[s & 3][ml & 7][32 * ks + 8 * kq]);
+        const u32x4 bl = *reinterpret_cast<const u32x4*>(&dgs_lo[s & 3][ml & 7][32 * ks + 8 * kq]);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bh, acc[mt]);
 #pragma unroll
@@ -1594,7 +1600,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
             const bool pending = sl == (s & 3) || (s % 3 == 1 && sl == ((s - 1) & 3));
             if (!pending) {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) { dgc_hi[4 * pu + i][sl][pj] = 0; dgc_lo[4 * pu + i][sl][pj] = 0; }
+              for (int i = 0; i < 1; ++i) {
+                *reinterpret_cast<uint2*>(&dgs_hi[sl][pj][4 * pu]) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(&dgs_lo[sl][pj][4 * pu]) = make_uint2(0u, 0u);
+              }
             }
           }
         }
@@ -1603,8 +1612,17 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       u32x4 ah[CT], al[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        ah[ct] = *reinterpret_cast<const u32x4*>(&dgc_hi[16 * ct + ml][kq][0]);
-        al[ct] = *reinterpret_cast<const u32x4*>(&dgc_lo[16 * ct + ml][kq][0]);
+        // lane (column 16 ct + ml, slot kq) <- rows 0..7 of that column of slot kq: lane 4 q + p of the 16-lane group
+        // supplies the address of row q (second read: row 4 + q), columns 16 ct + 4 p .. + 3
+        const int tq = ml >> 2, tp = ml & 3;
+        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs_hi[kq][tq][16 * ct + 4 * tp]);
+        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs_hi[kq][4 + tq][16 * ct + 4 * tp]);
+        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs_lo[kq][tq][16 * ct + 4 * tp]);
+        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs_lo[kq][4 + tq][16 * ct + 4 * tp]);
+        const uint2 h0u = __builtin_bit_cast(uint2, h0), h1u = __builtin_bit_cast(uint2, h1);
+        const uint2 l0u = __builtin_bit_cast(uint2, l0), l1u = __builtin_bit_cast(uint2, l1);
+        ah[ct] = (u32x4){h0u.x, h0u.y, h1u.x, h1u.y};
+        al[ct] = (u32x4){l0u.x, l0u.y, l1u.x, l1u.y};
       }
 #pragma unroll
       for (int ut = 0; ut < MTW; ++ut) {
@@ -1715,8 +1733,7 @@ int launch_bwd_bf3(const PersistArgs& a, hipStream_t stream) {
 template <int PH, int NR>
 int launch_bwd_rs(const PersistArgs& a, hipStream_t stream) {
   using RD = RsDims<PH>;
-  const size_t stat = (size_t)2 * PRG * RD::GST * 2 + (size_t)2 * 16 * RD::CT * 4 * PRG * 2 + (size_t)2 * PH * 4 * PRG * 2 +
-                      PRG * 16 * sizeof(float) + 64;
+  const size_t stat = (size_t)2 * 4 * PRG * RD::GST * 2 + (size_t)2 * PH * 4 * PRG * 2 + PRG * 16 * sizeof(float) + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
   hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_rs_kernel<PH, NR>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
