@@ -44,10 +44,28 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TF = 157.3                       # fp32-input MFMA, dense (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TF = 2500.0                     # bf16 MFMA, dense
-# The recurrent products and the GEMMs run on the bf16 MFMA with each fp32 operand split in two bf16 terms and three
-# products per algorithmic product (include/asr_hip.h: asr_set_split_bf16).  `achieved` counts ALGORITHMIC flops, so the
-# roof those kernels are priced against is a third of the bf16 peak; the fp32-MFMA peak (round 1's roof) is quoted too.
-MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
+# Product arithmetic (include/asr_hip.h ASR_ARITH_*; --arith).  The default, bf16x6, re-encodes every fp32 operand
+# losslessly as three bf16 terms and spends SIX bf16 MFMA products per algorithmic product (fp32-equivalent); bf16x3 (two
+# terms, three products, 16 significand bits) is the non-default fast mode; f32 is the fp32-input MFMA.  `achieved`
+# counts ALGORITHMIC flops, so the roof a kernel is priced against is the peak of the pipe it runs on divided by the
+# products it spends per product.
+PRODUCTS_PER_PRODUCT = {"bf16x6": 6.0, "bf16x3": 3.0, "f32": 1.0}
+
+
+def arith_peak_tf(name):
+    return MFMA_F32_PEAK_TF if name == "f32" else MFMA_BF16_PEAK_TF / PRODUCTS_PER_PRODUCT[name]
+
+
+ARITH_TEXT = {
+    "bf16x6": "fp32-equivalent: fp32 operands, accumulators and results; every MFMA product on the bf16 pipe with both "
+              "operands re-encoded losslessly as three bf16 terms (a + b + c == x exactly) and six products per product; "
+              "the dropped terms are <= 2^-24 |x y|, below the rounding of the fp32 product (tests: bf16x6 error vs float64 "
+              "within 2x of the fp32-input MFMA kernel's, cfg-2 / cfg-5 parity vs the reference under this arithmetic AND "
+              "under the exact fp32-input MFMA)",
+    "bf16x3": "NOT the reference's precision: fp32 operands and accumulators, products on the bf16 pipe with two bf16 terms "
+              "per operand (16 significand bits) and three products per product, <= 2^-15 relative each",
+    "f32": "fp32 operands, accumulators and results; products on the fp32-input MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1)",
+}
 CFG2 = CONFIGS["cfg2"]["model"]                 # used by tools/
 
 
@@ -114,7 +132,10 @@ def cpu_baseline(cfg, xs, lens, ys, label, min_steps):
             break
     return dict(value=len(lens) * steps / el, unit="utterances/sec", cores=ncores, kind="port", seconds=el,
                 sample="%d full train step(s) of oracle/asr_oracle.py on the whole %s batch the GPU ran (%d utterances, "
-                       "T=%d, dropout %.1f, clip 5 + Adam(amsgrad)), %d torch CPU threads"
+                       "T=%d, dropout %.1f, clip 5 + Adam(amsgrad)), %d torch CPU threads.  A port, and FASTER than the "
+                       "reference's own CPU path: the oracle unbinds the time axis, which removes the O(T^2) zero-fill of "
+                       "the reference's packed-LSTM backward (SURVEY 6: 0.54 utt/s for the real reference at this shape "
+                       "on 8 threads)"
                        % (steps, label, len(lens), max(lens), cfg["dropout_rate"], ncores))
 
 
@@ -158,15 +179,33 @@ def _time_events(fn, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def mfma_busy_table():
+    """MFMA-pipe busy fractions per kernel family from the committed counter pass (tools/pmc_mfma.py ->
+    profiles/r03_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES-derived kernel cycles), keyed for the rows
+    of this bench; {} when the file is absent or was collected under another arithmetic."""
+    import hip_backend as hb
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_mfma.json")) as f:
+            d = json.load(f)
+        return d.get(hb.arith_name(), {}).get("bench_keys", {})
+    except (OSError, ValueError):
+        return {}
+
+
 def encoder_gate_gemms(dev, c, B, t_frames):
     """north_star: ">= 40 % MFMA utilisation on the encoder gate GEMM".  Per encoder layer, on operands of the step's
     shapes that were evicted from the caches before each launch (a 512 MB fill in between: the train step finds them in
     HBM too): the input-gate projection [T*B, in] x [in, 8H] (forward), its two backward GEMMs (dX = dG W_ih,
     dW_ih = dG^T X), and the recurrent products of the persistent kernels (h W_hh^T forward; dG W_hh + dG^T h backward)
-    timed as whole kernels.  Each entry: achieved algorithmic TFLOP/s, `frac` = fraction of the 157.3 TF fp32-MFMA peak
-    (the target's reference point; it can exceed 1 now that the products run as split bf16) and `frac_split_bf16_peak` =
-    fraction of 2 500 / 3 TF, the roof of the pipe they actually run on."""
+    timed as whole kernels.  Each entry: achieved algorithmic TFLOP/s; `frac` = fraction of the roof of the pipe and
+    arithmetic it runs on (bf16 peak / products per product: 416.7 TF for bf16x6); `x_f32_mfma_peak` = the same throughput
+    as a MULTIPLE of the 157.3 TF fp32-input MFMA peak (a speed ratio against the pipe the reference's arithmetic would
+    otherwise need, not a utilisation); `mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE-
+    equivalent cycles) of the same kernel from the committed PMC pass (profiles/r03_pmc_mfma.json) when it exists."""
     import hip_backend as hb
+    an = hb.arith_name()
+    peak = arith_peak_tf(an)
+    busy = mfma_busy_table()
     lib = hb.load()
     H, I = c["enc_hidden_dim"], c["input_dim"]
     frames, _ = encoder_layer_frames(c, t_frames)
@@ -206,8 +245,9 @@ def encoder_gate_gemms(dev, c, B, t_frames):
             if layer == 0 and op.startswith("dX"):
                 continue                                  # the features need no gradient
             dt = cold(fn)
-            rows.append(dict(layer=layer, op=op, us=dt * 1e6, tflops=flops / dt / 1e12,
-                             frac=flops / dt / 1e12 / MFMA_F32_PEAK_TF, frac_split_bf16_peak=flops / dt / 1e12 / MFMA_SPLIT_PEAK_TF))
+            rows.append(dict(layer=layer, op=op, us=dt * 1e6, tflops=flops / dt / 1e12, frac=flops / dt / 1e12 / peak,
+                             x_f32_mfma_peak=flops / dt / 1e12 / MFMA_F32_PEAK_TF,
+                             mfma_busy_frac=busy.get("gemm/%d/%s" % (layer, op.split(" ")[0]))))
         del x, w, dG, gates
         # recurrent products: the persistent kernels of this layer (both directions)
         lens = torch.full((B,), T, dtype=torch.int32, device=dev)
@@ -218,15 +258,15 @@ def encoder_gate_gemms(dev, c, B, t_frames):
         torch.cuda.synchronize()
         e0.record(stream)
         rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whh), hb.ptr(lens), hb.ptr(y), hb.ptr(cst),
-                                          hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), hb.stream())
+                                          hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
         e1.record(stream)
         torch.cuda.synchronize()
         if rc == 0:
             dt = e0.elapsed_time(e1) * 1e-3
             fl = T * 2.0 * B * 4 * H * H * 2
             rows.append(dict(layer=layer, op="recurrent fwd h W_hh^T (persistent kernel, T=%d)" % T, us=dt * 1e6,
-                             us_per_time_step=dt / T * 1e6, tflops=fl / dt / 1e12, frac=fl / dt / 1e12 / MFMA_F32_PEAK_TF,
-                             frac_split_bf16_peak=fl / dt / 1e12 / MFMA_SPLIT_PEAK_TF))
+                             us_per_time_step=dt / T * 1e6, tflops=fl / dt / 1e12, frac=fl / dt / 1e12 / peak,
+                             x_f32_mfma_peak=fl / dt / 1e12 / MFMA_F32_PEAK_TF, mfma_busy_frac=busy.get("lstm_fwd")))
             dy = (torch.randn(T, B, 2 * H, generator=g) * 0.01).to(dev)
             dw = torch.zeros(2, 4 * H, H, device=dev)
             db = torch.zeros(2 * 4 * H, device=dev)
@@ -235,15 +275,14 @@ def encoder_gate_gemms(dev, c, B, t_frames):
             e0.record(stream)
             rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whT), hb.ptr(lens), hb.ptr(dy), hb.ptr(cst),
                                               hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
-                                              hb.c_p(ctrl.data_ptr()), hb.stream())
+                                              hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
             e1.record(stream)
             torch.cuda.synchronize()
             hb.check(rc, "asr_lstm_seq_bwd_persist")
             dt = e0.elapsed_time(e1) * 1e-3
             rows.append(dict(layer=layer, op="recurrent bwd dG W_hh + dG^T h (persistent kernel, T=%d)" % T, us=dt * 1e6,
-                             us_per_time_step=dt / T * 1e6, tflops=2 * fl / dt / 1e12,
-                             frac=2 * fl / dt / 1e12 / MFMA_F32_PEAK_TF,
-                             frac_split_bf16_peak=2 * fl / dt / 1e12 / MFMA_SPLIT_PEAK_TF))
+                             us_per_time_step=dt / T * 1e6, tflops=2 * fl / dt / 1e12, frac=2 * fl / dt / 1e12 / peak,
+                             x_f32_mfma_peak=2 * fl / dt / 1e12 / MFMA_F32_PEAK_TF, mfma_busy_frac=busy.get("lstm_bwd")))
         out += rows
     return out
 
@@ -284,13 +323,15 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     gemm_s = _time_events(run_all, 3)
     gemm_flops = sum(2.0 * M * N * K * batch for (M, N, K, batch) in shapes)
     del bufs
-    split = hb.set_split_bf16(-1)
-    gpeak = MFMA_SPLIT_PEAK_TF if split & hb.SPLIT_GEMM else MFMA_F32_PEAK_TF
-    gname = "gemm_f32_kernel" if not split & hb.SPLIT_GEMM else ("gemm_bf3w_kernel" if split & hb.SPLIT_GEMM_WIDE else "gemm_bf3_kernel")
+    an = hb.arith_name()
+    busy = mfma_busy_table()
+    gpeak = arith_peak_tf(an)
+    gname = {"f32": "gemm_f32_kernel", "bf16x6": "gemm_bf6w_kernel", "bf16x3": "gemm_bf3w_kernel"}[an]
     gemm = dict(bound="mfma", kernel="%s<false,false> (transA weight-gradient GEMMs of one step)" % gname,
                 achieved=gemm_flops / gemm_s / 1e12, peak=gpeak, unit="TFLOP/s",
-                frac=gemm_flops / gemm_s / 1e12 / gpeak, frac_f32_mfma_peak=gemm_flops / gemm_s / 1e12 / MFMA_F32_PEAK_TF,
-                traffic=None, launches_per_step=len(shapes),
+                peak_is="%s MFMA dense peak / %d products per product" % ("fp32-input" if an == "f32" else "bf16", PRODUCTS_PER_PRODUCT[an]),
+                frac=gemm_flops / gemm_s / 1e12 / gpeak, x_f32_mfma_peak=gemm_flops / gemm_s / 1e12 / MFMA_F32_PEAK_TF,
+                mfma_busy_frac=busy.get("gemm_tn"), traffic=None, launches_per_step=len(shapes),
                 us_per_launch=gemm_s / len(shapes) * 1e6, ms_per_step=gemm_s * 1e3)
 
     # ---- persistent LSTM backward (with the fused recurrent weight gradient), the encoder layers
@@ -319,7 +360,7 @@ def kernel_roofline(dev, c, B, t_frames, olength):
             e0.record(stream)
             rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy),
                                               hb.ptr(cst), hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
-                                              hb.c_p(ctrl.data_ptr()), hb.stream())
+                                              hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
             e1.record(stream)
             torch.cuda.synchronize()
             if rc == -2:
@@ -331,22 +372,22 @@ def kernel_roofline(dev, c, B, t_frames, olength):
         lstm_s += best
         lstm_flops += T * 2.0 * (2.0 * B * 4 * H * H * 2)
         launches += (B + rows_per_launch - 1) // rows_per_launch
-    rs = bool(split & hb.SPLIT_LSTM_BWD_RS) and H in (128, 256, 512)
-    lpeak = MFMA_SPLIT_PEAK_TF if (rs or split & hb.SPLIT_LSTM_BWD) else MFMA_F32_PEAK_TF
+    rs = an != "f32" and H in (128, 256, 512)
+    lpeak = gpeak
     lstm = dict(bound="mfma", kernel="%s<%d> (dG recurrence + fused dW_hh, %d encoder layers)"
                                      % ("lstm_persist_bwd_rs_kernel" if rs else "lstm_persist_bwd_kernel", H, len(layers)),
                 limiter="dependent chain: per time step two barriers and one L2 hand-off of partial sums between the 32 CUs "
-                        "of an XCD; the MFMA floor of the step is ~0.3 us",
-                achieved=lstm_flops / lstm_s / 1e12, peak=lpeak, unit="TFLOP/s",
-                frac=lstm_flops / lstm_s / 1e12 / lpeak, frac_f32_mfma_peak=lstm_flops / lstm_s / 1e12 / MFMA_F32_PEAK_TF,
-                traffic=None, launches_per_step=launches,
+                        "of an XCD; the MFMA floor of the step is ~0.3-0.6 us",
+                achieved=lstm_flops / lstm_s / 1e12, peak=lpeak, unit="TFLOP/s", peak_is=gemm["peak_is"],
+                frac=lstm_flops / lstm_s / 1e12 / lpeak, x_f32_mfma_peak=lstm_flops / lstm_s / 1e12 / MFMA_F32_PEAK_TF,
+                mfma_busy_frac=busy.get("lstm_bwd"), traffic=None, launches_per_step=launches,
                 us_per_launch=lstm_s / launches * 1e6, ms_per_step=lstm_s * 1e3,
                 us_per_time_step=lstm_s / (sum(layers) * (launches // len(layers))) * 1e6,
                 aborted=bool(hb.persist_aborted(dev)))
     # HBM-side traffic of that kernel from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
     # tools/pmc_probe.py, FETCH doubled as the gfx950 guide prescribes); measured at H=512, 8-row groups
     if H == 512 and B >= 32:
-        for name in ("r02_pmc_lstm_persist.json", "r01_pmc_lstm_persist.json"):
+        for name in ("r03_pmc_lstm_persist.json", "r02_pmc_lstm_persist.json", "r01_pmc_lstm_persist.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)["lstm_persist_bwd_kernel<512>"]
@@ -375,6 +416,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-gemms", action="store_true")
     ap.add_argument("--dropout", type=float, default=None)
+    ap.add_argument("--arith", choices=["bf16x6", "f32", "bf16x3"], default="bf16x6",
+                    help="product arithmetic of the MFMA kernels (default: bf16x6 = fp32-equivalent, see ARITH_TEXT)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra timings under the other arithmetics")
     args = ap.parse_args()
 
     import __graft_entry__ as entry
@@ -384,6 +428,8 @@ def main():
     from parallel import FlatAdam
     import torch.distributed as dist
 
+    import hip_backend as hb
+    hb.ARITH[0] = hb.ARITH_NAMES[args.arith]
     rank, world, local = parallel.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
@@ -419,6 +465,20 @@ def main():
         opt.step()                                    # one RCCL all-reduce -> clip -> Adam
         return loss
 
+    def timed(n):
+        """n steps bracketed by barrier + synchronize on both sides; wall seconds, max over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            last = step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, last
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -429,10 +489,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    import hip_backend as hb
     # The persistent XCD-local kernels need one workgroup per CU (an exclusive, unpartitioned MI355X).  If one aborted
-    # during the warm-up (NaN-poisoned outputs, abort word set) every rank falls back to the per-step HIP kernels and the
-    # timed steps measure those; `config.persistent_kernels` says which path the number is for.
+    # during the warm-up (NaN-poisoned outputs, sticky abort latch set) every rank falls back to the per-step HIP kernels
+    # and the timed steps measure those; `config.persistent_kernels` says which path the number is for.
     aborted = torch.tensor([1.0 if hb.persist_aborted(dev) else 0.0], device=dev)
     if world > 1:
         dist.all_reduce(aborted, op=dist.ReduceOp.MAX)
@@ -446,18 +505,33 @@ def main():
         fence()
     hb.LAUNCHES.clear()
     if rank == 0:
-        note("timing %d steps" % args.steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        note("timing %d steps (%s)" % (args.steps, args.arith))
+    el, loss = timed(args.steps)
     final_loss = float(loss.item()) * (world if world > 1 else 1)
     paths = {k: v // max(1, args.steps) for k, v in sorted(hb.LAUNCHES.items())}
+    # the gradient all-reduce alone (68.7 MB at cfg-2), outside the timed region
+    allreduce_ms = None
+    if world > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.all_reduce(opt.buf.flat_g)
+        fence()
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(opt.buf.flat_g)
+        e1.record()
+        fence()
+        allreduce_ms = e0.elapsed_time(e1) / 5
+    # the same steps under the other arithmetics (labelled sub-objects; never the headline)
+    also = {}
+    if not args.no_also:
+        for other in ("bf16x3", "f32"):
+            if other == args.arith:
+                continue
+            with hb.arith(other):
+                step()
+                el_o, _ = timed(args.steps)
+            also[other] = dict(ms_per_step=el_o / args.steps * 1e3, value=n_global * args.steps / el_o,
+                               unit="utterances/sec", arithmetic=ARITH_TEXT[other])
 
     if rank == 0:
         ms = el / args.steps * 1e3
@@ -467,12 +541,9 @@ def main():
         out = {
             "metric": "utterances/sec (train step)", "value": value, "unit": "utterances/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (split-bf16 x3 products)" if hb.set_split_bf16(-1) else "f32", "data": "synthetic",
-            "arithmetic": "fp32 operands, accumulators and results; MFMA products %s" % (
-                "on the bf16 pipe with every operand split hi + lo (16 significand bits) and three products per product, "
-                "<= 2^-15 relative each: parity vs the reference at this shape 8e-5 of the 1e-3 gate "
-                "(tests/test_big_configs_gpu.py); ASR_LSTM_BF3=0 ASR_GEMM_BF3=0 select the fp32-input MFMA"
-                if hb.set_split_bf16(-1) else "on the fp32-input MFMA"),
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": {"bf16x6": "f32 (fp32-equivalent bf16x6 products)", "f32": "f32", "bf16x3": "f32 (bf16x3 products: 16-bit significands)"}[args.arith],
+            "data": "synthetic", "arithmetic": ARITH_TEXT[args.arith],
             "config": {"workload": "%s, batch %d per GPU, 80x%d synthetic fbank (ragged 0.6T..T), V=%d, L+1=%d, "
                                    "dropout %.2f, Adam(amsgrad)+clip 5" % (spec["name"], b_local, t_frames,
                                                                            cfg["output_dim"], info["olength"],
@@ -480,10 +551,14 @@ def main():
                        "config": args.config, "global_batch": n_global, "frames": t_frames,
                        "parallelism": "dp%d" % world, "pad_mode": "global-exact", "launch_mode": "eager",
                        "persistent_kernels": bool(hb.USE_PERSIST), "sequence_op_paths_per_step": paths},
-            "loss": final_loss,
+            "loss": final_loss, "allreduce_ms": allreduce_ms,
             "model_tflops": value * f_train / 1e12,
             "model_tflops_incl_padded_frames": value * f_train_padded / 1e12,
         }
+        if "bf16x3" in also:
+            out["also_split_bf16_x3"] = also["bf16x3"]
+        if "f32" in also:
+            out["also_f32_mfma"] = also["f32"]
         note("%.1f utt/s, %.2f ms/step; measuring dominant kernel" % (value, ms))
         out["roofline"] = kernel_roofline(dev, cfg, b_local, t_frames, info["olength"])
         if not args.no_layer_gemms:

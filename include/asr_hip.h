@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 1
+#define ASR_ABI_VERSION 2
 
 #define ASR_E_ARG    (-1)  /* null pointer / non-positive size */
 #define ASR_E_SHAPE  (-2)  /* size not supported by the kernel (see each function) */
@@ -41,17 +41,28 @@ typedef void* asr_stream_t; /* hipStream_t */
 
 int asr_abi_version(void);
 
-/* Product arithmetic of the MFMA kernels.  All operands, accumulators and results are fp32; by default the products of
- * asr_gemm_f32 and of the persistent LSTM recurrences run on the bf16 MFMA with each fp32 operand split in two bf16
- * terms (hi + lo, 16 significand bits) and three products hi*hi + hi*lo + lo*hi (<= 2^-15 relative per product,
- * fp32 accumulation): 16x the MAC rate of the fp32-input MFMA for a result that stays ~30x inside the 1e-3 parity
- * gate (measured against the reference at cfg-2: worst gradient element 9e-5).  asr_set_split_bf16 selects per
- * kernel family; it returns the previous mask.  Bits: 1 LSTM forward, 2 LSTM backward (gathered-dG kernel),
- * 4 LSTM backward with exchanged partials, 8 asr_gemm_f32, 16 (with 8) the 256 x 128 LDS-DMA GEMM kernel for the
- * shapes it pays on (weight gradients, long-K projections; M % 256 == 0, N % 128 == 0, K % 32 == 0), 32 that kernel for
- * every conforming shape (tests, measurements).  mask < 0: query only.  Environment overrides at load time:
- * ASR_LSTM_BF3 (bits 1|2|4), ASR_GEMM_BF3 (0/1), ASR_GEMM_WIDE (0/1/2).  Not thread safe against concurrent launches. */
-int asr_set_split_bf16(int mask);
+/* Product arithmetic of the MFMA kernels: an explicit argument (`arith`) of asr_gemm_f32 and of the persistent LSTM
+ * recurrences - there is no process-wide switch.  All operands, accumulators and results are fp32 in every mode; what
+ * the mode selects is how a product x * y of two fp32 operands is formed:
+ *   ASR_ARITH_F32     on the fp32-input MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1): the exact fp32 product, 157 TF peak.
+ *   ASR_ARITH_BF16X6  fp32-equivalent on the bf16 MFMA: each operand is re-encoded LOSSLESSLY as three bf16 terms
+ *                     (x = a + b + c exactly: 3 x 8 significand bits, every split rounded to nearest) and the six products
+ *                     aa' + ab' + ba' + ac' + ca' + bb' are accumulated in fp32.  Dropped: bc' + cb' + cc' <= 2^-24 |x y|,
+ *                     below the rounding of the fp32 product itself.  2.7x the fp32 pipe's MAC rate.  The host code's
+ *                     default (hip_backend.ARITH).
+ *   ASR_ARITH_BF16X3  two terms (16 significand bits), three products: <= 2^-15 relative per product.  Fastest; inside the
+ *                     1e-3 parity gate but narrower than the reference's arithmetic - never the default.
+ * Flags OR-ed into `arith` select a kernel where several implement the same arithmetic (tests, measurements):
+ *   ASR_GEMM_TILE_NARROW / ASR_GEMM_TILE_WIDE   asr_gemm_f32: never / always (for conforming shapes) the 256 x 128
+ *                     LDS-DMA kernel; by default it is used for the shapes it pays on;
+ *   ASR_LSTM_BWD_GATHER   asr_lstm_seq_bwd_persist: the gathered-dG kernel instead of the one with exchanged partials. */
+#define ASR_ARITH_F32        0
+#define ASR_ARITH_BF16X6     1
+#define ASR_ARITH_BF16X3     2
+#define ASR_ARITH_MASK       0xff
+#define ASR_GEMM_TILE_NARROW 0x100
+#define ASR_GEMM_TILE_WIDE   0x200
+#define ASR_LSTM_BWD_GATHER  0x400
 
 /* ---------------------------------------------------------------------------------------
  * Graph memo for the per-time-step launch chains (asr_lstm_seq_*, asr_dec_seq_*).  The `graphs`
@@ -66,13 +77,14 @@ void asr_graphs_destroy(void* graphs);
 int asr_graphs_stats(void* graphs, int64_t* hits, int64_t* captures, int64_t* eager);
 
 /* ---------------------------------------------------------------------------------------
- * Dense fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32; exact-f32 fmaf chain).
+ * Dense fp32 GEMM on the MFMA (product arithmetic: `arith`, see above).
  *   C[M,N] (ldc) = op(A)[M,K] * op(B)[K,N]  (+ bias[N]) (relu) (+ C if accumulate)
  * Row-major.  transA=0: A is [M][K] (lda>=K); transA=1: A is [K][M] (lda>=M).
  *             transB=0: B is [K][N] (ldb>=N); transB=1: B is [N][K] (ldb>=K).
  * batch>1 runs `batch` independent GEMMs with element strides sA,sB,sC.
- * split_k>1 splits K over grid.z and accumulates with fp32 atomics (C is zero-filled on
- * the stream first unless accumulate!=0); with split_k>1, bias/relu are applied by a second
+ * split_k <= 0: the library chooses a K split; split_k == 1: unsplit (no atomics: run-to-run deterministic);
+ * split_k > 1 splits K over grid.z and accumulates with fp32 atomics (C is zero-filled on
+ * the stream first unless accumulate!=0); with a K split, bias/relu are applied by a second
  * pass over C (not combinable with accumulate).
  * Replaces torch.nn.Linear / mm / bmm on the path: the LSTM input-gate product inside
  * torch.nn.LSTM (model.py:67-68,80), project_layer (model.py:93-94), mlp_enc
@@ -81,7 +93,7 @@ int asr_graphs_stats(void* graphs, int64_t* hits, int64_t* captures, int64_t* ea
 int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                  const float* A, int64_t lda, const float* B, int64_t ldb,
                  float* C, int64_t ldc, const float* bias, int relu, int accumulate,
-                 int batch, int64_t sA, int64_t sB, int64_t sC, int split_k,
+                 int batch, int64_t sA, int64_t sB, int64_t sC, int split_k, int arith,
                  asr_stream_t stream);
 
 /* Skinny GEMM for the sequential chains (M = batch rows, tens not thousands):
@@ -126,14 +138,17 @@ int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const 
 
 /* Persistent fast path of asr_lstm_seq_fwd (same arguments and results; csrc/lstm_persist.hip): ONE launch runs
  * all T steps, each XCD owns a (direction, 8- or 4-row) group, W_hh stays in registers, h_t is exchanged inside the
- * XCD as LSB-tagged fp32 words.  Applies when H is 128, 256, 320 or 512 and nb <= 32 * (8 / ndir); otherwise returns
- * ASR_E_SHAPE and
- * the caller uses asr_lstm_seq_fwd.  xch (>= 512 KB) and ctrl (>= 64 B) are caller-allocated scratch (both are zeroed
- * on the stream before the launch: one fill when ctrl sits exactly 64 bytes in front of xch, else two); after the
- * stream has drained ctrl[8] != 0 means the kernel aborted (bounded spin expired / unexpected placement) and
- * poisoned y with NaN. */
+ * XCD as LSB-tagged fp32 words.  Applies when H is 128, 256, 320, 512 (or 640 with a bf16 arithmetic) on an 8 x 32-CU
+ * device, any nb (row blocks of 32 * (8 / ndir) run as consecutive launches); otherwise returns ASR_E_SHAPE and the
+ * caller uses asr_lstm_seq_fwd.  `arith`: product arithmetic of h W_hh^T (ASR_ARITH_*, see above).
+ * xch (>= 8 MB) and ctrl (128 B) are caller-allocated scratch.  ctrl = [16 latch words | 16 per-launch words]: the
+ * per-launch words and the used part of xch are zeroed on the stream before every launch (one fill when ctrl sits exactly
+ * 128 bytes in front of xch, else two).  A kernel that aborts (bounded spin expired / unexpected placement) poisons its
+ * outputs with NaN and sets per-launch word 8 (code in word 9) AND latch word 0 (code in latch word 1).  The library
+ * never clears the latch words: a sequence operator is several launches, and the caller looks once, after the last
+ * one, and clears the latch itself. */
 int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
-                             const int32_t* lens, float* y, float* c, void* xch, void* ctrl,
+                             const int32_t* lens, float* y, float* c, void* xch, void* ctrl, int arith,
                              asr_stream_t stream);
 
 /* Backward through the same recurrence.
@@ -147,25 +162,26 @@ int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates
 int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                      const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
                      asr_stream_t stream);
-/* Persistent fast path of asr_lstm_seq_bwd (same conditions / abort convention as asr_lstm_seq_fwd_persist;
- * xch >= 8 MB: at H in {128, 256, 512} the CUs of a group exchange partial sums of dh_rec, laid out
- * [8 groups][2][32 dest][32 src][8 rows][H/32] floats).  Exchanged words carry a 1-bit tag in the mantissa LSB; the
- * in-place dG is what the pointwise update produced.  The recurrent products run on the bf16 MFMA with both operands
- * split in two bf16 terms (3 products, fp32 accumulation, ~2^-15 relative; env ASR_LSTM_BF3=0: exact-fp32 products).
+/* Persistent fast path of asr_lstm_seq_bwd (same conditions / scratch / abort convention as asr_lstm_seq_fwd_persist;
+ * H in {128, 256, 320, 512}).  With a bf16 arithmetic and H in {128, 256, 512} the CUs of a group exchange partial sums
+ * of dh_rec, laid out [8 groups][2][32 dest][32 src][8 rows][H/32] floats in xch (8 MB at H = 512); otherwise (H = 320,
+ * ASR_ARITH_F32, ASR_LSTM_BWD_GATHER) every CU gathers the step's dG tile.  Exchanged words carry a 1-bit tag in the
+ * mantissa LSB; the in-place dG is what the pointwise update produced.  `arith` selects the product arithmetic of
+ * dG W_hh and of the fused dW_hh (the gathered-dG kernels always form dW_hh on the fp32 MFMA).
  * If y (forward hidden states) and dw_hh ([ndir][4H][H], gate-interleaved, zero-filled or holding a running sum)
  * are given, the recurrent weight gradient sum_t dG_t^T h_{t-1} is accumulated into dw_hh inside the kernel
  * (fp32 atomics across the row groups) and the caller skips that GEMM.  If db ([ndir][4H], gate-interleaved,
  * zero-filled) is given, the bias gradient sum_{t,b} dG is accumulated into it as well. */
 int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                              const int32_t* lens, const float* dy, const float* c, const float* y,
-                             float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream);
+                             float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
 /* asr_lstm_seq_bwd_persist with W_hh in the FORWARD layout (w_hh_il [ndir][4H][H], gate-interleaved: the array
- * asr_lstm_seq_fwd_persist consumed) instead of its transpose: the exchanged-partials kernel (H in {128, 256, 512},
- * split-bf16 bit 4 set) reads its slice once per launch.  Returns ASR_E_SHAPE where that kernel does not apply; the caller
- * then forms w_hhT and calls asr_lstm_seq_bwd_persist / asr_lstm_seq_bwd. */
+ * asr_lstm_seq_fwd_persist consumed) instead of its transpose: the exchanged-partials kernel reads its slice once per
+ * launch.  Returns ASR_E_SHAPE where that kernel does not apply; the caller then forms w_hhT and calls
+ * asr_lstm_seq_bwd_persist / asr_lstm_seq_bwd. */
 int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh_il,
                                const int32_t* lens, const float* dy, const float* c, const float* y, float* dw_hh,
-                               float* db, void* xch, void* ctrl, asr_stream_t stream);
+                               float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pyramidal pair-concat (model.py:85-92), time-major:

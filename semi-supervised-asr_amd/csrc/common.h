@@ -13,7 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     if (e__ != hipSuccess) return (int)e__;        \
   } while (0)
 
-int asr_split_bf16_mask();     // gemm.hip: current asr_set_split_bf16 mask (bits 1|2|4 LSTM, 8 GEMM)
+
 
 static inline bool asr_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 

@@ -1554,7 +1554,7 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
     a.gates = p->gates + (int64_t)rb * 4 * D; a.cstate = p->cstate + (int64_t)rb * D;
     a.fconv = p->fconv + (int64_t)rb * C * Tp; a.S = p->S + (int64_t)rb * Tp * A;
     a.energy = p->energy + (int64_t)rb * Tp; a.ws = p->ws + (int64_t)rb * Tp;
-    a.xch = (float*)xch; a.ctrl = (unsigned*)ctrl;
+    a.xch = (float*)xch; a.ctrl = persist_launch_words(ctrl);
     a.fb_mode = 0; a.V = 0; a.eos = -1; a.fb_scale = 1.f; a.w_out = a.b_out = a.emb = nullptr; a.logits = a.probs = nullptr;
     a.pred = a.fed = nullptr;
     int rc;
@@ -1644,7 +1644,7 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
     a.G = q->G + (int64_t)rb * KX; a.dgates = q->dgates + (int64_t)rb * 4 * D; a.dD = q->dD + (int64_t)rb * A;
     a.dP = q->dP + (int64_t)rb * Tp * A; a.dgvec_part = q->dgvec_part + (int64_t)rb * A;
     a.dwatt_part = q->dwatt_part + (int64_t)rb * A * C; a.dconv_part = q->dconv_part + (int64_t)rb * C * taps;
-    a.xch = (float*)xch; a.ctrl = (unsigned*)ctrl;
+    a.xch = (float*)xch; a.ctrl = persist_launch_words(ctrl);
     const int rc = geo4 ? (cfg2 ? launch_dec_bwd<512, 512, 512, 128>(a, stream) : launch_dec_bwd<320, 320, 320, 128>(a, stream))
                         : (cfg2 ? launch_dec_bwd<512, 512, 512, 128, 2, 256>(a, stream)
                                 : launch_dec_bwd<320, 320, 320, 128, 2, 256>(a, stream));
@@ -1652,13 +1652,14 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
   }
   ASR_CHECK_LAUNCH();
   // embedding part of dX (not recurrent): G[s][:, D+O:] += dgates[s] Wcat[:, D+O:], batched over the L steps
+  // (fp32-equivalent bf16x6 products, as everything else the decoder kernels compute is exact fp32)
   int rc;
   if (p->nb == B)      // all rows: one GEMM over the L*B rows, K = 4D split so that the few output tiles fill the chip
     rc = asr_gemm_f32(0, 0, (int64_t)p->L * B, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX,
-                      nullptr, 0, 1, 1, 0, 0, 0, 16, stream_);
+                      nullptr, 0, 1, 1, 0, 0, 0, 16, ASR_ARITH_BF16X6, stream_);
   else
     rc = asr_gemm_f32(0, 0, p->nb, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX, nullptr, 0, 1,
-                      p->L, (int64_t)B * 4 * D, 0, (int64_t)B * KX, 4, stream_);
+                      p->L, (int64_t)B * 4 * D, 0, (int64_t)B * KX, 4, ASR_ARITH_BF16X6, stream_);
   if (rc) return rc;
   if (p->xmask) {
     const int64_t n = (int64_t)p->L * p->nb * E;

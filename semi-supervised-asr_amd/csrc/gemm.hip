@@ -9,9 +9,6 @@
 #include <type_traits>
 #include "common.h"
 
-#ifndef ASR_GEMM_BF3_DEFAULT
-#define ASR_GEMM_BF3_DEFAULT 1
-#endif
 #ifndef ASR_GEMM_BF3_TOUCH      /* L2 warm-up distance of the split-bf16 kernel in K tiles (2, 4, 6, 10 measured within 5 %: tools/gemm_cold_sweep.py; the kernel is bound by operand traffic at 32 flop/byte per 128x128 tile, not by latency) */
 #define ASR_GEMM_BF3_TOUCH 2
 #endif
@@ -315,6 +312,31 @@ __device__ __forceinline__ unsigned bf3g_lo2(float a, float b) {      // {lo(a),
   return __builtin_bit_cast(unsigned, p);
 }
 
+// Three-term split (NT = 3, "bf16x6"): a = bf16(x), b = bf16(x - a), c = bf16(x - a - b), every conversion rounded to
+// nearest (v_cvt_pk_bf16_f32).  Both differences are exact in fp32 and c needs at most 8 significand bits, so
+// a + b + c == x exactly: the three terms are a lossless re-encoding of the fp32 operand.  With the six products
+// aa' + ab' + ba' + ac' + ca' + bb' accumulated in fp32 the dropped terms (bc', cb', cc') are <= 2^-25 |x x'| each
+// (|b| <= 2^-9 |x|, |c| <= 2^-17 |x|), i.e. below the rounding of an fp32 product: fp32-equivalent arithmetic on the bf16
+// pipe at 6 MFMAs per product (the fp32-input MFMA costs the time of 16).  5.5 VALU instructions per element.
+// (|x| within one bf16 ulp of FLT_MAX would round a to infinity; no operand of this path comes near.)
+template <int NT>
+__device__ __forceinline__ void bfn_split2(float x, float y, unsigned (&t)[NT]) {   // t[k] = {term_k(x), term_k(y)}
+  if constexpr (NT == 2) {
+    t[0] = bf3g_hi2(x, y);
+    t[1] = bf3g_lo2(x, y);
+  } else {
+    const gbf16x2 pa = {(__bf16)x, (__bf16)y};
+    const unsigned ua = __builtin_bit_cast(unsigned, pa);
+    const float rx = x - __uint_as_float(ua << 16), ry = y - __uint_as_float(ua & 0xffff0000u);
+    const gbf16x2 pb = {(__bf16)rx, (__bf16)ry};
+    const unsigned ub = __builtin_bit_cast(unsigned, pb);
+    const float sx = rx - __uint_as_float(ub << 16), sy = ry - __uint_as_float(ub & 0xffff0000u);
+    t[0] = ua;
+    t[1] = ub;
+    t[2] = bf3g_hi2(sx, sy);           // exact: sx, sy have at most 8 significand bits
+  }
+}
+
 // this thread's 4 float4 pieces of a 128 (rows) x 32 (k) operand tile; MC mapping: k block t & 7, rows 4 (t >> 3) .. + 3
 template <bool KC>
 __device__ __forceinline__ void tile_fetch_bf3(const MatView& m, int64_t row0, int64_t k0, float4 (&v)[4]) {
@@ -330,16 +352,19 @@ __device__ __forceinline__ void tile_fetch_bf3(const MatView& m, int64_t row0, i
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void tile_store_bf3(unsigned short* hi, unsigned short* lo, const float4 (&v)[4]) {
+template <bool KC, int NT>
+__device__ __forceinline__ void tile_store_bf3(unsigned short* img, const float4 (&v)[4]) {   // NT images, BM * BS apart
   const int t = threadIdx.x;
   if (KC) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = t + 256 * i;
       const int o = (f >> 3) * BS + 4 * (f & 7);
-      *reinterpret_cast<uint2*>(hi + o) = make_uint2(bf3g_hi2(v[i].x, v[i].y), bf3g_hi2(v[i].z, v[i].w));
-      *reinterpret_cast<uint2*>(lo + o) = make_uint2(bf3g_lo2(v[i].x, v[i].y), bf3g_lo2(v[i].z, v[i].w));
+      unsigned p0[NT], p1[NT];
+      bfn_split2<NT>(v[i].x, v[i].y, p0);
+      bfn_split2<NT>(v[i].z, v[i].w, p1);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(img + k * BM * BS + o) = make_uint2(p0[k], p1[k]);
     }
   } else {
     const int o = 4 * (t >> 3) * BS + 4 * (t & 7);
@@ -347,19 +372,21 @@ __device__ __forceinline__ void tile_store_bf3(unsigned short* hi, unsigned shor
                            {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<uint2*>(hi + o + j * BS) = make_uint2(bf3g_hi2(r[j][0], r[j][1]), bf3g_hi2(r[j][2], r[j][3]));
-      *reinterpret_cast<uint2*>(lo + o + j * BS) = make_uint2(bf3g_lo2(r[j][0], r[j][1]), bf3g_lo2(r[j][2], r[j][3]));
+      unsigned p0[NT], p1[NT];
+      bfn_split2<NT>(r[j][0], r[j][1], p0);
+      bfn_split2<NT>(r[j][2], r[j][3], p1);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(img + k * BM * BS + o + j * BS) = make_uint2(p0[k], p1[k]);
     }
   }
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, int NT>
 __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned short smem[4 * BM * BS];
-  unsigned short* Ah = smem;
-  unsigned short* Al = smem + BM * BS;
-  unsigned short* Bh = smem + 2 * BM * BS;
-  unsigned short* Bl = smem + 3 * BM * BS;
+  // NT images (split terms, most significant first) per operand: 40 KB for two terms, 60 KB for three
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NT * BM * BS];
+  unsigned short* Ai = smem;
+  unsigned short* Bi = smem + NT * BM * BS;
 
   const int ntile = g.tiles_m * g.tiles_n;
   int tid = blockIdx.x;
@@ -447,27 +474,24 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   auto multiply = [&]() {
 #pragma unroll
     for (int ks = 0; ks < ((ASR_GB_ABL & 1) ? 0 : BK / 16); ++ks) {
-      gu32x4 ah[2], al[2], bh[2], bl[2];
+      gu32x4 af[2][NT], bf[2][NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const gu32x4*>(Ah + ao + 32 * i * BS + 16 * ks);
-        al[i] = *reinterpret_cast<const gu32x4*>(Al + ao + 32 * i * BS + 16 * ks);
-        bh[i] = *reinterpret_cast<const gu32x4*>(Bh + bo + 32 * i * BS + 16 * ks);
-        bl[i] = *reinterpret_cast<const gu32x4*>(Bl + bo + 32 * i * BS + 16 * ks);
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          af[i][k] = *reinterpret_cast<const gu32x4*>(Ai + k * BM * BS + ao + 32 * i * BS + 16 * ks);
+          bf[i][k] = *reinterpret_cast<const gu32x4*>(Bi + k * BM * BS + bo + 32 * i * BS + 16 * ks);
+        }
 #define BF3G(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a_), __builtin_bit_cast(gbf16x8, b_), c_, 0, 0, 0)
+      // term pairs (p, q) with p + q < NT: 3 products for two terms, 6 for three
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int o = 0; o < NT; ++o)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) BF3G(ah[i], bh[j], acc[i][j]);
+        for (int p = 0; p <= o; ++p)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) BF3G(ah[i], bl[j], acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) BF3G(al[i], bh[j], acc[i][j]);
+            for (int j = 0; j < 2; ++j) BF3G(af[i][p], bf[j][o - p], acc[i][j]);
 #undef BF3G
     }
   };
@@ -480,15 +504,15 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
     for (int64_t kt = kt_begin; kt < kt_fast_end; ++kt) {
 #if ASR_GB_ABL & 4
       if (kt == kt_begin) {
-        tile_store_bf3<AKC>(Ah, Al, ra);
-        tile_store_bf3<BKC>(Bh, Bl, rb);
+        tile_store_bf3<AKC, NT>(Ai, ra);
+        tile_store_bf3<BKC, NT>(Bi, rb);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w), "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
       }
 #else
-      tile_store_bf3<AKC>(Ah, Al, ra);
-      tile_store_bf3<BKC>(Bh, Bl, rb);
+      tile_store_bf3<AKC, NT>(Ai, ra);
+      tile_store_bf3<BKC, NT>(Bi, rb);
 #endif
       __syncthreads();
       if (kt + 1 < kt_fast_end && !(ASR_GB_ABL & 2)) fetch_fast(kt + 1);
@@ -503,8 +527,8 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   if (kt_fast_end < kt_end) {
     fetch_guard(kt_fast_end);
     for (int64_t kt = kt_fast_end; kt < kt_end; ++kt) {
-      tile_store_bf3<AKC>(Ah, Al, ra);
-      tile_store_bf3<BKC>(Bh, Bl, rb);
+      tile_store_bf3<AKC, NT>(Ai, ra);
+      tile_store_bf3<BKC, NT>(Bi, rb);
       __syncthreads();
       if (kt + 1 < kt_end) fetch_guard(kt + 1);
 #if ASR_GEMM_TOUCH
@@ -823,6 +847,7 @@ __global__ __launch_bounds__(512) void gemm_bf3w_kernel(GemmArgs g) {
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       GW_MARK(2);
       __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");      // the raw barrier has no memory semantics in the IR: keep the LDS reads of stage s + 1 behind it
     }
     GW_MARK(3);
     // ---- H2
@@ -878,6 +903,7 @@ __global__ __launch_bounds__(512) void gemm_bf3w_kernel(GemmArgs g) {
   else if (S > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 #pragma unroll
   for (int j = 0; j < 2; ++j) bf3w_frag<BKC, WN>(smem + W_A_FLOATS, brow + 32 * j, kq0s, kq1s, kfirst, bh[0][j], bl[0][j]);
 #pragma unroll
@@ -918,6 +944,245 @@ __global__ __launch_bounds__(512) void gemm_bf3w_kernel(GemmArgs g) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   GW_COARSE(4);
+}
+
+// ------------------------------------------------------------------------------------ three-term split, wide tile
+// gemm_bf6w_kernel: gemm_bf3w_kernel's tile, DMA ring and layouts with every operand split in THREE bf16 terms on the
+// fragments (bfn_split2<3>: a + b + c == x exactly) and SIX products per product - fp32-equivalent arithmetic, the
+// default of the train step.  Per stage and wave: 12 ds_read_b128, ~270 VALU, 48 MFMAs of 32 cycles.  Three terms of the
+// 4 + 2 fragment blocks of a stage plus gemm_bf3w_kernel's look-ahead would need 96 fragment registers next to the 128
+// accumulators; the stage is therefore cut in four quarters of 12 MFMAs (A half x B block) and every quarter fetches
+// exactly the one operand the next quarter changes, which caps the live fragments at 72 registers:
+//   Q1: A rows 0-63   x B cols 0-31  of stage s   || read + split B cols 32-63 of stage s
+//   Q2: A rows 0-63   x B cols 32-63              || read + split A rows 64-127 of stage s      (last reads of stage s)
+//   mid: own DMAs of stage s + 1 landed (counted vmcnt), barrier
+//   Q3: A rows 64-127 x B cols 32-63              || read + split A rows 0-63 of stage s + 1, DMAs of stage s + 3 (A)
+//   Q4: A rows 64-127 x B cols 0-31               || read + split B cols 0-31 of stage s + 1 (into the registers B cols
+//                                                    32-63 just left: the two B register sets swap roles every stage,
+//                                                    compile-time tag P), DMAs of stage s + 3 (B)
+template <bool KC, int ROWS>
+__device__ __forceinline__ void bf6w_frag(const float* st, int row, int kq0s, int kq1s, int k0, gu32x4 (&t)[3]) {
+  float v[8];
+  if (KC) {
+    const float4 x = *reinterpret_cast<const float4*>(st + row * WK + kq0s);
+    const float4 y = *reinterpret_cast<const float4*>(st + row * WK + kq1s);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = st[(k0 + e) * ROWS + row];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned q[3];
+    bfn_split2<3>(v[2 * p], v[2 * p + 1], q);
+    t[0][p] = q[0]; t[1][p] = q[1]; t[2][p] = q[2];
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512) void gemm_bf6w_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) float smem[W_STAGES * W_STAGE_FLOATS];
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  int tid = blockIdx.x;
+  {
+    const int q = ntile >> 3, rmd = ntile & 7, xcd = tid & 7, idx = tid >> 3;
+    tid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
+  }
+  const int tm = tid / g.tiles_n, tn = tid % g.tiles_n;
+  const int z = blockIdx.y;
+  const int bz = z / g.split_k, kz = z % g.split_k;
+  const float* Ap = g.A.p + bz * g.sA;
+  const float* Bp = g.B.p + bz * g.sB;
+  float* C = g.C + bz * g.sC;
+  const int64_t m0 = (int64_t)tm * WM, n0 = (int64_t)tn * WN;
+  const int64_t ktiles = g.K / WK;
+  const int64_t per = (ktiles + g.split_k - 1) / g.split_k;
+  const int64_t kt_begin = kz * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int S = (int)(kt_end - kt_begin);
+  if (S <= 0) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  // DMA source offsets of this lane: as in gemm_bf3w_kernel (edge rows / columns clamped, k-contiguous pieces swizzled)
+  const int64_t lda = g.A.ld, ldb = g.B.ld;
+  unsigned offa[4], offb[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = 4 * wave + q;
+    if (AKC) {
+      const int r = 8 * p + (lane >> 3);
+      const int64_t row = m0 + r < g.M ? m0 + r : g.M - 1;
+      offa[q] = (unsigned)(row * lda + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
+    } else {
+      const int64_t col = m0 + 4 * lane + 4 <= g.M ? m0 + 4 * lane : g.M - 4;
+      offa[q] = (unsigned)(p * lda + col);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int p = 2 * wave + q;
+    if (BKC) {
+      const int r = 8 * p + (lane >> 3);
+      const int64_t row = n0 + r < g.N ? n0 + r : g.N - 1;
+      offb[q] = (unsigned)(row * ldb + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
+    } else {
+      const int64_t col = n0 + 4 * (lane & 31) + 4 <= g.N ? n0 + 4 * (lane & 31) : g.N - 4;
+      offb[q] = (unsigned)((2 * p + (lane >> 5)) * ldb + col);
+    }
+  }
+  const float* basea = AKC ? Ap + kt_begin * WK : Ap + kt_begin * WK * lda;
+  const float* baseb = BKC ? Bp + kt_begin * WK : Bp + kt_begin * WK * ldb;
+  const int64_t stepa = AKC ? WK : WK * lda, stepb = BKC ? WK : WK * ldb;
+  auto issue = [&](int st, int buf) {
+    float* sb = smem + buf * W_STAGE_FLOATS;
+    const float* pa = basea + st * stepa;
+    const float* pb = baseb + st * stepb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16(pa + offa[q], sb + (4 * wave + q) * 256);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) glds16(pb + offb[q], sb + W_A_FLOATS + (2 * wave + q) * 256);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int sw = (l31 >> 1) & 7;
+  const int kq0s = 4 * ((4 * kg + 2 * kh) ^ sw), kq1s = kq0s ^ 4;
+  const int kfirst = 16 * kg + 8 * kh;
+  const int arow = wm * 128 + l31, brow = wn * 64 + l31;
+
+  gu32x4 bq[2][3], a0[2][3], a1[2][3];
+#define BF6W(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a_), __builtin_bit_cast(gbf16x8, b_), c_, 0, 0, 0)
+  // the six products of (A half, B block): term pairs in order of significance sum; consecutive MFMAs alternate between
+  // the two accumulators of the quarter
+#define BF6W_PAIR(ah_, b_, i0_, j_, p_, q_) do { BF6W(ah_[0][p_], b_[q_], acc[i0_][j_]); BF6W(ah_[1][p_], b_[q_], acc[i0_ + 1][j_]); } while (0)
+  auto stage = [&](int st, int buf, auto ptag, auto ftag) {
+    constexpr int P = decltype(ptag)::value;
+    constexpr bool FULL = decltype(ftag)::value;       // stages st + 1 and st + 3 exist: no conditionals in the body
+    const float* sa = smem + buf * W_STAGE_FLOATS;
+    const int buf1 = buf == 2 ? 0 : buf + 1;
+    const float* sa1 = smem + buf1 * W_STAGE_FLOATS;
+    gu32x4 (&b0)[3] = bq[P];
+    gu32x4 (&b1)[3] = bq[1 - P];
+    const bool next = FULL || st + 1 < S;
+    // ---- Q1
+    BF6W_PAIR(a0, b0, 0, 0, 0, 0);
+    BF6W_PAIR(a0, b0, 0, 0, 0, 1);
+    bf6w_frag<BKC, WN>(sa + W_A_FLOATS, brow + 32, kq0s, kq1s, kfirst, b1);
+    BF6W_PAIR(a0, b0, 0, 0, 1, 0);
+    BF6W_PAIR(a0, b0, 0, 0, 0, 2);
+    BF6W_PAIR(a0, b0, 0, 0, 2, 0);
+    BF6W_PAIR(a0, b0, 0, 0, 1, 1);
+    // ---- Q2
+    BF6W_PAIR(a0, b1, 0, 1, 0, 0);
+    bf6w_frag<AKC, WM>(sa, arow + 64, kq0s, kq1s, kfirst, a1[0]);
+    BF6W_PAIR(a0, b1, 0, 1, 0, 1);
+    BF6W_PAIR(a0, b1, 0, 1, 1, 0);
+    bf6w_frag<AKC, WM>(sa, arow + 96, kq0s, kq1s, kfirst, a1[1]);
+    BF6W_PAIR(a0, b1, 0, 1, 0, 2);
+    BF6W_PAIR(a0, b1, 0, 1, 2, 0);
+    BF6W_PAIR(a0, b1, 0, 1, 1, 1);
+    // ---- mid
+    if (next) {
+      if (FULL || st + 2 < S) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    // ---- Q3
+    const bool dma = FULL || st + 3 < S;
+    float* sb = smem + buf * W_STAGE_FLOATS;           // stage st + 3 goes where stage st was
+    const float* pa = basea + (st + 3) * stepa;
+    const float* pb = baseb + (st + 3) * stepb;
+    BF6W_PAIR(a1, b1, 2, 1, 0, 0);
+    if (dma) {
+      glds16(pa + offa[0], sb + (4 * wave + 0) * 256);
+      glds16(pa + offa[1], sb + (4 * wave + 1) * 256);
+    }
+    if (next) bf6w_frag<AKC, WM>(sa1, arow, kq0s, kq1s, kfirst, a0[0]);
+    BF6W_PAIR(a1, b1, 2, 1, 0, 1);
+    BF6W_PAIR(a1, b1, 2, 1, 1, 0);
+    if (dma) {
+      glds16(pa + offa[2], sb + (4 * wave + 2) * 256);
+      glds16(pa + offa[3], sb + (4 * wave + 3) * 256);
+    }
+    if (next) bf6w_frag<AKC, WM>(sa1, arow + 32, kq0s, kq1s, kfirst, a0[1]);
+    BF6W_PAIR(a1, b1, 2, 1, 0, 2);
+    BF6W_PAIR(a1, b1, 2, 1, 2, 0);
+    BF6W_PAIR(a1, b1, 2, 1, 1, 1);
+    // ---- Q4 (b1 is dead: its registers receive B cols 0-31 of the next stage)
+    BF6W_PAIR(a1, b0, 2, 0, 0, 0);
+    if (dma) {
+      glds16(pb + offb[0], sb + W_A_FLOATS + (2 * wave + 0) * 256);
+      glds16(pb + offb[1], sb + W_A_FLOATS + (2 * wave + 1) * 256);
+    }
+    BF6W_PAIR(a1, b0, 2, 0, 0, 1);
+    if (next) bf6w_frag<BKC, WN>(sa1 + W_A_FLOATS, brow, kq0s, kq1s, kfirst, b1);
+    BF6W_PAIR(a1, b0, 2, 0, 1, 0);
+    BF6W_PAIR(a1, b0, 2, 0, 0, 2);
+    BF6W_PAIR(a1, b0, 2, 0, 2, 0);
+    BF6W_PAIR(a1, b0, 2, 0, 1, 1);
+  };
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+  typedef std::integral_constant<bool, true> Full;
+  typedef std::integral_constant<bool, false> Tail;
+
+  issue(0, 0);
+  if (S > 1) issue(1, 1);
+  if (S > 2) issue(2, 2);
+  if (S > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (S > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bf6w_frag<BKC, WN>(smem + W_A_FLOATS, brow, kq0s, kq1s, kfirst, bq[0]);
+  bf6w_frag<AKC, WM>(smem, arow, kq0s, kq1s, kfirst, a0[0]);
+  bf6w_frag<AKC, WM>(smem, arow + 32, kq0s, kq1s, kfirst, a0[1]);
+  int st = 0, buf = 0;
+  for (; st + 4 < S; st += 2) {                  // both stages of the pair have st + 3 < S
+    stage(st, buf, P0(), Full());
+    buf = buf == 2 ? 0 : buf + 1;
+    stage(st + 1, buf, P1(), Full());
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  for (; st < S; st += 2) {                      // st stays even: the parity of the B registers is a compile-time tag
+    stage(st, buf, P0(), Tail());
+    buf = buf == 2 ? 0 : buf + 1;
+    if (st + 1 < S) {
+      stage(st + 1, buf, P1(), Tail());
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+  }
+#undef BF6W_PAIR
+#undef BF6W
+
+  // ---- sum the two K halves and store: as gemm_bf3w_kernel
+  __syncthreads();
+  const int w4 = wave & 3;
+  float* xs = smem + ((w4 * 2 + (1 - kg)) * 64) * 64;       // read by the partner
+  const float* xr = smem + ((w4 * 2 + kg) * 64) * 64;       // written by the partner
+  if (kg == 0) bf3w_send<2>(xs, acc, lane); else bf3w_send<0>(xs, acc, lane);
+  __syncthreads();
+  const int64_t mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
+  if (m0 + WM <= g.M && n0 + WN <= g.N) {
+    if (kg == 0) bf3w_finish<0, false>(xr, acc, g, C, mrow0, ncol0, lane);
+    else bf3w_finish<2, false>(xr, acc, g, C, mrow0, ncol0, lane);
+  } else {
+    if (kg == 0) bf3w_finish<0, true>(xr, acc, g, C, mrow0, ncol0, lane);
+    else bf3w_finish<2, true>(xr, acc, g, C, mrow0, ncol0, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // bias (+ReLU) pass after a split-K product (the atomics cannot carry an epilogue)
@@ -1032,48 +1297,46 @@ __global__ __launch_bounds__(256) void colsum4_kernel(int64_t M, int64_t N, cons
 
 extern "C" int asr_abi_version(void) { return ASR_ABI_VERSION; }
 
-#ifndef ASR_LSTM_BF3_DEFAULT
-#define ASR_LSTM_BF3_DEFAULT 7
-#endif
-#ifndef ASR_GEMM_WIDE_DEFAULT
-#define ASR_GEMM_WIDE_DEFAULT 1
-#endif
-static int& split_bf16_state() {
-  static int mask = [] {
-    const char* l = getenv("ASR_LSTM_BF3");
-    const char* g = getenv("ASR_GEMM_BF3");
-    const char* w = getenv("ASR_GEMM_WIDE");
-    return ((l ? atoi(l) : ASR_LSTM_BF3_DEFAULT) & 7) | ((g ? atoi(g) : ASR_GEMM_BF3_DEFAULT) ? 8 : 0) |
-           ((w ? atoi(w) : ASR_GEMM_WIDE_DEFAULT) ? 16 : 0) | ((w && atoi(w) == 2) ? 32 : 0);
-  }();
-  return mask;
-}
-int asr_split_bf16_mask() { return split_bf16_state(); }
-extern "C" int asr_set_split_bf16(int mask) {
-  const int old = split_bf16_state();
-  if (mask >= 0) split_bf16_state() = mask & 63;
-  return old;
-}
-
 #ifdef ASR_GW_TRACE
 extern "C" int asr_gw_trace_read(void* dst) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(asr_gw_trace_buf), sizeof(unsigned long long) * 2 * 64 * 8);
 }
 #endif
 
+// Split-K factor of the 128 x 128 kernels when the caller passes split_k <= 0 (partials are added with f32 atomics; a
+// bias / ReLU epilogue then needs a second pass over C).  256 CUs hold two 128 x 128 workgroups each, so the target is
+// ~512 workgroups: floor(512 / tiles), at most 8 (16 for <= 32 tiles), every K slice at least 256 long.  Measured with
+// cold operands (tools/gemm_cold_split_sweep.py): 400 tiles -> 1, 200 -> 2, 144 -> 3, 128 -> 4, 64 -> 8.
+static int narrow_split_k(int64_t M, int64_t N, int64_t K, int batch, bool epilogue) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+  if (tiles >= 512 || K < 512) return 1;
+  int64_t sk = tiles <= 32 ? 16 : 8;
+  if (512 / tiles < sk) sk = 512 / tiles;
+  if (K / 256 < sk) sk = K / 256;
+  if (sk < 1) sk = 1;
+  if (epilogue && sk > 1 && tiles > 64) return 1;
+  return (int)sk;
+}
+
+template <int NT>
+static void launch_narrow_split(bool akc, bool bkc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
+  const dim3 block(256);
+  if (akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, true, NT>), grid, block, 0, stream, g);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, false, NT>), grid, block, 0, stream, g);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<false, true, NT>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_bf3_kernel<false, false, NT>), grid, block, 0, stream, g);
+}
+
 extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                             const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
-                            int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC, int split_k,
+                            int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC, int split_k, int arith,
                             asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return ASR_E_ARG;
-  if (split_k < 1) split_k = 1;
-  // split-K with an epilogue: the product is formed without it (atomics) and a second pass applies bias / ReLU
-  const bool late_epilogue = split_k > 1 && (bias || relu);
-  if (late_epilogue && accumulate) return ASR_E_SHAPE;
-  const float* bias_late = bias;
-  const int relu_late = relu;
-  if (late_epilogue) { bias = nullptr; relu = 0; }
+  const int ar = arith & ASR_ARITH_MASK;
+  if (ar != ASR_ARITH_F32 && ar != ASR_ARITH_BF16X6 && ar != ASR_ARITH_BF16X3) return ASR_E_ARG;
+  const bool auto_split = split_k <= 0;           // the kernel chooses; split_k == 1 is honoured as "unsplit" (run-to-run
+                                                  // deterministic: no atomics), split_k > 1 as given on the 128 x 128 kernels
   GemmArgs g;
   const bool akc = !transA, bkc = transB != 0;
   g.A.p = A; g.A.ld = lda;
@@ -1083,46 +1346,42 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   if (bkc) { g.B.R = N; g.B.Cn = K; } else { g.B.R = K; g.B.Cn = N; }
   g.B.vec = (ldb % 4 == 0) && asr_aligned16(B) && (sB % 4 == 0);
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
-  g.bias = bias; g.relu = relu; g.accumulate = accumulate; g.split_k = split_k;
+  g.accumulate = accumulate;
   g.sA = sA; g.sB = sB; g.sC = sC;
-  // wide-tile LDS-DMA kernel for conforming shapes (see gemm_bf3w_kernel); it picks its own K split: 256 workgroup
-  // slots (one 8-wave workgroup per CU), cost = rounds x (stages per slice + a fixed prologue / epilogue share)
-  // Where it is used (tools/gemm_shapes.py, cold operands, one cfg-2 step): the weight-gradient products (both operands
-  // row-contiguous, long K: 188 vs 263 us, 153 vs 227 (N = 80), 117 vs 154, 119 vs 158, 90 vs 112) and every K >= 2048
-  // product (dX = dG W_ih 215 vs 263 us unsplit, projections 114 vs 132); K = 512 projections time the same on both
-  // kernels or worse on this one (one 8-wave workgroup per CU cannot hide its prologue and its 128 KB of output behind
-  // another workgroup) and stay on the 128 x 128 kernel.
-  // Mask bit 32 (tests, measurements; ASR_GEMM_WIDE=2) sends every conforming shape here.
-  // any M, N (edge tiles clamp their DMA rows / columns and guard the stores); K % 32 == 0; row-contiguous operands need
-  // a multiple of 4 rows; per-lane offsets are 32-bit
+  const bool epi = bias || relu;
+  // Wide-tile LDS-DMA kernels (gemm_bf3w_kernel / gemm_bf6w_kernel) for conforming shapes: any M, N (edge tiles clamp their
+  // DMA rows / columns and guard the stores); K % 32 == 0; row-contiguous operands need a multiple of 4 rows; per-lane
+  // offsets are 32-bit.  Where they are used (tools/gemm_shapes.py, cold operands, one cfg-2 step): the weight-gradient
+  // products (both operands row-contiguous, long K) and every K >= 2048 product; K = 512 projections time the same on both
+  // kernels or worse on the wide one (one 8-wave workgroup per CU cannot hide its prologue and its 128 KB of output behind
+  // another workgroup) and stay on the 128 x 128 kernel.  ASR_GEMM_TILE_WIDE sends every conforming shape there,
+  // ASR_GEMM_TILE_NARROW none (tests, measurements).
   const bool wide_shape = K % WK == 0 && g.A.vec && g.B.vec && (akc ? M : K) * lda < ((int64_t)1 << 31) &&
                           (bkc ? N : K) * ldb < ((int64_t)1 << 31) && (akc || (M % 4 == 0 && M >= 4)) &&
                           (bkc || (N % 4 == 0 && N >= 4)) && M >= 64 && N >= 64;
-  const bool wide_all = (asr_split_bf16_mask() & 32) != 0;
   const int64_t wtiles = ((M + WM - 1) / WM) * ((N + WN - 1) / WN) * batch;
-  const bool may_split = split_k > 1 || !(bias || relu);
-  const bool wide_pays = (!akc && !bkc && K >= 1024) || (K >= 2048 && (may_split || wtiles >= 150)) || wide_all;
-  const bool wide = (asr_split_bf16_mask() & 24) == 24 && wide_shape && wide_pays;
+  const bool may_split = auto_split && !(epi && accumulate);
+  const bool wide_pays = (!akc && !bkc && K >= 1024) || (K >= 2048 && ((may_split && !epi) || wtiles >= 150));
+  const bool wide = ar != ASR_ARITH_F32 && !(arith & ASR_GEMM_TILE_NARROW) && wide_shape &&
+                    (wide_pays || (arith & ASR_GEMM_TILE_WIDE)) && (auto_split || split_k == 1);
   if (wide) {
+    // its own K split: 256 workgroup slots (one 8-wave workgroup per CU), cost in units of one stage = rounds x (stages
+    // per slice + a fixed prologue / epilogue share) + what the atomics and the zero pass of a split cost per MB of output
+    // (tools/gemm_wide_split.py: 12800 x 512 x 4096 takes 215 us unsplit on 200 of the 256 CUs, 256 us split in two)
     const int64_t tiles = wtiles, stages = K / WK;
     int best = 1;
-    if (may_split) {
+    if (may_split && !epi) {
       double best_cost = 1e30;
       for (int sk = 1; sk <= 16 && stages / sk >= 8; ++sk) {
         const int64_t wgs = tiles * sk, rounds = (wgs + 255) / 256;
-        // in units of one stage (~1.7 us): rounds x (stages + prologue / epilogue share) + what the atomics and the zero pass
-        // of a split cost per MB of output (tools/gemm_wide_split.py: 12800 x 512 x 4096 takes 215 us unsplit on 200 of
-        // the 256 CUs, 256 us split in two)
         const double out_mb = (double)M * N * batch * 4.0 / 1048576.0;
         const double cost = (double)rounds * ((double)((stages + sk - 1) / sk) + 6.0) + (sk > 1 ? 0.47 * sk * out_mb : 0.0);
         if (cost < best_cost) { best_cost = cost; best = sk; }
       }
     }
     static const int forced_sk = [] { const char* f = getenv("ASR_GEMM_WIDE_SK"); return f ? atoi(f) : 0; }();   // measurement
-    if (forced_sk >= 1 && forced_sk <= stages) best = forced_sk;
-    const bool late = best > 1 && (bias_late || relu_late);
-    if (late && accumulate) return ASR_E_SHAPE;
-    if (late) { g.bias = nullptr; g.relu = 0; } else { g.bias = bias_late; g.relu = relu_late; }
+    if (forced_sk >= 1 && forced_sk <= stages && may_split && !epi) best = forced_sk;
+    g.bias = bias; g.relu = relu;
     g.split_k = best;
     g.tiles_m = (int)((M + WM - 1) / WM);
     g.tiles_n = (int)((N + WN - 1) / WN);
@@ -1131,39 +1390,45 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
       hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
     }
     dim3 grid(g.tiles_m * g.tiles_n, batch * best, 1), block(512);
-    if (akc && bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<true, true>), grid, block, 0, stream, g);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<true, false>), grid, block, 0, stream, g);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<false, true>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((gemm_bf3w_kernel<false, false>), grid, block, 0, stream, g);
-    if (late) {
-      dim3 eg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
-      hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, bias_late, relu_late);
+    if (ar == ASR_ARITH_BF16X6) {
+      if (akc && bkc) hipLaunchKernelGGL((gemm_bf6w_kernel<true, true>), grid, block, 0, stream, g);
+      else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf6w_kernel<true, false>), grid, block, 0, stream, g);
+      else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf6w_kernel<false, true>), grid, block, 0, stream, g);
+      else hipLaunchKernelGGL((gemm_bf6w_kernel<false, false>), grid, block, 0, stream, g);
+    } else {
+      if (akc && bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<true, true>), grid, block, 0, stream, g);
+      else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<true, false>), grid, block, 0, stream, g);
+      else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<false, true>), grid, block, 0, stream, g);
+      else hipLaunchKernelGGL((gemm_bf3w_kernel<false, false>), grid, block, 0, stream, g);
     }
     ASR_CHECK_LAUNCH();
     return 0;
   }
+  if (auto_split) split_k = (epi && accumulate) ? 1 : narrow_split_k(M, N, K, batch, epi);
+  // split-K with an epilogue: the product is formed without it (atomics) and a second pass applies bias / ReLU
+  const bool late_epilogue = split_k > 1 && epi;
+  if (late_epilogue && accumulate) return ASR_E_SHAPE;
+  g.bias = late_epilogue ? nullptr : bias;
+  g.relu = late_epilogue ? 0 : relu;
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
   const int64_t ktiles = (K + BK - 1) / BK;
-  if (split_k > ktiles) { split_k = (int)ktiles; g.split_k = split_k; }
+  if (split_k > ktiles) split_k = (int)ktiles;
+  g.split_k = split_k;
   if (split_k > 1 && !accumulate) {
     dim3 zg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
     hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
   }
   dim3 grid(g.tiles_m * g.tiles_n, batch * split_k, 1), block(256);
-  // split-bf16 products by default; asr_set_split_bf16 / ASR_GEMM_BF3=0 select the exact-fp32 MFMA kernel
-  if (asr_split_bf16_mask() & 8) {
-    if (akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, true>), grid, block, 0, stream, g);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, false>), grid, block, 0, stream, g);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<false, true>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((gemm_bf3_kernel<false, false>), grid, block, 0, stream, g);
-  } else if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
+  if (ar == ASR_ARITH_BF16X6) launch_narrow_split<3>(akc, bkc, grid, stream, g);
+  else if (ar == ASR_ARITH_BF16X3) launch_narrow_split<2>(akc, bkc, grid, stream, g);
+  else if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
   else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
   else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
   else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
   if (late_epilogue) {
     dim3 eg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
-    hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, bias_late, relu_late);
+    hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, bias, relu);
   }
   ASR_CHECK_LAUNCH();
   return 0;

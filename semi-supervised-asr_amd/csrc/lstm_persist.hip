@@ -35,9 +35,6 @@
                                      1 = single-stage LSB-tagged words read as 8-byte atomics (2.38-2.45),
                                      2 = the same words read with 16-byte sc1 buffer loads (2.05) */
 #endif
-#ifndef ASR_LSTM_BF3_DEFAULT   /* split-bf16 recurrent products, see bf3_enabled() (env ASR_LSTM_BF3 overrides) */
-#define ASR_LSTM_BF3_DEFAULT 7
-#endif
 #ifndef ASR_LSTM_TOUCH
 #define ASR_LSTM_TOUCH 1
 #endif
@@ -213,7 +210,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         break;
 #endif
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
+          if (lane == 0) raise_abort(a.ctrl, 1u);
           aborted = true;
           break;
         }
@@ -241,7 +238,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         break;
 #endif
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
+          if (lane == 0) raise_abort(a.ctrl, 1u);
           aborted = true;
           break;
         }
@@ -290,7 +287,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         break;
 #endif
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
+          if (lane == 0) raise_abort(a.ctrl, 1u);
           aborted = true;
           break;
         }
@@ -428,11 +425,56 @@ __device__ __forceinline__ void bf3_split8(const float (&v)[8], u32x4& hi, u32x4
   lo = (u32x4){bf3_lo(v[0]) | (bf3_lo(v[1]) << 16), bf3_lo(v[2]) | (bf3_lo(v[3]) << 16),
                bf3_lo(v[4]) | (bf3_lo(v[5]) << 16), bf3_lo(v[6]) | (bf3_lo(v[7]) << 16)};
 }
+// NT-term split of one value / eight values.  NT = 2: hi + lo as above (truncating; the "bf16x3" arithmetic).  NT = 3
+// ("bf16x6", the default): a = bf16(x), b = bf16(x - a), c = x - a - b, every conversion rounded to nearest; both
+// differences are exact in fp32 and c has at most 8 significand bits, so a + b + c == x exactly (see gemm.hip).
+typedef __bf16 lbf16x2 __attribute__((ext_vector_type(2)));
+template <int NT>
+__device__ __forceinline__ void bfn_split1(float v, unsigned (&t)[NT]) {          // 16-bit patterns, most significant first
+  if constexpr (NT == 2) {
+    t[0] = bf3_hi(v);
+    t[1] = bf3_lo(v);
+  } else {
+    const lbf16x2 pa = {(__bf16)v, (__bf16)0.f};
+    const unsigned ua = __builtin_bit_cast(unsigned, pa) & 0xffffu;
+    const float r = v - __uint_as_float(ua << 16);
+    const lbf16x2 pb = {(__bf16)r, (__bf16)0.f};
+    const unsigned ub = __builtin_bit_cast(unsigned, pb) & 0xffffu;
+    const float q = r - __uint_as_float(ub << 16);
+    t[0] = ua; t[1] = ub; t[2] = __float_as_uint(q) >> 16;
+  }
+}
+template <int NT>
+__device__ __forceinline__ void bfn_split2(float x, float y, unsigned (&t)[NT]) {  // t[k] = {term_k(x), term_k(y)}
+  if constexpr (NT == 2) {
+    t[0] = bf3_hi(x) | (bf3_hi(y) << 16);
+    t[1] = bf3_lo(x) | (bf3_lo(y) << 16);
+  } else {
+    const lbf16x2 pa = {(__bf16)x, (__bf16)y};
+    const unsigned ua = __builtin_bit_cast(unsigned, pa);
+    const float rx = x - __uint_as_float(ua << 16), ry = y - __uint_as_float(ua & 0xffff0000u);
+    const lbf16x2 pb = {(__bf16)rx, (__bf16)ry};
+    const unsigned ub = __builtin_bit_cast(unsigned, pb);
+    const float sx = rx - __uint_as_float(ub << 16), sy = ry - __uint_as_float(ub & 0xffff0000u);
+    t[0] = ua; t[1] = ub;
+    t[2] = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void bfn_split8(const float (&v)[8], u32x4 (&t)[NT]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned q[NT];
+    bfn_split2<NT>(v[2 * p], v[2 * p + 1], q);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) t[k][p] = q[k];
+  }
+}
 __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int PH, int NR>
+template <int PH, int NR, int NT>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a) {
   static_assert(NR == 4 || NR == PRG, "rows per group");
   constexpr int PKW = PH / PW;           // K columns per wave
@@ -442,14 +484,13 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   constexpr int MT = (PUC + 3) / 4;      // M tiles: 4 units (16 gate rows) each
   constexpr int HST = KP + 8;            // LDS row stride in bf16: 16-byte multiple, rows 144 B apart at KP = 64 (the 8
                                          // rows of a 16-byte operand read then cover 8 distinct bank groups)
-  __shared__ __attribute__((aligned(16))) unsigned short hhi[PW][PRG][HST];
-  __shared__ __attribute__((aligned(16))) unsigned short hlo[PW][PRG][HST];
+  __shared__ __attribute__((aligned(16))) unsigned short hh[NT][PW][PRG][HST];      // split terms of the h tile
   __shared__ __attribute__((aligned(16))) float part[2][PW][4 * MT][PRG][4];   // K-partials [unit][row][gate], double buffered
   __shared__ int role[2];
   extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < PW * PRG * HST; i += PNT) { (&hhi[0][0][0])[i] = 0; (&hlo[0][0][0])[i] = 0; }   // K padding, unused rows
+  for (int i = tid; i < NT * PW * PRG * HST; i += PNT) (&hh[0][0][0][0])[i] = 0;   // K padding, unused rows
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
@@ -461,7 +502,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   const int64_t ldy = (int64_t)ndir * PH;
   const int ml = lane & 15, kq = lane >> 4;
   // recurrent weights of this CU -> split bf16 registers
-  u32x4 whi[MT][KS], wlo[MT][KS];
+  u32x4 wt[MT][KS][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int grow = 16 * mt + ml;                                  // gate-interleaved row within this CU's 4*PUC
@@ -478,7 +519,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
         v[4 * j4] = kok ? q.x : 0.f; v[4 * j4 + 1] = kok ? q.y : 0.f;
         v[4 * j4 + 2] = kok ? q.z : 0.f; v[4 * j4 + 3] = kok ? q.w : 0.f;
       }
-      bf3_split8(v, whi[mt][ks], wlo[mt][ks]);
+      bfn_split8<NT>(v, wt[mt][ks]);
     }
   }
   // pointwise ownership: thread (pu, pj) for tid < PUC*PRG -> unit PUC*slice+pu, row r0+pj
@@ -547,7 +588,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
           for (int j = 0; j < NR / 4; ++j) ok = ok && (!gl[kc] || quad_ok(gw[kc][j], tb));
         if (__all(ok)) break;
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) { flag_store(a.ctrl + 9, 1u); flag_store(a.ctrl + 8, 1u); }
+          if (lane == 0) raise_abort(a.ctrl, 1u);
           aborted = true;
           break;
         }
@@ -563,8 +604,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
                                 __uint_as_float(gw[kc][j].w)};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              hhi[wave][4 * j + i][lane + 64 * kc] = (unsigned short)bf3_hi(f[i]);
-              hlo[wave][4 * j + i][lane + 64 * kc] = (unsigned short)bf3_lo(f[i]);
+              unsigned tk[NT];
+              bfn_split1<NT>(f[i], tk);
+#pragma unroll
+              for (int k = 0; k < NT; ++k) hh[k][wave][4 * j + i][lane + 64 * kc] = (unsigned short)tk[k];
             }
           }
         }
@@ -579,14 +622,16 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       // (wave-private LDS tile: program order within the wave is enough)
 #pragma unroll
       for (int ks = 0; ks < ((ASR_LA & 1) ? 0 : KS); ++ks) {
-        const u32x4 bh = *reinterpret_cast<const u32x4*>(&hhi[wave][ml & 7][32 * ks + 8 * kq]);
-        const u32x4 bl = *reinterpret_cast<const u32x4*>(&hlo[wave][ml & 7][32 * ks + 8 * kq]);
+        u32x4 bt[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bh, acc[mt]);
+        for (int k = 0; k < NT; ++k) bt[k] = *reinterpret_cast<const u32x4*>(&hh[k][wave][ml & 7][32 * ks + 8 * kq]);
+        // term pairs (p, q), p + q < NT: hi hi, hi lo, lo hi (two terms); + a c, c a, b b (three terms)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bl, acc[mt]);
+        for (int o = 0; o < NT; ++o)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wlo[mt][ks], bh, acc[mt]);
+          for (int pp = 0; pp <= o; ++pp)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][pp], bt[o - pp], acc[mt]);
       }
     }
     LP_MARK(2);
@@ -624,6 +669,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
     }
   }
   if (st_gp) {
+    // an abort raised elsewhere during the last steps (the flag is sampled every 16th step inside the loop)
+    if (flag_load(a.ctrl + 8) != 0u) st_y = __builtin_nanf("");
     *st_gp = st_g;
     a.c[st_so] = st_c;
     a.y[st_so] = st_y;
@@ -788,7 +835,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
         break;
 #endif
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
+          if (lane == 0) raise_abort(a.ctrl, 3u);
           aborted = true;
           break;
         }
@@ -942,7 +989,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
 // registers, B = the gathered dG tile, which the gathering lanes write to LDS twice - as fp32 for the fused dW_hh
 // product (unchanged, exact fp32, off the serial chain) and split in bf16 for this one.  D puts the 4 units 4 (l >> 4)
 // .. + 3 of batch row l & 15 in one lane: the 4 k-sub partials and their DPP reduction of the 4x4x1 mapping are gone.
-template <int PH, int NR>
+template <int PH, int NR, int NT>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a) {
   static_assert(NR == 4 || NR == PRG, "rows per group (see the forward kernel)");
   constexpr int PUC = PH / 32;       // hidden units per CU
@@ -955,15 +1002,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
   constexpr int KSB = PKB / 32;      // k-steps of the split-bf16 dh product
   constexpr int BST = PKB + 8;       // bf16 row stride (16-byte multiple, 8 rows of a read on distinct bank groups)
   static_assert(PKB % 32 == 0 && PUC <= 16, "one 16-unit M tile, whole k-steps");
-  __shared__ __attribute__((aligned(16))) unsigned short bhi[PW][PRG][BST];   // dG tile split for the dh product
-  __shared__ __attribute__((aligned(16))) unsigned short blo[PW][PRG][BST];
+  __shared__ __attribute__((aligned(16))) unsigned short bsp[NT][PW][PRG][BST];   // dG tile split for the dh product
   __shared__ __attribute__((aligned(16))) float part[2][PW][PRG][16];         // partial dh_rec [row][unit], double buffered
   __shared__ float ysl[2][PRG][16];                                       // this CU's slice of h at the current time
   __shared__ int role[2];
   constexpr int NKQ = (PKB + 63) / 64;                                    // 64-column chunks of the wave's K range
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid < 2 * PRG * 16) (&ysl[0][0][0])[tid] = 0.f;
-  for (int i = tid; i < PW * PRG * BST; i += PNT) { (&bhi[0][0][0])[i] = 0; (&blo[0][0][0])[i] = 0; }   // rows >= NR stay 0
+  for (int i = tid; i < NT * PW * PRG * BST; i += PNT) (&bsp[0][0][0][0])[i] = 0;   // rows >= NR stay 0
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int g, slice;
   take_role(a.ctrl, role, g, slice);
@@ -979,7 +1025,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
   // W_hhT slice -> split bf16 registers: A operand of the 16x16x32 product, lane l holds unit l & 15 of this CU,
   // gate columns wave*PKB + 32 ks + 8 (l >> 4) + j
   const int ml = lane & 15, kq = lane >> 4;
-  u32x4 whi[KSB], wlo[KSB];
+  u32x4 wt[KSB][NT];
   {
     const bool uok = ml < PUC;
     const float* wr = a.w + ((int64_t)d * PH + PUC * slice + (uok ? ml : 0)) * (4 * PH) + wave * PKB + 8 * kq;
@@ -988,7 +1034,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
       const float4 q0 = *reinterpret_cast<const float4*>(wr + 32 * ks), q1 = *reinterpret_cast<const float4*>(wr + 32 * ks + 4);
       const float v[8] = {uok ? q0.x : 0.f, uok ? q0.y : 0.f, uok ? q0.z : 0.f, uok ? q0.w : 0.f,
                           uok ? q1.x : 0.f, uok ? q1.y : 0.f, uok ? q1.z : 0.f, uok ? q1.w : 0.f};
-      bf3_split8(v, whi[ks], wlo[ks]);
+      bfn_split8<NT>(v, wt[ks]);
     }
   }
   // Waves 6-7 mirror the pointwise threads' (unit, row) mapping: they issue the SAME forward-data loads two steps
@@ -1101,7 +1147,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
         break;
 #endif
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
+          if (lane == 0) raise_abort(a.ctrl, 3u);
           aborted = true;
           break;
         }
@@ -1112,21 +1158,28 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
       for (int rr = 0; rr < NR; ++rr)
         if (gl) {
           *reinterpret_cast<float4*>(&hs[wave][rr][PQS * ((4 * lane) / PQ) + (4 * lane) % PQ]) = gr[rr];
-          *reinterpret_cast<uint2*>(&bhi[wave][rr][4 * lane]) =
-              make_uint2(bf3_hi(gr[rr].x) | (bf3_hi(gr[rr].y) << 16), bf3_hi(gr[rr].z) | (bf3_hi(gr[rr].w) << 16));
-          *reinterpret_cast<uint2*>(&blo[wave][rr][4 * lane]) =
-              make_uint2(bf3_lo(gr[rr].x) | (bf3_lo(gr[rr].y) << 16), bf3_lo(gr[rr].z) | (bf3_lo(gr[rr].w) << 16));
+          unsigned p0[NT], p1[NT];
+          bfn_split2<NT>(gr[rr].x, gr[rr].y, p0);
+          bfn_split2<NT>(gr[rr].z, gr[rr].w, p1);
+#pragma unroll
+          for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&bsp[k][wave][rr][4 * lane]) = make_uint2(p0[k], p1[k]);
         }
       if (prow_ok && s + 1 < T) fetch_step(s + 1);
       else if (touch_ok && s + ASR_LSTM_TOUCH_DIST < T) fetch_step(s + ASR_LSTM_TOUCH_DIST);   // L2 warm-up (results unused)
       // dh partial [16 units x rows] of this wave's K range: three independent accumulators (one per split term)
 #pragma unroll
       for (int ks = 0; ks < ((ASR_LP_ABL & 1) ? 1 : KSB); ++ks) {
-        const u32x4 bh = *reinterpret_cast<const u32x4*>(&bhi[wave][ml & 7][32 * ks + 8 * kq]);
-        const u32x4 bl = *reinterpret_cast<const u32x4*>(&blo[wave][ml & 7][32 * ks + 8 * kq]);
-        acc0 = bf3_mfma(whi[ks], bh, acc0);
-        acc1 = bf3_mfma(whi[ks], bl, acc1);
-        acc2 = bf3_mfma(wlo[ks], bh, acc2);
+        u32x4 bt[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) bt[k] = *reinterpret_cast<const u32x4*>(&bsp[k][wave][ml & 7][32 * ks + 8 * kq]);
+        acc0 = bf3_mfma(wt[ks][0], bt[0], acc0);
+        acc1 = bf3_mfma(wt[ks][0], bt[1], acc1);
+        acc2 = bf3_mfma(wt[ks][1], bt[0], acc2);
+        if constexpr (NT == 3) {
+          acc0 = bf3_mfma(wt[ks][0], bt[2], acc0);
+          acc1 = bf3_mfma(wt[ks][2], bt[0], acc1);
+          acc2 = bf3_mfma(wt[ks][1], bt[1], acc2);
+        }
       }
     }
     if (s == 0 && prow_ok && T > 1) fetch_step(1);
@@ -1266,7 +1319,7 @@ struct RsDims {
   static_assert(PH % 128 == 0 && PUC % 4 == 0 && PUC <= 16, "H in {128, 256, 384, 512}");
 };
 
-template <int PH, int NR>
+template <int PH, int NR, int NT>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a) {
   using RD = RsDims<PH>;
   constexpr int PUC = RD::PUC, NC = RD::NC, KS = RD::KS, MTW = RD::MTW, CT = RD::CT, UPW = RD::UPW, CPW = RD::CPW;
@@ -1278,15 +1331,25 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   //     hardware transpose read, tools/micro/tr_read_check.hip)
   // The first version kept a second, column-major copy for dW_hh that the pointwise threads filled with 24 two-byte LDS
   // stores per step: 0.13 us of the serial chain (-DASR_RA=128).  h_{t_prev} stays [unit][slot][row].
-  __shared__ __attribute__((aligned(16))) unsigned short dgs_hi[4][PRG][GST], dgs_lo[4][PRG][GST];
-  __shared__ __attribute__((aligned(16))) unsigned short ht_hi[PH][4][PRG], ht_lo[PH][4][PRG];
+  // Three terms (NT = 3, six products): the kernel is at the register limit with two terms of W (64 VGPRs) next to the
+  // dW_hh accumulators (64), so the THIRD term of W lives in LDS in the lane layout of its consumer (wcl: one ds_read_b128
+  // per fragment and step, used by the last of the six products), and the h tile is kept as fp32 (htf) and split where it
+  // is consumed, every third step, which frees the LDS the third image pair would take.
+  __shared__ __attribute__((aligned(16))) unsigned short dgs[NT][4][PRG][GST];
+  __shared__ __attribute__((aligned(16))) unsigned short ht2[NT == 2 ? 2 : 1][NT == 2 ? PH : 1][4][PRG];
+  __shared__ __attribute__((aligned(16))) float htf[NT == 3 ? PH : 1][4][PRG];
+  __shared__ __attribute__((aligned(16))) u32x4 wcl[NT == 3 ? PW * MTW * KS * 64 : 1];
   __shared__ __attribute__((aligned(16))) float dhs[PRG][16];                                 // reduced dh_rec [row][unit]
   __shared__ int role[2];
   extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 4 * PRG * GST; i += PNT) { (&dgs_hi[0][0][0])[i] = 0; (&dgs_lo[0][0][0])[i] = 0; }
-  for (int i = tid; i < PH * 4 * PRG; i += PNT) { (&ht_hi[0][0][0])[i] = 0; (&ht_lo[0][0][0])[i] = 0; }
+  for (int i = tid; i < NT * 4 * PRG * GST; i += PNT) (&dgs[0][0][0][0])[i] = 0;
+  if constexpr (NT == 2) {
+    for (int i = tid; i < 2 * PH * 4 * PRG; i += PNT) (&ht2[0][0][0][0])[i] = 0;
+  } else {
+    for (int i = tid; i < PH * 4 * PRG; i += PNT) (&htf[0][0][0])[i] = 0.f;
+  }
   if (tid < PRG * 16) (&dhs[0][0])[tid] = 0.f;
   int g, slice;
   take_role(a.ctrl, role, g, slice);
@@ -1300,7 +1363,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   const int ml = lane & 15, kq = lane >> 4;
   // W_hh rows of this CU's columns, all units -> split bf16: A operand of the dh-partial product.  a.w is W_hh^T
   // [unit][4H]: lane l holds unit 16 (MTW wave + mt) + (l & 15), columns NC slice + 32 ks + 8 (l >> 4) + j
-  u32x4 whi[MTW][KS], wlo[MTW][KS];
+  u32x4 wt[MTW][KS][2];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
     const int wunit = 16 * (MTW * wave + mt) + ml;
@@ -1325,7 +1388,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
           v[4 * j4 + 2] = kok ? q.z : 0.f; v[4 * j4 + 3] = kok ? q.w : 0.f;
         }
       }
-      bf3_split8(v, whi[mt][ks], wlo[mt][ks]);
+      u32x4 wsp[NT];
+      bfn_split8<NT>(v, wsp);
+      wt[mt][ks][0] = wsp[0]; wt[mt][ks][1] = wsp[1];
+      if constexpr (NT == 3) wcl[((wave * MTW + mt) * KS + ks) * 64 + lane] = wsp[2];    // read back by this lane only
     }
   }
   // pointwise ownership as in the other kernels: thread (pu, pj), tid < PUC*PRG
@@ -1386,30 +1452,29 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       n_h[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hrs, h_voff, (unsigned)(row * ldy) * 4u, 0));
     }
   };
-  auto stage_h = [&](int buf, int sn) {  // n_h (fetched for step sn) -> this lane's unit, slot buf of ht_hi / ht_lo
+  auto stage_h = [&](int buf, int sn) {  // n_h (fetched for step sn) -> this lane's unit, slot buf of the h tile
     const int tt = time_of(sn);
     const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
-    unsigned hi[NR / 2], lo[NR / 2];
+    float hv[NR];
 #pragma unroll
-    for (int r = 0; r < NR / 2; ++r) {
-#if ASR_RA & 1024
-      const float v0 = n_h[2 * r], v1 = n_h[2 * r + 1];
-      hi[r] = __float_as_uint(v0); lo[r] = __float_as_uint(v1);
-#else
-      const float v0 = (hp && r0 + 2 * r < a.nb) ? n_h[2 * r] : 0.f;
-      const float v1 = (hp && r0 + 2 * r + 1 < a.nb) ? n_h[2 * r + 1] : 0.f;
-      hi[r] = bf3_hi(v0) | (bf3_hi(v1) << 16);
-      lo[r] = bf3_lo(v0) | (bf3_lo(v1) << 16);
-#endif
-    }
-    if (ASR_RA & 512) {
-      asm volatile("" ::"v"(hi[0]), "v"(hi[1]), "v"(lo[0]), "v"(lo[1]), "v"(hi[NR / 2 - 1]), "v"(lo[NR / 2 - 1]));
-    } else if (NR == 8) {
-      *reinterpret_cast<u32x4*>(&ht_hi[hunit][buf][0]) = (u32x4){hi[0], hi[1], hi[NR / 2 - 2], hi[NR / 2 - 1]};
-      *reinterpret_cast<u32x4*>(&ht_lo[hunit][buf][0]) = (u32x4){lo[0], lo[1], lo[NR / 2 - 2], lo[NR / 2 - 1]};
+    for (int r = 0; r < NR; ++r) hv[r] = (hp && r0 + r < a.nb) ? n_h[r] : 0.f;
+    if constexpr (NT == 2) {
+      unsigned hi[NR / 2], lo[NR / 2];
+#pragma unroll
+      for (int r = 0; r < NR / 2; ++r) {
+        hi[r] = bf3_hi(hv[2 * r]) | (bf3_hi(hv[2 * r + 1]) << 16);
+        lo[r] = bf3_lo(hv[2 * r]) | (bf3_lo(hv[2 * r + 1]) << 16);
+      }
+      if (NR == 8) {
+        *reinterpret_cast<u32x4*>(&ht2[0][hunit][buf][0]) = (u32x4){hi[0], hi[1], hi[NR / 2 - 2], hi[NR / 2 - 1]};
+        *reinterpret_cast<u32x4*>(&ht2[1][hunit][buf][0]) = (u32x4){lo[0], lo[1], lo[NR / 2 - 2], lo[NR / 2 - 1]};
+      } else {
+        *reinterpret_cast<uint2*>(&ht2[0][hunit][buf][0]) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(&ht2[1][hunit][buf][0]) = make_uint2(lo[0], lo[1]);
+      }
     } else {
-      *reinterpret_cast<uint2*>(&ht_hi[hunit][buf][0]) = make_uint2(hi[0], hi[1]);
-      *reinterpret_cast<uint2*>(&ht_lo[hunit][buf][0]) = make_uint2(lo[0], lo[1]);
+      *reinterpret_cast<float4*>(&htf[hunit][buf][0]) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      if (NR == 8) *reinterpret_cast<float4*>(&htf[hunit][buf][4]) = make_float4(hv[NR - 4], hv[NR - 3], hv[NR - 2], hv[NR - 1]);
     }
   };
   // gather descriptors (loop invariant): byte offset of this lane's quads in parity 0, and whether they exist
@@ -1490,7 +1555,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         for (int e = 0; e < NE; ++e) ok = ok && (!guse || quad_ok(q[e], tb));
         if (__all(ok)) break;
         if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) { flag_store(a.ctrl + 9, 3u); flag_store(a.ctrl + 8, 1u); }
+          if (lane == 0) raise_abort(a.ctrl, 3u);
           aborted = true;
           break;
         }
@@ -1534,11 +1599,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         dcarry = dcn;
         {
           const int sl = s & 3, zs = (s + 1) & 3;          // this step's slot; the slot the NEXT step's h is staged into
-          *reinterpret_cast<uint2*>(&dgs_hi[sl][pj][4 * pu]) = make_uint2(bf3_hi(da.x) | (bf3_hi(da.y) << 16), bf3_hi(da.z) | (bf3_hi(da.w) << 16));
-          *reinterpret_cast<uint2*>(&dgs_lo[sl][pj][4 * pu]) = make_uint2(bf3_lo(da.x) | (bf3_lo(da.y) << 16), bf3_lo(da.z) | (bf3_lo(da.w) << 16));
+          unsigned p0[NT], p1[NT];
+          bfn_split2<NT>(da.x, da.y, p0);
+          bfn_split2<NT>(da.z, da.w, p1);
+#pragma unroll
+          for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][sl][pj][4 * pu]) = make_uint2(p0[k], p1[k]);
           if (fuse_dw && !(ASR_RA & 128)) {                // must read as zero in the flush that does not cover it
-            *reinterpret_cast<uint2*>(&dgs_hi[zs][pj][4 * pu]) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2*>(&dgs_lo[zs][pj][4 * pu]) = make_uint2(0u, 0u);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][zs][pj][4 * pu]) = make_uint2(0u, 0u);
           }
         }
         if (prow_ok) {
@@ -1558,14 +1626,27 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < ((ASR_RA & 4) ? 0 : KS); ++ks) {
-        const u32x4 bh = *reinterpret_cast<const u32x4*>(&dgs_hi[s & 3][ml & 7][32 * ks + 8 * kq]);
-        const u32x4 bl = *reinterpret_cast<const u32x4*>(&dgs_lo[s & 3][ml & 7][32 * ks + 8 * kq]);
+        u32x4 bt[NT], wc[NT == 3 ? MTW : 1];
+        if constexpr (NT == 3) {
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bh, acc[mt]);
+          for (int mt = 0; mt < MTW; ++mt) wc[mt] = wcl[((wave * MTW + mt) * KS + ks) * 64 + lane];
+        }
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(whi[mt][ks], bl, acc[mt]);
+        for (int k = 0; k < NT; ++k) bt[k] = *reinterpret_cast<const u32x4*>(&dgs[k][s & 3][ml & 7][32 * ks + 8 * kq]);
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wlo[mt][ks], bh, acc[mt]);
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], bt[0], acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], bt[1], acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][1], bt[0], acc[mt]);
+        if constexpr (NT == 3) {
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], bt[2], acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][1], bt[1], acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wc[mt], bt[0], acc[mt]);
+        }
       }
       LP_MARK(6);
       // D: lane l holds units 16 tile + 4 (l >> 4) .. + 3 of batch row l & 15 -> one tagged quad to their owner's slot
@@ -1600,51 +1681,87 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
             const bool pending = sl == (s & 3) || (s % 3 == 1 && sl == ((s - 1) & 3));
             if (!pending) {
 #pragma unroll
-              for (int i = 0; i < 1; ++i) {
-                *reinterpret_cast<uint2*>(&dgs_hi[sl][pj][4 * pu]) = make_uint2(0u, 0u);
-                *reinterpret_cast<uint2*>(&dgs_lo[sl][pj][4 * pu]) = make_uint2(0u, 0u);
-              }
+              for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][sl][pj][4 * pu]) = make_uint2(0u, 0u);
             }
           }
         }
         __syncthreads();
       }
-      u32x4 ah[CT], al[CT];
+      // lane (column 16 ct + ml, slot kq) <- rows 0..7 of that column of slot kq: lane 4 q + p of the 16-lane group
+      // supplies the address of row q (second read: row 4 + q), columns 16 ct + 4 p .. + 3
+      const int tq = ml >> 2, tp = ml & 3;
+      auto a_frag = [&](int k, int ct) -> u32x4 {
+        const s16x4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs[k][kq][tq][16 * ct + 4 * tp]);
+        const s16x4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs[k][kq][4 + tq][16 * ct + 4 * tp]);
+        const uint2 u0 = __builtin_bit_cast(uint2, f0), u1 = __builtin_bit_cast(uint2, f1);
+        return (u32x4){u0.x, u0.y, u1.x, u1.y};
+      };
+      auto first_attempt = [&]() {
+        // first attempt at the next step's partials, issued half way through this block: the round trip runs under
+        // the remaining MFMAs, and the poll at the top of the next step starts by looking at what came back
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        // lane (column 16 ct + ml, slot kq) <- rows 0..7 of that column of slot kq: lane 4 q + p of the 16-lane group
-        // supplies the address of row q (second read: row 4 + q), columns 16 ct + 4 p .. + 3
-        const int tq = ml >> 2, tp = ml & 3;
-        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs_hi[kq][tq][16 * ct + 4 * tp]);
-        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs_hi[kq][4 + tq][16 * ct + 4 * tp]);
-        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs_lo[kq][tq][16 * ct + 4 * tp]);
-        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)&dgs_lo[kq][4 + tq][16 * ct + 4 * tp]);
-        const uint2 h0u = __builtin_bit_cast(uint2, h0), h1u = __builtin_bit_cast(uint2, h1);
-        const uint2 l0u = __builtin_bit_cast(uint2, l0), l1u = __builtin_bit_cast(uint2, l1);
-        ah[ct] = (u32x4){h0u.x, h0u.y, h1u.x, h1u.y};
-        al[ct] = (u32x4){l0u.x, l0u.y, l1u.x, l1u.y};
-      }
+        for (int e = 0; e < NE; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[e] + (unsigned)((s & 1) * PARSZ) * 4u, 0, 16);
+        q_inflight = true;
+      };
+      if constexpr (NT == 2) {
+        u32x4 ah[CT], al[CT];
 #pragma unroll
-      for (int ut = 0; ut < MTW; ++ut) {
-        if (ut == (MTW + 1) / 2 && s + 1 < T) {
-          // first attempt at the next step's partials, issued half way through this block: the round trip runs under
-          // the remaining MFMAs, and the poll at the top of the next step starts by looking at what came back
+        for (int ct = 0; ct < CT; ++ct) { ah[ct] = a_frag(0, ct); al[ct] = a_frag(1, ct); }
 #pragma unroll
-          for (int e = 0; e < NE; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[e] + (unsigned)((s & 1) * PARSZ) * 4u, 0, 16);
-          q_inflight = true;
+        for (int ut = 0; ut < MTW; ++ut) {
+          if (ut == (MTW + 1) / 2 && s + 1 < T) first_attempt();
+          const int un = 16 * (MTW * wave + ut) + ml;
+          const u32x4 bh = *reinterpret_cast<const u32x4*>(&ht2[0][un][kq][0]);
+          const u32x4 bl = *reinterpret_cast<const u32x4*>(&ht2[1][un][kq][0]);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(ah[ct], bh, dwacc[ct][ut]);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(ah[ct], bl, dwacc[ct][ut]);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(al[ct], bh, dwacc[ct][ut]);
         }
-        const int un = 16 * (MTW * wave + ut) + ml;
-        const u32x4 bh = *reinterpret_cast<const u32x4*>(&ht_hi[un][kq][0]);
-        const u32x4 bl = *reinterpret_cast<const u32x4*>(&ht_lo[un][kq][0]);
+      } else {
+        // three terms: the A fragments of half the column tiles at a time (24 registers instead of 48); the h fragments are
+        // read as fp32 and split here, once per pass
+#ifndef ASR_RS_CH
+#define ASR_RS_CH 2
+#endif
+        constexpr int CH = (CT + ASR_RS_CH - 1) / ASR_RS_CH;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(ah[ct], bh, dwacc[ct][ut]);
+        for (int c0 = 0; c0 < CT; c0 += CH) {
+          u32x4 at[CH][3];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(ah[ct], bl, dwacc[ct][ut]);
+          for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(al[ct], bh, dwacc[ct][ut]);
+            for (int k = 0; k < 3; ++k) at[c][k] = a_frag(k, c0 + c < CT ? c0 + c : CT - 1);
+#pragma unroll
+          for (int ut = 0; ut < MTW; ++ut) {
+            if (c0 + CH >= CT && ut == (MTW + 1) / 2 && s + 1 < T) first_attempt();
+            const int un = 16 * (MTW * wave + ut) + ml;
+            const float4 h0 = *reinterpret_cast<const float4*>(&htf[un][kq][0]);
+            const float4 h1 = *reinterpret_cast<const float4*>(&htf[un][kq][4]);
+            const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            u32x4 bt[3];
+            bfn_split8<3>(hv, bt);
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+#pragma unroll
+              for (int pp = 0; pp <= o; ++pp)
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                  if (c0 + c < CT) dwacc[c0 + c][ut] = bf3_mfma(at[c][pp], bt[o - pp], dwacc[c0 + c][ut]);
+          }
+        }
       }
       LP_MARK(8);
     }
+  }
+  // an abort raised by another workgroup during the last steps (inside the loop the flag is sampled every 16th step only):
+  // this CU's partial sums were incomplete then, so its last dG row and its weight / bias gradients are poisoned as well
+  if (flag_load(a.ctrl + 8) != 0u) {
+    st_da.x = __builtin_nanf("");
+    dbacc.x = __builtin_nanf("");
+    dwacc[0][0][0] = __builtin_nanf("");
   }
   if (st_gp) *st_gp = st_da;
   if (a.db != nullptr && pw_lane) {
@@ -1688,21 +1805,15 @@ int launch_fwd(const PersistArgs& a, hipStream_t stream) {
   return 0;
 }
 
-// split-bf16 products: on by default (ASR_LSTM_BF3=0 selects the exact-fp32 4x4x1 products)
-// bit 0: forward gate product, bit 1: backward dh product (gathered-dG kernel), bit 2: backward with exchanged dh
-// partials (lstm_persist_bwd_rs_kernel; H in {128, 256, 512}, takes precedence over bit 1); bit 3 belongs to gemm.hip.
-// Shared, process-wide switch (asr_set_split_bf16).
-int bf3_enabled() { return asr_split_bf16_mask(); }
-
-template <int PH, int NR>
+template <int PH, int NR, int NT>
 int launch_fwd_bf3(const PersistArgs& a, hipStream_t stream) {
   constexpr int KP = ((PH / PW + 31) / 32) * 32, MT = (PH / 32 + 3) / 4;
-  const size_t stat = (size_t)2 * PW * PRG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * PRG * 4 + 64;
+  const size_t stat = (size_t)NT * PW * PRG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * PRG * 4 + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_bf3_kernel<PH, NR>,
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
+  hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR, NT>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
@@ -1717,32 +1828,34 @@ int launch_bwd(const PersistArgs& a, hipStream_t stream) {
   return 0;
 }
 
-template <int PH, int NR>
+template <int PH, int NR, int NT>
 int launch_bwd_bf3(const PersistArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * ((size_t)PW * PRG * 4 * (PH / 2 / 4 + 4) + 2 * PW * PRG * 16 + 2 * PRG * 16) +
-                     (size_t)2 * PW * PRG * (PH / 2 + 8) * 2 + 64;
-  if (lds > 160 * 1024) return ASR_E_SHAPE;
+                     (size_t)NT * PW * PRG * (PH / 2 + 8) * 2 + 64;
   const size_t pad = lds > 82 * 1024 ? 0 : 82 * 1024 - lds;
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_bf3_kernel<PH, NR>,
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_bf3_kernel<PH, NR, NT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_bwd_bf3_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
+  hipLaunchKernelGGL((lstm_persist_bwd_bf3_kernel<PH, NR, NT>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
-template <int PH, int NR>
+template <int PH, int NR, int NT>
 int launch_bwd_rs(const PersistArgs& a, hipStream_t stream) {
   using RD = RsDims<PH>;
-  const size_t stat = (size_t)2 * 4 * PRG * RD::GST * 2 + (size_t)2 * PH * 4 * PRG * 2 + PRG * 16 * sizeof(float) + 64;
+  const size_t stat = (size_t)NT * 4 * PRG * RD::GST * 2 + PRG * 16 * sizeof(float) + 64 +
+                      (NT == 2 ? (size_t)2 * PH * 4 * PRG * 2
+                               : (size_t)PH * 4 * PRG * sizeof(float) + (size_t)PW * RD::MTW * RD::KS * 64 * 16);
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_rs_kernel<PH, NR>,
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_rs_kernel<PH, NR, NT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_bwd_rs_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
+  hipLaunchKernelGGL((lstm_persist_bwd_rs_kernel<PH, NR, NT>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
 bool persist_supported(int H) { return H == 128 || H == 256 || H == 320 || H == 512; }
+bool rs_supported(int H) { return H == 128 || H == 256 || H == 512; }
 
 // rows per XCD group: 4 when the whole batch fits 4-row groups (half the MFMA work and gather per step), else 8
 int rows_per_group(int nb, int ndir) {
@@ -1751,25 +1864,52 @@ int rows_per_group(int nb, int ndir) {
   return nb <= 4 * (8 / ndir) ? 4 : PRG;
 }
 
+// arith (include/asr_hip.h): ASR_ARITH_F32 -> the 4x4x1 fp32-MFMA kernels; ASR_ARITH_BF16X6 / _BF16X3 -> the bf16-MFMA
+// kernels with three / two split terms.  H = 640 (the judge's width) exists on the bf16 kernels only.
+template <int NR, int NT>
+int dispatch_fwd_split(int H, const PersistArgs& a, hipStream_t stream) {
+  return H == 640 ? launch_fwd_bf3<640, NR, NT>(a, stream) : H == 512 ? launch_fwd_bf3<512, NR, NT>(a, stream)
+       : H == 320 ? launch_fwd_bf3<320, NR, NT>(a, stream) : H == 256 ? launch_fwd_bf3<256, NR, NT>(a, stream)
+                                                           : launch_fwd_bf3<128, NR, NT>(a, stream);
+}
 template <int NR>
-int dispatch_fwd(int H, const PersistArgs& a, hipStream_t stream) {
-  if (H == 640) return launch_fwd_bf3<640, NR>(a, stream);          // the judge's width: split-bf16 kernel only
-  if (bf3_enabled() & 1)
-    return H == 512 ? launch_fwd_bf3<512, NR>(a, stream) : H == 320 ? launch_fwd_bf3<320, NR>(a, stream)
-         : H == 256 ? launch_fwd_bf3<256, NR>(a, stream) : launch_fwd_bf3<128, NR>(a, stream);
+int dispatch_fwd(int H, int arith, const PersistArgs& a, hipStream_t stream) {
+  const int ar = arith & ASR_ARITH_MASK;
+  if (ar == ASR_ARITH_BF16X6) return dispatch_fwd_split<NR, 3>(H, a, stream);
+  if (ar == ASR_ARITH_BF16X3) return dispatch_fwd_split<NR, 2>(H, a, stream);
+  if (H == 640) return ASR_E_SHAPE;
   return H == 512 ? launch_fwd<512, NR>(a, stream) : H == 320 ? launch_fwd<320, NR>(a, stream)
        : H == 256 ? launch_fwd<256, NR>(a, stream) : launch_fwd<128, NR>(a, stream);
 }
+// which backward kernel a call takes: 0 fp32 gathered-dG, 1 split gathered-dG, 2 split exchanged partials, -1 none
+int bwd_kernel_kind(int H, int arith) {
+  const int ar = arith & ASR_ARITH_MASK;
+  if (ar == ASR_ARITH_F32) return 0;
+  if (rs_supported(H) && !(arith & ASR_LSTM_BWD_GATHER)) return 2;
+  // the gathered-dG kernel with three terms needs 171 KB of LDS at H = 512
+  if (ar == ASR_ARITH_BF16X6 && H > 320) return -1;
+  return 1;
+}
+template <int NR, int NT>
+int dispatch_bwd_split(int H, int kind, const PersistArgs& a, hipStream_t stream) {
+  if (kind == 2)
+    return H == 512 ? launch_bwd_rs<512, NR, NT>(a, stream) : H == 256 ? launch_bwd_rs<256, NR, NT>(a, stream)
+                                                            : launch_bwd_rs<128, NR, NT>(a, stream);
+  if constexpr (NT == 2) {
+    if (H == 512) return launch_bwd_bf3<512, NR, 2>(a, stream);
+  }
+  return H == 320 ? launch_bwd_bf3<320, NR, NT>(a, stream) : H == 256 ? launch_bwd_bf3<256, NR, NT>(a, stream)
+                                                           : launch_bwd_bf3<128, NR, NT>(a, stream);
+}
 template <int NR>
-int dispatch_bwd(int H, const PersistArgs& a, hipStream_t stream) {
-  if ((bf3_enabled() & 4) && (H == 512 || H == 256 || H == 128))
-    return H == 512 ? launch_bwd_rs<512, NR>(a, stream) : H == 256 ? launch_bwd_rs<256, NR>(a, stream)
-                                                        : launch_bwd_rs<128, NR>(a, stream);
-  if (bf3_enabled() & 2)
-    return H == 512 ? launch_bwd_bf3<512, NR>(a, stream) : H == 320 ? launch_bwd_bf3<320, NR>(a, stream)
-         : H == 256 ? launch_bwd_bf3<256, NR>(a, stream) : launch_bwd_bf3<128, NR>(a, stream);
-  return H == 512 ? launch_bwd<512, NR>(a, stream) : H == 320 ? launch_bwd<320, NR>(a, stream)
-       : H == 256 ? launch_bwd<256, NR>(a, stream) : launch_bwd<128, NR>(a, stream);
+int dispatch_bwd(int H, int arith, const PersistArgs& a, hipStream_t stream) {
+  const int kind = bwd_kernel_kind(H, arith);
+  if (kind < 0) return ASR_E_SHAPE;
+  if (kind == 0)
+    return H == 512 ? launch_bwd<512, NR>(a, stream) : H == 320 ? launch_bwd<320, NR>(a, stream)
+         : H == 256 ? launch_bwd<256, NR>(a, stream) : launch_bwd<128, NR>(a, stream);
+  return (arith & ASR_ARITH_MASK) == ASR_ARITH_BF16X6 ? dispatch_bwd_split<NR, 3>(H, kind, a, stream)
+                                                     : dispatch_bwd_split<NR, 2>(H, kind, a, stream);
 }
 
 }  // namespace
@@ -1787,17 +1927,24 @@ bool asr_persist_device_ok() {
   return cached == 1;
 }
 
+static bool arith_ok(int arith) {
+  const int ar = arith & ASR_ARITH_MASK;
+  return ar == ASR_ARITH_F32 || ar == ASR_ARITH_BF16X6 || ar == ASR_ARITH_BF16X3;
+}
+
 // Returns ASR_E_SHAPE when the fast path does not apply (caller falls back to asr_lstm_seq_fwd).  Batches larger
 // than 8 * (8 / ndir) rows run as consecutive launches over row blocks (rows are independent; any batch size: a
 // single-GPU batch of 256 is 8 launches per layer).
-// xch: >= 8 MB (the backward's exchanged partials at H = 512), ctrl: >= 64 B; zeroed here on the stream before every launch.
+// xch: >= 8 MB (the backward's exchanged partials at H = 512), ctrl: 128 B (persist.h: 16 latch words + 16 per-launch
+// words; the per-launch words and the exchange area are zeroed here on the stream before every launch).
 extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
-                                        const int32_t* lens, float* y, float* c, void* xch, void* ctrl,
+                                        const int32_t* lens, float* y, float* c, void* xch, void* ctrl, int arith,
                                         asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
+  if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B || !arith_ok(arith)) return ASR_E_ARG;
   // H = 640 (the judge LM, config.yaml dis_hidden_dim): forward only - 20 units per CU = 5 M tiles of the bf16 MFMA
   if (!(persist_supported(H) || H == 640) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
+  if (H == 640 && (arith & ASR_ARITH_MASK) == ASR_ARITH_F32) return ASR_E_SHAPE;
   const int nr = rows_per_group(nb, ndir);
   const int rows_per_launch = nr * (8 / ndir);
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
@@ -1807,8 +1954,8 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
     a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
     a.y = y + (int64_t)rb * ndir * H; a.c = c + (int64_t)rb * ndir * H;
-    a.dy = nullptr; a.yfwd = nullptr; a.dw = nullptr; a.db = nullptr; a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
-    int rc = nr == 4 ? dispatch_fwd<4>(H, a, stream) : dispatch_fwd<PRG>(H, a, stream);
+    a.dy = nullptr; a.yfwd = nullptr; a.dw = nullptr; a.db = nullptr; a.xch = (u64*)xch; a.ctrl = persist_launch_words(ctrl);
+    int rc = nr == 4 ? dispatch_fwd<4>(H, arith, a, stream) : dispatch_fwd<PRG>(H, arith, a, stream);
     if (rc) return rc;
   }
   ASR_CHECK_LAUNCH();
@@ -1818,19 +1965,20 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
 // Persistent fast path of asr_lstm_seq_bwd (same arguments and results except that no dcarry scratch is needed).
 static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT, const float* w_hh_il,
                                      const int32_t* lens, const float* dy, const float* c, const float* y,
-                                     float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream_) {
+                                     float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!gates || (!w_hhT && !w_hh_il) || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
+  if (!gates || (!w_hhT && !w_hh_il) || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B || !arith_ok(arith)) return ASR_E_ARG;
   if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
+  const int kind = bwd_kernel_kind(H, arith);
+  if (kind < 0) return ASR_E_SHAPE;
   // the forward-layout weights are only read by the exchanged-partials kernel
-  if (!w_hhT && !((bf3_enabled() & 4) && (H == 512 || H == 256 || H == 128))) return ASR_E_SHAPE;
+  if (!w_hhT && kind != 2) return ASR_E_SHAPE;
   const int nr = rows_per_group(nb, ndir);
   const int rows_per_launch = nr * (8 / ndir);
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
-    const bool rs = (bf3_enabled() & 4) && (H == 512 || H == 256 || H == 128);
     // exchanged-partials kernel: [8 groups][2 parities][32 dest][32 src][8 rows][H/32 units] floats (8 MB at H = 512)
-    const size_t xbytes = rs ? (size_t)8 * 2 * 32 * 32 * PRG * (H / 32) * sizeof(float)
-                             : (size_t)2 * 8 * PRG * 4 * H * sizeof(float);
+    const size_t xbytes = kind == 2 ? (size_t)8 * 2 * 32 * 32 * PRG * (H / 32) * sizeof(float)
+                                    : (size_t)2 * 8 * PRG * 4 * H * sizeof(float);
     hipError_t e = persist_reset(xch, ctrl, xbytes, stream);
     if (e != hipSuccess) return (int)e;
     PersistArgs a = {};
@@ -1839,8 +1987,8 @@ static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, floa
     a.c = const_cast<float*>(c) + (int64_t)rb * ndir * H; a.dy = dy + (int64_t)rb * ndir * H;
     a.yfwd = (y && dw_hh) ? y + (int64_t)rb * ndir * H : nullptr; a.dw = (y && dw_hh) ? dw_hh : nullptr;
     a.db = db;
-    a.xch = (u64*)xch; a.ctrl = (unsigned*)ctrl;
-    int rc = nr == 4 ? dispatch_bwd<4>(H, a, stream) : dispatch_bwd<PRG>(H, a, stream);
+    a.xch = (u64*)xch; a.ctrl = persist_launch_words(ctrl);
+    int rc = nr == 4 ? dispatch_bwd<4>(H, arith, a, stream) : dispatch_bwd<PRG>(H, arith, a, stream);
     if (rc) return rc;
   }
   ASR_CHECK_LAUNCH();
@@ -1849,17 +1997,18 @@ static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, floa
 
 extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                                         const int32_t* lens, const float* dy, const float* c, const float* y,
-                                        float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream) {
+                                        float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream) {
   if (!w_hhT) return ASR_E_ARG;
-  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, w_hhT, nullptr, lens, dy, c, y, dw_hh, db, xch, ctrl, stream);
+  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, w_hhT, nullptr, lens, dy, c, y, dw_hh, db, xch, ctrl, arith, stream);
 }
 
 // Same, taking W_hh in the FORWARD layout ([ndir][4H][H], what asr_lstm_seq_fwd_persist consumed): the exchanged-partials
 // kernel reads its slice of it once per launch, so the caller needs no transposed copy.  ASR_E_SHAPE when that kernel
-// does not apply (H not in {128, 256, 512}, or switched off): the caller then transposes and uses asr_lstm_seq_bwd_persist.
+// does not apply (H not in {128, 256, 512}, fp32-MFMA arithmetic, ASR_LSTM_BWD_GATHER): the caller then transposes and uses
+// asr_lstm_seq_bwd_persist.
 extern "C" int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh_il,
                                           const int32_t* lens, const float* dy, const float* c, const float* y,
-                                          float* dw_hh, float* db, void* xch, void* ctrl, asr_stream_t stream) {
+                                          float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream) {
   if (!w_hh_il) return ASR_E_ARG;
-  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, nullptr, w_hh_il, lens, dy, c, y, dw_hh, db, xch, ctrl, stream);
+  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, nullptr, w_hh_il, lens, dy, c, y, dw_hh, db, xch, ctrl, arith, stream);
 }

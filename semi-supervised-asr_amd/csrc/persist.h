@@ -43,11 +43,26 @@ __device__ __forceinline__ void word_store(float* p, float v, unsigned bit) {
   __hip_atomic_store((gu32*)p, (__float_as_uint(v) & ~1u) | bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Host side: zero the control words and `bytes` of exchange before a launch.  When the caller placed the 64-byte
-// control block directly in front of the exchange buffer (hip_backend.persist_scratch does) it is ONE fill.
+// Control block handed over by the caller: 32 words = [16 latch words | 16 per-launch words].
+//   per-launch words (what the kernels receive as `ctrl`; zeroed before every launch): [0..7] tickets per XCC, [8] abort,
+//     [9] abort code;
+//   latch words (ctrl - 16 inside a kernel; NEVER written by the host side of the library): [0] abort latch, [1] code of the
+//     abort that set it.  A sequence operator is several launches (one per LSTM layer, per row block, the decoder); the
+//     per-launch abort word of all but the last is gone when the host looks, the latch is not.  The caller clears it.
+static inline unsigned* persist_launch_words(void* ctrl) { return (unsigned*)ctrl + 16; }
+__device__ __forceinline__ void raise_abort(unsigned* ctrl, unsigned code) {
+  flag_store(ctrl + 9, code);
+  flag_store(ctrl + 8, 1u);
+  flag_store(ctrl - 15, code);
+  flag_store(ctrl - 16, 1u);
+}
+
+// Host side: zero the per-launch control words and `bytes` of exchange before a launch.  When the caller placed the
+// 128-byte control block directly in front of the exchange buffer (hip_backend.persist_scratch does) it is ONE fill.
 static inline hipError_t persist_reset(void* xch, void* ctrl, size_t bytes, hipStream_t stream) {
-  if ((char*)ctrl + 64 == (char*)xch) return hipMemsetAsync(ctrl, 0, 64 + bytes, stream);
-  hipError_t e = hipMemsetAsync(ctrl, 0, 16 * sizeof(unsigned), stream);
+  char* lw = (char*)persist_launch_words(ctrl);
+  if (lw + 64 == (char*)xch) return hipMemsetAsync(lw, 0, 64 + bytes, stream);
+  hipError_t e = hipMemsetAsync(lw, 0, 16 * sizeof(unsigned), stream);
   if (e != hipSuccess) return e;
   return hipMemsetAsync(xch, 0, bytes, stream);
 }
@@ -59,7 +74,7 @@ __device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g,
     const unsigned tk = atomicAdd(ctrl + x, 1u);
     lds_role[0] = (int)x;
     lds_role[1] = tk < 32u ? (int)tk : -1;
-    if (tk >= 32u) { flag_store(ctrl + 9, 2u); flag_store(ctrl + 8, 1u); }   // unexpected placement
+    if (tk >= 32u) raise_abort(ctrl, 2u);   // unexpected placement
   }
   __syncthreads();
   // workgroup-uniform: in SGPRs, so that everything derived from the role (direction, rows, slices of the weights,
@@ -107,7 +122,7 @@ __device__ __forceinline__ void poll_pairs(const u64* const (&p)[N], unsigned wa
     return;
 #endif
     if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(ctrl + 8) != 0u)) {
-      if ((threadIdx.x & 63) == 0) { flag_store(ctrl + 9, code); flag_store(ctrl + 8, 1u); }
+      if ((threadIdx.x & 63) == 0) raise_abort(ctrl, code);
       aborted = true;
       return;
     }
@@ -157,7 +172,7 @@ __device__ __forceinline__ void poll_quads(__amdgpu_buffer_rsrc_t rs, const unsi
     return;
 #endif
     if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(ctrl + 8) != 0u)) {
-      if ((threadIdx.x & 63) == 0) { flag_store(ctrl + 9, code); flag_store(ctrl + 8, 1u); }
+      if ((threadIdx.x & 63) == 0) raise_abort(ctrl, code);
       aborted = true;
       return;
     }

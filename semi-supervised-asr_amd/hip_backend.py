@@ -11,10 +11,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libasr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
-    "asr_abi_version", "asr_set_split_bf16", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
+    "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_lstm_seq_bwd_persist_w", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
@@ -61,20 +61,19 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     for name in EXPORTS:
         getattr(lib, name).restype = c_i
-    lib.asr_set_split_bf16.argtypes = [c_i]
     lib.asr_graphs_create.restype = c_p
     lib.asr_graphs_create.argtypes = [c_i]
     lib.asr_graphs_destroy.restype = None
     lib.asr_graphs_destroy.argtypes = [c_p]
     lib.asr_graphs_stats.argtypes = [c_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
     lib.asr_gemm_f32.argtypes = [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_i,
-                                 c_i, c_i64, c_i64, c_i64, c_i, c_p]
+                                 c_i, c_i64, c_i64, c_i64, c_i, c_i, c_p]
     lib.asr_gemm_skinny_f32.argtypes = [c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p,
                                         c_i64, c_i64, c_p]
     lib.asr_colsum_f32.argtypes = [c_i64, c_i64, c_p, c_i64, c_p, c_i, c_p]
     lib.asr_lstm_seq_fwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
-    lib.asr_lstm_seq_fwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
-    lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_fwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]
+    lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]
     lib.asr_lstm_seq_bwd_persist_w.argtypes = lib.asr_lstm_seq_bwd_persist.argtypes
     lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -114,29 +113,49 @@ def load():
     return lib
 
 
-SPLIT_LSTM_FWD, SPLIT_LSTM_BWD, SPLIT_LSTM_BWD_RS, SPLIT_GEMM = 1, 2, 4, 8
-SPLIT_GEMM_WIDE = 16      # with SPLIT_GEMM: the 256 x 128 LDS-DMA kernel (gemm_bf3w_kernel) for the shapes it pays on
-SPLIT_GEMM_WIDE_ALL = 32  # ... for every conforming shape (tests, measurements)
+# Product arithmetic of the MFMA kernels (include/asr_hip.h: ASR_ARITH_*): an explicit argument of every C-ABI call.
+# This module only holds the host code's DEFAULT for calls that do not name one: bf16x6 (three-term split, six products:
+# fp32-equivalent), overridable with ASR_ARITH=f32|bf16x6|bf16x3 or `with hb.arith("f32"):`.
+ARITH_F32, ARITH_BF16X6, ARITH_BF16X3 = 0, 1, 2
+GEMM_TILE_NARROW, GEMM_TILE_WIDE, LSTM_BWD_GATHER = 0x100, 0x200, 0x400
+ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "bf16x3": ARITH_BF16X3}
+ARITH_LABEL = {ARITH_F32: "f32", ARITH_BF16X6: "bf16x6", ARITH_BF16X3: "bf16x3"}
 
 
-def set_split_bf16(mask):
-    """Select split-bf16 (hi + lo, three products) or exact-fp32 MFMA products per kernel family (asr_set_split_bf16);
-    returns the previous mask.  mask < 0 only queries."""
-    return int(load().asr_set_split_bf16(int(mask)))
+def _arith_code(a):
+    if isinstance(a, str):
+        code = 0
+        for part in a.lower().split("+"):
+            code |= {"narrow": GEMM_TILE_NARROW, "wide": GEMM_TILE_WIDE, "gather": LSTM_BWD_GATHER}.get(part, 0) or \
+                    ARITH_NAMES[part]
+        return code
+    return int(a)
 
 
-class split_bf16(object):
-    """Context manager: run with the given product-arithmetic mask (0 = every product on the fp32-input MFMA)."""
+ARITH = [_arith_code(os.environ.get("ASR_ARITH", "bf16x6"))]
 
-    def __init__(self, mask):
-        self.mask = mask
+
+def current_arith():
+    return ARITH[0]
+
+
+def arith_name(a=None):
+    return ARITH_LABEL[(ARITH[0] if a is None else _arith_code(a)) & 0xff]
+
+
+class arith(object):
+    """Context manager: host-side default arithmetic for the calls inside (name, code, or name+flag: "bf16x3+wide")."""
+
+    def __init__(self, a):
+        self.code = _arith_code(a)
 
     def __enter__(self):
-        self.old = set_split_bf16(self.mask)
+        self.old = ARITH[0]
+        ARITH[0] = self.code
         return self
 
     def __exit__(self, *exc):
-        set_split_bf16(self.old)
+        ARITH[0] = self.old
         return False
 
 
@@ -167,24 +186,9 @@ def _rowmajor(t):
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1))
 
 
-def auto_split_k(M, N, K, batch=1, epilogue=False):
-    """Split-K factor (partials are added with f32 atomics; a bias/ReLU epilogue then needs a second pass over C).
-    256 CUs hold two 128x128 workgroups each, so the target is ~512 workgroups: floor(512 / tiles), at most 8 (16 for <= 32 tiles), every
-    K slice at least 256 long.  Measured on MI355X with cold operands and the split-bf16 kernel
-    (tools/gemm_cold_split_sweep.py, round 2): 400 tiles -> 1 (120 us vs 171 at the 5 the round-1 model picked: the
-    product got 2x cheaper, the atomics, the zero fill and the late epilogue did not), 200 -> 2, 144 -> 3, 128 -> 4,
-    64 -> 8; within 5 % of the best factor for every large GEMM of the cfg-2 step."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    if tiles >= 512 or K < 512:
-        return 1
-    sk = max(1, min(16 if tiles <= 32 else 8, 512 // tiles, K // 256))
-    if epilogue and sk > 1 and tiles > 64:
-        return 1
-    return int(sk)
-
-
-def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, split_k=None):
-    """out[M,N] = op(A) op(B) (+bias)(relu)(+out).  A, B, out are 2-D row-major views (row stride free)."""
+def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, split_k=None, arith=None):
+    """out[M,N] = op(A) op(B) (+bias)(relu)(+out).  A, B, out are 2-D row-major views (row stride free).
+    split_k None: the library chooses (asr_gemm_f32 with split_k = 0); 1: unsplit, run-to-run deterministic."""
     A, lda = _rowmajor(_dev(A, "A"))
     B, ldb = _rowmajor(_dev(B, "B"))
     M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
@@ -194,19 +198,17 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, ac
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     out, ldc = _rowmajor(out)
     assert out.shape == (M, N)
-    if split_k is None:
-        split_k = auto_split_k(M, N, K, epilogue=(bias is not None or relu))
-        if accumulate and (bias is not None or relu):
-            split_k = 1
     check(load().asr_gemm_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
-                              ptr(bias), int(relu), int(accumulate), 1, 0, 0, 0, split_k, stream()), "asr_gemm_f32")
+                              ptr(bias), int(relu), int(accumulate), 1, 0, 0, 0, 0 if split_k is None else int(split_k),
+                              ARITH[0] if arith is None else _arith_code(arith), stream()), "asr_gemm_f32")
     return out
 
 
-def gemm_batched(A, B, out, trans_a, trans_b, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, accumulate=False):
+def gemm_batched(A, B, out, trans_a, trans_b, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, accumulate=False, arith=None):
     """Raw batched form (pointer + strides); tensors only provide the base pointers."""
     check(load().asr_gemm_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, None, 0,
-                              int(accumulate), batch, sA, sB, sC, 1, stream()), "asr_gemm_f32(batched)")
+                              int(accumulate), batch, sA, sB, sC, 1, ARITH[0] if arith is None else _arith_code(arith),
+                              stream()), "asr_gemm_f32(batched)")
     return out
 
 
@@ -514,8 +516,10 @@ class require_persistent(object):
 
 
 def persist_scratch(device, trace=False):
-    """(xch, ctrl) scratch of the persistent kernels, one pair per device (calls are stream-ordered).  trace=True: a
-    separate 4 KB control buffer whose words 16.. receive the clock stamps of the measurement builds (tools/)."""
+    """(xch, ctrl) scratch of the persistent kernels, one pair per device (calls are stream-ordered).  ctrl = 32 int32 words:
+    [0] abort latch, [1] its code (set by any aborting launch, cleared only by persist_clear_abort), [16..31] the
+    per-launch words the library zeroes before every launch (csrc/persist.h).  trace=True: a separate 4 KB control buffer
+    whose words behind the per-launch block receive the clock stamps of the measurement builds (tools/)."""
     if trace:
         tkey = str(device) + "/trace"
         if tkey not in _persist_scratch:
@@ -524,32 +528,48 @@ def persist_scratch(device, trace=False):
         return _persist_scratch[tkey]
     key = str(device)
     if key not in _persist_scratch:
-        # one allocation: [64-byte control block | 8 MB exchange] so that the pre-launch reset is a single fill
-        # (persist.h: persist_reset), plus a separate trace area used only by the measurement builds
-        base = torch.zeros(8 + XCH_BYTES // 8, dtype=torch.int64, device=device)
-        _persist_scratch[key] = (base[8:], base[:8].view(torch.int32), base)
+        # one allocation: [128-byte control block | 8 MB exchange] so that the pre-launch reset is a single fill
+        # (persist.h: persist_reset)
+        base = torch.zeros(16 + XCH_BYTES // 8, dtype=torch.int64, device=device)
+        _persist_scratch[key] = (base[16:], base[:16].view(torch.int32), base)
     return _persist_scratch[key][:2]
 
 
 def persist_abort_code(device):
-    """Which wait gave up (ctrl[9]; 2 = unexpected workgroup placement, others = the poll site).  Synchronises."""
+    """Which wait gave up first since the latch was cleared (ctrl[1]; 2 = unexpected workgroup placement, others = the
+    poll site).  Synchronises."""
     key = str(device)
-    return int(_persist_scratch[key][1][9].item()) if key in _persist_scratch else 0
+    return int(_persist_scratch[key][1][1].item()) if key in _persist_scratch else 0
+
+
+def persist_clear_abort(device):
+    """Clear the abort latch (start of a step / after the caller has dealt with an abort); stream-ordered, no sync."""
+    key = str(device)
+    if key in _persist_scratch:
+        _persist_scratch[key][1][:2].zero_()
 
 
 def disable_persistent(device=None):
     """Route every sequence operator of this process to the per-step HIP kernels (after an abort, or when several
-    processes share one GPU) and clear the abort word."""
+    processes share one GPU) and clear the abort latch."""
     global USE_PERSIST, USE_PERSIST_DEC, USE_PERSIST_DEC_BWD
     USE_PERSIST = USE_PERSIST_DEC = USE_PERSIST_DEC_BWD = False
-    if device is not None and str(device) in _persist_scratch:
-        _persist_scratch[str(device)][1].zero_()
+    if device is not None:
+        persist_clear_abort(device)
 
 
 def persist_aborted(device):
-    """True if the last persistent launch on `device` aborted (synchronises; for tests / end-of-step checks)."""
+    """True if ANY persistent launch on `device` aborted since the latch was last cleared (synchronises; for tests /
+    end-of-step checks).  The latch is sticky across launches: the per-launch abort word is zeroed before every launch,
+    and a sequence operator is several launches."""
     key = str(device)
-    return key in _persist_scratch and int(_persist_scratch[key][1][8].item()) != 0
+    return key in _persist_scratch and int(_persist_scratch[key][1][0].item()) != 0
+
+
+def persist_abort_flag(device):
+    """The abort latch as a 1-element int32 device tensor (no sync): lets a data-parallel step add it to the values its
+    all-reduce carries."""
+    return persist_scratch(device)[1][:1]
 
 
 def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
@@ -559,7 +579,7 @@ def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
     if USE_PERSIST:
         xch, ctrl = persist_scratch(gates.device)
         rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(y), ptr(c),
-                                          c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
+                                          c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ARITH[0], stream())
         if rc == 0:
             count_path("lstm_fwd", True)
             return
@@ -588,7 +608,7 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None,
     if USE_PERSIST and w_hh is not None:
         xch, ctrl = persist_scratch(gates.device)
         rc = lib.asr_lstm_seq_bwd_persist_w(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(dy), ptr(c),
-                                            ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
+                                            ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ARITH[0], stream())
         if rc == 0:
             count_path("lstm_bwd", True)
             return y is not None and dw_hh is not None
@@ -599,7 +619,7 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None,
     if USE_PERSIST:
         xch, ctrl = persist_scratch(gates.device)
         rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hhT), ptr(lens), ptr(dy), ptr(c),
-                                          ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), stream())
+                                          ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ARITH[0], stream())
         if rc == 0:
             count_path("lstm_bwd", True)
             return y is not None and dw_hh is not None

@@ -232,12 +232,17 @@ class FlatAdam(object):
     def zero_grad(self):
         self.buf.zero_grad()
 
-    def step(self, max_grad_norm=None, group=None):
-        """all-reduce (if distributed) -> global grad norm -> clip + Adam.  Returns the device scalar
-        holding ||g||^2 (read it with .item() only if you need the number)."""
+    def reduce(self, group=None):
+        """First half of a step: gather the gradients into the flat buffer and (if distributed) all-reduce it together
+        with the aux scalars behind it.  A caller that has to look at the reduced aux values before committing to the
+        update (Solver._dp_step: the abort flag of the persistent kernels) calls reduce(), reads, then apply()."""
+        self.buf.allreduce_grads(group)
+
+    def apply(self, max_grad_norm=None):
+        """Second half: global grad norm -> clip + Adam on the (reduced) flat buffer.  Returns the device scalar holding
+        ||g||^2 (read it with .item() only if you need the number)."""
         import hip_backend as hb
         clip = self.max_grad_norm if max_grad_norm is None else max_grad_norm
-        self.buf.allreduce_grads(group)                # gathers the gradients into the flat buffer first
         g = self.param_groups[0]
         self.t += 1
         b1, b2 = g["betas"]
@@ -255,6 +260,11 @@ class FlatAdam(object):
                                        float(b2), float(g["eps"]), float(g["weight_decay"]),
                                        1.0 - b1 ** self.t, 1.0 - b2 ** self.t, hb.stream()), "asr_adam_clip_f32")
         return self.gnorm_sq
+
+    def step(self, max_grad_norm=None, group=None):
+        """all-reduce (if distributed) -> global grad norm -> clip + Adam; no host sync."""
+        self.reduce(group)
+        return self.apply(max_grad_norm)
 
     # ---- torch.optim.Adam-compatible (de)serialisation
     def state_dict(self):

@@ -228,38 +228,51 @@ class Solver(object):
         in that case this process switches to the per-step HIP kernels for good and repeats the step, so an abort costs
         one step instead of the run.  A non-finite loss without the abort word set is the model's own and passes through
         unchanged, as in the reference.  -> (loss, aux, float(loss))"""
-        loss, aux = make_loss()
-        opt.zero_grad()
-        loss.backward()
-        value = loss.item()
-        if not math.isfinite(value) and loss.is_cuda and hb.persist_aborted(loss.device):
-            print("persistent kernels aborted (code %d): continuing on the per-step kernels"
-                  % hb.persist_abort_code(loss.device))
-            hb.disable_persistent(loss.device)
+        def run():
             loss, aux = make_loss()
             opt.zero_grad()
             loss.backward()
-            value = loss.item()
+            if not loss.is_cuda:
+                return loss, aux, loss.item(), False
+            # the loss and the abort latch of the persistent kernels in ONE read.  The latch is sticky across launches
+            # (csrc/persist.h): it also catches an abort in the backward kernels, after a finite loss was formed.
+            both = torch.stack([loss.detach().reshape(()), hb.persist_abort_flag(loss.device)[0].float()]).tolist()
+            return loss, aux, both[0], both[1] != 0.0
+        loss, aux, value, aborted = run()
+        if aborted:
+            print("persistent kernels aborted (code %d): continuing on the per-step kernels"
+                  % hb.persist_abort_code(loss.device))
+            hb.disable_persistent(loss.device)          # also clears the latch
+            loss, aux, value, _ = run()
         return loss, aux, value
 
     def _dp_step(self, make_loss, opt, n_aux):
         """One data-parallel step: zero_grad -> backward of this rank's local loss -> ONE all-reduce of the flat buffer
-        (gradients + the per-rank partial scalars in its aux slots) -> clip -> Adam.  make_loss() -> (local loss or None
-        for an empty shard, [scalars]); returns the scalars summed over ranks = the single-process values.  The only host
-        sync is the read of those scalars after the step.  Repeating a step locally (as _backward_guarded does after an
-        aborted persistent kernel) would desynchronise the collectives, so an abort is an error here."""
+        (gradients + the per-rank partial scalars + this rank's abort latch in its aux slots) -> clip -> Adam.
+        make_loss() -> (local loss or None for an empty shard, [scalars]); returns the scalars summed over ranks = the
+        single-process values.  Repeating a step locally (as _backward_guarded does after an aborted persistent kernel)
+        would desynchronise the collectives, so an abort is an error here - raised by EVERY rank, before the update is
+        applied: the abort latch rides in the last aux slot of the same all-reduce, so all ranks see the same sum and
+        none is left waiting in the next collective with NaN parameters."""
         loss, scalars = make_loss()
         opt.zero_grad()
         if loss is not None:
             loss.backward()
-        opt.buf.set_aux([v if v is not None else 0.0 for v in scalars[:n_aux]])
-        opt.step()
-        values = opt.buf.aux[:n_aux].tolist()
         dev = opt.buf.flat_g.device
-        if not all(math.isfinite(v) for v in values) and dev.type == "cuda" and hb.persist_aborted(dev):
-            raise RuntimeError("persistent kernels aborted (code %d) in a data-parallel step; set ASR_PERSIST=0 on "
-                               "every rank to train on the per-step kernels" % hb.persist_abort_code(dev))
-        return values
+        flag_slot = opt.buf.NAUX - 1
+        assert n_aux <= flag_slot
+        aux = [v if v is not None else 0.0 for v in scalars[:n_aux]] + [0.0] * (flag_slot - n_aux)
+        aux.append(hb.persist_abort_flag(dev)[0].float() if dev.type == "cuda" else 0.0)
+        opt.buf.set_aux(aux)
+        opt.reduce()
+        values = opt.buf.aux.tolist()                   # the step's one host sync, between the all-reduce and the update
+        if values[flag_slot] != 0.0:
+            raise RuntimeError("persistent kernels aborted on %d rank(s) (this rank: %s, code %d) in a data-parallel "
+                               "step; nothing was applied - restart with ASR_PERSIST=0 on every rank to train on the "
+                               "per-step kernels" % (int(values[flag_slot]), hb.persist_aborted(dev),
+                                                     hb.persist_abort_code(dev)))
+        opt.apply()
+        return values[:n_aux]
 
     def _step(self, make_local, opt, n_scalars):
         """Run one optimiser step on make_local() -> (local loss, [scalar tensors]); returns the scalars as floats,

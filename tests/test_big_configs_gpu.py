@@ -33,6 +33,7 @@ def _rel(got, want):
 def _run_big(golden_dir, name, shape, dec_bwd_persistent=True):
     dev = _gpu()
     import hip_backend as hb
+    hb.persist_clear_abort(dev)
     import model as M
     g = dict(np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False))
     cfg = synth.CFG2
@@ -87,12 +88,25 @@ def _run_big(golden_dir, name, shape, dec_bwd_persistent=True):
         name, float(loss), float(g["loss"]), worst, dict(hb.LAUNCHES)))
 
 
-def test_cfg2_against_golden(golden_dir):
+# The default arithmetic (bf16x6: fp32-equivalent products on the bf16 MFMA) AND the exact fp32-input MFMA kernels are
+# both held to the reference at the headline shapes; bf16x3 (non-default, 16 significand bits per operand) as well.
+ARITHS = ["bf16x6", "f32", "bf16x3"]
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_cfg2_against_golden(golden_dir, arith):
     """cfg-2 (BASELINE.json configs[1], the bench workload) end to end on the persistent kernels vs the reference."""
-    _run_big(golden_dir, "cfg2", synth.CFG2_SHAPE)
+    import hip_backend as hb
+    _gpu()
+    with hb.arith(arith):
+        _run_big(golden_dir, "cfg2", synth.CFG2_SHAPE)
 
 
-def test_cfg5_against_golden(golden_dir):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_cfg5_against_golden(golden_dir, arith):
     """cfg-5 (configs[4]: 80x1600 frames, batch 8, T'=200, L+1=201) vs the reference: 4-row LSTM groups, both decoder
     kernels in the T' <= 256 geometry (2 utterances per XCD group)."""
-    _run_big(golden_dir, "cfg5", synth.CFG5_SHAPE)
+    import hip_backend as hb
+    _gpu()
+    with hb.arith(arith):
+        _run_big(golden_dir, "cfg5", synth.CFG5_SHAPE)

@@ -75,9 +75,13 @@ def test_solver_end_to_end(tmp_path, monkeypatch):
     assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"}
 
 
-def test_solver_recovers_from_aborted_persistent_kernel(tmp_path, monkeypatch):
-    """A persistent kernel that aborts poisons its output with NaN; the solver must notice before the optimiser step,
-    switch this process to the per-step kernels and repeat the step (the parameters never see the NaN)."""
+@pytest.mark.parametrize("poison_loss", [True, False])
+def test_solver_recovers_from_aborted_persistent_kernel(tmp_path, monkeypatch, poison_loss):
+    """A persistent kernel that aborts poisons its output with NaN and sets the STICKY abort latch (csrc/persist.h: the
+    per-launch abort word is zeroed before the next launch, the latch is not); the solver reads loss and latch together
+    before the optimiser step, switches this process to the per-step kernels and repeats the step (the parameters never
+    see the NaN).  poison_loss=False is the case ADVICE r2 describes: the abort happened in a launch whose NaN never
+    reached the loss (e.g. a backward kernel) - the latch alone must trigger the repeat."""
     import __graft_entry__ as entry
     entry.build()
     import hip_backend as hb
@@ -89,27 +93,73 @@ def test_solver_recovers_from_aborted_persistent_kernel(tmp_path, monkeypatch):
     torch.manual_seed(0)
     np.random.seed(0)
     solver = Solver(_config(root))
+    dev = next(solver.model.parameters()).device
     state = {"calls": 0}
     real_forward = solver._sharded_forward
 
-    def poisoned_once(xs, ilens, ys, tf_rate):
+    def aborted_once(xs, ilens, ys, tf_rate):
         loss = real_forward(xs, ilens, ys, tf_rate)
         state["calls"] += 1
-        return loss * float("nan") if state["calls"] == 2 else loss
+        if state["calls"] == 2:
+            latch = hb.persist_scratch(dev)[1]
+            latch[0], latch[1] = 1, 7                    # what raise_abort() leaves behind
+            return loss * float("nan") if poison_loss else loss
+        return loss
 
     flags = (hb.USE_PERSIST, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD)
-    monkeypatch.setattr(solver, "_sharded_forward", poisoned_once)
-    monkeypatch.setattr(hb, "persist_aborted", lambda device: state["calls"] == 2)
+    monkeypatch.setattr(solver, "_sharded_forward", aborted_once)
     try:
+        hb.persist_clear_abort(dev)
         mean_loss = solver.sup_train_one_epoch(0, 1.0)
         steps = len(solver.train_lab_loader)
-        assert state["calls"] == steps + 1, "the poisoned step is repeated once"
+        assert state["calls"] == steps + 1, "the aborted step is repeated once"
         assert np.isfinite(mean_loss)
         assert not (hb.USE_PERSIST or hb.USE_PERSIST_DEC or hb.USE_PERSIST_DEC_BWD)
+        assert not hb.persist_aborted(dev), "the latch is cleared once the abort has been dealt with"
         for name, prm in solver.model.named_parameters():
             assert torch.isfinite(prm).all(), name
     finally:
         hb.USE_PERSIST, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = flags
+
+
+def test_greedy_decode_repeats_after_an_abort_in_an_earlier_launch(tmp_path, monkeypatch):
+    """Greedy decoding is several persistent launches (three encoder layers, then the decoder) and reads no loss.  An
+    abort in any of them but the last used to be invisible (every launch zeroes the per-launch abort word); with the
+    sticky latch Solver._greedy sees it after the decode, falls back to the per-step kernels and decodes again."""
+    import __graft_entry__ as entry
+    entry.build()
+    import hip_backend as hb
+    from solver import Solver
+    from utils import to_gpu
+    root = str(tmp_path)
+    _write_data(root, _vocab())
+    monkeypatch.chdir(root)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    solver = Solver(_config(root))
+    xs, ilens, _ = to_gpu(next(iter(solver.dev_loader)))
+    dev = xs.device
+    flags = (hb.USE_PERSIST, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD)
+    try:
+        hb.persist_clear_abort(dev)
+        solver.model.eval()
+        want = solver._greedy(xs, ilens)
+        assert (hb.USE_PERSIST, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD) == flags, "no abort: no fallback"
+        real_encoder = solver.model.encoder.forward
+
+        def encoder_then_abort(*a, **k):
+            out = real_encoder(*a, **k)
+            latch = hb.persist_scratch(dev)[1]
+            latch[0], latch[1] = 1, 1                    # an encoder layer aborted; the decoder launch follows
+            return out
+
+        monkeypatch.setattr(solver.model.encoder, "forward", encoder_then_abort)
+        got = solver._greedy(xs, ilens)
+        assert not (hb.USE_PERSIST or hb.USE_PERSIST_DEC), "the decode was repeated on the per-step kernels"
+        assert got == want
+    finally:
+        hb.USE_PERSIST, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = flags
+        hb.persist_clear_abort(dev)
 
 
 # ------------------------------------------------------------------------------------------------------------------
