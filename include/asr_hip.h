@@ -175,6 +175,12 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
 int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                              const int32_t* lens, const float* dy, const float* c, const float* y,
                              float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
+/* Does asr_lstm_seq_bwd_persist(_w) with this (H, arith) accumulate dW_hh itself when given y and dw_hh?  1 yes; 0 no -
+ * the ASR_ARITH_BF16X6 exchanged-partials kernel (H in {128, 256, 512}) leaves dW_hh = sum_t dG_t^T h_{t-1} to the caller
+ * (one batched asr_gemm_f32 over the two directions: with six products per product the fused form costs more time on the
+ * kernel's serial chain than the GEMM does) and ignores y / dw_hh; -1 no persistent backward for this H / arith.  The
+ * bias gradient db is accumulated by every persistent backward kernel. */
+int asr_lstm_bwd_persist_fuses_dw(int H, int arith);
 /* asr_lstm_seq_bwd_persist with W_hh in the FORWARD layout (w_hh_il [ndir][4H][H], gate-interleaved: the array
  * asr_lstm_seq_fwd_persist consumed) instead of its transpose: the exchanged-partials kernel reads its slice once per
  * launch.  Returns ASR_E_SHAPE where that kernel does not apply; the caller then forms w_hhT and calls

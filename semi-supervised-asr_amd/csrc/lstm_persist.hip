@@ -470,6 +470,20 @@ __device__ __forceinline__ void bfn_split8(const float (&v)[8], u32x4 (&t)[NT]) 
     for (int k = 0; k < NT; ++k) t[k][p] = q[k];
   }
 }
+// Three-term products on a 16-column MFMA whose batch side has only 8 rows: the idle columns 8..15 carry a second term of
+// the batch-side operand, so that the six products of a (weight tile, k-step) take FOUR instructions instead of six:
+//   B1 = [a | b] (columns 0..7 | 8..15),  B2 = [c | 0]
+//   D += Wa B1 + Wb B1 + Wc B1 + Wa B2   ->   columns 0..7: aa + ba + ca + ac,   columns 8..15: ab + bb + cb
+// (cb' is one of the three dropped 2^-24 terms; it comes for free and is kept).  The two halves are added once, after the
+// k loop, with one row_ror:8 DPP add per accumulator element (done on scalar copies: applied to the elements of the MFMA
+// accumulator vector in place, hipcc 7.2 paired the rotations with the wrong elements).
+__device__ __forceinline__ void fold_halves(f32x4& acc) {
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x128, 0xf, 0xf, true));
+  acc = (f32x4){v[0], v[1], v[2], v[3]};
+}
 __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -484,13 +498,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   constexpr int MT = (PUC + 3) / 4;      // M tiles: 4 units (16 gate rows) each
   constexpr int HST = KP + 8;            // LDS row stride in bf16: 16-byte multiple, rows 144 B apart at KP = 64 (the 8
                                          // rows of a 16-byte operand read then cover 8 distinct bank groups)
-  __shared__ __attribute__((aligned(16))) unsigned short hh[NT][PW][PRG][HST];      // split terms of the h tile
+  constexpr int NIMG = NT == 3 ? 4 : NT;  // three terms: + an image that stays zero (the idle half of B2, see fold_halves)
+  __shared__ __attribute__((aligned(16))) unsigned short hh[NIMG][PW][PRG][HST];    // split terms of the h tile
   __shared__ __attribute__((aligned(16))) float part[2][PW][4 * MT][PRG][4];   // K-partials [unit][row][gate], double buffered
   __shared__ int role[2];
   extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < NT * PW * PRG * HST; i += PNT) (&hh[0][0][0][0])[i] = 0;   // K padding, unused rows
+  for (int i = tid; i < NIMG * PW * PRG * HST; i += PNT) (&hh[0][0][0][0])[i] = 0;   // K padding, unused rows
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
@@ -622,20 +637,40 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       // (wave-private LDS tile: program order within the wave is enough)
 #pragma unroll
       for (int ks = 0; ks < ((ASR_LA & 1) ? 0 : KS); ++ks) {
-        u32x4 bt[NT];
+        if constexpr (NT == 3) {
+          // columns 8..15 of the batch side carry a second term (fold_halves): four MFMAs per tile and k-step
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(&hh[ml >> 3][wave][ml & 7][32 * ks + 8 * kq]);
+          const u32x4 b2 = *reinterpret_cast<const u32x4*>(&hh[2 + (ml >> 3)][wave][ml & 7][32 * ks + 8 * kq]);
 #pragma unroll
-        for (int k = 0; k < NT; ++k) bt[k] = *reinterpret_cast<const u32x4*>(&hh[k][wave][ml & 7][32 * ks + 8 * kq]);
-        // term pairs (p, q), p + q < NT: hi hi, hi lo, lo hi (two terms); + a c, c a, b b (three terms)
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], b1, acc[mt]);
 #pragma unroll
-        for (int o = 0; o < NT; ++o)
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][1], b1, acc[mt]);
 #pragma unroll
-          for (int pp = 0; pp <= o; ++pp)
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], b2, acc[mt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][pp], bt[o - pp], acc[mt]);
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][2], b1, acc[mt]);
+        } else {
+          u32x4 bt[NT];
+#pragma unroll
+          for (int k = 0; k < NT; ++k) bt[k] = *reinterpret_cast<const u32x4*>(&hh[k][wave][ml & 7][32 * ks + 8 * kq]);
+          // hi hi, hi lo, lo hi
+#pragma unroll
+          for (int o = 0; o < NT; ++o)
+#pragma unroll
+            for (int pp = 0; pp <= o; ++pp)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][pp], bt[o - pp], acc[mt]);
+        }
       }
     }
     LP_MARK(2);
     if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
+    if constexpr (NT == 3) {
+      if (s > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fold_halves(acc[mt]);
+      }
+    }
     if (ml < NR) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -1331,24 +1366,23 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   //     hardware transpose read, tools/micro/tr_read_check.hip)
   // The first version kept a second, column-major copy for dW_hh that the pointwise threads filled with 24 two-byte LDS
   // stores per step: 0.13 us of the serial chain (-DASR_RA=128).  h_{t_prev} stays [unit][slot][row].
-  // Three terms (NT = 3, six products): the kernel is at the register limit with two terms of W (64 VGPRs) next to the
-  // dW_hh accumulators (64), so the THIRD term of W lives in LDS in the lane layout of its consumer (wcl: one ds_read_b128
-  // per fragment and step, used by the last of the six products), and the h tile is kept as fp32 (htf) and split where it
-  // is consumed, every third step, which frees the LDS the third image pair would take.
-  __shared__ __attribute__((aligned(16))) unsigned short dgs[NT][4][PRG][GST];
-  __shared__ __attribute__((aligned(16))) unsigned short ht2[NT == 2 ? 2 : 1][NT == 2 ? PH : 1][4][PRG];
-  __shared__ __attribute__((aligned(16))) float htf[NT == 3 ? PH : 1][4][PRG];
-  __shared__ __attribute__((aligned(16))) u32x4 wcl[NT == 3 ? PW * MTW * KS * 64 : 1];
+  // Three terms (NT = 3, six products per product): dW_hh is NOT fused.  With three terms of W in registers (96 VGPRs)
+  // the 64 accumulator registers of dW_hh do not fit, and a first version that kept the third term of W in LDS and the h
+  // tile as fp32 measured the fused product at 1.08 us per time step (2 x the MFMAs of the two-term form, all of it on
+  // the serial chain: every CU is producer and consumer) - 1.5 ms per cfg-2 step, against 1.2 ms for the same sums as two
+  // batched 256 x 128 GEMMs after the kernel (ops._LstmLayer).  FUSE is therefore a property of the two-term kernel.
+  constexpr bool FUSE = NT == 2;
+  constexpr int NIMG = NT == 3 ? 4 : NT;  // three terms: + an image that stays zero (the idle half of B2, see fold_halves)
+  __shared__ __attribute__((aligned(16))) unsigned short dgs[NIMG][FUSE ? 4 : 1][PRG][GST];
+  __shared__ __attribute__((aligned(16))) unsigned short ht2[FUSE ? 2 : 1][FUSE ? PH : 1][4][PRG];
   __shared__ __attribute__((aligned(16))) float dhs[PRG][16];                                 // reduced dh_rec [row][unit]
   __shared__ int role[2];
   extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < NT * 4 * PRG * GST; i += PNT) (&dgs[0][0][0][0])[i] = 0;
-  if constexpr (NT == 2) {
+  for (int i = tid; i < NIMG * (FUSE ? 4 : 1) * PRG * GST; i += PNT) (&dgs[0][0][0][0])[i] = 0;
+  if constexpr (FUSE) {
     for (int i = tid; i < 2 * PH * 4 * PRG; i += PNT) (&ht2[0][0][0][0])[i] = 0;
-  } else {
-    for (int i = tid; i < PH * 4 * PRG; i += PNT) (&htf[0][0][0])[i] = 0.f;
   }
   if (tid < PRG * 16) (&dhs[0][0])[tid] = 0.f;
   int g, slice;
@@ -1363,7 +1397,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   const int ml = lane & 15, kq = lane >> 4;
   // W_hh rows of this CU's columns, all units -> split bf16: A operand of the dh-partial product.  a.w is W_hh^T
   // [unit][4H]: lane l holds unit 16 (MTW wave + mt) + (l & 15), columns NC slice + 32 ks + 8 (l >> 4) + j
-  u32x4 wt[MTW][KS][2];
+  u32x4 wt[MTW][KS][NT];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
     const int wunit = 16 * (MTW * wave + mt) + ml;
@@ -1388,10 +1422,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
           v[4 * j4 + 2] = kok ? q.z : 0.f; v[4 * j4 + 3] = kok ? q.w : 0.f;
         }
       }
-      u32x4 wsp[NT];
-      bfn_split8<NT>(v, wsp);
-      wt[mt][ks][0] = wsp[0]; wt[mt][ks][1] = wsp[1];
-      if constexpr (NT == 3) wcl[((wave * MTW + mt) * KS + ks) * 64 + lane] = wsp[2];    // read back by this lane only
+      bfn_split8<NT>(v, wt[mt][ks]);
     }
   }
   // pointwise ownership as in the other kernels: thread (pu, pj), tid < PUC*PRG
@@ -1408,7 +1439,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   constexpr int PARSZ = 32 * 32 * PRG * PUC;      // floats per parity
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
   bool aborted = false;
-  const bool fuse_dw = a.dw != nullptr && a.yfwd != nullptr;
+  const bool fuse_dw = FUSE && a.dw != nullptr && a.yfwd != nullptr;
   // gather role: the 16 lanes of DPP row rr = lane >> 4 sum the 32 sources of combo CPW wave + rr = (row, unit quad), two
   // sources (2 sp, 2 sp + 1) per lane: one add and a 16-lane DPP reduction per value.  (With one source per lane and 32
   // lanes per combo the two DPP rows had to be joined through v_readlane: 0.29 us of the 2.52 us step, tools/persist_bench.py
@@ -1453,12 +1484,12 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     }
   };
   auto stage_h = [&](int buf, int sn) {  // n_h (fetched for step sn) -> this lane's unit, slot buf of the h tile
-    const int tt = time_of(sn);
-    const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
-    float hv[NR];
+    if constexpr (FUSE) {
+      const int tt = time_of(sn);
+      const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
+      float hv[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) hv[r] = (hp && r0 + r < a.nb) ? n_h[r] : 0.f;
-    if constexpr (NT == 2) {
+      for (int r = 0; r < NR; ++r) hv[r] = (hp && r0 + r < a.nb) ? n_h[r] : 0.f;
       unsigned hi[NR / 2], lo[NR / 2];
 #pragma unroll
       for (int r = 0; r < NR / 2; ++r) {
@@ -1472,9 +1503,6 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         *reinterpret_cast<uint2*>(&ht2[0][hunit][buf][0]) = make_uint2(hi[0], hi[1]);
         *reinterpret_cast<uint2*>(&ht2[1][hunit][buf][0]) = make_uint2(lo[0], lo[1]);
       }
-    } else {
-      *reinterpret_cast<float4*>(&htf[hunit][buf][0]) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-      if (NR == 8) *reinterpret_cast<float4*>(&htf[hunit][buf][4]) = make_float4(hv[NR - 4], hv[NR - 3], hv[NR - 2], hv[NR - 1]);
     }
   };
   // gather descriptors (loop invariant): byte offset of this lane's quads in parity 0, and whether they exist
@@ -1598,15 +1626,17 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
         dcarry = dcn;
         {
-          const int sl = s & 3, zs = (s + 1) & 3;          // this step's slot; the slot the NEXT step's h is staged into
+          const int sl = FUSE ? (s & 3) : 0, zs = (s + 1) & 3;   // this step's slot; the slot the NEXT step's h is staged into
           unsigned p0[NT], p1[NT];
           bfn_split2<NT>(da.x, da.y, p0);
           bfn_split2<NT>(da.z, da.w, p1);
 #pragma unroll
           for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][sl][pj][4 * pu]) = make_uint2(p0[k], p1[k]);
-          if (fuse_dw && !(ASR_RA & 128)) {                // must read as zero in the flush that does not cover it
+          if constexpr (FUSE) {
+            if (fuse_dw && !(ASR_RA & 128)) {              // must read as zero in the flush that does not cover it
 #pragma unroll
-            for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][zs][pj][4 * pu]) = make_uint2(0u, 0u);
+              for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][zs][pj][4 * pu]) = make_uint2(0u, 0u);
+            }
           }
         }
         if (prow_ok) {
@@ -1626,27 +1656,32 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < ((ASR_RA & 4) ? 0 : KS); ++ks) {
-        u32x4 bt[NT], wc[NT == 3 ? MTW : 1];
         if constexpr (NT == 3) {
+          // columns 8..15 of the batch side carry a second term (fold_halves): four MFMAs per tile and k-step
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(&dgs[ml >> 3][0][ml & 7][32 * ks + 8 * kq]);
+          const u32x4 b2 = *reinterpret_cast<const u32x4*>(&dgs[2 + (ml >> 3)][0][ml & 7][32 * ks + 8 * kq]);
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) wc[mt] = wcl[((wave * MTW + mt) * KS + ks) * 64 + lane];
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], b1, acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][1], b1, acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], b2, acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][2], b1, acc[mt]);
+        } else {
+          const u32x4 bh = *reinterpret_cast<const u32x4*>(&dgs[0][s & 3][ml & 7][32 * ks + 8 * kq]);
+          const u32x4 bl = *reinterpret_cast<const u32x4*>(&dgs[1][s & 3][ml & 7][32 * ks + 8 * kq]);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], bh, acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], bl, acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][1], bh, acc[mt]);
         }
+      }
+      if constexpr (NT == 3) {
 #pragma unroll
-        for (int k = 0; k < NT; ++k) bt[k] = *reinterpret_cast<const u32x4*>(&dgs[k][s & 3][ml & 7][32 * ks + 8 * kq]);
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], bt[0], acc[mt]);
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], bt[1], acc[mt]);
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][1], bt[0], acc[mt]);
-        if constexpr (NT == 3) {
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], bt[2], acc[mt]);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][1], bt[1], acc[mt]);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wc[mt], bt[0], acc[mt]);
-        }
+        for (int mt = 0; mt < MTW; ++mt) fold_halves(acc[mt]);
       }
       LP_MARK(6);
       // D: lane l holds units 16 tile + 4 (l >> 4) .. + 3 of batch row l & 15 -> one tagged quad to their owner's slot
@@ -1671,7 +1706,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     // three steps just done.  A single step only fills 8 of the K = 32 of the bf16 MFMA and every shape costs the same
     // 16 cycles, so a per-step product was 1 536 MFMA cycles per SIMD and step; the fourth slot is the one the next
     // step's h is being staged into (its dG slot is kept zero), which lets the staging stay where the prefetch needs it.
-    if (fuse_dw && (s % 3 == 2 || s == T - 1)) {
+    if constexpr (FUSE) if (fuse_dw && (s % 3 == 2 || s == T - 1)) {
       if (s % 3 != 2) {
         // tail of the sequence (1 or 2 pending steps): slots of steps that were flushed already must read as zero
         __syncthreads();
@@ -1703,7 +1738,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         for (int e = 0; e < NE; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[e] + (unsigned)((s & 1) * PARSZ) * 4u, 0, 16);
         q_inflight = true;
       };
-      if constexpr (NT == 2) {
+      if constexpr (FUSE) {
         u32x4 ah[CT], al[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { ah[ct] = a_frag(0, ct); al[ct] = a_frag(1, ct); }
@@ -1719,38 +1754,6 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
           for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(ah[ct], bl, dwacc[ct][ut]);
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) dwacc[ct][ut] = bf3_mfma(al[ct], bh, dwacc[ct][ut]);
-        }
-      } else {
-        // three terms: the A fragments of half the column tiles at a time (24 registers instead of 48); the h fragments are
-        // read as fp32 and split here, once per pass
-#ifndef ASR_RS_CH
-#define ASR_RS_CH 2
-#endif
-        constexpr int CH = (CT + ASR_RS_CH - 1) / ASR_RS_CH;
-#pragma unroll
-        for (int c0 = 0; c0 < CT; c0 += CH) {
-          u32x4 at[CH][3];
-#pragma unroll
-          for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) at[c][k] = a_frag(k, c0 + c < CT ? c0 + c : CT - 1);
-#pragma unroll
-          for (int ut = 0; ut < MTW; ++ut) {
-            if (c0 + CH >= CT && ut == (MTW + 1) / 2 && s + 1 < T) first_attempt();
-            const int un = 16 * (MTW * wave + ut) + ml;
-            const float4 h0 = *reinterpret_cast<const float4*>(&htf[un][kq][0]);
-            const float4 h1 = *reinterpret_cast<const float4*>(&htf[un][kq][4]);
-            const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-            u32x4 bt[3];
-            bfn_split8<3>(hv, bt);
-#pragma unroll
-            for (int o = 0; o < 3; ++o)
-#pragma unroll
-              for (int pp = 0; pp <= o; ++pp)
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                  if (c0 + c < CT) dwacc[c0 + c][ut] = bf3_mfma(at[c][pp], bt[o - pp], dwacc[c0 + c][ut]);
-          }
         }
       }
       LP_MARK(8);
@@ -1808,7 +1811,7 @@ int launch_fwd(const PersistArgs& a, hipStream_t stream) {
 template <int PH, int NR, int NT>
 int launch_fwd_bf3(const PersistArgs& a, hipStream_t stream) {
   constexpr int KP = ((PH / PW + 31) / 32) * 32, MT = (PH / 32 + 3) / 4;
-  const size_t stat = (size_t)NT * PW * PRG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * PRG * 4 + 64;
+  const size_t stat = (size_t)(NT == 3 ? 4 : NT) * PW * PRG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * PRG * 4 + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
   hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
@@ -1843,9 +1846,8 @@ int launch_bwd_bf3(const PersistArgs& a, hipStream_t stream) {
 template <int PH, int NR, int NT>
 int launch_bwd_rs(const PersistArgs& a, hipStream_t stream) {
   using RD = RsDims<PH>;
-  const size_t stat = (size_t)NT * 4 * PRG * RD::GST * 2 + PRG * 16 * sizeof(float) + 64 +
-                      (NT == 2 ? (size_t)2 * PH * 4 * PRG * 2
-                               : (size_t)PH * 4 * PRG * sizeof(float) + (size_t)PW * RD::MTW * RD::KS * 64 * 16);
+  const size_t stat = (size_t)(NT == 3 ? 4 : NT) * (NT == 2 ? 4 : 1) * PRG * RD::GST * 2 + PRG * 16 * sizeof(float) + 64 +
+                      (NT == 2 ? (size_t)2 * PH * 4 * PRG * 2 : (size_t)64);
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
   hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_rs_kernel<PH, NR, NT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
@@ -1925,6 +1927,16 @@ bool asr_persist_device_ok() {
     cached = cus == 256 ? 1 : 0;
   }
   return cached == 1;
+}
+
+// 1 when asr_lstm_seq_bwd_persist* with these arguments accumulates dW_hh inside the kernel (given y and dw_hh), 0 when the
+// caller has to form it (the three-term exchanged-partials kernel: see lstm_persist_bwd_rs_kernel), -1 when no persistent
+// backward kernel applies.  The bias gradient is accumulated by every persistent backward kernel.
+extern "C" int asr_lstm_bwd_persist_fuses_dw(int H, int arith) {
+  if (!persist_supported(H)) return -1;
+  const int kind = bwd_kernel_kind(H, arith);
+  if (kind < 0) return -1;
+  return (kind == 2 && (arith & ASR_ARITH_MASK) == ASR_ARITH_BF16X6) ? 0 : 1;
 }
 
 static bool arith_ok(int arith) {

@@ -15,7 +15,7 @@ ABI_VERSION = 2
 
 EXPORTS = (
     "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
-    "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_lstm_seq_bwd_persist_w", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
+    "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_lstm_seq_bwd_persist_w", "asr_lstm_bwd_persist_fuses_dw", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
@@ -75,6 +75,7 @@ def load():
     lib.asr_lstm_seq_fwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]
     lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]
     lib.asr_lstm_seq_bwd_persist_w.argtypes = lib.asr_lstm_seq_bwd_persist.argtypes
+    lib.asr_lstm_bwd_persist_fuses_dw.argtypes = [c_i, c_i]
     lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -204,11 +205,13 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, ac
     return out
 
 
-def gemm_batched(A, B, out, trans_a, trans_b, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, accumulate=False, arith=None):
-    """Raw batched form (pointer + strides); tensors only provide the base pointers."""
-    check(load().asr_gemm_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, None, 0,
-                              int(accumulate), batch, sA, sB, sC, 1, ARITH[0] if arith is None else _arith_code(arith),
-                              stream()), "asr_gemm_f32(batched)")
+def gemm_batched(A, B, out, trans_a, trans_b, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, accumulate=False, arith=None,
+                 split_k=None, a_off=0, b_off=0):
+    """Raw batched form (pointer + strides in elements; strides may be negative); tensors only provide the base pointers
+    (a_off / b_off: element offsets of the first operand elements inside A / B)."""
+    check(load().asr_gemm_f32(int(trans_a), int(trans_b), M, N, K, _off(A, a_off), lda, _off(B, b_off), ldb, ptr(out), ldc,
+                              None, 0, int(accumulate), batch, sA, sB, sC, 0 if split_k is None else int(split_k),
+                              ARITH[0] if arith is None else _arith_code(arith), stream()), "asr_gemm_f32(batched)")
     return out
 
 
@@ -598,20 +601,25 @@ def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
 
 
 def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None, w_hh=None):
-    """Returns True when dW_hh (and the bias gradient `db`, if given) were accumulated by the persistent kernel itself.
+    """-> (fused_dw, fused_db): whether dW_hh and the bias gradient `db` were accumulated by the persistent kernel itself
+    (db: by every persistent backward kernel; dW_hh: by all of them except the bf16x6 exchanged-partials kernel, see
+    asr_lstm_bwd_persist_fuses_dw - the caller then forms it with a GEMM).
     w_hhT: the transposed recurrent weights [ndir][H][4H], or a callable producing them on demand; w_hh: the forward
     layout [ndir][4H][H] - when given, the kernel that can read it directly is tried first and the transpose is only
     formed if that kernel does not apply."""
     T, B, ndir, H4 = gates.shape
     H = H4 // 4
     lib = load()
+    ar = ARITH[0]
+    fuses = USE_PERSIST and lib.asr_lstm_bwd_persist_fuses_dw(H, ar) == 1 and y is not None and dw_hh is not None
+    yk, dwk = (y, dw_hh) if fuses else (None, None)
     if USE_PERSIST and w_hh is not None:
         xch, ctrl = persist_scratch(gates.device)
         rc = lib.asr_lstm_seq_bwd_persist_w(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(dy), ptr(c),
-                                            ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ARITH[0], stream())
+                                            ptr(yk), ptr(dwk), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ar, stream())
         if rc == 0:
             count_path("lstm_bwd", True)
-            return y is not None and dw_hh is not None
+            return fuses, db is not None
         if rc != -2:
             check(rc, "asr_lstm_seq_bwd_persist_w")
     if callable(w_hhT):
@@ -619,10 +627,10 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None,
     if USE_PERSIST:
         xch, ctrl = persist_scratch(gates.device)
         rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hhT), ptr(lens), ptr(dy), ptr(c),
-                                          ptr(y), ptr(dw_hh), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ARITH[0], stream())
+                                          ptr(yk), ptr(dwk), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ar, stream())
         if rc == 0:
             count_path("lstm_bwd", True)
-            return y is not None and dw_hh is not None
+            return fuses, db is not None
         if rc != -2:
             check(rc, "asr_lstm_seq_bwd_persist")
     count_path("lstm_bwd", False, "H=%d B=%d ndir=%d persist=%s" % (H, B, ndir, USE_PERSIST))
@@ -636,7 +644,7 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None,
                                    st), "asr_lstm_seq_bwd")
 
     run_grouped(groups, one)
-    return False
+    return False, False
 
 
 # dropout masks regenerated inside the consuming kernels from a seed (off: materialised fp32 masks, as injected by tests)

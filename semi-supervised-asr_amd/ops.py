@@ -159,25 +159,21 @@ class _LstmLayer(torch.autograd.Function):
         ws["zbuf"].zero_()                     # dcarry, dw_hh, db
         gates, y = ws["gates"], ws["y"]
         # the transposed recurrent weights are only formed if the kernel that reads the forward layout does not apply
-        fused_dw = hb.lstm_seq_bwd(gates, lambda: ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2)), ws["lens"], dyc, ws["c"],
-                                   ws["dcarry"], y=y, dw_hh=ws["dw_hh"], db=ws["db"], w_hh=ws["w_hh"])   # gates <- dG in place
+        fused_dw, fused_db = hb.lstm_seq_bwd(gates, lambda: ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2)), ws["lens"], dyc,
+                                             ws["c"], ws["dcarry"], y=y, dw_hh=ws["dw_hh"], db=ws["db"],
+                                             w_hh=ws["w_hh"])                                   # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = hb.gemm(dG, x2, trans_a=True)                     # [ndir*4H, I]
-        db = ws["db"] if fused_dw else hb.colsum(dG)       # the persistent kernel sums the bias gradient itself
-        if not fused_dw:
-            y2 = y.view(T * B, ndir * H)
-            for d in range(ndir):
-                if T > 1:
-                    if d == 0:     # h_{t-1} = y[t-1]
-                        a = dG[B:, d * 4 * H:(d + 1) * 4 * H]
-                        hprev = y2[:(T - 1) * B, d * H:(d + 1) * H]
-                    else:          # reverse direction: predecessor in processing order is y[t+1]
-                        a = dG[:(T - 1) * B, d * 4 * H:(d + 1) * 4 * H]
-                        hprev = y2[B:, d * H:(d + 1) * H]
-                    hb.gemm(a, hprev, trans_a=True, out=ws["dw_hh"][d])
-                else:
-                    ws["dw_hh"][d].zero_()
+        db = ws["db"] if fused_db else hb.colsum(dG)       # the persistent kernels sum the bias gradient themselves
+        if not fused_dw and T > 1:
+            # dW_hh[d] = sum_t dG_t[d]^T h_prev(t), h_prev = y[t-1] (d = 0) or y[t+1] (reverse direction): ONE batched GEMM
+            # over the directions, K = (T-1)*B, accumulated into the zeroed dw_hh (no zero pass of its own).
+            #   d = 0: A = dG[B:, 0:4H],        B = y[:(T-1)B, 0:H]
+            #   d = 1: A = dG[:(T-1)B, 4H:8H],  B = y[B:, H:2H]          -> batch strides relative to d = 0 (may be negative)
+            ldg, ldy = ndir * 4 * H, ndir * H
+            hb.gemm_batched(dG, y, ws["dw_hh"], True, False, 4 * H, H, (T - 1) * B, ldg, ldy, H, ndir,
+                            4 * H - B * ldg, B * ldy + H, 4 * H * H, accumulate=True, a_off=B * ldg, b_off=0)
         # gate-interleaved gradients -> torch layout, one launch
         g_ih, g_hh, g_b, g_b2 = hb.lstm_unpack(H, I, ndir, dw_ih, ws["dw_hh"], db, two_biases=True)
         grads = []

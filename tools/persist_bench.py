@@ -26,20 +26,23 @@ def timeit(fn, n=3):
         e0.record(); rc = fn(); e1.record(); torch.cuda.synchronize(); assert rc == 0, rc
         best = min(best, e0.elapsed_time(e1) * 1e3 / T)
     return best
+ARITHS = [hb._arith_code(a) for a in os.environ.get("PB_ARITH", "bf16x6,bf16x3").split(",")]
 paths = [hb.LIB_PATH] + sorted(glob.glob(ROOT + '/scratchlibs/lib_*.so'))
 libs = {p: ctypes.CDLL(p) for p in paths}
-best = {p: [1e9, 1e9, 1e9] for p in paths}
+best = {(p, a): [1e9, 1e9, 1e9] for p in paths for a in ARITHS}
 for rep in range(4):                 # interleaved repetitions: clocks / placement drift between runs
     for path in paths:
+      for ar in ARITHS:
         l = libs[path]
         ga = gates0.clone()
-        tf = timeit(lambda: l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), st))
+        tf = timeit(lambda: l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), ar, st))
         gb = gact.clone()
-        tb = timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), None, P(xch), P(ctrl), st))
+        tb = timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), None, P(xch), P(ctrl), ar, st))
         gb = gact.clone()
-        tb0 = timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), None, None, None, P(xch), P(ctrl), st))
-        best[path] = [min(a_, b_) for a_, b_ in zip(best[path], (tf, tb, tb0))]
-        if int(ctrl[8].item()) != 0: print('ABORT in', os.path.basename(path), 'code', int(ctrl[9].item()), 'rep', rep, flush=True)
+        tb0 = timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), None, None, None, P(xch), P(ctrl), ar, st))
+        best[(path, ar)] = [min(a_, b_) for a_, b_ in zip(best[(path, ar)], (tf, tb, tb0))]
+        if int(ctrl[0].item()) != 0: print('ABORT in', os.path.basename(path), 'code', int(ctrl[1].item()), 'rep', rep, flush=True); ctrl[:2].zero_()
 for path in paths:
-    tf, tb, tb0 = best[path]
-    print('%-26s fwd %.2f us/step | bwd %.2f us/step (no dW: %.2f)' % (os.path.basename(path), tf, tb, tb0), flush=True)
+    for ar in ARITHS:
+        tf, tb, tb0 = best[(path, ar)]
+        print('%-26s %-7s fwd %.2f us/step | bwd %.2f us/step (no dW: %.2f)' % (os.path.basename(path), hb.arith_name(ar), tf, tb, tb0), flush=True)
