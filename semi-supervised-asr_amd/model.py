@@ -224,6 +224,30 @@ class Decoder(torch.nn.Module):
             # plain attribute, not a buffer -> absent from state_dict
             self.vlabeldist = cc(torch.from_numpy(np.array(labeldist, dtype=np.float32)))
 
+    def zero_state(self, enc_pad, dim=None):
+        """model.py:276-280."""
+        return enc_pad.new_zeros(enc_pad.size(0), dim if dim else self.hidden_dim)
+
+    def forward_step(self, emb, dec_z, dec_c, c, w, enc_pad, enc_len):
+        """One decoder step with the reference's signature (model.py:283-294): dropout(cat[emb, c]) -> LSTMCell ->
+        attention -> output layer; returns (logit, dec_z, dec_c, c, w).  Thin, forward-only entry for callers that drive
+        the loop themselves (inspection, custom search): the products run on the library's GEMM and attention-step
+        kernels, the gate arithmetic on torch elementwise ops.  Training and Decoder.forward never come through here -
+        they run all steps inside the fused sequence kernels (ops.decoder_sequence), which is what the fixtures pin; the
+        tests hold this method to that path."""
+        with torch.no_grad():
+            cell = self.LSTMCell
+            cell_inp = self.dropout_layer(torch.cat([emb, c], dim=-1)).contiguous()
+            gates = hb.gemm(cell_inp, cell.weight_ih, trans_b=True, bias=cell.bias_ih)
+            hb.gemm(dec_z.contiguous(), cell.weight_hh, trans_b=True, bias=cell.bias_hh, out=gates, accumulate=True)
+            gi, gf, gg, go = gates.chunk(4, dim=1)
+            dec_c = torch.sigmoid(gf) * dec_c + torch.sigmoid(gi) * torch.tanh(gg)
+            dec_z = torch.sigmoid(go) * torch.tanh(dec_c)
+            c, w = self.attention(enc_pad, enc_len, dec_z, w)
+            logit = hb.gemm(torch.cat([dec_z, c], dim=-1).contiguous(), self.output_layer.weight, trans_b=True,
+                            bias=self.output_layer.bias)
+        return logit, dec_z, dec_c, c, w
+
     def _label_matrices(self, ys, olength=None):
         """ys_in = [BOS, y], ys_out = [y, EOS], both padded with EOS (model.py:301-306), as [B, L] matrices.
         One concatenation + one gather on the device with indices built on the host from the (host-known) label
@@ -397,20 +421,45 @@ class LM(torch.nn.Module):
         predictions = torch.argmax(logits, dim=-1)
         return ys_log_probs, ys_probs, predictions
 
+    def zero_state(self, ref, dim=None):
+        """model.py:486-490."""
+        return ref.new_zeros(self.n_layers, ref.size(0), dim if dim else self.hidden_dim)
+
+    def forward_step(self, emb, dec_z=None, dec_c=None):
+        """One step of the stacked LSTM + output layer with carried state (model.py:534-542; decode stage only, no
+        autograd): emb [B, 1, E], dec_z / dec_c [n_layers, B, H] or None -> (logit [B, V], dec_z, dec_c).  The products
+        run on asr_gemm_f32; inter-layer dropout as nn.LSTM(dropout=p) applies it (training mode only)."""
+        with torch.no_grad():
+            x = emb.reshape(emb.size(0), -1).contiguous()
+            if dec_z is None:
+                dec_z, dec_c = self.zero_state(x), self.zero_state(x)
+            new_z, new_c = [], []
+            for l in range(self.n_layers):
+                w_ih, w_hh, b_ih, b_hh = self.LSTM.direction_params(l)
+                gates = hb.gemm(x, w_ih, trans_b=True, bias=b_ih)
+                hb.gemm(dec_z[l].contiguous(), w_hh, trans_b=True, bias=b_hh, out=gates, accumulate=True)
+                gi, gf, gg, go = gates.chunk(4, dim=1)
+                cl = torch.sigmoid(gf) * dec_c[l] + torch.sigmoid(gi) * torch.tanh(gg)
+                zl = torch.sigmoid(go) * torch.tanh(cl)
+                new_z.append(zl)
+                new_c.append(cl)
+                x = zl
+                if l + 1 < self.n_layers and self.training and self.dropout_rate > 0:
+                    x = F.dropout(x, self.dropout_rate, True)
+            logit = hb.gemm(x.contiguous(), self.output_layer.weight, trans_b=True, bias=self.output_layer.bias)
+        return logit, torch.stack(new_z), torch.stack(new_c)
+
     def decode(self, n_samples=5, sample=False, max_dec_timesteps=500):
-        """Free-running generation (model.py:544-563).  Diagnostic only (lm_validation): re-runs the
-        prefix through the fused sequence kernel each step instead of carrying state."""
+        """Free-running generation with carried state (model.py:544-563; lm_validation's samples)."""
         dev = self.embedding.weight.device
-        toks = torch.full((n_samples, 1), self.bos, dtype=torch.long, device=dev)
+        prev = torch.full((n_samples,), self.bos, dtype=torch.long, device=dev)
+        dec_z = dec_c = None
         preds = []
         with torch.no_grad():
             for t in range(max_dec_timesteps):
-                lens_dev = torch.full((n_samples,), toks.size(1), dtype=torch.int32, device=dev)
-                out = self._run_lstm(self.embedding(toks).transpose(0, 1).contiguous(), lens_dev)[-1]
-                logit = ops.linear(out, self.output_layer.weight, self.output_layer.bias)
-                nxt = torch.distributions.Categorical(logits=logit).sample() if sample else logit.argmax(-1)
-                preds.append(nxt)
-                toks = torch.cat([toks, nxt.unsqueeze(1)], dim=1)
+                logit, dec_z, dec_c = self.forward_step(self.embedding(prev).unsqueeze(1), dec_z, dec_c)
+                prev = torch.distributions.Categorical(logits=logit).sample() if sample else logit.argmax(-1)
+                preds.append(prev)
         return torch.stack(preds, dim=1)
 
     def mask_and_cal_sum(self, log_probs, ys, mask=None):

@@ -304,13 +304,62 @@ def gen_big(name, shape):
                ws_first=npy(ws[:, 0]), ws_mid=npy(ws[:, ws.size(1) // 2]), ws_last=npy(ws[:, -1]),
                enc_h_b0=npy(enc_h[0]), enc_h_blast=npy(enc_h[-1]), enc_lens=np.asarray(enc_lens),
                masked_loss=npy(m.mask_and_cal_loss(lp, ys)))
-    for n, p in m.named_parameters():
+    _store_grads(out, m)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%s: loss %.6f" % (name, float(loss)))
+
+
+def _store_grads(out, m):
+    """Per parameter: gradient norm, first / last 16 elements and a seeded sample of 4 096 elements (synth.grad_sample_index:
+    an error confined to the interior of a large gradient moves neither the norm nor the ends)."""
+    for i, (n, p) in enumerate(m.named_parameters()):
         g = npy(p.grad).ravel()
         out["gnorm/" + n] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
         out["ghead/" + n] = g[:16].copy()
         out["gtail/" + n] = g[-16:].copy()
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-    print("%s: loss %.6f" % (name, float(loss)))
+        out["gsample/" + n] = g[synth.grad_sample_index(i, g.size)].copy()
+        out["gmax/" + n] = np.float32(np.abs(g).max())
+
+
+def gen_big_ssl():
+    """The semi-supervised generator step at the real width, held by the reference: solver.py:460-483's arithmetic with
+    the 3x512 model and the 2x640 judge (dis_dropout_rate 0), 8 unlabeled + 8 labeled utterances of T = 400:
+    unlabeled greedy smooth-embedding decode with gradients (int(T * proportion) = 50 steps), judge probabilities of the
+    hypothesis, unsup = -sum(p_LM * log p * [pred != EOS]) / sum([pred != EOS]), labeled teacher-forced pass,
+    loss = sup + unsup_weight * unsup, backward.  Stored: the three losses, the hypothesis, its log-probs, the judge's
+    probabilities, and every generator gradient as norm + ends + seeded sample."""
+    import time
+    sh = synth.BIG_SSL_SHAPE
+    cfg = synth.CFG2
+    m, _ = build_e2e(cfg, sh["wseed"], sh["ldseed"])
+    lm, _ = build_lm(synth.CFG_JUDGE, sh["jseed"], sh["jldseed"])
+    xs_np, ilens, ys_np = synth.ragged_batch(sh["n_lab"], sh["t_max"], cfg["input_dim"], cfg["output_dim"], sh["bseed"])
+    uxs_np, uilens, _ = synth.ragged_batch(sh["n_unlab"], sh["t_max"], cfg["input_dim"], cfg["output_dim"], sh["ubseed"])
+    xs, ys = to_t(xs_np, ys_np)
+    uxs = torch.from_numpy(uxs_np)
+    t0 = time.time()
+    u_logits, u_lp, u_pred, _ = m(uxs, uilens, ys=None, sample=False, label_smoothing=False,
+                                  max_dec_timesteps=int(uxs.size(1) * sh["proportion"]), smooth=True, scaling=sh["scaling"])
+    _, lm_p, _ = lm(ys=u_pred, discrete_input=False)
+    mask = (u_pred != 2).float()
+    unsup = -torch.sum(lm_p * u_lp * mask) / torch.sum(mask)
+    np.random.seed(9)
+    _, l_lp, _, _ = m(xs, ilens, ys=ys, tf_rate=1.0, sample=False)
+    sup = -torch.mean(l_lp)
+    loss = sup + sh["unsup_weight"] * unsup
+    m.zero_grad()
+    lm.zero_grad()
+    loss.backward()
+    print("big_ssl: reference step %.1f s" % (time.time() - t0))
+    top2 = torch.topk(u_logits, 2, dim=2).values
+    margin = float((top2[..., 0] - top2[..., 1]).min())
+    out = dict(unsup=npy(unsup), sup=npy(sup), loss=npy(loss), u_pred=npy(u_pred), u_lp=npy(u_lp), lm_p=npy(lm_p),
+               n_hyp_tokens=np.float32(mask.sum()), min_top2_margin=np.float32(margin),
+               ilens=np.asarray(ilens), uilens=np.asarray(uilens))
+    _store_grads(out, m)
+    np.savez_compressed(os.path.join(HERE, "big_ssl.npz"), **out)
+    print("big_ssl: sup %.6f unsup %.6f, %d hypothesis tokens, smallest top-2 logit margin %.3e"
+          % (float(sup), float(unsup), int(mask.sum()), margin))
 
 
 def gen_tiny_opt():
@@ -369,6 +418,6 @@ if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "4")))
     jobs = dict(tiny_e2e=gen_tiny_e2e, tiny_lm=gen_tiny_lm, tiny_ssl=gen_tiny_ssl, cfg1=gen_cfg1, text=gen_text,
                 tiny_opt=gen_tiny_opt, cfg2=lambda: gen_big("cfg2", synth.CFG2_SHAPE),
-                cfg5=lambda: gen_big("cfg5", synth.CFG5_SHAPE))
+                cfg5=lambda: gen_big("cfg5", synth.CFG5_SHAPE), big_ssl=gen_big_ssl)
     for name in (sys.argv[1:] or list(jobs)):          # no arguments: everything (cfg2 / cfg5 take minutes)
         jobs[name]()

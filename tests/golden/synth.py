@@ -26,6 +26,18 @@ CFG2 = dict(input_dim=80, enc_hidden_dim=512, enc_n_layers=3, subsample=[2, 2, 2
 CFG2_SHAPE = dict(n_utt=32, t_max=800, wseed=99, bseed=1234, ldseed=5)
 CFG5_SHAPE = dict(n_utt=8, t_max=1600, wseed=99, bseed=1235, ldseed=5)
 
+# the judge at its config.yaml width (dis_hidden_dim 640, dis_embedding_dim 256, 2 layers) and the semi-supervised step
+# fixture at the 3x512 model's own width (make_golden.py gen_big_ssl): 8 labeled + 8 unlabeled utterances of T = 400
+CFG_JUDGE = dict(output_dim=34, embedding_dim=256, hidden_dim=640, dropout_rate=0.0, n_layers=2, ls_weight=0.05)
+BIG_SSL_SHAPE = dict(n_lab=8, n_unlab=8, t_max=400, wseed=99, jseed=77, bseed=2234, ubseed=2235, ldseed=5, jldseed=6,
+                     proportion=0.125, unsup_weight=0.5, scaling=3.0)
+
+
+def grad_sample_index(i, numel, n=4096):
+    """Seeded element sample of parameter number i's gradient (fixtures store the values, tests regenerate the indices)."""
+    return np.random.RandomState(7000 + i).randint(0, numel, size=min(n, numel))
+
+
 TINY_LM = dict(output_dim=9, embedding_dim=16, hidden_dim=16, dropout_rate=0.0, n_layers=2,
                ls_weight=0.05)
 

@@ -1271,3 +1271,217 @@ def test_greedy_decode_early_stop(eos_bias):
         assert (early == 2).all()
     if eos_bias == 0.0:
         assert (full == early).all() or (full == 2).any()
+
+
+# ------------------------------------------------------------------------------ round 3: pins the verdict asked for
+def test_free_running_persistent_decoder_against_oracle_d512():
+    """The kernel cfg-4 and validation actually run - dec_persist_fwd_kernel<512,512,512,128,FB=true>, free-running with
+    the smooth-embedding feedback computed inside the kernel - directly against the oracle's Decoder.forward
+    (model.py:296-367, ys=None, smooth=True) at D = A = O = 512, B = 32, T' = 100, 20 steps: logits, log-probs, the
+    hypothesis, attention weights, and the gradients of a loss over log-probs and attention weights with respect to the
+    encoder output and every decoder / attention parameter."""
+    dev = _gpu()
+    import hip_backend as hb
+    import model as M
+    cfg = dict(synth.CFG2)
+    B, Tp, L = 32, 100, 20
+    w = synth.e2e_weights(cfg, 123)
+    g = torch.Generator().manual_seed(17)
+    enc = (torch.randn(B, Tp, cfg["enc_hidden_dim"], generator=g) * 0.5)
+    enc_lens = sorted([int(v) for v in torch.randint(Tp // 2, Tp + 1, (B,), generator=g)], reverse=True)
+    enc_lens[0] = Tp
+    r_lp = torch.randn(B, L, generator=g)
+    r_ws = torch.randn(B, L, Tp, generator=g) * 0.1
+    # ---- oracle (CPU)
+    sd = O.make_leaf_state(w)
+    enc_c = enc.clone().requires_grad_(True)
+    lg_o, lp_o, pred_o, ws_o = O.decoder_forward(sd, enc_c, enc_lens, ys=None, max_dec_timesteps=L, smooth=True, scaling=3.0,
+                                                 label_smoothing=False)
+    names = [n for n in O.unique_param_names(sd) if n.startswith(("attention.", "decoder."))]
+    loss_o = (lp_o * r_lp).sum() + (ws_o * r_ws).sum()
+    grads_o = torch.autograd.grad(loss_o, [enc_c] + [sd[n] for n in names])
+    # ---- product (GPU), persistent kernel required
+    net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 5), **cfg).to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    net.train()
+    enc_g = enc.to(dev).requires_grad_(True)
+    hb.persist_clear_abort(dev)
+    hb.LAUNCHES.clear()
+    with hb.require_persistent():
+        lg, lp, pred, ws = net.decoder(enc_g, enc_lens, ys=None, max_dec_timesteps=L, smooth=True, scaling=3.0,
+                                       label_smoothing=False)
+    assert hb.LAUNCHES["dec_free_persist"] == 1, dict(hb.LAUNCHES)
+    assert not hb.persist_aborted(dev)
+    assert torch.equal(pred.cpu(), pred_o), "hypotheses differ"
+    _close(lg, lg_o, rtol=2e-4, atol=2e-5, what="logits")
+    _close(lp, lp_o, rtol=2e-4, atol=2e-5, what="log-probs")
+    _close(ws, ws_o, rtol=2e-4, atol=2e-6, what="attention weights")
+    net.zero_grad()
+    ((lp * r_lp.to(dev)).sum() + (ws * r_ws.to(dev)).sum()).backward()
+    _close(enc_g.grad, grads_o[0], rtol=1e-3, atol=1e-6, what="d enc_h")
+    got = dict(net.named_parameters())
+    for n, gr in zip(names, grads_o[1:]):
+        _close(got[n].grad, gr, rtol=1e-3, atol=1e-6, what="grad " + n)
+
+
+def test_thirty_optimizer_steps_track_the_oracle():
+    """Drift proxy for "CER within 0.3 abs after equal steps" while WSJ is absent: 30 clip + Adam(amsgrad) steps at the
+    cfg-1 model shape (1x128 encoder, 320 decoder, B = 4, T = 200) on the GPU under the bench's default arithmetic against
+    the oracle's trajectory on the CPU from the same weights and batches: the loss of every step and the final weights.
+    Adam normalises every update to ~lr, so a gradient error of relative size e moves a weight by ~e * lr per step (and
+    elements whose gradient sits at the fp32 noise floor by more); asserted: every step's loss within the 1e-3 parity
+    gate (observed ~1e-6) and, after 30 steps, every weight tensor within 10 % of the largest distance any of its elements
+    has travelled (observed: printed)."""
+    dev = _gpu()
+    import hip_backend as hb
+    import model as M
+    from parallel import FlatAdam
+    cfg = dict(synth.CFG1)
+    ld = synth.labeldist(cfg["output_dim"], 23)
+    w0 = synth.e2e_weights(cfg, 21)
+    steps = 30
+    batches = [synth.batch(cfg["input_dim"], cfg["output_dim"], synth.CFG1_ILENS, synth.CFG1_YLENS, 500 + i) for i in range(3)]
+    # ---- oracle trajectory
+    sd = O.make_leaf_state(w0)
+    names = O.unique_param_names(sd)
+    opt_o = O.AdamAmsgrad(names, lr=5e-4, weight_decay=1e-6)
+    mcfg = dict(cfg, labeldist=ld)
+    losses_o = []
+    for s in range(steps):
+        xs, ilens, ys = batches[s % 3]
+        np.random.seed(100 + s)
+        out = O.sup_train_step(sd, mcfg, opt_o, torch.from_numpy(xs), ilens, [torch.from_numpy(y) for y in ys], max_grad_norm=5.0)
+        losses_o.append(float(out[0] if isinstance(out, (tuple, list)) else out))
+    # ---- product trajectory (default arithmetic)
+    assert hb.arith_name() == "bf16x6"
+    net = M.E2E(labeldist=ld, **cfg).to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    net.train()
+    opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0)
+    losses = []
+    for s in range(steps):
+        xs, ilens, ys = batches[s % 3]
+        np.random.seed(100 + s)
+        _, lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys], tf_rate=1.0)
+        loss = -lp.mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    for s, (a, b) in enumerate(zip(losses, losses_o)):
+        assert abs(a - b) <= 1e-3 * abs(b), "loss of step %d: %.7f vs oracle %.7f" % (s, a, b)
+    worst = 0.0
+    for n, p in net.named_parameters():
+        start = torch.from_numpy(w0[n])
+        want = sd[n].detach()
+        travelled = float((want - start).abs().max())
+        err = float((p.detach().cpu() - want).abs().max())
+        worst = max(worst, err / max(travelled, 1e-12))
+        assert err <= 0.10 * travelled + 1e-7, (n, err, travelled)
+    worst_loss = max(abs(a - b) / abs(b) for a, b in zip(losses, losses_o))
+    print("30 steps: last loss %.6f (oracle %.6f), worst loss error %.2e, worst weight error %.3f %% of the distance travelled"
+          % (losses[-1], losses_o[-1], worst_loss, 100 * worst))
+
+
+def test_decoder_and_lm_forward_step_methods():
+    """The thin per-step methods of the reference's class surface (Decoder.forward_step / zero_state, model.py:276-294;
+    LM.forward_step / zero_state, model.py:486-490,534-542) against the fused sequence paths the fixtures pin: driving
+    the loop by hand reproduces Decoder.forward's teacher-forced logits and LM.forward's log-probabilities."""
+    dev = _gpu()
+    import model as M
+    cfg = dict(synth.TINY)
+    net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 12), **cfg).to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.e2e_weights(cfg, 11).items()})
+    net.eval()
+    xs, ilens, ys = synth.batch(cfg["input_dim"], cfg["output_dim"], synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+    with torch.no_grad():
+        enc_h, enc_lens = net.encoder(xs_d, ilens)
+        logits, _, _, ws = net.decoder(enc_h, enc_lens, ys_d, tf_rate=1.0)
+        dec = net.decoder
+        tok_in, _ = dec._label_matrices(ys_d)
+        z, cst = dec.zero_state(enc_h), dec.zero_state(enc_h)
+        c, w = dec.zero_state(enc_h, dim=dec.att_odim), None
+        assert z.shape == (len(ys), cfg["dec_hidden_dim"]) and c.shape == (len(ys), cfg["att_odim"])
+        dec.attention.reset()
+        for s in range(tok_in.size(1)):
+            logit, z, cst, c, w = dec.forward_step(dec.embedding(tok_in[:, s]), z, cst, c, w, enc_h, enc_lens)
+            _close(logit, logits[:, s], rtol=2e-4, atol=2e-5, what="forward_step logits, step %d" % s)
+            _close(w, ws[:, s], rtol=2e-4, atol=2e-6, what="forward_step attention weights, step %d" % s)
+    lcfg = dict(synth.TINY_LM)
+    lm = M.LM(bos=1, eos=2, pad=0, labeldist=synth.labeldist(lcfg["output_dim"], 32), **lcfg).to(dev)
+    lm.load_state_dict({k: torch.from_numpy(v) for k, v in synth.lm_weights(lcfg, 31).items()})
+    lm.eval()
+    dense = torch.randint(3, lcfg["output_dim"], (3, 7), generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        lp, _, _ = lm(dense, discrete_input=False)
+        inp = torch.cat([torch.full((3, 1), 1, dtype=torch.long, device=dev), dense[:, :-1]], dim=1)
+        zs = cs = None
+        assert lm.zero_state(dense).shape == (lcfg["n_layers"], 3, lcfg["hidden_dim"])
+        for s in range(7):
+            logit, zs, cs = lm.forward_step(lm.embedding(inp[:, s]).unsqueeze(1), zs, cs)
+            step_lp = torch.log_softmax(logit, dim=-1).gather(1, dense[:, s:s + 1]).squeeze(1)
+            _close(step_lp, lp[:, s], rtol=2e-4, atol=2e-5, what="LM.forward_step log-prob, step %d" % s)
+        samples = lm.decode(n_samples=3, sample=False, max_dec_timesteps=5)
+        assert samples.shape == (3, 5)
+
+
+def _rccl_child(out_path):
+    """Fresh process, no GPU call before init_process_group: backend nccl (= RCCL on ROCm), world_size 1."""
+    import os, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "semi-supervised-asr_amd"), os.path.join(root, "tests", "golden")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    import numpy as np
+    import synth, parallel, model as M
+    from parallel import FlatAdam
+    dev = torch.device("cuda", 0)
+    cfg = dict(synth.TINY)
+    res = {}
+    for tag in ("collective", "plain"):
+        net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 12), **cfg).to(dev)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.e2e_weights(cfg, 11).items()})
+        net.train()
+        opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0)
+        xs, ilens, ys = synth.batch(cfg["input_dim"], cfg["output_dim"], synth.TINY_ILENS, synth.TINY_YLENS, 13)
+        np.random.seed(5)
+        _, lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
+        opt.zero_grad()
+        (-lp.mean()).backward()
+        if tag == "collective":
+            opt.buf.set_aux([1.5, 2.5])
+            opt.buf.collect()
+            dist.all_reduce(opt.buf.flat_g, op=dist.ReduceOp.SUM)        # THE collective of a data-parallel step, on RCCL
+            res["aux"] = opt.buf.aux[:2].tolist()
+            res["backend"] = dist.get_backend()
+            opt.apply()
+        else:
+            opt.step()
+        res[tag] = [float(p.detach().double().abs().sum()) for p in net.parameters()]
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_rccl_allreduce_of_the_flat_gradient_buffer(tmp_path):
+    """RCCL touched on hardware (world_size 1 is all a one-GPU box allows): a freshly spawned child initialises the `nccl`
+    backend before any other GPU call, pushes the flat gradient buffer (+ aux scalars) through dist.all_reduce and applies
+    the fused clip + Adam; the weights equal those of the non-distributed step."""
+    _gpu()
+    import json
+    import subprocess
+    import sys
+    out = os.path.join(str(tmp_path), "rccl.json")
+    code = "import sys; sys.path.insert(0, %r); import test_hip_parity as t; t._rccl_child(%r)" % (os.path.dirname(os.path.abspath(__file__)), out)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert res["backend"] == "nccl" and res["aux"] == [1.5, 2.5]
+    for a, b in zip(res["collective"], res["plain"]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (a, b)

@@ -226,6 +226,38 @@ def test_big_shapes(golden_dir, name, shape):
         scale = float(np.abs(flat).max())
         assert np.abs(flat[:16] - g["ghead/" + n]).max() <= 2e-5 * scale + 1e-9, n
         assert np.abs(flat[-16:] - g["gtail/" + n]).max() <= 2e-5 * scale + 1e-9, n
+        samp = flat[synth.grad_sample_index(names.index(n), flat.size)]
+        assert np.abs(samp - g["gsample/" + n]).max() <= 2e-5 * scale + 1e-9, n
+
+
+def test_big_ssl_step(golden_dir):
+    """The oracle's semi-supervised generator step at the real width (3x512 model + 2x640 judge, 8 + 8 utterances of
+    T = 400) against what the reference's solver.py:460-483 arithmetic produced there: the hypothesis of the smooth
+    free-running decode, its log-probs, the judge's probabilities, the three losses and every gradient (norm, ends,
+    seeded 4 096-element sample)."""
+    g = _load(golden_dir, "big_ssl.npz")
+    sh = synth.BIG_SSL_SHAPE
+    cfg = dict(synth.CFG2, labeldist=synth.labeldist(34, sh["ldseed"]))
+    sd = O.make_leaf_state(synth.e2e_weights(synth.CFG2, sh["wseed"]))
+    jsd = {k: torch.tensor(v, requires_grad=True) for k, v in synth.lm_weights(synth.CFG_JUDGE, sh["jseed"]).items()}
+    jcfg = dict(n_layers=2, ls_weight=0.05, labeldist=synth.labeldist(34, sh["jldseed"]))
+    xs, ilens, ys = synth.ragged_batch(sh["n_lab"], sh["t_max"], 80, 34, sh["bseed"])
+    uxs, uilens, _ = synth.ragged_batch(sh["n_unlab"], sh["t_max"], 80, 34, sh["ubseed"])
+    assert ilens == g["ilens"].tolist() and uilens == g["uilens"].tolist()
+    np.random.seed(9)
+    sup, unsup = O.ssl_losses(sd, jsd, cfg, jcfg, torch.from_numpy(xs), ilens, [torch.from_numpy(y) for y in ys],
+                              torch.from_numpy(uxs), uilens, sh["proportion"], scaling=sh["scaling"])
+    _close(sup, g["sup"], rtol=1e-6)
+    _close(unsup, g["unsup"], rtol=1e-5)
+    loss = sup + sh["unsup_weight"] * unsup
+    names = O.unique_param_names(sd)
+    grads = torch.autograd.grad(loss, [sd[n] for n in names])
+    for i, (n, gr) in enumerate(zip(names, grads)):
+        flat = gr.numpy().ravel()
+        np.testing.assert_allclose(np.sqrt((flat.astype(np.float64) ** 2).sum()), g["gnorm/" + n], rtol=5e-5)
+        scale = float(g["gmax/" + n])
+        samp = flat[synth.grad_sample_index(i, flat.size)]
+        assert np.abs(samp - g["gsample/" + n]).max() <= 5e-5 * scale + 1e-9, n
 
 
 def test_text_helpers(golden_dir):

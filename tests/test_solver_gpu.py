@@ -192,12 +192,13 @@ def _tiny_solver(root, monkeypatch, **over):
     solver = Solver(cfg)
     dev = next(solver.model.parameters()).device
     with torch.no_grad():
+        wm, wj = synth.e2e_weights(t, seeds[0]), synth.lm_weights(l, seeds[1])
         for k, v in solver.model.state_dict().items():
-            v.copy_(torch.from_numpy(synth.e2e_weights(t, 11)[k]))
+            v.copy_(torch.from_numpy(wm[k]))
         for k, v in solver.judge.state_dict().items():
-            v.copy_(torch.from_numpy(synth.lm_weights(l, 31)[k]))
-    for mod, seed in ((solver.model.decoder, 12), (solver.judge, 32)):
-        mod.labeldist = synth.labeldist(9, seed)
+            v.copy_(torch.from_numpy(wj[k]))
+    for mod, seed in ((solver.model.decoder, seeds[2]), (solver.judge, seeds[3])):
+        mod.labeldist = synth.labeldist(nv, seed)
         mod.vlabeldist = torch.from_numpy(np.asarray(mod.labeldist, dtype=np.float32)).to(dev)
     solver.model.decoder._dist_dev = {}
     solver.proportion = 0.5
@@ -234,6 +235,55 @@ def test_gen_train_one_iteration_against_golden(tmp_path, monkeypatch):
         assert not torch.equal(p.detach(), before[n]) or float(np.abs(want).max()) == 0.0, n      # generator stepped
     for n, p in solver.judge.named_parameters():       # ... and the judge is not (solver.py:486-489)
         assert torch.equal(p.detach(), judge_before[n]), n
+
+
+def test_gen_train_one_iteration_at_cfg4_width_against_golden(tmp_path, monkeypatch):
+    """The semi-supervised generator step at the width cfg-4 runs (3x512 model + 2x640 judge, config.yaml:26-34) through
+    Solver.gen_train_one_iteration, against what the reference's arithmetic produced at that width
+    (tests/golden/big_ssl.npz, make_golden.py gen_big_ssl; solver.py:460-495): the three losses and every generator
+    gradient (norm, ends, seeded 4 096-element sample).  The launch counters must show the kernels this workload is
+    meant to run on: the free-running persistent decoder (forward AND backward), the persistent encoder recurrences of
+    both passes, the judge's H = 640 persistent forward."""
+    import __graft_entry__ as entry
+    entry.build()
+    import synth
+    import hip_backend as hb
+    g = _golden("big_ssl.npz")
+    sh = synth.BIG_SSL_SHAPE
+    solver, dev = _tiny_solver(str(tmp_path), monkeypatch, t=synth.CFG2, l=synth.CFG_JUDGE,
+                               seeds=(sh["wseed"], sh["jseed"], sh["ldseed"], sh["jldseed"]),
+                               unsup_weight=sh["unsup_weight"], softmax_scaling=sh["scaling"])
+    solver.proportion = sh["proportion"]
+    xs, ilens, ys = synth.ragged_batch(sh["n_lab"], sh["t_max"], 80, 34, sh["bseed"])
+    uxs, uilens, _ = synth.ragged_batch(sh["n_unlab"], sh["t_max"], 80, 34, sh["ubseed"])
+    judge_before = {n: p.detach().clone() for n, p in solver.judge.named_parameters()}
+    hb.persist_clear_abort(dev)
+    hb.LAUNCHES.clear()
+    np.random.seed(9)
+    with hb.require_persistent():
+        meta = solver.gen_train_one_iteration(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys],
+                                              torch.from_numpy(uxs).to(dev), uilens)
+    assert not hb.persist_aborted(dev)
+    launches = dict(hb.LAUNCHES)
+    assert launches.get("dec_free_persist") == 1 and launches.get("dec_fwd_persist") == 1, launches
+    assert launches.get("dec_bwd_persist") == 2 and "dec_bwd_step" not in launches, launches
+    assert launches.get("lstm_fwd_persist") == 3 + 3 + 2 and launches.get("lstm_bwd_persist") == 3 + 3, launches
+    assert abs(meta["sup_loss"] - float(g["sup"])) <= 1e-5 * abs(float(g["sup"])), (meta, float(g["sup"]))
+    assert abs(meta["unsup_loss"] - float(g["unsup"])) <= 1e-4 * abs(float(g["unsup"])), (meta, float(g["unsup"]))
+    assert abs(meta["loss"] - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    worst = 0.0
+    for i, (n, p) in enumerate(solver.model.named_parameters()):      # the flat gradient buffer still holds what the step consumed
+        flat = p.grad.detach().cpu().numpy().ravel()
+        norm = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        assert abs(norm - float(g["gnorm/" + n])) <= 1e-3 * float(g["gnorm/" + n]), (n, norm, float(g["gnorm/" + n]))
+        scale = float(g["gmax/" + n])
+        e = max(np.abs(flat[:16] - g["ghead/" + n]).max(), np.abs(flat[-16:] - g["gtail/" + n]).max(),
+                np.abs(flat[synth.grad_sample_index(i, flat.size)] - g["gsample/" + n]).max()) / scale
+        worst = max(worst, float(e))
+        assert e <= 1e-3, (n, float(e))
+    for n, p in solver.judge.named_parameters():       # the judge is not stepped (solver.py:486-489)
+        assert torch.equal(p.detach(), judge_before[n]), n
+    print("big_ssl: %s, worst gradient element error %.2e, launches %s" % (meta, worst, launches))
 
 
 def test_judge_train_one_iteration_against_golden(tmp_path, monkeypatch):
