@@ -147,9 +147,9 @@ def encoder_layer_frames(c, t_frames):
     return out, t
 
 
-def tn_gemm_shapes(c, B, t_frames, olength):
-    """The weight-gradient (transA) GEMM launches of ONE train step: (M, N, K, batch).  dW_hh is not among them: the
-    persistent LSTM backward kernel accumulates it."""
+def tn_gemm_shapes(c, B, t_frames, olength, fused_dw_hh=True):
+    """The weight-gradient (transA) GEMM launches of ONE train step: (M, N, K, batch).  dW_hh is among them only when the
+    persistent LSTM backward kernel does not accumulate it itself (bf16x6: one GEMM per layer, batched over the directions)."""
     H, I = c["enc_hidden_dim"], c["input_dim"]
     D, O, E, A, V = c["dec_hidden_dim"], c["att_odim"], c["embedding_dim"], c["att_dim"], c["output_dim"]
     shapes = []
@@ -157,6 +157,8 @@ def tn_gemm_shapes(c, B, t_frames, olength):
     for layer, t in enumerate(frames):
         idim = I if layer == 0 else H
         shapes.append((8 * H, idim, t * B, 1))                       # dW_ih (both directions)
+        if not fused_dw_hh and t > 1:
+            shapes.append((4 * H, H, (t - 1) * B, 2))                # dW_hh = dG^T h_prev, batched over the directions
         sub = c["subsample"][layer] > 1
         shapes.append((H, 4 * H if sub else 2 * H, ((t + 1) // 2 if sub else t) * B, 1))   # dW of the projection
     L = olength
@@ -280,9 +282,12 @@ def encoder_gate_gemms(dev, c, B, t_frames):
             torch.cuda.synchronize()
             hb.check(rc, "asr_lstm_seq_bwd_persist")
             dt = e0.elapsed_time(e1) * 1e-3
-            rows.append(dict(layer=layer, op="recurrent bwd dG W_hh + dG^T h (persistent kernel, T=%d)" % T, us=dt * 1e6,
-                             us_per_time_step=dt / T * 1e6, tflops=2 * fl / dt / 1e12, frac=2 * fl / dt / 1e12 / peak,
-                             x_f32_mfma_peak=2 * fl / dt / 1e12 / MFMA_F32_PEAK_TF, mfma_busy_frac=busy.get("lstm_bwd")))
+            fused = lib.asr_lstm_bwd_persist_fuses_dw(H, hb.current_arith()) == 1
+            nprod = 2 if fused else 1          # bf16x6: dW_hh is a GEMM after the kernel, the kernel's flops are dh_rec alone
+            rows.append(dict(layer=layer, op="recurrent bwd dG W_hh%s (persistent kernel, T=%d)" % (" + dG^T h" if fused else "", T),
+                             us=dt * 1e6, us_per_time_step=dt / T * 1e6, tflops=nprod * fl / dt / 1e12,
+                             frac=nprod * fl / dt / 1e12 / peak, x_f32_mfma_peak=nprod * fl / dt / 1e12 / MFMA_F32_PEAK_TF,
+                             mfma_busy_frac=busy.get("lstm_bwd")))
         out += rows
     return out
 
@@ -295,7 +300,8 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     as the roofline (the other goes to `also`):
       * lstm_persist_bwd_rs_kernel<H> (lstm_persist_bwd_kernel<H> where the exchanged-partials form does not apply): one
         launch per encoder layer and row block; algorithmic flops per time step =
-        2*B*4H*H*ndir for dh_rec = dG W_hh plus the same again for the fused dW_hh += dG^T h.
+        2*B*4H*H*ndir for dh_rec = dG W_hh, plus the same again where the kernel fuses dW_hh += dG^T h (bf16x3 / f32; under
+        the default bf16x6 that product is a batched GEMM after the kernel and counts with the GEMMs).
       * gemm_bf3w_kernel<false,false> (gemm_bf3_kernel / gemm_f32_kernel with the wide tile or the split products switched
         off): the transA GEMMs that form the remaining weight gradients.
     `achieved` = algorithmic flops of those launches / their total time; us_per_launch is directly comparable with
@@ -306,7 +312,8 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     # ---- transA GEMMs
-    shapes = tn_gemm_shapes(c, B, t_frames, olength)
+    shapes = tn_gemm_shapes(c, B, t_frames, olength,
+                            fused_dw_hh=lib.asr_lstm_bwd_persist_fuses_dw(c["enc_hidden_dim"], hb.current_arith()) != 0)
     bufs = []
     for (M, N, K, batch) in shapes:
         bufs.append((torch.randn(batch * K, M, device=dev) if batch == 1 else torch.randn(K, batch, M, device=dev),
@@ -349,6 +356,7 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     dw = torch.zeros(2, 4 * H, H, device=dev)
     xch, ctrl = hb.persist_scratch(dev)
     lstm_s, lstm_flops, launches = 0.0, 0.0, 0
+    fused = lib.asr_lstm_bwd_persist_fuses_dw(H, hb.current_arith()) == 1
     db = torch.zeros(2 * 4 * H, device=dev)
     rows_per_launch = 16 if B <= 16 else 32
     for T in layers:
@@ -370,12 +378,14 @@ def kernel_roofline(dev, c, B, t_frames, olength):
                 dt = e0.elapsed_time(e1) * 1e-3
                 best = dt if best is None else min(best, dt)
         lstm_s += best
-        lstm_flops += T * 2.0 * (2.0 * B * 4 * H * H * 2)
+        lstm_flops += T * (2.0 if fused else 1.0) * (2.0 * B * 4 * H * H * 2)
         launches += (B + rows_per_launch - 1) // rows_per_launch
     rs = an != "f32" and H in (128, 256, 512)
     lpeak = gpeak
-    lstm = dict(bound="mfma", kernel="%s<%d> (dG recurrence + fused dW_hh, %d encoder layers)"
-                                     % ("lstm_persist_bwd_rs_kernel" if rs else "lstm_persist_bwd_kernel", H, len(layers)),
+    lstm = dict(bound="mfma", kernel="%s<%d> (dG recurrence%s, %d encoder layers)"
+                                     % ("lstm_persist_bwd_rs_kernel" if rs else "lstm_persist_bwd_kernel", H,
+                                        " + fused dW_hh" if fused else "; dW_hh is a batched GEMM after it", len(layers)),
+                algorithmic_flops_per_time_step=(2.0 if fused else 1.0) * (2.0 * B * 4 * H * H * 2),
                 limiter="dependent chain: per time step two barriers and one L2 hand-off of partial sums between the 32 CUs "
                         "of an XCD; the MFMA floor of the step is ~0.3-0.6 us",
                 achieved=lstm_flops / lstm_s / 1e12, peak=lpeak, unit="TFLOP/s", peak_is=gemm["peak_is"],

@@ -30,7 +30,7 @@ def _rel(got, want):
     return float(np.abs(got - want).max()) / max(1e-30, float(np.abs(want).max()))
 
 
-def _run_big(golden_dir, name, shape, dec_bwd_persistent=True):
+def _run_big(golden_dir, name, shape, dec_bwd_persistent=True, RTOL=RTOL):
     dev = _gpu()
     import hip_backend as hb
     hb.persist_clear_abort(dev)
@@ -75,7 +75,7 @@ def _run_big(golden_dir, name, shape, dec_bwd_persistent=True):
     assert agree > 0.999, "argmax agreement %.5f" % agree          # ties within fp32 noise may flip a handful
     assert abs(float(net.mask_and_cal_loss(lp, ys_d).detach()) - float(g["masked_loss"])) <= 1e-4 * abs(float(g["masked_loss"]))
     # ---- every parameter gradient: norm, and head / tail elements relative to the gradient's own scale
-    worst = 0.0
+    worst, per_param = 0.0, []
     for pi, (n, p) in enumerate(net.named_parameters()):
         flat = p.grad.detach().cpu().numpy().ravel()
         norm = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
@@ -87,30 +87,35 @@ def _run_big(golden_dir, name, shape, dec_bwd_persistent=True):
         samp = flat[synth.grad_sample_index(pi, flat.size)]
         e = max(float(e), float(np.abs(samp - g["gsample/" + n]).max()) / scale)
         worst = max(worst, float(e))
+        per_param.append((float(e), n))
         assert e <= RTOL, (n, float(e))
-    print("%s: loss %.6f (ref %.6f), worst gradient element error %.2e, launches %s" % (
-        name, float(loss), float(g["loss"]), worst, dict(hb.LAUNCHES)))
+    print("%s [%s]: loss %.6f (ref %.6f), worst gradient element error %.2e (%s), launches %s" % (
+        name, hb.arith_name(), float(loss.detach()), float(g["loss"]), worst,
+        ", ".join("%s %.1e" % (n.replace("encoder.enc2.", ""), e) for e, n in sorted(per_param, reverse=True)[:4]), dict(hb.LAUNCHES)))
 
 
 # The default arithmetic (bf16x6: fp32-equivalent products on the bf16 MFMA) AND the exact fp32-input MFMA kernels are
-# both held to the reference at the headline shapes; bf16x3 (non-default, 16 significand bits per operand) as well.
-ARITHS = ["bf16x6", "f32", "bf16x3"]
+# both held to the reference at the headline shapes at the north-star gate, 1e-3 relative.  bf16x3 (round 2's default: 16
+# significand bits per operand) does NOT meet that gate once the gradients are sampled all over each tensor: at cfg-5
+# (1 600-step recurrences) the layer-0 dW_ih sample is 2.2e-3 off - round 2's fixtures (norm + first / last 16 elements)
+# could not see it.  It stays selectable and is held to 5e-3 here, which is why it is not the default.
+ARITHS = [("bf16x6", RTOL), ("f32", RTOL), ("bf16x3", 5e-3)]
 
 
-@pytest.mark.parametrize("arith", ARITHS)
-def test_cfg2_against_golden(golden_dir, arith):
+@pytest.mark.parametrize("arith,gate", ARITHS)
+def test_cfg2_against_golden(golden_dir, arith, gate):
     """cfg-2 (BASELINE.json configs[1], the bench workload) end to end on the persistent kernels vs the reference."""
     import hip_backend as hb
     _gpu()
     with hb.arith(arith):
-        _run_big(golden_dir, "cfg2", synth.CFG2_SHAPE)
+        _run_big(golden_dir, "cfg2", synth.CFG2_SHAPE, RTOL=gate)
 
 
-@pytest.mark.parametrize("arith", ARITHS)
-def test_cfg5_against_golden(golden_dir, arith):
+@pytest.mark.parametrize("arith,gate", ARITHS)
+def test_cfg5_against_golden(golden_dir, arith, gate):
     """cfg-5 (configs[4]: 80x1600 frames, batch 8, T'=200, L+1=201) vs the reference: 4-row LSTM groups, both decoder
     kernels in the T' <= 256 geometry (2 utterances per XCD group)."""
     import hip_backend as hb
     _gpu()
     with hb.arith(arith):
-        _run_big(golden_dir, "cfg5", synth.CFG5_SHAPE)
+        _run_big(golden_dir, "cfg5", synth.CFG5_SHAPE, RTOL=gate)

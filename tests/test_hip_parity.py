@@ -1477,7 +1477,9 @@ def test_rccl_allreduce_of_the_flat_gradient_buffer(tmp_path):
     import subprocess
     import sys
     out = os.path.join(str(tmp_path), "rccl.json")
-    code = "import sys; sys.path.insert(0, %r); import test_hip_parity as t; t._rccl_child(%r)" % (os.path.dirname(os.path.abspath(__file__)), out)
+    here = os.path.dirname(os.path.abspath(__file__))
+    paths = [here, os.path.join(here, "golden"), os.path.dirname(here), os.path.join(os.path.dirname(here), "semi-supervised-asr_amd")]
+    code = "import sys; sys.path[:0] = %r; import test_hip_parity as t; t._rccl_child(%r)" % (paths, out)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -165,21 +165,26 @@ def test_greedy_decode_repeats_after_an_abort_in_an_earlier_launch(tmp_path, mon
 # ------------------------------------------------------------------------------------------------------------------
 # The Solver's own step methods against the reference's numbers (tests/golden/tiny_ssl.npz, tiny_lm.npz) and against
 # themselves under data parallelism.
-def _tiny_solver(root, monkeypatch, **over):
-    """Solver whose model / judge have the shapes of synth.TINY / synth.TINY_LM and the fixtures' weights."""
+def _tiny_solver(root, monkeypatch, t=None, l=None, seeds=(11, 31, 12, 32), **over):
+    """Solver whose model / judge have the shapes of synth.TINY / synth.TINY_LM (or the given dims) and the fixtures'
+    weights.  seeds = (model weights, judge weights, model labeldist, judge labeldist)."""
     import synth
     from solver import Solver
-    vocab = {s: i for i, s in enumerate(["<PAD>", "<BOS>", "<EOS>", "a", "b", "c", "d", "<space>", "<NOISE>"])}
+    t = synth.TINY if t is None else t
+    l = synth.TINY_LM if l is None else l
+    nv = t["output_dim"]
+    syms = ["<PAD>", "<BOS>", "<EOS>"] + ["s%d" % i for i in range(nv - 5)] + ["<space>", "<NOISE>"]
+    vocab = {s: i for i, s in enumerate(syms)}
+    assert len(vocab) == nv
     from dataset import synthetic_utterances
     for name, n, seed in (("train", 12, 1), ("dev", 4, 2)):
         with open(os.path.join(root, name + ".pkl"), "wb") as f:
-            pickle.dump(synthetic_utterances(n, 8, len(vocab), 24, seed), f)
+            pickle.dump(synthetic_utterances(n, t["input_dim"], len(vocab), 24, seed), f)
     with open(os.path.join(root, "vocab_dict.pkl"), "wb") as f:
         pickle.dump(vocab, f)
     with open(os.path.join(root, "non_lang_syms.pkl"), "wb") as f:
         pickle.dump(["<NOISE>", "<PAD>", "<BOS>", "<EOS>"], f)
     cfg = _config(root)
-    t, l = synth.TINY, synth.TINY_LM
     cfg.update(input_dim=t["input_dim"], enc_hidden_dim=t["enc_hidden_dim"], enc_n_layers=t["enc_n_layers"],
                subsample=t["subsample"], dropout_rate=0.0, dec_hidden_dim=t["dec_hidden_dim"], att_dim=t["att_dim"],
                conv_channels=t["conv_channels"], conv_kernel_size=t["conv_kernel_size"], att_odim=t["att_odim"],

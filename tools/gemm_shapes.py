@@ -28,10 +28,10 @@ lib = hb.load()
 real = lib.asr_gemm_f32
 calls = []
 class Spy(object):
-    def __call__(self, ta, tb, M_, N, K, A, lda, B, ldb, C, ldc, bias, relu, acc, batch, sA, sB, sC, sk, st):
+    def __call__(self, ta, tb, M_, N, K, A, lda, B, ldb, C, ldc, bias, relu, acc, batch, sA, sB, sC, sk, ar, st):
         v = lambda x: int(getattr(x, 'value', x) or 0)
         calls.append((int(ta), int(tb), int(M_), int(N), int(K), int(batch), v(bias) != 0, int(relu), int(acc), int(sk), int(lda), int(ldb), int(ldc)))
-        return real(ta, tb, M_, N, K, A, lda, B, ldb, C, ldc, bias, relu, acc, batch, sA, sB, sC, sk, st)
+        return real(ta, tb, M_, N, K, A, lda, B, ldb, C, ldc, bias, relu, acc, batch, sA, sB, sC, sk, ar, st)
 lib.asr_gemm_f32 = Spy()
 step(); torch.cuda.synchronize()
 lib.asr_gemm_f32 = real
@@ -46,18 +46,18 @@ for (ta, tb, M_, N, K, batch, bias, relu, acc, sk, lda, ldb, ldc), n in agg.item
     out = torch.zeros(M_, ldc, device=dev); bv = torch.randn(N, device=dev) if bias else None
     Av = A[:, :M_] if ta else A[:, :K]; Bv = B[:, :K] if tb else B[:, :N]
     res = []
-    for mode in (24, 8):
-        hb.set_split_bf16((hb.set_split_bf16(-1) & 7) | mode)
+    base = os.environ.get('GS_ARITH', 'bf16x6')
+    for mode in (base, base + '+narrow', base + '+wide'):
         ts = []
         for _ in range(4):
             flush.fill_(1.0); torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); hb.gemm(Av, Bv, trans_a=bool(ta), trans_b=bool(tb), bias=bv, relu=bool(relu), out=out[:, :N], accumulate=bool(acc), split_k=sk); e1.record(); torch.cuda.synchronize()
+            e0.record(); hb.gemm(Av, Bv, trans_a=bool(ta), trans_b=bool(tb), bias=bv, relu=bool(relu), out=out[:, :N], accumulate=bool(acc), split_k=sk, arith=mode); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         res.append(sorted(ts)[1])
     wide = M_ % 256 == 0 and N % 128 == 0 and K % 32 == 0
-    rows.append((res[0] * n, '%s%s M%6d N%5d K%6d sk%2d %s%s%s x%d: %6.0f us wide-enabled / %6.0f us narrow each  (%5.1f TF)%s' % (
-        'T' if ta else 'N', 'T' if tb else 'N', M_, N, K, sk, 'b' if bias else '-', 'r' if relu else '-', 'a' if acc else '-', n, res[0], res[1],
+    rows.append((res[0] * n, '%s%s M%6d N%5d K%6d sk%2d %s%s%s x%d: %6.0f us policy / %6.0f narrow / %6.0f wide each  (%5.1f TF)%s' % (
+        'T' if ta else 'N', 'T' if tb else 'N', M_, N, K, sk, 'b' if bias else '-', 'r' if relu else '-', 'a' if acc else '-', n, res[0], res[1], res[2],
         2.0 * M_ * N * K / res[0] / 1e6, '  [conforms]' if wide else '')))
 tot = sum(r[0] for r in rows)
 for t, s in sorted(rows, key=lambda r: -r[0]): print(s)
