@@ -123,7 +123,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
   constexpr int PPR = GEO::PPR, LR = GEO::LR, FPT = GEO::FPT, NFQ = GEO::NFQ, FROWS = GEO::FROWS, DP_WLEN = GEO::WLEN;
   constexpr int DX_Z = GEO::X_Z, DX_C = GEO::X_C, DX_F = GEO::X_F, DX_E = GEO::X_E, DX_U = GEO::X_U, DX_M = GEO::X_M;
   constexpr int DX_S = GEO::X_S, DX_GROUP = GEO::X_GROUP;
-  static_assert(!FB || RG == 4, "the free-running feedback is written for 4 rows per group");
+  // free-running feedback: written for the 4 row slots of the exchange / LDS layouts; with RG = 2 (T' <= 256) rows 2, 3 of
+  // every slot are dead weight: never polled (nobody publishes them), never stored to memory, counted as finished
   constexpr int KX = DM::KX, KXW = DM::KXW, DU = DM::DU, AU = DM::AU, OQ = DM::OQ, DKW = DM::DKW, DKQ = DM::DKQ;
   constexpr int XS = DM::XS, NZ = DM::NZ, NC = DM::NC, NE = DM::NE;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -302,14 +303,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
           for (int i = 0; i < NC; ++i) {
             const int id = tid_ + DP_NT * i;
             const int row = (2 * id) / OO, o = 2 * id - row * OO;
-            p[i] = reinterpret_cast<const u64*>(ux + ((2 * id < 4 * OO) ? row * 512 + o : 0));
+            p[i] = reinterpret_cast<const u64*>(ux + ((2 * id < RG * OO) ? row * 512 + o : 0));
           }
           poll_pairs<NC, ASR_DP_FULL>(p, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 16u);
 #pragma unroll
           for (int i = 0; i < NC; ++i) {
             const int id = tid_ + DP_NT * i;
             const int row = (2 * id) / OO, o = 2 * id - row * OO;
-            if (2 * id < 4 * OO) { cu[row * 512 + o] = pair_lo(v[i]); cu[row * 512 + o + 1] = pair_hi(v[i]); }
+            if (2 * id < RG * OO) { cu[row * 512 + o] = pair_lo(v[i]); cu[row * 512 + o + 1] = pair_hi(v[i]); }
           }
         }
         __syncthreads();
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         __syncthreads();
         if (wave < 4) {
           const int b = r0 + wave;
-          const bool bok = b < nb, lv = lane_ < a.V;
+          const bool bok = wave < RG && b < nb, lv = lane_ < a.V;
           const float l = lv ? lgs[wave * 64 + lane_] : -INFINITY;
           const float mx = wave_max_dpp(l);
           const unsigned long long hit = __ballot(lv && l == mx);
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         }
         {
           const int row = tid_ >> 7, e = tid_ & 127, b = r0 + row;
-          const bool bok = b < nb;
+          const bool bok = row < RG && b < nb;
           const int bc = bok ? b : r0;
           float v = 0.f;
           if (a.fb_mode == 2) {
@@ -1532,11 +1533,11 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
   const int TpP = (p->Tp + 3) & ~3;
   if (p->Tp <= 0 || p->C <= 0 || p->C > 12 || p->K < 0 || p->K > DP_KMAX) return ASR_E_SHAPE;
   // geometry: 4 utterances per group while the conv features of 4 rows fit the z / f poll (2 quads per thread: T' <= 102
-  // at 10 channels), else 2 utterances per group on 16 CUs each (T' <= 256; teacher-forced only)
+  // at 10 channels), else 2 utterances per group on 16 CUs each (T' <= 256), teacher-forced and free-running alike
   using G4 = DecGeo<4, DP_TPM>;
   using G2 = DecGeo<2, 256>;
   const bool geo4 = p->Tp <= G4::TPM && 4 * p->C * (TpP / 4) <= G4::NFQ * DP_NT;
-  const bool geo2 = !geo4 && !f && p->Tp <= G2::TPM && 2 * p->C * (TpP / 4) <= G2::NFQ * DP_NT;
+  const bool geo2 = !geo4 && p->Tp <= G2::TPM && 2 * p->C * (TpP / 4) <= G2::NFQ * DP_NT;
   if (!geo4 && !geo2) return ASR_E_SHAPE;
   if (!asr_persist_device_ok()) return ASR_E_SHAPE;
   const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;
@@ -1562,7 +1563,9 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
       a.fb_mode = f->mode; a.V = f->V; a.eos = f->eos; a.fb_scale = f->scaling; a.w_out = f->w_out; a.b_out = f->b_out; a.emb = f->emb;
       a.logits = f->logits + (int64_t)rb * f->V; a.probs = f->probs ? f->probs + (int64_t)rb * f->V : nullptr;
       a.pred = (long long*)f->pred + rb; a.fed = (long long*)f->fed + rb;
-      rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true>(a, stream) : launch_dec_fwd<320, 320, 320, 128, true>(a, stream);
+      if (geo4) rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true>(a, stream) : launch_dec_fwd<320, 320, 320, 128, true>(a, stream);
+      else rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true, 2, 256>(a, stream)
+                     : launch_dec_fwd<320, 320, 320, 128, true, 2, 256>(a, stream);
     } else if (geo4) {
       rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, false>(a, stream) : launch_dec_fwd<320, 320, 320, 128, false>(a, stream);
     } else {

@@ -1093,7 +1093,10 @@ def test_decoder_feedback_kernels(B, V, E, DO):
 @pytest.mark.parametrize("dim,B,Tp,L,drop,kind", [(512, 32, 100, 6, True, "smooth"), (512, 32, 100, 5, True, "greedy"),
                                                   (320, 7, 37, 5, False, "smooth"), (512, 9, 60, 6, True, "mixed"),
                                                   (512, 40, 100, 4, False, "greedy"), (320, 6, 50, 7, True, "smooth"),
-                                                  (512, 5, 30, 1, True, "smooth"), (320, 8, 16, 2, False, "greedy")])
+                                                  (512, 5, 30, 1, True, "smooth"), (320, 8, 16, 2, False, "greedy"),
+                                                  # T' > 102: the free-running kernel in the 2-rows-per-group geometry
+                                                  (512, 9, 200, 6, False, "greedy"), (512, 12, 130, 5, True, "smooth"),
+                                                  (320, 5, 256, 4, False, "smooth"), (512, 19, 200, 3, True, "greedy")])
 def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
     """Free-running decoder sequences (smooth embedding with grad as in solver.py:460-495, greedy, scheduled sampling)
     with the fused per-step feedback kernel against the same steps through torch glue: outputs and every gradient.
