@@ -348,6 +348,28 @@ int asr_dec_seq_bwd(const asr_dec_bwd_t* p, int s_begin, int s_end, void* graphs
  * are not used.  The embedding part of dX is formed by one batched GEMM after the recurrence. */
 int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* p, float* mbuf, void* xch, void* ctrl, asr_stream_t stream);
 
+/* Persistent backward of a FREE-RUNNING sequence with the smooth-embedding feedback (forward:
+ * asr_dec_seq_fwd_persist_free, mode 2; Decoder.forward with ys=None, smooth=True: model.py:334-341 - the unlabeled
+ * decode of the semi-supervised generator step, solver.py:465-470).  Step s's embedding input is
+ * softmax(scaling * logit_{s-1}) @ emb, so d(emb_s) flows into logit_{s-1} and from there into [z_{s-1}, ctx_{s-1}]:
+ * the kernel carries that path inside the recurrence (two more XCD-local hand-offs per step).
+ *   probs [L-1][B][V]  the probabilities the forward saved;  w_out [V][D+O];  emb [V][E]
+ *   dlfb  [L][B][V]    out (zero-filled by the caller): gradient reaching logit_s through the feedback; the caller adds
+ *                      it to the upstream d(logits) before forming the output-layer weight gradients
+ * On return G[s][:, D+O:] holds d(emb_s) (dropout-masked) for every step.  V <= 36, E = 128, the 4-row geometry of
+ * asr_dec_seq_bwd_persist (T' <= 100 at 10 conv channels); otherwise ASR_E_SHAPE (per-step kernels +
+ * asr_dec_feedback_bwd). */
+typedef struct {
+  int V;
+  float scaling;
+  const float* w_out;
+  const float* emb;
+  const float* probs;
+  float* dlfb;
+} asr_dec_feedback_bwd_t;
+int asr_dec_seq_bwd_persist_free(const asr_dec_bwd_t* p, const asr_dec_feedback_bwd_t* fb, float* mbuf, void* xch,
+                                 void* ctrl, asr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Parameter layout conversion: torch layout of nn.LSTM / nn.LSTMCell (gate-major rows i,f,g,o; model.py:67-68,262)
  * <-> the kernels' gate-interleaved rows (unit*4+gate).  w_ih/w_hh/b_ih/b_hh: arrays of `ndir` device pointers.

@@ -774,7 +774,10 @@ struct BwdX {
   static constexpr int W_ = C_ + 2 * 4 * 512;       // [2][4][TPM]
   static constexpr int D_ = W_ + 2 * 4 * TPM;       // [2][4][512]
   static constexpr int G_ = D_ + 2 * 4 * 512;       // [2][4][2048]
-  static constexpr int GROUP = G_ + 2 * 4 * 2048;
+  // free-running (smooth feedback) backward only:
+  static constexpr int P_ = G_ + 2 * 4 * 2048;      // [2][32 source CUs][4][36]  partial d(probabilities) of the CU's embedding columns
+  static constexpr int L_ = P_ + 2 * 32 * 4 * 36;   // [2][4][36]                 d(logits_{s-1}) through the smooth embedding
+  static constexpr int GROUP = L_ + 2 * 4 * 36;
 };
 
 struct DecPersistBwdArgs {
@@ -786,6 +789,13 @@ struct DecPersistBwdArgs {
   float* dbg;          // measurement builds only (ASR_DP_DEBUG): d(conv features) of the last step, [B][C][Tp]
   float* xch;
   unsigned* ctrl;
+  // smooth-embedding feedback (kernel template FB): emb_s = softmax(fb_scale * logit_{s-1}) @ emb couples step s to the
+  // logits of step s - 1 (model.py:341).  probs [L-1][B][V] saved by the forward; dlfb [L][B][V] receives the gradient
+  // that reaches logit_{s-1} through it (the caller adds it to the upstream d(logits) for the output-layer weights)
+  int V;
+  float fb_scale;
+  const float *w_out, *emb, *probs;
+  float* dlfb;
 };
 
 template <int DD, int AA, int OO>
@@ -803,11 +813,11 @@ struct DecBwdDims {
 
 // LDS plan of the backward kernel (floats), sized from the run-time T', C, K
 struct BwdLds {
-  int dgs, part, qs, dcx, fs, dps, Fs, dfh, wph, des, dwr, wsl, dds, ddp, dwext, ugs, total;
+  int dgs, part, qs, dcx, fs, dps, Fs, dfh, wph, des, dwr, wsl, dds, ddp, dwext, ugs, wos, total;
   int dfs_stride, taps4;
 };
 template <int DD, int AA, int OO, int RG = 4, int TPM = DP_TPM>
-__host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K) {
+__host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K, int fbV = 0) {
   using BM = DecBwdDims<DD, AA, OO>;
   const int TpP = (Tp + 3) & ~3;
   BwdLds l;
@@ -833,12 +843,23 @@ __host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K) {
   l.ddp = o; o += 8 * 4 * 16;
   l.dwext = o; o += 16;
   l.ugs = o; o += 16;
+  l.wos = o; o += fbV * 32;            // free-running backward: W_out[v][my 16 z + 16 ctx columns]
   l.total = o + 8;
   return l;
 }
 
-template <int DD, int AA, int OO, int EE, int RG = 4, int TPM = DP_TPM>
+// FB = backward of a free-running sequence with the smooth-embedding feedback (the semi-supervised generator step,
+// solver.py:465-470): per step, after the dgates of the group's rows have been gathered for the dX product,
+//   (g2) CU j forms d(emb_s) for ITS E/32 embedding columns from the gathered dgates (K = 4D; its slice of W_cat^T streamed
+//        from L2, 16 values per thread), applies the dropout mask, stores it (the embedding-weight gradient is a GEMM
+//        after the kernel) and publishes its share of d(probabilities): pdp[row][v] = sum_{e mine} d(emb)[row][e] E[v][e];
+//   (g3) slice 0 sums the 32 shares, runs the softmax backward with the saved probabilities,
+//        dl = k p (dp - sum_u p_u dp_u), stores dl (-> dlfb) and publishes it;
+//   (g4) every CU adds dl W_out for its 16 z / 16 ctx columns (W_out slice in LDS) to the dX it hands to step s - 1.
+// Two more hand-offs per step; written for the 4-row geometry (T' <= 100 with 10 channels: the LDS plan is full).
+template <int DD, int AA, int OO, int EE, int RG = 4, int TPM = DP_TPM, bool FB = false>
 __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArgs a) {
+  static_assert(!FB || (RG == 4 && EE == 128), "the feedback backward is written for 4 rows per group and E = 128");
   using BM = DecBwdDims<DD, AA, OO>;
   using GEO = DecGeo<RG, TPM>;
   using BX = BwdX<TPM>;
@@ -854,7 +875,9 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Tp = a.Tp, C = a.C, K = a.K, B = a.B, L = a.L, nb = a.nb;
   const int TpP = (Tp + 3) & ~3;
-  const BwdLds ld = bwd_lds_plan<DD, AA, OO, RG, TPM>(Tp, C, K);
+  const BwdLds ld = bwd_lds_plan<DD, AA, OO, RG, TPM>(Tp, C, K, FB ? a.V : 0);
+  constexpr int BX_P = BX::P_, BX_L = BX::L_;
+  float* wos = sm + ld.wos;      // [V][32]          FB: W_out[v][z columns of my units | my ctx columns]
   float* dgs = sm + ld.dgs;      // [4][GS]          gathered dgates of the 4 rows
   float* part = sm + ld.part;    // [8][64][5]       K-partials of both MFMA products
   float* Qs = sm + ld.qs;        // [16][OO]         Q rows of this CU's 16 frames
@@ -934,6 +957,19 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
     if (tid < C)
       for (int aa = 0; aa < AA; ++aa) v += a.watt[(int64_t)aa * C + tid] * a.gvec[aa];
     ugs[tid] = v;
+  }
+  float ereg[4] = {0.f, 0.f, 0.f, 0.f};     // FB: E[v][my 4 embedding columns] of thread (row = tid / 36, v = tid % 36)
+  if (FB) {
+    for (int i = tid; i < a.V * 32; i += DP_NT) {
+      const int v = i >> 5, ci = i & 31;
+      const bool ok = ci < 16 ? ci < DU : ci - 16 < OU;
+      const int col = ci < 16 ? DU * slice + ci : DD + OU * slice + ci - 16;
+      wos[i] = ok ? a.w_out[(int64_t)v * (DD + OO) + col] : 0.f;
+    }
+    if (tid < 144 && tid % 36 < a.V) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ereg[e] = a.emb[(tid % 36) * EE + 4 * slice + e];
+    }
   }
   // score lanes (as in the forward kernel): column a_l = lane&15 of this CU's slice, frame quarter lane>>4
   const float gv = (lane & 15) < AU ? a.gvec[AU * slice + (lane & 15)] : 0.f;
@@ -1344,6 +1380,24 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       }
     }
     __syncthreads();
+    // FB: this thread's 16 values of W_cat^T for (embedding column 4 slice + (wave & 3), k chunk 64 (wave >> 2) + lane), the
+    // dropout mask of d(emb) and (slice 0) the saved probabilities: L2 / HBM loads issued here, consumed after the dX product
+    float4 wfe[4];
+    float fb_mask = 1.f, fb_prob = 0.f;
+    if (FB) {
+      const int kcg = 64 * (wave >> 2) + lane_;                       // k chunk of 16; chunks beyond 4D / 16 idle (D < 512)
+      const float4* wp = reinterpret_cast<const float4*>(a.wcatT + (int64_t)(DD + OO + 4 * slice + (wave & 3)) * GK +
+                                                          (16 * kcg < GK ? 16 * kcg : 0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wfe[i] = wp[i];
+      const int mrow = tid_ & 3, mb = r0 + mrow;
+      if (drop && tid_ < 16)
+        fb_mask = a.xmask[((int64_t)s * B + (mb < nb ? mb : r0)) * (OO + EE) + OO + 4 * slice + (tid_ >> 2)];
+      if (slice == 0 && wave < 4) {
+        const int pb2 = r0 + wave;
+        fb_prob = (lane_ < a.V && pb2 < nb) ? a.probs[((int64_t)(s - 1) * B + pb2) * a.V + lane_] : 0.f;
+      }
+    }
     // Forward data of the next iteration (independent of the recurrence), issued right after the last poll of this
     // iteration: vmcnt retires in order, so these HBM first-touch loads would hold back any poll issued behind them;
     // from here the next poll is ~2 us away and the data is consumed ~4 us later.
@@ -1367,19 +1421,111 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       for (int i = 0; i < 4; ++i) pp[i] = acc[i];
     }
     __syncthreads();
+    float vdx = 0.f, vfb = 0.f;               // dX of (column ci = tid >> 2, row = tid & 3), threads tid < 128; FB: + dl W_out
     if (tid_ < 128) {
       // (column index ci = tid>>2: 0..15 z, 16..31 ctx; row = tid&3): lanes 4*(2*cg + ks) + row, register ci&3
       const int ci = tid_ >> 2, row = tid_ & 3, cg = ci >> 2, ii = ci & 3;
-      float v = 0.f;
 #pragma unroll
       for (int w2 = 0; w2 < 8; ++w2)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) v += part[(w2 * 64 + 4 * (2 * cg + ks) + row) * 5 + ii];
+        for (int ks = 0; ks < 2; ++ks) vdx += part[(w2 * 64 + 4 * (2 * cg + ks) + row) * 5 + ii];
+    }
+    if (FB) {
+      // ---- (g2) d(emb_s) of my 4 embedding columns, my share of d(probabilities)
+      float* fbr = dDp;                        // [8 waves][4 rows] wave sums; [32..47] d(emb)[row][ec]; [64..207] dl of the 4 rows
+      {
+        float pr[4] = {0.f, 0.f, 0.f, 0.f};
+        const int kcg = 64 * (wave >> 2) + lane_;
+        const bool kok = 16 * kcg < GK;
+        const float* dg = dgs + (kok ? 16 * kcg : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float4 x = *reinterpret_cast<const float4*>(dg + r * GS + 4 * i);
+            pr[r] += wfe[i].x * x.x + wfe[i].y * x.y + wfe[i].z * x.z + wfe[i].w * x.w;
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = wave_sum_dpp(kok ? pr[r] : 0.f);
+          if (lane_ == 0) fbr[wave * 4 + r] = t;
+        }
+      }
+      __syncthreads();
+      if (tid_ < 16) {
+        const int row = tid_ & 3, ec = tid_ >> 2, b = r0 + row;
+        const float v = (fbr[ec * 4 + row] + fbr[(ec + 4) * 4 + row]) * fb_mask;
+        if (b < nb) a.G[((int64_t)s * B + b) * KX + DD + OO + 4 * slice + ec] = v;
+        fbr[32 + row * 4 + ec] = v;
+      }
+      __syncthreads();
+      if (tid_ < 144) {
+        const int row = tid_ / 36;
+        const float* dm = fbr + 32 + row * 4;
+        const float pdp = dm[0] * ereg[0] + dm[1] * ereg[1] + dm[2] * ereg[2] + dm[3] * ereg[3];
+        word_store(xg + BX_P + (slot * 32 + slice) * 144 + tid_, pdp, bit);
+      }
+      // ---- (g3) slice 0: sum of the 32 shares, softmax backward, publish dl
+      if (slice == 0) {
+        constexpr int NPQ = 3;                 // 32 x 36 quads over 512 threads
+        const unsigned pbase = (unsigned)((xg - a.xch) + BX_P + slot * 32 * 144) * 4u;
+        unsigned off[NPQ];
+        u4v v[NPQ];
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i) {
+          const int q = tid_ + DP_NT * i;
+          off[i] = pbase + (unsigned)(q < 32 * 36 ? q : 0) * 16u;
+        }
+        poll_quads<NPQ, true>(xrs, off, bit, v, a.ctrl, aborted, 25u);
+        __syncthreads();                       // every thread is done with the gathered dgates: dgs becomes scratch
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i) {
+          const int q = tid_ + DP_NT * i;
+          if (q < 32 * 36)
+            *reinterpret_cast<float4*>(dgs + 4 * q) = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y),
+                                                                  __uint_as_float(v[i].z), __uint_as_float(v[i].w));
+        }
+        __syncthreads();
+        if (wave < 4) {
+          float dp = 0.f;
+          if (lane_ < 36) {
+#pragma unroll 8
+            for (int src = 0; src < 32; ++src) dp += dgs[src * 144 + wave * 36 + lane_];
+          }
+          const float pdot = wave_sum_dpp(fb_prob * dp);
+          const float dl = a.fb_scale * fb_prob * (dp - pdot);          // 0 beyond V and for rows beyond the batch
+          const int b = r0 + wave;
+          if (lane_ < a.V && b < nb) a.dlfb[((int64_t)(s - 1) * B + b) * a.V + lane_] = dl;
+          if (lane_ < 36) word_store(xg + BX_L + slot * 144 + wave * 36 + lane_, dl, bit);
+        }
+      }
+      // ---- (g4) dl W_out for my columns
+      {
+        const unsigned lbase = (unsigned)((xg - a.xch) + BX_L + slot * 144) * 4u;
+        unsigned off[1] = {lbase + (unsigned)(tid_ < 36 ? tid_ : 0) * 16u};
+        u4v v[1];
+        poll_quads<1, true>(xrs, off, bit, v, a.ctrl, aborted, 26u);
+        if (tid_ < 36)
+          *reinterpret_cast<float4*>(fbr + 64 + 4 * tid_) = make_float4(__uint_as_float(v[0].x), __uint_as_float(v[0].y),
+                                                                         __uint_as_float(v[0].z), __uint_as_float(v[0].w));
+      }
+      __syncthreads();
+      if (tid_ < 128) {
+        const int ci = tid_ >> 2, row = tid_ & 3;
+        const float* dl = fbr + 64 + row * 36;
+        float acc = 0.f;
+        for (int v = 0; v < a.V; ++v) acc += dl[v] * wos[v * 32 + ci];
+        vfb = acc;
+      }
+    }
+    if (tid_ < 128) {
+      const int ci = tid_ >> 2, row = tid_ & 3;
+      const float v = vdx;
       if (ci < 16) {
-        dxz = v;                                                  // gradient wrt z_{s-1} of my unit (same thread as in (f))
+        dxz = v + vfb;                                            // gradient wrt z_{s-1} of my unit (same thread as in (f))
       } else if (ci - 16 < OU) {
         const int col = OU * slice + ci - 16, b = r0 + row;
-        const float tot = gc + v * xm;                        // total d(ctx_{s-1}) = output layer + masked cell input
+        const float tot = gc + v * xm + vfb;                  // total d(ctx_{s-1}) = output layer (+ feedback) + masked cell input
         if (row < RG && b < nb) a.G[((int64_t)s * B + b) * KX + DD + col] = tot;
         word_store(xg + BX_C + (((n + 1) & 1) * 4 + row) * 512 + col, tot, tag_bit_of_step(n + 1));
       }
@@ -1496,16 +1642,16 @@ __global__ void mask_emb_kernel(int L, int B, int nb, int D, int O, int E, const
   G[((int64_t)s * B + b) * (D + O + E) + D + O + e] *= xmask[((int64_t)s * B + b) * (O + E) + O + e];
 }
 
-template <int DD, int AA, int OO, int EE, int RG = 4, int TPM = DP_TPM>
+template <int DD, int AA, int OO, int EE, int RG = 4, int TPM = DP_TPM, bool FB = false>
 int launch_dec_bwd(const DecPersistBwdArgs& a, hipStream_t stream) {
-  const BwdLds ld = bwd_lds_plan<DD, AA, OO, RG, TPM>(a.Tp, a.C, a.K);
+  const BwdLds ld = bwd_lds_plan<DD, AA, OO, RG, TPM>(a.Tp, a.C, a.K, FB ? a.V : 0);
   size_t lds = (size_t)ld.total * sizeof(float);
   if (lds > 160 * 1024) return ASR_E_SHAPE;                          // must fit ...
   if (lds <= 82 * 1024) lds = 82 * 1024 + 64;                        // ... and must force one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_bwd_kernel<DD, AA, OO, EE, RG, TPM>,
+  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_bwd_kernel<DD, AA, OO, EE, RG, TPM, FB>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((dec_persist_bwd_kernel<DD, AA, OO, EE, RG, TPM>), dim3(256), dim3(DP_NT), lds, stream, a);
+  hipLaunchKernelGGL((dec_persist_bwd_kernel<DD, AA, OO, EE, RG, TPM, FB>), dim3(256), dim3(DP_NT), lds, stream, a);
   return 0;
 }
 
@@ -1602,10 +1748,12 @@ extern "C" int asr_dec_seq_fwd_persist_free(const asr_dec_fwd_t* p, const asr_de
 // dconv_part hold the sums in other rows than the per-step path does; the caller reduces over rows either way).
 // mbuf: scratch [L][B][C][Tp].  dwext / dwraw / dfpart / dcell of q are not used.  Returns ASR_E_SHAPE when the
 // fast path does not apply.
-extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void* xch, void* ctrl,
-                                       asr_stream_t stream_) {
+static int dec_bwd_persist_impl(const asr_dec_bwd_t* q, const asr_dec_feedback_bwd_t* fb, float* mbuf, void* xch, void* ctrl,
+                                asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!q || !mbuf || !xch || !ctrl) return ASR_E_ARG;
+  if (fb && (!fb->w_out || !fb->emb || !fb->probs || !fb->dlfb || fb->V <= 0)) return ASR_E_ARG;
+  if (fb && (fb->V > 36 || q->f.E != 128)) return ASR_E_SHAPE;
   const asr_dec_fwd_t* p = &q->f;
   if (!p->Q || !p->wcat || !p->convw || !p->watt || !p->gvec || !p->w0 || !p->gates || !p->cstate || !p->fconv ||
       !p->S || !p->ws || !q->wcatT || !q->wdecT || !q->G || !q->dgates || !q->dD || !q->dP || !q->dgvec_part ||
@@ -1620,7 +1768,7 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
   // geometry as in the forward: 4 utterances per group while the per-thread prefetch registers cover the conv features
   // and M of 4 rows (T' <= 102 at 10 channels), else 2 utterances per group on 16 CUs each (T' <= 256)
   const bool geo4 = p->Tp <= DP_TPM && p->C * TpP <= 2 * DP_NT && 4 * p->C * TpP <= 8 * DP_NT;
-  const bool geo2 = !geo4 && p->Tp <= 256 && p->C * TpP <= 5 * DP_NT && 2 * p->C * TpP <= 10 * DP_NT;
+  const bool geo2 = !geo4 && !fb && p->Tp <= 256 && p->C * TpP <= 5 * DP_NT && 2 * p->C * TpP <= 10 * DP_NT;
   if (!geo4 && !geo2) return ASR_E_SHAPE;
   if (!asr_persist_device_ok()) return ASR_E_SHAPE;
   const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;
@@ -1648,27 +1796,54 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
     a.dP = q->dP + (int64_t)rb * Tp * A; a.dgvec_part = q->dgvec_part + (int64_t)rb * A;
     a.dwatt_part = q->dwatt_part + (int64_t)rb * A * C; a.dconv_part = q->dconv_part + (int64_t)rb * C * taps;
     a.xch = (float*)xch; a.ctrl = persist_launch_words(ctrl);
-    const int rc = geo4 ? (cfg2 ? launch_dec_bwd<512, 512, 512, 128>(a, stream) : launch_dec_bwd<320, 320, 320, 128>(a, stream))
-                        : (cfg2 ? launch_dec_bwd<512, 512, 512, 128, 2, 256>(a, stream)
-                                : launch_dec_bwd<320, 320, 320, 128, 2, 256>(a, stream));
+    a.V = 0; a.fb_scale = 1.f; a.w_out = a.emb = a.probs = nullptr; a.dlfb = nullptr;
+    int rc;
+    if (fb) {
+      a.V = fb->V; a.fb_scale = fb->scaling; a.w_out = fb->w_out; a.emb = fb->emb;
+      a.probs = fb->probs + (int64_t)rb * fb->V; a.dlfb = fb->dlfb + (int64_t)rb * fb->V;
+      rc = cfg2 ? launch_dec_bwd<512, 512, 512, 128, 4, DP_TPM, true>(a, stream)
+                : launch_dec_bwd<320, 320, 320, 128, 4, DP_TPM, true>(a, stream);
+    } else {
+      rc = geo4 ? (cfg2 ? launch_dec_bwd<512, 512, 512, 128>(a, stream) : launch_dec_bwd<320, 320, 320, 128>(a, stream))
+                : (cfg2 ? launch_dec_bwd<512, 512, 512, 128, 2, 256>(a, stream)
+                        : launch_dec_bwd<320, 320, 320, 128, 2, 256>(a, stream));
+    }
     if (rc) return rc;
   }
   ASR_CHECK_LAUNCH();
-  // embedding part of dX (not recurrent): G[s][:, D+O:] += dgates[s] Wcat[:, D+O:], batched over the L steps
+  // embedding part of dX: G[s][:, D+O:] += dgates[s] Wcat[:, D+O:] (masked), batched over the steps.  Teacher-forced: not
+  // recurrent, all L steps here.  Free-running: the kernel formed it for steps >= 1 (it feeds the previous step's logits);
+  // step 0 (the <BOS> embedding) is left for here.
   // (fp32-equivalent bf16x6 products, as everything else the decoder kernels compute is exact fp32)
+  const int Lg = fb ? 1 : p->L;
   int rc;
   if (p->nb == B)      // all rows: one GEMM over the L*B rows, K = 4D split so that the few output tiles fill the chip
-    rc = asr_gemm_f32(0, 0, (int64_t)p->L * B, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX,
+    rc = asr_gemm_f32(0, 0, (int64_t)Lg * B, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX,
                       nullptr, 0, 1, 1, 0, 0, 0, 16, ASR_ARITH_BF16X6, stream_);
   else
     rc = asr_gemm_f32(0, 0, p->nb, E, 4 * D, q->dgates, 4 * D, p->wcat + D + O, KX, q->G + D + O, KX, nullptr, 0, 1,
-                      p->L, (int64_t)B * 4 * D, 0, (int64_t)B * KX, 4, ASR_ARITH_BF16X6, stream_);
+                      Lg, (int64_t)B * 4 * D, 0, (int64_t)B * KX, 4, ASR_ARITH_BF16X6, stream_);
   if (rc) return rc;
   if (p->xmask) {
-    const int64_t n = (int64_t)p->L * p->nb * E;
-    hipLaunchKernelGGL(mask_emb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p->L, B, p->nb, D, O, E,
+    const int64_t n = (int64_t)Lg * p->nb * E;
+    hipLaunchKernelGGL(mask_emb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, Lg, B, p->nb, D, O, E,
                        p->xmask, q->G);
     ASR_CHECK_LAUNCH();
   }
   return 0;
+}
+
+extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void* xch, void* ctrl, asr_stream_t stream) {
+  return dec_bwd_persist_impl(q, nullptr, mbuf, xch, ctrl, stream);
+}
+
+// Backward of a FREE-RUNNING sequence with the smooth-embedding feedback (asr_dec_seq_fwd_persist_free, mode 2): as
+// asr_dec_seq_bwd_persist, plus the gradient that every step sends into the previous step's logits through
+// emb_s = softmax(k logit_{s-1}) @ E (kernel template FB).  fb->dlfb [L][B][V] (zero-filled by the caller) receives that
+// gradient per step; G[s][:, D+O:] holds d(emb_s) for every s.  4-row geometry only (T' <= 100 at 10 channels): otherwise
+// ASR_E_SHAPE and the caller uses the per-step kernels + asr_dec_feedback_bwd.
+extern "C" int asr_dec_seq_bwd_persist_free(const asr_dec_bwd_t* q, const asr_dec_feedback_bwd_t* fb, float* mbuf, void* xch,
+                                            void* ctrl, asr_stream_t stream) {
+  if (!fb) return ASR_E_ARG;
+  return dec_bwd_persist_impl(q, fb, mbuf, xch, ctrl, stream);
 }

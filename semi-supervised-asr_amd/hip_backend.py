@@ -18,7 +18,7 @@ EXPORTS = (
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_lstm_seq_bwd_persist_w", "asr_lstm_bwd_persist_fuses_dw", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
-    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist",
+    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
@@ -33,6 +33,11 @@ class DecFeedback(ctypes.Structure):
     """asr_dec_feedback_t"""
     _fields_ = [("mode", c_i), ("V", c_i), ("eos", c_i), ("scaling", c_f), ("w_out", c_p), ("b_out", c_p), ("emb", c_p), ("logits", c_p),
                 ("probs", c_p), ("pred", c_p), ("fed", c_p)]
+
+
+class DecFeedbackBwd(ctypes.Structure):
+    """asr_dec_feedback_bwd_t"""
+    _fields_ = [("V", c_i), ("scaling", c_f), ("w_out", c_p), ("emb", c_p), ("probs", c_p), ("dlfb", c_p)]
 
 
 class DecFwd(ctypes.Structure):
@@ -93,6 +98,7 @@ def load():
     lib.asr_dec_step_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_p]
     lib.asr_dec_seq_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_i, c_p, c_p]
     lib.asr_dec_seq_bwd_persist.argtypes = [ctypes.POINTER(DecBwd), c_p, c_p, c_p, c_p]
+    lib.asr_dec_seq_bwd_persist_free.argtypes = [ctypes.POINTER(DecBwd), ctypes.POINTER(DecFeedbackBwd), c_p, c_p, c_p, c_p]
     lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                       c_f, c_p]
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]

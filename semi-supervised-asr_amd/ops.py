@@ -524,7 +524,32 @@ class _DecoderSeq(torch.autograd.Function):
             bs = _dec_bwd_struct(d, w, 0, B)
             k = ctx.smooth_scaling
             fused = torch.is_tensor(probs_saved)
-            if fused:
+            done = False
+            if fused and hb.USE_PERSIST_DEC_BWD and L > 1 and len(hb.row_groups(B)) == 1:
+                # the whole free-running sequence in one launch: the feedback path (d(emb_s) -> logit_{s-1} -> [z, ctx]_{s-1})
+                # is carried inside the persistent kernel (dec_persist.hip, template FB)
+                emb_c, w_out_c = emb_w.contiguous(), w_out.contiguous()
+                dlfb = torch.zeros(L, B, V, device=dev, dtype=torch.float32)
+                fbs = hb.DecFeedbackBwd(V=V, scaling=float(k), w_out=_p(w_out_c), emb=_p(emb_c), probs=_p(probs_saved),
+                                        dlfb=_p(dlfb))
+                xch, ctrl = hb.persist_scratch(dev)
+                rc = lib.asr_dec_seq_bwd_persist_free(ctypes.byref(bs), ctypes.byref(fbs), _p(wk["Mf"]),
+                                                      ctypes.c_void_p(xch.data_ptr()), ctypes.c_void_p(ctrl.data_ptr()),
+                                                      hb.stream())
+                if rc == 0:
+                    done = True
+                    dtot = dlog2.view(L, B, V) + dlfb
+                    dw_out = hb.gemm(dtot.view(L * B, V), XO, trans_a=True)
+                    db_out = hb.colsum(dtot.view(L * B, V))
+                    hb.gemm(probs_saved[:L - 1].view((L - 1) * B, V), G[1:L].view((L - 1) * B, KX)[:, D + O:], trans_a=True,
+                            out=demb_w, accumulate=True, split_k=1)
+                elif rc != -2:
+                    hb.check(rc, "asr_dec_seq_bwd_persist_free")
+            hb.count_path("dec_bwd", done, "free-running smooth: D=%d A=%d O=%d E=%d Tp=%d B=%d V=%d L=%d fused-feedback=%s" % (
+                D, A, O, E, Tp, B, V, L, fused))
+            if done:
+                pass
+            elif fused:
                 # one kernel per step carries the embedding gradient back into logit_{s-1} and [z_{s-1}, c_{s-1}];
                 # the weight gradients that depend on it are taken once over the whole sequence afterwards
                 dtot = dlog2.clone().view(L, B, V)
@@ -539,7 +564,7 @@ class _DecoderSeq(torch.autograd.Function):
                 if L > 1:
                     hb.gemm(probs_saved[:L - 1].view((L - 1) * B, V), G[1:L].view((L - 1) * B, KX)[:, D + O:], trans_a=True,
                             out=demb_w, accumulate=True, split_k=1)
-            for s in (range(L - 1, -1, -1) if not fused else ()):
+            for s in (range(L - 1, -1, -1) if not (fused or done) else ()):
                 hb.check(lib.asr_dec_step_bwd(ctypes.byref(bs), s, hb.stream()), "asr_dec_step_bwd")
                 if s >= 1:
                     demb = G[s][:, D + O:]

@@ -1096,7 +1096,10 @@ def test_decoder_feedback_kernels(B, V, E, DO):
                                                   (512, 5, 30, 1, True, "smooth"), (320, 8, 16, 2, False, "greedy"),
                                                   # T' > 102: the free-running kernel in the 2-rows-per-group geometry
                                                   (512, 9, 200, 6, False, "greedy"), (512, 12, 130, 5, True, "smooth"),
-                                                  (320, 5, 256, 4, False, "smooth"), (512, 19, 200, 3, True, "greedy")])
+                                                  (320, 5, 256, 4, False, "smooth"), (512, 19, 200, 3, True, "greedy"),
+                                                  # longer smooth sequences: the feedback path through many steps
+                                                  (512, 32, 100, 12, True, "smooth"), (512, 7, 50, 9, False, "smooth"),
+                                                  (320, 10, 64, 8, True, "smooth")])
 def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
     """Free-running decoder sequences (smooth embedding with grad as in solver.py:460-495, greedy, scheduled sampling)
     with the fused per-step feedback kernel against the same steps through torch glue: outputs and every gradient.
@@ -1130,8 +1133,8 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
     names = list(base.keys())
 
     def run(fused, persist=False):
-        old = hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC
-        hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC = fused, persist
+        old = hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD
+        hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = fused, persist, persist
         try:
             par = {k: v.clone().requires_grad_(True) for k, v in base.items()}
             opts = dict(L=L, tokens=tokens, tf_flags=flags, smooth=kind == "smooth", smooth_scaling=3.0, sample=False,
@@ -1145,9 +1148,14 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
             if fused and kind != "mixed":
                 assert hb.LAUNCHES["dec_free_persist" if persist else "dec_free_step"] == 1, (persist, dict(hb.LAUNCHES))
                 assert hb.LAUNCHES["dec_free_step" if persist else "dec_free_persist"] == 0, (persist, dict(hb.LAUNCHES))
+            if fused and kind == "smooth" and L > 1:
+                # the backward of the smooth free-running sequence: persistent (feedback carried inside the kernel) in the
+                # 4-row geometry, per-step kernels + feedback kernel otherwise
+                want = "dec_bwd_persist" if (persist and Tp <= 100) else "dec_bwd_step"
+                assert hb.LAUNCHES[want] == 1, (persist, Tp, dict(hb.LAUNCHES))
             return logits.detach(), ws.detach(), pred.clone(), {k: par[k].grad.detach() for k in names}
         finally:
-            hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC = old
+            hb.USE_FEEDBACK_KERNEL, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = old
 
     lr, wr, pr, gr = run(False)
     # per-step kernels + fused feedback kernel, then (sequences without teacher tokens) the whole sequence in the

@@ -247,8 +247,9 @@ def test_gen_train_one_iteration_at_cfg4_width_against_golden(tmp_path, monkeypa
     Solver.gen_train_one_iteration, against what the reference's arithmetic produced at that width
     (tests/golden/big_ssl.npz, make_golden.py gen_big_ssl; solver.py:460-495): the three losses and every generator
     gradient (norm, ends, seeded 4 096-element sample).  The launch counters must show the kernels this workload is
-    meant to run on: the free-running persistent decoder forward, the persistent teacher-forced decoder forward and
-    backward, the persistent encoder recurrences of both passes, the judge's H = 640 persistent forward."""
+    meant to run on: the free-running persistent decoder (forward AND backward, the smooth-embedding feedback carried
+    inside the kernels), the persistent teacher-forced decoder, the persistent encoder recurrences of both passes, the
+    judge's H = 640 persistent forward."""
     import __graft_entry__ as entry
     entry.build()
     import synth
@@ -265,13 +266,13 @@ def test_gen_train_one_iteration_at_cfg4_width_against_golden(tmp_path, monkeypa
     hb.persist_clear_abort(dev)
     hb.LAUNCHES.clear()
     np.random.seed(9)
-    meta = solver.gen_train_one_iteration(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys],
-                                          torch.from_numpy(uxs).to(dev), uilens)
+    with hb.require_persistent():
+        meta = solver.gen_train_one_iteration(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys],
+                                              torch.from_numpy(uxs).to(dev), uilens)
     assert not hb.persist_aborted(dev)
     launches = dict(hb.LAUNCHES)
     assert launches.get("dec_free_persist") == 1 and launches.get("dec_fwd_persist") == 1, launches
-    # the backward of the free-running sequence still runs on the per-step kernels (+ the fused feedback kernel)
-    assert launches.get("dec_bwd_persist") == 1, launches
+    assert launches.get("dec_bwd_persist") == 2 and "dec_bwd_step" not in launches, launches
     assert launches.get("lstm_fwd_persist") == 3 + 3 + 2 and launches.get("lstm_bwd_persist") == 3 + 3, launches
     assert abs(meta["sup_loss"] - float(g["sup"])) <= 1e-5 * abs(float(g["sup"])), (meta, float(g["sup"]))
     assert abs(meta["unsup_loss"] - float(g["unsup"])) <= 1e-4 * abs(float(g["unsup"])), (meta, float(g["unsup"]))
