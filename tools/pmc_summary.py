@@ -20,8 +20,10 @@ def rows(path, counter):
 f, fk = rows(fcsv, 'FETCH_SIZE'); w, wk = rows(wcsv, 'WRITE_SIZE')
 # algorithmic bytes per time step (both directions, 32 rows): forward = pre-activations read + activated gates written
 # (2 x 16 B x 4H/4 ... = 2 x B x ndir x 4H x 4) + c, y written; backward = gates read + dG written + dy, c read + the h rows of dW_hh
-alg = {'fwd': B * ndir * (2 * 4 * H + 2 * H) * 4, 'bwd': B * ndir * (2 * 4 * H + 2 * H + H) * 4}
-res = {'shape': 'T=%d B=%d H=%d ndir=%d (cfg-2 encoder layer 0), fused dW_hh; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+# (bf16x6, the default: dW_hh is a GEMM after the kernel, so the backward does not read the h rows: PMC_FUSED_DW=0)
+fused = os.environ.get('PMC_FUSED_DW', '0') == '1'
+alg = {'fwd': B * ndir * (2 * 4 * H + 2 * H) * 4, 'bwd': B * ndir * (2 * 4 * H + 2 * H + (H if fused else 0)) * 4}
+res = {'shape': 'T=%d B=%d H=%d ndir=%d (cfg-2 encoder layer 0); separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
                 'passes of tools/pmc_probe.py, FETCH_SIZE doubled as the gfx950 guide prescribes' % (T, B, H, ndir)}
 for kind, key in (('bwd', 'lstm_persist_bwd_kernel<512>'), ('fwd', 'lstm_persist_fwd_kernel<512>')):
     hbm = (2.0 * f[kind][1] + w[kind][1]) * 1024.0
