@@ -1340,24 +1340,31 @@ __device__ __forceinline__ f32x4 bf3_mfma16(const uint2& a, const uint2& b, cons
 
 template <int PH>
 struct RsDims {
-  static constexpr int PUC = PH / 32;            // units per CU
+  // Units per CU: PUR real ones; the exchange, the MFMA tiles and the (row, unit quad) gather work on PUC = PUR rounded up
+  // to a multiple of 4.  H = 320 (config.yaml's own width): 10 real units in 12 slots per CU - a padded unit has zero
+  // weights, is never computed by the pointwise threads and never reaches memory; the padded hidden size PHP = 384 is what
+  // the tile counts below follow.  (Unfused three-term kernel only: the fused dW_hh path indexes h by storage unit.)
+  static constexpr int PUR = PH / 32;
+  static constexpr int PUC = (PUR + 3) / 4 * 4;
+  static constexpr int PHP = 32 * PUC;
+  static constexpr int NCR = 4 * PUR;            // real local gate columns
   static constexpr int NC = 4 * PUC;             // local gate columns
   static constexpr int KS = (NC + 31) / 32;      // k-steps of the dh-partial product
   static constexpr int KP = KS * 32;
-  static constexpr int MTW = (PH / 16) / PW;     // 16-unit tiles per wave (dh partial M tiles = dW unit tiles)
+  static constexpr int MTW = (PHP / 16) / PW;    // 16-unit tiles per wave (dh partial M tiles = dW unit tiles)
   static constexpr int CT = (NC + 15) / 16;      // 16-column tiles of dW
-  static constexpr int UPW = PH / PW;            // units per wave
+  static constexpr int UPW = PHP / PW;           // units per wave
   static constexpr int CPW = PUC / 4;            // (row, unit-quad) combos gathered per wave
   static constexpr int QPU = PUC / 4;            // unit quads per (source, row)
   static constexpr int GST = KP + 8;             // bf16 row stride of the row-major local dG
   static constexpr size_t group_floats = (size_t)2 * 32 * 32 * PRG * PUC;     // exchange per group (both parities)
-  static_assert(PH % 128 == 0 && PUC % 4 == 0 && PUC <= 16, "H in {128, 256, 384, 512}");
+  static_assert(PH % 32 == 0 && PHP % 128 == 0 && PUC <= 16, "H in {128, 256, 320, 512}");
 };
 
 template <int PH, int NR, int NT>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a) {
   using RD = RsDims<PH>;
-  constexpr int PUC = RD::PUC, NC = RD::NC, KS = RD::KS, MTW = RD::MTW, CT = RD::CT, UPW = RD::UPW, CPW = RD::CPW;
+  constexpr int PUC = RD::PUC, PUR = RD::PUR, NC = RD::NC, NCR = RD::NCR, KS = RD::KS, MTW = RD::MTW, CT = RD::CT, UPW = RD::UPW, CPW = RD::CPW;
   constexpr int QPU = RD::QPU, GST = RD::GST;
   constexpr int NE = 2;                           // quads per lane in the gather: two sources of one (row, unit quad)
   // local dG of the last four steps, row-major [slot s & 3][row][col] (split bf16).  One image serves both products:
@@ -1372,6 +1379,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   // the serial chain: every CU is producer and consumer) - 1.5 ms per cfg-2 step, against 1.2 ms for the same sums as two
   // batched 256 x 128 GEMMs after the kernel (ops._LstmLayer).  FUSE is therefore a property of the two-term kernel.
   constexpr bool FUSE = NT == 2;
+  static_assert(!FUSE || PUR == PUC, "padded units per CU exist in the unfused kernel only");
   constexpr int NIMG = NT == 3 ? 4 : NT;  // three terms: + an image that stays zero (the idle half of B2, see fold_halves)
   __shared__ __attribute__((aligned(16))) unsigned short dgs[NIMG][FUSE ? 4 : 1][PRG][GST];
   __shared__ __attribute__((aligned(16))) unsigned short ht2[FUSE ? 2 : 1][FUSE ? PH : 1][4][PRG];
@@ -1400,8 +1408,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   u32x4 wt[MTW][KS][NT];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
-    const int wunit = 16 * (MTW * wave + mt) + ml;
-    const float* wr = a.w + ((int64_t)d * PH + wunit) * (4 * PH) + NC * slice;
+    const int cu = 16 * (MTW * wave + mt) + ml;                     // unit slot (padded index); its owner CU and slot there
+    const int csl = cu / PUC, cuu = cu - csl * PUC;
+    const bool ureal = cuu < PUR;
+    const int wunit = PUR * csl + (ureal ? cuu : 0);                // storage unit
+    const float* wr = a.w + ((int64_t)d * PH + wunit) * (4 * PH) + NCR * slice;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k0 = 32 * ks + 8 * kq;
@@ -1409,14 +1420,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       if (a.w_il != nullptr) {      // forward layout [4H columns][H units]: the same elements, one at a time (once per launch)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const bool kok = k0 + j < NC;
-          const float q = a.w_il[((int64_t)d * 4 * PH + NC * slice + (kok ? k0 + j : 0)) * PH + wunit];
+          const bool kok = ureal && k0 + j < NCR;
+          const float q = a.w_il[((int64_t)d * 4 * PH + NCR * slice + (kok ? k0 + j : 0)) * PH + wunit];
           v[j] = kok ? q : 0.f;
         }
       } else {
 #pragma unroll
         for (int j4 = 0; j4 < 2; ++j4) {
-          const bool kok = k0 + 4 * j4 < NC;
+          const bool kok = ureal && k0 + 4 * j4 < NCR;
           const float4 q = *reinterpret_cast<const float4*>(wr + (kok ? k0 + 4 * j4 : 0));
           v[4 * j4] = kok ? q.x : 0.f; v[4 * j4 + 1] = kok ? q.y : 0.f;
           v[4 * j4 + 2] = kok ? q.z : 0.f; v[4 * j4 + 3] = kok ? q.w : 0.f;
@@ -1427,11 +1438,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   }
   // pointwise ownership as in the other kernels: thread (pu, pj), tid < PUC*PRG
   const int pu = tid >> 3, pj = tid & 7;
-  const bool pw_lane = tid < PUC * PRG;
+  const bool pw_lane = tid < PUR * PRG;
   const bool pw_thread = pw_lane && pj < NR;
   const int prow = r0 + pj;
   const bool prow_ok = pw_thread && prow < a.nb;
-  const int punit = PUC * slice + pu;
+  const int punit = PUR * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1857,7 +1868,12 @@ int launch_bwd_rs(const PersistArgs& a, hipStream_t stream) {
 }
 
 bool persist_supported(int H) { return H == 128 || H == 256 || H == 320 || H == 512; }
-bool rs_supported(int H) { return H == 128 || H == 256 || H == 512; }
+// exchanged-partials backward: H with a multiple of 4 units per CU; H = 320 (10 units per CU in 12 slots) in the unfused
+// three-term kernel only
+bool rs_supported(int H, int arith) {
+  return H == 128 || H == 256 || H == 512 || (H == 320 && (arith & ASR_ARITH_MASK) == ASR_ARITH_BF16X6);
+}
+int rs_slots_per_cu(int H) { return (H / 32 + 3) / 4 * 4; }
 
 // rows per XCD group: 4 when the whole batch fits 4-row groups (half the MFMA work and gather per step), else 8
 int rows_per_group(int nb, int ndir) {
@@ -1887,16 +1903,20 @@ int dispatch_fwd(int H, int arith, const PersistArgs& a, hipStream_t stream) {
 int bwd_kernel_kind(int H, int arith) {
   const int ar = arith & ASR_ARITH_MASK;
   if (ar == ASR_ARITH_F32) return 0;
-  if (rs_supported(H) && !(arith & ASR_LSTM_BWD_GATHER)) return 2;
+  if (rs_supported(H, arith) && !(arith & ASR_LSTM_BWD_GATHER)) return 2;
   // the gathered-dG kernel with three terms needs 171 KB of LDS at H = 512
   if (ar == ASR_ARITH_BF16X6 && H > 320) return -1;
   return 1;
 }
 template <int NR, int NT>
 int dispatch_bwd_split(int H, int kind, const PersistArgs& a, hipStream_t stream) {
-  if (kind == 2)
+  if (kind == 2) {
+    if constexpr (NT == 3) {
+      if (H == 320) return launch_bwd_rs<320, NR, 3>(a, stream);
+    }
     return H == 512 ? launch_bwd_rs<512, NR, NT>(a, stream) : H == 256 ? launch_bwd_rs<256, NR, NT>(a, stream)
                                                             : launch_bwd_rs<128, NR, NT>(a, stream);
+  }
   if constexpr (NT == 2) {
     if (H == 512) return launch_bwd_bf3<512, NR, 2>(a, stream);
   }
@@ -1989,7 +2009,7 @@ static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, floa
   const int rows_per_launch = nr * (8 / ndir);
   for (int rb = 0; rb < nb; rb += rows_per_launch) {
     // exchanged-partials kernel: [8 groups][2 parities][32 dest][32 src][8 rows][H/32 units] floats (8 MB at H = 512)
-    const size_t xbytes = kind == 2 ? (size_t)8 * 2 * 32 * 32 * PRG * (H / 32) * sizeof(float)
+    const size_t xbytes = kind == 2 ? (size_t)8 * 2 * 32 * 32 * PRG * rs_slots_per_cu(H) * sizeof(float)
                                     : (size_t)2 * 8 * PRG * 4 * H * sizeof(float);
     hipError_t e = persist_reset(xch, ctrl, xbytes, stream);
     if (e != hipSuccess) return (int)e;
