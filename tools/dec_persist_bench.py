@@ -45,5 +45,5 @@ for path in libs:
         ref = ws["ws"].clone()
         print('per-step chain: %.2f us/step' % te, flush=True)
     tp = timeit(lambda: l.asr_dec_seq_fwd_persist(ctypes.byref(fs), ctypes.c_void_p(xch.data_ptr()), ctypes.c_void_p(ctrl.data_ptr()), st))
-    print('%-28s persistent %.2f us/step  abort %d err %d  max |dw| %.2e' % (os.path.basename(path), tp, int(ctrl[8].item()),
-          int(ctrl[9].item()), float((ws["ws"] - ref).abs().max())), flush=True)
+    print('%-28s persistent %.2f us/step  abort %d err %d  max |dw| %.2e' % (os.path.basename(path), tp, int(ctrl[0].item()),
+          int(ctrl[1].item()), float((ws["ws"] - ref).abs().max())), flush=True)

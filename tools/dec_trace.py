@@ -35,7 +35,7 @@ l.asr_dec_seq_fwd_persist.argtypes = [ctypes.POINTER(hb.DecFwd), ctypes.c_void_p
 l.asr_dec_seq_bwd_persist.argtypes = [ctypes.POINTER(hb.DecBwd), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 X, C_ = ctypes.c_void_p(xch.data_ptr()), ctypes.c_void_p(ctrl.data_ptr())
 def report(name, nmarks):
-    t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)[:, :nmarks]
+    t = ctrl[32:32 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)[:, :nmarks]
     dl = np.diff(t, axis=1).mean(0)
     step = (t[1:, 0] - t[:-1, 0]).mean()
     print(name, 'cycles/step %.0f' % step, ' deltas:', ' '.join('%d:%.0f' % (i + 1, x) for i, x in enumerate(dl)))
@@ -47,5 +47,5 @@ for _ in range(2):
     ctrl.zero_()
     assert l.asr_dec_seq_bwd_persist(ctypes.byref(bs), hb.ptr(ws["Mf"]), X, C_, st) == 0
     torch.cuda.synchronize(); report('bwd', 10)
-    t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    t = ctrl[32:32 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     print('   (e) split: df+barrier %.0f | dwext %.0f | dconv %.0f | prefetchA %.0f' % ((t[:, 10] - t[:, 4]).mean(), (t[:, 11] - t[:, 10]).mean(), (t[:, 12] - t[:, 11]).mean(), (t[:, 5] - t[:, 12]).mean()))

@@ -23,18 +23,18 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = hb.stream()
 l = ctypes.CDLL(ROOT + '/scratchlibs/lib_lptrace2.so')
 def show(name):
-    t = ctrl[:1024].cpu().numpy().view(np.int64).reshape(32, 8, 2)
+    t = ctrl[16:16 + 1024].cpu().numpy().view(np.int64).reshape(32, 8, 2)
     wait = (t[:, :, 1] - t[:, :, 0]).mean(1)
     top = (t[:, :, 0] - t[:, :, 0].min(0, keepdims=True)).mean(1)
     print(name, 'poll wait per CU (cycles):', ' '.join('%d' % x for x in wait))
     print(name, 'arrival at the top of a step relative to the earliest CU:', ' '.join('%d' % x for x in top))
 for _ in range(2):
     gb = gact.clone()
-    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), st) == 0
+    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), hb.current_arith(), st) == 0
     torch.cuda.synchronize()
 show('bwd')
 for _ in range(2):
     ga = gates0.clone()
-    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), st) == 0
+    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), hb.current_arith(), st) == 0
     torch.cuda.synchronize()
 show('fwd')

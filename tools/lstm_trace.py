@@ -22,26 +22,26 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = hb.stream()
 l = ctypes.CDLL(ROOT + '/scratchlibs/' + (sys.argv[1] if len(sys.argv) > 1 else 'lib_lptrace.so'))
 def report(name, n):
-    t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)[:, :n]
+    t = ctrl[32:32 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)[:, :n]
     print(name, 'cycles/step %.0f' % (t[1:, 0] - t[:-1, 0]).mean(), ' deltas:', ' '.join('%d:%.0f' % (i + 1, x) for i, x in enumerate(np.diff(t, axis=1).mean(0))),
           ' tail->next top: %.0f' % (t[1:, 0] - t[:-1, n - 1]).mean())
 for _ in range(2):
     ga = gates0.clone(); ctrl.zero_()
-    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), st) == 0
+    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), hb.current_arith(), st) == 0
     torch.cuda.synchronize(); report('fwd', 7)
-    t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    t = ctrl[32:32 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     print('   fwd poll split: top->sentinel ok %.0f | sentinel ok->tile gathered %.0f | failed polls %.1f' % ((t[:, 7] - t[:, 0]).mean(), (t[:, 1] - t[:, 7]).mean(), t[:, 8].mean()))
-    t7 = ctrl[16 + 256:16 + 256 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    t7 = ctrl[32 + 256:32 + 256 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     print('   wave 7 relative to wave 0 top of the same step: top %.0f | sentinel ok %.0f | gathered %.0f | MFMA done %.0f | barrier passed %.0f ; wave 0: gathered %.0f | MFMA done %.0f | barrier %.0f | published %.0f' % (
         (t7[:, 0] - t[:, 0]).mean(), (t7[:, 7] - t[:, 0]).mean(), (t7[:, 1] - t[:, 0]).mean(), (t7[:, 2] - t[:, 0]).mean(), (t7[:, 4] - t[:, 0]).mean(),
         (t[:, 1] - t[:, 0]).mean(), (t[:, 2] - t[:, 0]).mean(), (t[:, 4] - t[:, 0]).mean(), (t[:, 6] - t[:, 0]).mean()))
 for _ in range(2):
     gb = gact.clone(); ctrl.zero_()
-    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), st) == 0
+    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), hb.current_arith(), st) == 0
     torch.cuda.synchronize(); report('bwd', 6)
-    t = ctrl[16:16 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    t = ctrl[32:32 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     print('   bwd pointwise split: partial sums %.0f | math+tags %.0f | publish %.0f | bulk store+db %.0f' % ((t[:, 9] - t[:, 4]).mean(), (t[:, 10] - t[:, 9]).mean(), (t[:, 11] - t[:, 10]).mean(), (t[:, 5] - t[:, 11]).mean()))
-    t7 = ctrl[16 + 256:16 + 256 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
+    t7 = ctrl[32 + 256:32 + 256 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     names = {0: 'top', 1: 'gathered', 2: 'dh MFMA done', 3: 'partials written', 4: 'barrier passed', 9: 'partials summed', 10: 'math+tags', 11: 'published', 5: 'stores done (dW starts)'}
     for wname, tt in (('wave 0', t), ('wave 7', t7)):
         print('   %s, cycles after wave 0 top of the same step: ' % wname + ' | '.join('%s %.0f' % (names[k], (tt[:, k] - t[:, 0]).mean()) for k in (0, 1, 2, 3, 4, 9, 10, 11, 5) if tt[:, k].min() > 0) +
