@@ -577,55 +577,120 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // single-stage hand-off: a lane owns k = lane (+ 64 for H > 512) of the wave's range and reads its NR rows as
-      // 16-byte quads
-      constexpr int NKC = (PKW + 63) / 64;
-      bool gl[NKC];
-      unsigned boff[NKC];
-#pragma unroll
-      for (int kc = 0; kc < NKC; ++kc) {
-        gl[kc] = lane + 64 * kc < PKW;
-        boff[kc] = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
-                              (wave * PKW + (gl[kc] ? lane + 64 * kc : 0)) * PRG) * 4u;
-      }
-      const unsigned tb = tag_bit_of_step(s - 1);
-      u32x4 gw[NKC][NR / 4];
-      unsigned spins = 0;
-      while (true) {
-#pragma unroll
-        for (int kc = 0; kc < NKC; ++kc)
-#pragma unroll
-          for (int j = 0; j < NR / 4; ++j) gw[kc][j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff[kc] + 16u * j, 0, 16);
-        bool ok = true;
-#pragma unroll
-        for (int kc = 0; kc < NKC; ++kc)
-#pragma unroll
-          for (int j = 0; j < NR / 4; ++j) ok = ok && (!gl[kc] || quad_ok(gw[kc][j], tb));
-        if (__all(ok)) break;
-        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) raise_abort(a.ctrl, 1u);
-          aborted = true;
-          break;
+      if constexpr (NR == 8) {
+        // single-stage hand-off: a lane owns two adjacent k of the wave's range for half of the rows (job = (k pair, row
+        // half): 64 jobs at H = 512; H = 640 needs a second job on 16 lanes) and reads them as two 16-byte quads.  The pair is what makes the staging cheap: one packed split (v_cvt_pk_bf16_f32 works on two values
+        // anyway) and one 4-byte LDS store per row and term - with one k and all NR rows per lane the same tile took 24
+        // two-byte stores per lane (1.85 -> 1.77 us per time step at 8 rows)
+        constexpr int RJ = 4;                           // rows per job
+        constexpr int NPAIR = PKW / 2, NJOB = NPAIR * 2, NJC = (NJOB + 63) / 64;
+        static_assert(PKW % 2 == 0, "k pairs");
+        bool gl[NJC];
+        unsigned boff[NJC];
+        int gpair[NJC], ghalf[NJC];
+  #pragma unroll
+        for (int jc = 0; jc < NJC; ++jc) {
+          const int jb = lane + 64 * jc;
+          gl[jc] = jb < NJOB;
+          ghalf[jc] = gl[jc] ? jb / NPAIR : 0;
+          gpair[jc] = gl[jc] ? jb - ghalf[jc] * NPAIR : 0;
+          boff[jc] = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
+                                (wave * PKW + 2 * gpair[jc]) * PRG + RJ * ghalf[jc]) * 4u;
         }
-        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
-      }
-      LP_MARK(7);
-#pragma unroll
-      for (int kc = 0; kc < NKC; ++kc)
-        if (gl[kc] && !(ASR_LA & 2)) {
-#pragma unroll
-          for (int j = 0; j < NR / 4; ++j) {
-            const float f[4] = {__uint_as_float(gw[kc][j].x), __uint_as_float(gw[kc][j].y), __uint_as_float(gw[kc][j].z),
-                                __uint_as_float(gw[kc][j].w)};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+        const unsigned tb = tag_bit_of_step(s - 1);
+        unsigned gw[NJC][2][RJ];
+        unsigned spins = 0;
+        while (true) {
+          bool ok = true;
+  #pragma unroll
+          for (int jc = 0; jc < NJC; ++jc)
+  #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff[jc] + (unsigned)(PRG * 4) * u, 0, 16);
+              gw[jc][u][0] = q.x; gw[jc][u][1] = q.y; gw[jc][u][2] = q.z; gw[jc][u][3] = q.w;
+            }
+  #pragma unroll
+          for (int jc = 0; jc < NJC; ++jc) {
+            unsigned bad = 0u;
+  #pragma unroll
+            for (int u = 0; u < 2; ++u)
+  #pragma unroll
+              for (int i = 0; i < RJ; ++i) bad |= gw[jc][u][i] ^ tb;
+            ok = ok && (!gl[jc] || (bad & 1u) == 0u);
+          }
+          if (__all(ok)) break;
+          if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+            if (lane == 0) raise_abort(a.ctrl, 1u);
+            aborted = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+        }
+        LP_MARK(7);
+  #pragma unroll
+        for (int jc = 0; jc < NJC; ++jc)
+          if (gl[jc] && !(ASR_LA & 2)) {
+  #pragma unroll
+            for (int i = 0; i < RJ; ++i) {
               unsigned tk[NT];
-              bfn_split1<NT>(f[i], tk);
-#pragma unroll
-              for (int k = 0; k < NT; ++k) hh[k][wave][4 * j + i][lane + 64 * kc] = (unsigned short)tk[k];
+              bfn_split2<NT>(__uint_as_float(gw[jc][0][i]), __uint_as_float(gw[jc][1][i]), tk);
+  #pragma unroll
+              for (int k = 0; k < NT; ++k) *reinterpret_cast<unsigned*>(&hh[k][wave][RJ * ghalf[jc] + i][2 * gpair[jc]]) = tk[k];
             }
           }
+      } else {
+        // 4-row groups: one k per lane, ONE quad - the number of load instructions per lane is what a gather costs
+        // (two 8-byte loads per lane for a k pair: 1.51 -> 1.65 us per time step)
+        // single-stage hand-off: a lane owns k = lane (+ 64 for H > 512) of the wave's range and reads its 4 rows as
+        // 16-byte quads
+        constexpr int NKC = (PKW + 63) / 64;
+        bool gl[NKC];
+        unsigned boff[NKC];
+  #pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+          gl[kc] = lane + 64 * kc < PKW;
+          boff[kc] = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
+                                (wave * PKW + (gl[kc] ? lane + 64 * kc : 0)) * PRG) * 4u;
         }
+        const unsigned tb = tag_bit_of_step(s - 1);
+        u32x4 gw[NKC][NR / 4];
+        unsigned spins = 0;
+        while (true) {
+  #pragma unroll
+          for (int kc = 0; kc < NKC; ++kc)
+  #pragma unroll
+            for (int j = 0; j < NR / 4; ++j) gw[kc][j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff[kc] + 16u * j, 0, 16);
+          bool ok = true;
+  #pragma unroll
+          for (int kc = 0; kc < NKC; ++kc)
+  #pragma unroll
+            for (int j = 0; j < NR / 4; ++j) ok = ok && (!gl[kc] || quad_ok(gw[kc][j], tb));
+          if (__all(ok)) break;
+          if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+            if (lane == 0) raise_abort(a.ctrl, 1u);
+            aborted = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+        }
+        LP_MARK(7);
+  #pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+          if (gl[kc] && !(ASR_LA & 2)) {
+  #pragma unroll
+            for (int j = 0; j < NR / 4; ++j) {
+              const float f[4] = {__uint_as_float(gw[kc][j].x), __uint_as_float(gw[kc][j].y), __uint_as_float(gw[kc][j].z),
+                                  __uint_as_float(gw[kc][j].w)};
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                unsigned tk[NT];
+                bfn_split1<NT>(f[i], tk);
+  #pragma unroll
+                for (int k = 0; k < NT; ++k) hh[k][wave][4 * j + i][lane + 64 * kc] = (unsigned short)tk[k];
+              }
+            }
+          }
+      }
       LP_MARK(1);
       if (st_gp && !(ASR_LA & 4)) {   // previous step's outputs (stores after the poll: vmcnt retires in order)
         *st_gp = st_g;
