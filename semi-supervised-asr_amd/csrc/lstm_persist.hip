@@ -1446,18 +1446,19 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   constexpr bool FUSE = NT == 2;
   static_assert(!FUSE || PUR == PUC, "padded units per CU exist in the unfused kernel only");
   constexpr int NIMG = NT == 3 ? 4 : NT;  // three terms: + an image that stays zero (the idle half of B2, see fold_halves)
-  __shared__ __attribute__((aligned(16))) unsigned short dgs[NIMG][FUSE ? 4 : 1][PRG][GST];
+  __shared__ __attribute__((aligned(16))) unsigned short dgs[NIMG][FUSE ? 4 : 2][PRG][GST];
   __shared__ __attribute__((aligned(16))) unsigned short ht2[FUSE ? 2 : 1][FUSE ? PH : 1][4][PRG];
-  __shared__ __attribute__((aligned(16))) float dhs[PRG][16];                                 // reduced dh_rec [row][unit]
+  __shared__ __attribute__((aligned(16))) float dbs[PRG][4 * PUC];                            // bias-gradient sums per row (epilogue)
+  __shared__ __attribute__((aligned(16))) float dhs[PRG][16];                                 // reduced dh_rec [row][unit] (fused kernel)
   __shared__ int role[2];
   extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < NIMG * (FUSE ? 4 : 1) * PRG * GST; i += PNT) (&dgs[0][0][0][0])[i] = 0;
+  for (int i = tid; i < NIMG * (FUSE ? 4 : 2) * PRG * GST; i += PNT) (&dgs[0][0][0][0])[i] = 0;
   if constexpr (FUSE) {
     for (int i = tid; i < 2 * PH * 4 * PRG; i += PNT) (&ht2[0][0][0][0])[i] = 0;
   }
-  if (tid < PRG * 16) (&dhs[0][0])[tid] = 0.f;
+  for (int i = tid; i < PRG * 4 * PUC; i += PNT) (&dbs[0][0])[i] = 0.f;
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
@@ -1501,9 +1502,17 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       bfn_split8<NT>(v, wt[mt][ks]);
     }
   }
-  // pointwise ownership as in the other kernels: thread (pu, pj), tid < PUC*PRG
-  const int pu = tid >> 3, pj = tid & 7;
-  const bool pw_lane = tid < PUR * PRG;
+  // Pointwise ownership.  Unfused kernel (ROWPW): it follows the gather - the 16 lanes of DPP row rr of wave w sum the 32
+  // partials of (row w, unit quad rr), every lane of the row ends up with the four totals, and lanes 0..3 of the row go on
+  // with the pointwise backward of (row w, unit 4 rr + lane) on the spot: no LDS round trip of the reduced dh, no barrier
+  // between gather and pointwise phase, two alternating dG slots instead (1.88 -> 1.83 us per time step).  The fused
+  // two-term kernel keeps the first mapping, thread (pu, pj) of waves 0 and 1 behind barrier A: its dW_hh block needs that
+  // barrier anyway, and with the pointwise code in all eight waves it measured 2.17 instead of 2.02 us.
+  constexpr bool ROWPW = !FUSE;
+  static_assert(QPU == CPW, "a wave gathers exactly one row");
+  const int rr = lane >> 4, sp = lane & 15;
+  const int pu = ROWPW ? 4 * (rr < CPW ? rr : 0) + (sp & 3) : tid >> 3, pj = ROWPW ? wave : tid & 7;
+  const bool pw_lane = ROWPW ? (sp < 4 && rr < CPW && pu < PUR) : tid < PUR * PRG;
   const bool pw_thread = pw_lane && pj < NR;
   const int prow = r0 + pj;
   const bool prow_ok = pw_thread && prow < a.nb;
@@ -1520,7 +1529,6 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   // sources (2 sp, 2 sp + 1) per lane: one add and a 16-lane DPP reduction per value.  (With one source per lane and 32
   // lanes per combo the two DPP rows had to be joined through v_readlane: 0.29 us of the 2.52 us step, tools/persist_bench.py
   // with -DASR_RA=1.)
-  const int rr = lane >> 4, sp = lane & 15;
   // h_{t_prev} loader: lane l < UPW of wave w owns unit UPW w + l (this wave's own dW unit tiles: wave-private LDS rows)
   const bool h_lane = fuse_dw && lane < UPW;
   const int hunit = UPW * wave + (lane < UPW ? lane : 0);
@@ -1627,6 +1635,21 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.z) : "v"(n2_av.z));
     asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.w) : "v"(n2_av.w));
     const float cp = s + 1 < T ? n1_ct : 0.f;                     // c at the time that feeds this one
+    // Everything of the pointwise backward that only needs forward data (the tanh, the gate derivatives) is formed HERE,
+    // before the gather: after it the chain is dh -> dc -> dG, seven multiply-adds (the compiler left all of it behind
+    // barrier A, two transcendentals and ~25 dependent VALU instructions on the serial chain)
+    float k_dc = 0.f, k_i = 0.f, k_f = 0.f, k_g = 0.f, k_o = 0.f, k_cn = 0.f;
+    if (pw_thread) {
+      const float tc = (ASR_RA & 8) ? ct_ * 0.1f : asr_fast_tanh(ct_);
+      const bool live = t < plen;
+      k_dc = av.w * (1.f - tc * tc);
+      k_i = live ? av.z * av.x * (1.f - av.x) : 0.f;
+      k_f = live ? cp * av.y * (1.f - av.y) : 0.f;
+      k_g = live ? av.x * (1.f - av.z * av.z) : 0.f;
+      k_o = live ? tc * av.w * (1.f - av.w) : 0.f;
+      k_cn = live ? av.y : 0.f;
+      asm volatile("" : "+v"(k_dc), "+v"(k_i), "+v"(k_f), "+v"(k_g), "+v"(k_o), "+v"(k_cn));
+    }
 #if ASR_POLL_FIRST
     if (s > 0 && !q_inflight) {
 #if ASR_POLL_FIRST_SLEEP
@@ -1645,6 +1668,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     float4* gp = nullptr;
     if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
     // ---------------------------------------------------------------- (1) gather the partials addressed to this CU
+    float dh_rec = 0.f;
     if (s > 0) {
       const unsigned tb = tag_bit_of_step(s - 1);
       unsigned spins = 0;
@@ -1670,39 +1694,40 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         float v[4] = {__uint_as_float(q[0].x) + __uint_as_float(q[1].x), __uint_as_float(q[0].y) + __uint_as_float(q[1].y),
                       __uint_as_float(q[0].z) + __uint_as_float(q[1].z), __uint_as_float(q[0].w) + __uint_as_float(q[1].w)};
         row16_sum4(v);                               // every lane of a 16-lane row holds the row's total
-        if (sp == 0 && guse) *reinterpret_cast<float4*>(&dhs[grow][4 * guq]) = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (ROWPW) dh_rec = (sp & 2) ? ((sp & 1) ? v[3] : v[2]) : ((sp & 1) ? v[1] : v[0]);
+        else if (sp == 0 && guse) *reinterpret_cast<float4*>(&dhs[grow][4 * guq]) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
     if (st_gp && !(ASR_RA & (2 | 64))) { // previous step's dG (bulk store after the poll: vmcnt retires in order)
       *st_gp = st_da;
       st_gp = nullptr;
     }
-#if !ASR_STAGE_H_TOP
-    if (h_lane && s + 1 < T && !(ASR_RA & 256)) stage_h((s + 1) & 3, s + 1);
-#endif
     // prefetches: right after the poll, i.e. as far ahead of the next one as possible
     if (prow_ok && s + 2 < T && !(ASR_RA & (2 | 32))) fetch_step(s + 2, n2_dy, n2_ct, n2_av);
-    if (h_lane && s + 2 < T && !(ASR_RA & (2 | 16))) fetch_h(s + 2);
-    LP_MARK(2);
-    __syncthreads();                                                                                     // A
-    LP_MARK(3);
+    if constexpr (FUSE) {
+#if !ASR_STAGE_H_TOP
+      if (h_lane && s + 1 < T && !(ASR_RA & 256)) stage_h((s + 1) & 3, s + 1);
+#endif
+      if (h_lane && s + 2 < T && !(ASR_RA & (2 | 16))) fetch_h(s + 2);
+      LP_MARK(2);
+      __syncthreads();                 // A: the h tile / dG slots of the fused dW_hh block (the unfused kernel alternates two
+      LP_MARK(3);                      // dG slots instead: a slot is rewritten two barriers B after its last reader)
+    }
     // ---------------------------------------------------------------- (2) pointwise LSTM backward of this CU's units
     if (pw_lane) {
       float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pw_thread) {
-        const float dh = dyv + (s > 0 ? dhs[pj][pu] : 0.f);
-        const float tc = (ASR_RA & 8) ? ct_ * 0.1f : asr_fast_tanh(ct_);
-        const float dc = dcarry + dh * av.w * (1.f - tc * tc);
-        da.x = dc * av.z * av.x * (1.f - av.x);
-        da.y = dc * cp * av.y * (1.f - av.y);
-        da.z = dc * av.x * (1.f - av.z * av.z);
-        da.w = dh * tc * av.w * (1.f - av.w);
-        float dcn = dc * av.y;
-        if (t >= plen) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
+        const float dh = dyv + (ROWPW ? dh_rec : (s > 0 ? dhs[pj][pu] : 0.f));
+        const float dc = dcarry + dh * k_dc;
+        da.x = dc * k_i;
+        da.y = dc * k_f;
+        da.z = dc * k_g;
+        da.w = dh * k_o;
+        const float dcn = dc * k_cn;
         if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
         dcarry = dcn;
         {
-          const int sl = FUSE ? (s & 3) : 0, zs = (s + 1) & 3;   // this step's slot; the slot the NEXT step's h is staged into
+          const int sl = FUSE ? (s & 3) : (s & 1), zs = (s + 1) & 3;   // this step's slot; the slot the NEXT step's h is staged into
           unsigned p0[NT], p1[NT];
           bfn_split2<NT>(da.x, da.y, p0);
           bfn_split2<NT>(da.z, da.w, p1);
@@ -1734,8 +1759,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
       for (int ks = 0; ks < ((ASR_RA & 4) ? 0 : KS); ++ks) {
         if constexpr (NT == 3) {
           // columns 8..15 of the batch side carry a second term (fold_halves): four MFMAs per tile and k-step
-          const u32x4 b1 = *reinterpret_cast<const u32x4*>(&dgs[ml >> 3][0][ml & 7][32 * ks + 8 * kq]);
-          const u32x4 b2 = *reinterpret_cast<const u32x4*>(&dgs[2 + (ml >> 3)][0][ml & 7][32 * ks + 8 * kq]);
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(&dgs[ml >> 3][s & 1][ml & 7][32 * ks + 8 * kq]);
+          const u32x4 b2 = *reinterpret_cast<const u32x4*>(&dgs[2 + (ml >> 3)][s & 1][ml & 7][32 * ks + 8 * kq]);
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], b1, acc[mt]);
 #pragma unroll
@@ -1843,17 +1868,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     dwacc[0][0][0] = __builtin_nanf("");
   }
   if (st_gp) *st_gp = st_da;
-  if (a.db != nullptr && pw_lane) {
-    float v[4] = {dbacc.x, dbacc.y, dbacc.z, dbacc.w};
+  if (a.db != nullptr) {        // one atomic per (unit, gate) and CU; the rows are summed through LDS
+    if (pw_lane) *reinterpret_cast<float4*>(&dbs[pj][4 * pu]) = dbacc;
+    __syncthreads();
+    if (tid < 4 * PUR) {
+      float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[k] += __shfl_xor(v[k], 1, 64);
-      v[k] += __shfl_xor(v[k], 2, 64);
-      v[k] += __shfl_xor(v[k], 4, 64);
-    }
-    if (pj == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) atomicAdd(a.db + (int64_t)d * 4 * PH + punit * 4 + k, v[k]);
+      for (int r = 0; r < PRG; ++r) v += dbs[r][tid];
+      atomicAdd(a.db + (int64_t)d * 4 * PH + PUR * slice * 4 + tid, v);
     }
   }
   if (fuse_dw) {
