@@ -163,9 +163,10 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
                      const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
                      asr_stream_t stream);
 /* Persistent fast path of asr_lstm_seq_bwd (same conditions / scratch / abort convention as asr_lstm_seq_fwd_persist;
- * H in {128, 256, 320, 512}).  With a bf16 arithmetic and H in {128, 256, 512} the CUs of a group exchange partial sums
- * of dh_rec, laid out [8 groups][2][32 dest][32 src][8 rows][H/32] floats in xch (8 MB at H = 512); otherwise (H = 320,
- * ASR_ARITH_F32, ASR_LSTM_BWD_GATHER) every CU gathers the step's dG tile.  Exchanged words carry a 1-bit tag in the
+ * H in {128, 256, 320, 512}).  With a bf16 arithmetic and H in {128, 256, 512} - and H = 320 under ASR_ARITH_BF16X6 (10
+ * units per CU in 12 slots) - the CUs of a group exchange partial sums of dh_rec, laid out [8 groups][2][32 dest][32 src]
+ * [8 rows][slots per CU] floats in xch (8 MB at H = 512); otherwise (H = 320 with two terms, ASR_ARITH_F32,
+ * ASR_LSTM_BWD_GATHER) every CU gathers the step's dG tile.  Exchanged words carry a 1-bit tag in the
  * mantissa LSB; the in-place dG is what the pointwise update produced.  `arith` selects the product arithmetic of
  * dG W_hh and of the fused dW_hh (the gathered-dG kernels always form dW_hh on the fp32 MFMA).
  * If y (forward hidden states) and dw_hh ([ndir][4H][H], gate-interleaved, zero-filled or holding a running sum)
@@ -176,7 +177,7 @@ int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates
                              const int32_t* lens, const float* dy, const float* c, const float* y,
                              float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
 /* Does asr_lstm_seq_bwd_persist(_w) with this (H, arith) accumulate dW_hh itself when given y and dw_hh?  1 yes; 0 no -
- * the ASR_ARITH_BF16X6 exchanged-partials kernel (H in {128, 256, 512}) leaves dW_hh = sum_t dG_t^T h_{t-1} to the caller
+ * the ASR_ARITH_BF16X6 exchanged-partials kernel (H in {128, 256, 320, 512}) leaves dW_hh = sum_t dG_t^T h_{t-1} to the caller
  * (one batched asr_gemm_f32 over the two directions: with six products per product the fused form costs more time on the
  * kernel's serial chain than the GEMM does) and ignores y / dw_hh; -1 no persistent backward for this H / arith.  The
  * bias gradient db is accumulated by every persistent backward kernel. */

@@ -6,7 +6,7 @@ db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end from kernels order by start"))
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
 step = rows[adam[-3] + 1:adam[-2] + 1]
-big = ('lstm_persist', 'gemm_f32', 'gemm_bf3', 'dec_persist', 'att_m', 'pyramid', 'colsum', 'adam', 'sumsq')
+big = ('lstm_persist', 'gemm_f32', 'gemm_bf3', 'gemm_bf6', 'dec_persist', 'att_m', 'pyramid', 'colsum', 'adam', 'sumsq')
 t0 = step[0][1]; prev_end = t0; groups = []; cur = []
 for nm, st, en in step:
     nm = nm.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').replace('void at::native::', '')
