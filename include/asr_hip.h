@@ -302,6 +302,11 @@ typedef struct {
   float* probs;        /* [L-1][B][V], mode 2 */
   int64_t* pred;       /* [L][B] */
   int64_t* fed;        /* [L][B] */
+  /* scheduled sampling (mode 1, eos = -1; Decoder.forward with ys and tf_rate < 1, model.py:328-333): step s >= 1 is fed
+   * tokens[b][s] where teacher[s] != 0 (the host's per-step draw) and its own argmax elsewhere; NULL: never the teacher */
+  const int64_t* tokens;        /* [B][ld_tokens], ld_tokens >= L, or NULL */
+  int64_t ld_tokens;
+  const unsigned char* teacher; /* [L] */
 } asr_dec_feedback_t;
 int asr_dec_seq_fwd_persist_free(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, void* xch, void* ctrl,
                                  asr_stream_t stream);

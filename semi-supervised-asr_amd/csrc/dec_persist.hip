@@ -84,6 +84,10 @@ struct DecPersistArgs {
   const float *w_out, *b_out, *emb;
   float *logits, *probs;
   long long *pred, *fed;
+  // scheduled sampling (fb_mode 1): step s >= 1 is fed tok[b][s] where tf[s] != 0, its own prediction elsewhere
+  const long long* tok;
+  long long ldtok;
+  const unsigned char* tf;
 };
 
 __device__ __forceinline__ float dp_tanh(float x) {   // same formula as decoder.hip:fast_tanh
@@ -369,10 +373,13 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
           const float mx = wave_max_dpp(l);
           const unsigned long long hit = __ballot(lv && l == mx);
           const int am = hit ? __ffsll(hit) - 1 : 0;          // lowest index among the maxima; all-NaN row: 0
+          // scheduled sampling: the teacher's token where the host drew "teacher" for this step (model.py:328-333)
+          int feed = am;
+          if (a.tok != nullptr && a.tf[s] != 0) feed = (int)a.tok[(int64_t)(bok ? b : r0) * a.ldtok + s];
           if (lv && bok) a.logits[((int64_t)(s - 1) * B + b) * a.V + lane_] = l;
           if (lane_ == 0 && bok) {
             a.pred[(int64_t)(s - 1) * B + b] = am;
-            a.fed[(int64_t)s * B + b] = a.fb_mode == 2 ? -1 : am;
+            a.fed[(int64_t)s * B + b] = a.fb_mode == 2 ? -1 : feed;
           }
           if (a.fb_mode == 2) {
             const float sl = lv ? a.fb_scale * l : -INFINITY;
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
               if (bok) a.probs[((int64_t)(s - 1) * B + b) * a.V + lane_] = p;
             }
           } else if (lane_ == 0) {
-            prs[wave * 64] = __int_as_float(am);
+            prs[wave * 64] = __int_as_float(feed);
           }
           if (lane_ == 0) cred[512 + wave] = __int_as_float((am == a.eos || !bok) ? 1 : 0);
         }
@@ -1671,6 +1678,7 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
     if ((f->mode != 1 && f->mode != 2) || !f->w_out || !f->emb || !f->logits || !f->pred || !f->fed || f->V <= 0)
       return ASR_E_ARG;
     if (f->mode == 2 && !f->probs) return ASR_E_ARG;
+    if (f->tokens && (f->mode != 1 || !f->teacher || f->ld_tokens < p->L || f->eos >= 0)) return ASR_E_ARG;
     if (f->V > 64) return ASR_E_SHAPE;
   }
   const bool cfg2 = p->D == 512 && p->A == 512 && p->O == 512 && p->E == 128;
@@ -1704,11 +1712,13 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
     a.xch = (float*)xch; a.ctrl = persist_launch_words(ctrl);
     a.fb_mode = 0; a.V = 0; a.eos = -1; a.fb_scale = 1.f; a.w_out = a.b_out = a.emb = nullptr; a.logits = a.probs = nullptr;
     a.pred = a.fed = nullptr;
+    a.tok = nullptr; a.ldtok = 0; a.tf = nullptr;
     int rc;
     if (f) {
       a.fb_mode = f->mode; a.V = f->V; a.eos = f->eos; a.fb_scale = f->scaling; a.w_out = f->w_out; a.b_out = f->b_out; a.emb = f->emb;
       a.logits = f->logits + (int64_t)rb * f->V; a.probs = f->probs ? f->probs + (int64_t)rb * f->V : nullptr;
       a.pred = (long long*)f->pred + rb; a.fed = (long long*)f->fed + rb;
+      if (f->tokens) { a.tok = (const long long*)f->tokens + (int64_t)rb * f->ld_tokens; a.ldtok = f->ld_tokens; a.tf = f->teacher; }
       if (geo4) rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true>(a, stream) : launch_dec_fwd<320, 320, 320, 128, true>(a, stream);
       else rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true, 2, 256>(a, stream)
                      : launch_dec_fwd<320, 320, 320, 128, true, 2, 256>(a, stream);

@@ -32,7 +32,7 @@ c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_vo
 class DecFeedback(ctypes.Structure):
     """asr_dec_feedback_t"""
     _fields_ = [("mode", c_i), ("V", c_i), ("eos", c_i), ("scaling", c_f), ("w_out", c_p), ("b_out", c_p), ("emb", c_p), ("logits", c_p),
-                ("probs", c_p), ("pred", c_p), ("fed", c_p)]
+                ("probs", c_p), ("pred", c_p), ("fed", c_p), ("tokens", c_p), ("ld_tokens", ctypes.c_int64), ("teacher", c_p)]
 
 
 class DecFeedbackBwd(ctypes.Structure):

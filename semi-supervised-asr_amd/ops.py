@@ -382,17 +382,25 @@ class _DecoderSeq(torch.autograd.Function):
                 X[0, :, D + O:] = emb_c[fed[0]]
                 if drop:
                     Xd[0, :, D + O:] = X[0, :, D + O:] * xmask[0, :, O:]
-                if hb.USE_PERSIST_DEC and tok_c is None and V <= 64 and len(hb.row_groups(B)) == 1:
-                    # no teacher tokens at all: the whole sequence in one launch, the feedback computed in the kernel
+                if hb.USE_PERSIST_DEC and (tok_c is None or not smooth) and V <= 64 and len(hb.row_groups(B)) == 1:
+                    # the whole sequence in one launch, the feedback computed in the kernel: no teacher tokens at all, or
+                    # scheduled sampling (the host's per-step draws go along as a byte per step)
                     # decoding without autograd: a group of 4 utterances stops once all of them have emitted <EOS>; the
                     # outputs of the steps that are not run read <EOS> / zero logits / zero attention weights
                     eos = int(opts.get("eos", -1))
-                    stop = hb.DECODE_EARLY_STOP and eos >= 0 and not torch.is_grad_enabled()
+                    stop = hb.DECODE_EARLY_STOP and eos >= 0 and not torch.is_grad_enabled() and tok_c is None
                     if stop:
                         pred.fill_(eos)
                         logits.zero_()
                         ws["ws"].zero_()
+                    tf_dev = None
+                    if tok_c is not None:
+                        tf_dev = torch.tensor([1 if (tf_flags is None or tf_flags[i]) else 0 for i in range(L)],
+                                              dtype=torch.uint8).to(dev, non_blocking=True)
                     fb = hb.DecFeedback(
+                        tokens=ctypes.c_void_p(tok_c.data_ptr()) if tok_c is not None else None,
+                        ld_tokens=int(tok_c.stride(0)) if tok_c is not None else 0,
+                        teacher=ctypes.c_void_p(tf_dev.data_ptr()) if tf_dev is not None else None,
                         mode=2 if smooth else 1, V=V, eos=eos if stop else -1,
                         scaling=float(opts.get("smooth_scaling", 1.0)), w_out=_p(w_out_c),
                         b_out=_p(b_out.contiguous()), emb=_p(emb_c), logits=_p(logits),
@@ -465,6 +473,9 @@ class _DecoderSeq(torch.autograd.Function):
         ctx.dims = (B, Tp, A, O, D, E, V, C, K, L, KX)
         ctx.smooth = smooth and tokens is None
         ctx.all_teacher = all_teacher
+        # a scheduled-sampling sequence that ran in the persistent kernel takes the persistent backward as well: no gradient
+        # flows through an argmax, the backward only needs what the forward saved (X, fed)
+        ctx.free_persist = (not all_teacher) and bool(done) and not (smooth and tokens is None)
         ctx.smooth_scaling = float(opts.get("smooth_scaling", 1.0))
         ctx.mark_non_differentiable(pred)
         ctx.set_materialize_grads(False)       # an unused `ws` output arrives as None instead of a zero tensor + copy
@@ -500,7 +511,7 @@ class _DecoderSeq(torch.autograd.Function):
         if not ctx.smooth:
             groups = hb.row_groups(B)
             done = False
-            if hb.USE_PERSIST_DEC_BWD and ctx.all_teacher and len(groups) == 1:
+            if hb.USE_PERSIST_DEC_BWD and (ctx.all_teacher or ctx.free_persist) and len(groups) == 1:
                 bg = _dec_bwd_struct(d, w, 0, B)
                 xch, ctrl = hb.persist_scratch(dev)
                 rc = lib.asr_dec_seq_bwd_persist(ctypes.byref(bg), _p(wk["Mf"]), ctypes.c_void_p(xch.data_ptr()),

@@ -1099,7 +1099,10 @@ def test_decoder_feedback_kernels(B, V, E, DO):
                                                   (320, 5, 256, 4, False, "smooth"), (512, 19, 200, 3, True, "greedy"),
                                                   # longer smooth sequences: the feedback path through many steps
                                                   (512, 32, 100, 12, True, "smooth"), (512, 7, 50, 9, False, "smooth"),
-                                                  (320, 10, 64, 8, True, "smooth")])
+                                                  (320, 10, 64, 8, True, "smooth"),
+                                                  # scheduled sampling at full batch, at the other width, in the wide geometry
+                                                  (512, 32, 100, 6, True, "mixed"), (320, 6, 40, 6, False, "mixed"),
+                                                  (512, 9, 150, 5, False, "mixed")])
 def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
     """Free-running decoder sequences (smooth embedding with grad as in solver.py:460-495, greedy, scheduled sampling)
     with the fused per-step feedback kernel against the same steps through torch glue: outputs and every gradient.
@@ -1145,9 +1148,12 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
                                                     par["gvec"], par["bo"], par["w_out"], par["b_out"], w0, opts)
             ((logits * dlog).sum() + (ws * dws).sum()).backward()
             torch.cuda.synchronize()
-            if fused and kind != "mixed":
+            if fused:
                 assert hb.LAUNCHES["dec_free_persist" if persist else "dec_free_step"] == 1, (persist, dict(hb.LAUNCHES))
                 assert hb.LAUNCHES["dec_free_step" if persist else "dec_free_persist"] == 0, (persist, dict(hb.LAUNCHES))
+            if fused and kind == "mixed":
+                # scheduled sampling: the host's per-step draws travel with the launch, both directions persistent
+                assert hb.LAUNCHES["dec_bwd_persist" if persist else "dec_bwd_step"] == 1, (persist, dict(hb.LAUNCHES))
             if fused and kind == "smooth" and L > 1:
                 # the backward of the smooth free-running sequence: persistent (feedback carried inside the kernel) in the
                 # 4-row geometry, per-step kernels + feedback kernel otherwise
@@ -1160,7 +1166,7 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
     lr, wr, pr, gr = run(False)
     # per-step kernels + fused feedback kernel, then (sequences without teacher tokens) the whole sequence in the
     # persistent kernel with the feedback computed inside it
-    for persist in ((False, True) if kind != "mixed" else (False,)):
+    for persist in (False, True):
         lf, wf, pf, gf = run(True, persist)
         assert not hb.persist_aborted(dev), persist
         assert torch.equal(pf, pr), "predictions differ (persist=%s)" % persist
@@ -1329,6 +1335,57 @@ def test_free_running_persistent_decoder_against_oracle_d512():
     _close(ws, ws_o, rtol=2e-4, atol=2e-6, what="attention weights")
     net.zero_grad()
     ((lp * r_lp.to(dev)).sum() + (ws * r_ws.to(dev)).sum()).backward()
+    _close(enc_g.grad, grads_o[0], rtol=1e-3, atol=1e-6, what="d enc_h")
+    got = dict(net.named_parameters())
+    for n, gr in zip(names, grads_o[1:]):
+        _close(got[n].grad, gr, rtol=1e-3, atol=1e-6, what="grad " + n)
+
+
+def test_scheduled_sampling_persistent_decoder_against_oracle_d512():
+    """Scheduled sampling (Decoder.forward with ys and tf_rate < 1, model.py:324-351: one numpy draw per step decides between
+    the teacher's token and the model's own argmax) on the persistent kernels in both directions, against the oracle at
+    D = A = O = 512, B = 32, T' = 100 with the same numpy stream: logits, log-probs, predictions, attention weights and
+    every gradient.  Until round 3 this mode ran on the per-step kernels."""
+    dev = _gpu()
+    import hip_backend as hb
+    import model as M
+    cfg = dict(synth.CFG2)
+    B, Tp = 32, 100
+    w = synth.e2e_weights(cfg, 77)
+    g = torch.Generator().manual_seed(29)
+    enc = (torch.randn(B, Tp, cfg["enc_hidden_dim"], generator=g) * 0.5)
+    enc_lens = sorted([int(v) for v in torch.randint(Tp // 2, Tp + 1, (B,), generator=g)], reverse=True)
+    enc_lens[0] = Tp
+    ys = [torch.randint(3, cfg["output_dim"], (int(n),), generator=g) for n in torch.randint(8, 17, (B,), generator=g)]
+    L = max(len(y) for y in ys) + 1
+    r_lp = torch.randn(B, L, generator=g)
+    r_ws = torch.randn(B, L, Tp, generator=g) * 0.1
+    sd = O.make_leaf_state(w)
+    enc_c = enc.clone().requires_grad_(True)
+    np.random.seed(5)
+    lg_o, lp_o, pred_o, ws_o = O.decoder_forward(sd, enc_c, enc_lens, ys=ys, tf_rate=0.5, label_smoothing=False)
+    names = [n for n in O.unique_param_names(sd) if n.startswith(("attention.", "decoder."))]
+    loss_o = (lp_o * r_lp).sum() + (ws_o * r_ws).sum()
+    grads_o = torch.autograd.grad(loss_o, [enc_c] + [sd[n] for n in names])
+    net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 5), **cfg).to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    net.train()
+    net.decoder.dropout_rate = 0.0
+    enc_g = enc.to(dev).requires_grad_(True)
+    hb.persist_clear_abort(dev)
+    hb.LAUNCHES.clear()
+    np.random.seed(5)
+    with hb.require_persistent():
+        lg, lp, pred, ws = net.decoder(enc_g, enc_lens, ys=[y.to(dev) for y in ys], tf_rate=0.5, label_smoothing=False)
+        assert hb.LAUNCHES["dec_free_persist"] == 1, dict(hb.LAUNCHES)
+        assert torch.equal(pred.cpu(), pred_o), "predictions differ"
+        _close(lg, lg_o, rtol=2e-4, atol=2e-5, what="logits")
+        _close(lp, lp_o, rtol=2e-4, atol=2e-5, what="log-probs")
+        _close(ws, ws_o, rtol=2e-4, atol=2e-6, what="attention weights")
+        net.zero_grad()
+        ((lp * r_lp.to(dev)).sum() + (ws * r_ws.to(dev)).sum()).backward()
+    assert hb.LAUNCHES["dec_bwd_persist"] == 1, dict(hb.LAUNCHES)
+    assert not hb.persist_aborted(dev)
     _close(enc_g.grad, grads_o[0], rtol=1e-3, atol=1e-6, what="d enc_h")
     got = dict(net.named_parameters())
     for n, gr in zip(names, grads_o[1:]):
