@@ -141,7 +141,7 @@ int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const 
  * XCD as LSB-tagged fp32 words.  Applies when H is 128, 256, 320, 512 (or 640 with a bf16 arithmetic) on an 8 x 32-CU
  * device, any nb (row blocks of 32 * (8 / ndir) run as consecutive launches); otherwise returns ASR_E_SHAPE and the
  * caller uses asr_lstm_seq_fwd.  `arith`: product arithmetic of h W_hh^T (ASR_ARITH_*, see above).
- * xch (>= 8 MB) and ctrl (128 B) are caller-allocated scratch.  ctrl = [16 latch words | 16 per-launch words]: the
+ * xch (>= 8 MB; 10 MB for the H = 640 backward) and ctrl (128 B) are caller-allocated scratch.  ctrl = [16 latch words | 16 per-launch words]: the
  * per-launch words and the used part of xch are zeroed on the stream before every launch (one fill when ctrl sits exactly
  * 128 bytes in front of xch, else two).  A kernel that aborts (bounded spin expired / unexpected placement) poisons its
  * outputs with NaN and sets per-launch word 8 (code in word 9) AND latch word 0 (code in latch word 1).  The library
@@ -163,8 +163,9 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
                      const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
                      asr_stream_t stream);
 /* Persistent fast path of asr_lstm_seq_bwd (same conditions / scratch / abort convention as asr_lstm_seq_fwd_persist;
- * H in {128, 256, 320, 512}).  With a bf16 arithmetic and H in {128, 256, 512} - and H = 320 under ASR_ARITH_BF16X6 (10
- * units per CU in 12 slots) - the CUs of a group exchange partial sums of dh_rec, laid out [8 groups][2][32 dest][32 src]
+ * H in {128, 256, 320, 512}, and 640 under ASR_ARITH_BF16X6).  With a bf16 arithmetic and H in {128, 256, 512} - and
+ * H = 320 (10 units per CU in 12 slots) / H = 640 (20 units per CU, its own kernel) under ASR_ARITH_BF16X6 - the CUs of a
+ * group exchange partial sums of dh_rec, laid out [8 groups][2][32 dest][32 src]
  * [8 rows][slots per CU] floats in xch (8 MB at H = 512); otherwise (H = 320 with two terms, ASR_ARITH_F32,
  * ASR_LSTM_BWD_GATHER) every CU gathers the step's dG tile.  Exchanged words carry a 1-bit tag in the
  * mantissa LSB; the in-place dG is what the pointwise update produced.  `arith` selects the product arithmetic of
@@ -177,7 +178,7 @@ int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates
                              const int32_t* lens, const float* dy, const float* c, const float* y,
                              float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
 /* Does asr_lstm_seq_bwd_persist(_w) with this (H, arith) accumulate dW_hh itself when given y and dw_hh?  1 yes; 0 no -
- * the ASR_ARITH_BF16X6 exchanged-partials kernel (H in {128, 256, 320, 512}) leaves dW_hh = sum_t dG_t^T h_{t-1} to the caller
+ * the ASR_ARITH_BF16X6 exchanged-partials kernels (H in {128, 256, 320, 512, 640}) leave dW_hh = sum_t dG_t^T h_{t-1} to the caller
  * (one batched asr_gemm_f32 over the two directions: with six products per product the fused form costs more time on the
  * kernel's serial chain than the GEMM does) and ignores y / dw_hh; -1 no persistent backward for this H / arith.  The
  * bias gradient db is accumulated by every persistent backward kernel. */

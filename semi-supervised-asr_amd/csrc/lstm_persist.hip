@@ -1891,6 +1891,258 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   }
 }
 
+// ------------------------------------------------------ backward, exchanged partials, H = 640 (the judge LM's width)
+// lstm_persist_bwd_rs_kernel's unfused three-term form for 20 units per CU, which its layout does not reach:
+//   * 80 local gate columns = two k-steps of 32 plus ONE OF 16 on v_mfma_f32_16x16x16_bf16 (three full k-steps would be 180
+//     weight registers; this is 150), 40 unit tiles = 5 per wave;
+//   * 5 unit quads per row: DPP rows 0..3 of wave w gather quads 0..3 of row w as there, and row 0 gathers quad 4 on top
+//     (two more quads for its 16 lanes);
+//   * pointwise lanes: lanes 0..3 of DPP row rr -> unit 4 rr + lane, lanes 4..7 of row 0 -> units 16..19.
+// Everything else (exchange layout [dest][src][row][unit], tags, abort handling, stores / prefetches behind the poll, two
+// dG slots, forward-data factors formed in front of the gather) is that kernel's.  dW_hh is left to the caller, db is summed.
+template <int NR>
+__global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs a) {
+  constexpr int PH = 640, NT = 3, PUC = 20, NC = 80, MTW = 5, GST = 96 + 8, NE = 2;
+  constexpr int PARSZ = 32 * 32 * PRG * PUC;      // floats per parity
+  __shared__ __attribute__((aligned(16))) unsigned short dgs[4][2][PRG][GST];   // terms a, b, c + a zero image; two slots
+  __shared__ __attribute__((aligned(16))) float dbs[PRG][4 * PUC];
+  __shared__ int role[2];
+  extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 4 * 2 * PRG * GST; i += PNT) (&dgs[0][0][0][0])[i] = 0;
+  for (int i = tid; i < PRG * 4 * PUC; i += PNT) (&dbs[0][0])[i] = 0.f;
+  int g, slice;
+  take_role(a.ctrl, role, g, slice);
+  if (slice < 0) return;
+  const int T = a.T, B = a.B, ndir = a.ndir;
+  const int d = ndir == 2 ? (g & 1) : 0;
+  const int rowgroup = ndir == 2 ? (g >> 1) : g;
+  const int r0 = rowgroup * NR;
+  if (r0 >= a.nb) return;
+  const int64_t ldy = (int64_t)ndir * PH, ldg = (int64_t)ndir * 4 * PH;
+  const int ml = lane & 15, kq = lane >> 4;
+  // W_hh rows of this CU's 80 columns, all 640 units -> split bf16: lane l holds unit 16 (5 wave + mt) + (l & 15);
+  // full k-steps: columns 32 ks + 8 (l >> 4) + j, tail: columns 64 + 4 (l >> 4) + j
+  u32x4 wt[MTW][2][NT];
+  uint2 wtl[MTW][NT];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int cu = 16 * (MTW * wave + mt) + ml;
+    auto wel = [&](int k) -> float {
+      return a.w_il != nullptr ? a.w_il[((int64_t)d * 4 * PH + NC * slice + k) * PH + cu]
+                               : a.w[((int64_t)d * PH + cu) * (4 * PH) + NC * slice + k];
+    };
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = wel(32 * ks + 8 * kq + j);
+      bfn_split8<NT>(v, wt[mt][ks]);
+    }
+    unsigned p0[NT], p1[NT];
+    bfn_split2<NT>(wel(64 + 4 * kq), wel(64 + 4 * kq + 1), p0);
+    bfn_split2<NT>(wel(64 + 4 * kq + 2), wel(64 + 4 * kq + 3), p1);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) wtl[mt][k] = make_uint2(p0[k], p1[k]);
+  }
+  const int rr = lane >> 4, sp = lane & 15;
+  const int pu = sp < 4 ? 4 * rr + sp : 16 + (sp & 3), pj = wave;
+  const bool pw_lane = sp < 4 || (rr == 0 && sp < 8);
+  const bool pw_thread = pw_lane && pj < NR;
+  const int prow = r0 + pj;
+  const bool prow_ok = pw_thread && prow < a.nb;
+  const int punit = PUC * slice + pu;
+  const int plen = prow_ok ? a.lens[prow] : 0;
+  float dcarry = 0.f;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* xg = reinterpret_cast<float*>(a.xch) + (int64_t)g * (2 * PARSZ);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
+  bool aborted = false;
+  float n1_dy = 0.f, n1_ct = 0.f, n2_dy = 0.f, n2_ct = 0.f;
+  float4 n1_av = make_float4(0.f, 0.f, 0.f, 0.f), n2_av = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto time_of = [&](int sn) { return d == 0 ? T - 1 - sn : sn; };
+  auto fetch_step = [&](int sn, float& o_dy, float& o_ct, float4& o_av) {
+    const int tt = time_of(sn);
+    const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
+    o_dy = a.dy[so];
+    o_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    o_ct = a.c[so];
+  };
+  // gather descriptors: DPP row rr sums the 32 sources of (row = wave, unit quad rr), two sources per lane; row 0 also quad 4
+  const bool guse = wave < NR && r0 + wave < a.nb;
+  unsigned goff[NE], goff4[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const unsigned base = (unsigned)((xg - reinterpret_cast<float*>(a.xch)) + ((slice * 32 + 2 * sp + e) * PRG + (guse ? wave : 0)) * PUC);
+    goff[e] = (base + 4 * rr) * 4u;
+    goff4[e] = (base + 16) * 4u;
+  }
+  u32x4 q[NE], q4[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) q4[e] = (u32x4){0u, 0u, 0u, 0u};
+  if (prow_ok) {
+    fetch_step(0, n1_dy, n1_ct, n1_av);
+    if (T > 1) fetch_step(1, n2_dy, n2_ct, n2_av);
+  }
+  float4 st_da = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* st_gp = nullptr;
+  __syncthreads();                             // LDS zero fill
+  unsigned abort_seen = 0u;
+  for (int s = 0; s < T; ++s) {
+    const int t = time_of(s);
+    if (ASR_ABORT_PERIOD_MASK == 0 || (s & ASR_ABORT_PERIOD_MASK) == 0) {
+      if (pw_thread && flag_load(a.ctrl + 8) != 0u) abort_seen = 1u;
+    }
+    const float dyv = n1_dy, ct_ = n1_ct;
+    const float4 av = n1_av;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_dy) : "v"(n2_dy));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_ct) : "v"(n2_ct));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.x) : "v"(n2_av.x));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.y) : "v"(n2_av.y));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.z) : "v"(n2_av.z));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1_av.w) : "v"(n2_av.w));
+    const float cp = s + 1 < T ? n1_ct : 0.f;                     // c at the time that feeds this one
+    // forward-data factors of the pointwise backward: in front of the gather (see lstm_persist_bwd_rs_kernel)
+    float k_dc = 0.f, k_i = 0.f, k_f = 0.f, k_g = 0.f, k_o = 0.f, k_cn = 0.f;
+    if (pw_thread) {
+      const float tc = asr_fast_tanh(ct_);
+      const bool live = t < plen;
+      k_dc = av.w * (1.f - tc * tc);
+      k_i = live ? av.z * av.x * (1.f - av.x) : 0.f;
+      k_f = live ? cp * av.y * (1.f - av.y) : 0.f;
+      k_g = live ? av.x * (1.f - av.z * av.z) : 0.f;
+      k_o = live ? tc * av.w * (1.f - av.w) : 0.f;
+      k_cn = live ? av.y : 0.f;
+      asm volatile("" : "+v"(k_dc), "+v"(k_i), "+v"(k_f), "+v"(k_g), "+v"(k_o), "+v"(k_cn));
+    }
+    float4* gp = nullptr;
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    // ---------------------------------------------------------------- (1) gather the partials addressed to this CU
+    float dh_rec = 0.f;
+    if (s > 0) {
+      const unsigned tb = tag_bit_of_step(s - 1);
+      const unsigned par = (unsigned)(((s - 1) & 1) * PARSZ) * 4u;
+      unsigned spins = 0;
+      while (true) {
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) q[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[e] + par, 0, 16);
+        if (rr == 0) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) q4[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff4[e] + par, 0, 16);
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ok = ok && (!guse || (quad_ok(q[e], tb) && (rr != 0 || quad_ok(q4[e], tb))));
+        if (__all(ok)) break;
+        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (lane == 0) raise_abort(a.ctrl, 3u);
+          aborted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+      }
+      float v[4] = {__uint_as_float(q[0].x) + __uint_as_float(q[1].x), __uint_as_float(q[0].y) + __uint_as_float(q[1].y),
+                    __uint_as_float(q[0].z) + __uint_as_float(q[1].z), __uint_as_float(q[0].w) + __uint_as_float(q[1].w)};
+      float v4[4] = {__uint_as_float(q4[0].x) + __uint_as_float(q4[1].x), __uint_as_float(q4[0].y) + __uint_as_float(q4[1].y),
+                     __uint_as_float(q4[0].z) + __uint_as_float(q4[1].z), __uint_as_float(q4[0].w) + __uint_as_float(q4[1].w)};
+      row16_sum4(v);                               // every lane of a 16-lane row holds the row's totals
+      row16_sum4(v4);                              // (meaningful in DPP row 0 only)
+      const float pa = (sp & 2) ? ((sp & 1) ? v[3] : v[2]) : ((sp & 1) ? v[1] : v[0]);
+      const float pb = (sp & 2) ? ((sp & 1) ? v4[3] : v4[2]) : ((sp & 1) ? v4[1] : v4[0]);
+      dh_rec = sp < 4 ? pa : pb;
+    }
+    if (st_gp) {                                  // previous step's dG (bulk store after the poll: vmcnt retires in order)
+      *st_gp = st_da;
+      st_gp = nullptr;
+    }
+    if (prow_ok && s + 2 < T) fetch_step(s + 2, n2_dy, n2_ct, n2_av);
+    // ---------------------------------------------------------------- (2) pointwise LSTM backward in the gather lanes
+    if (pw_thread) {
+      const float dh = dyv + dh_rec;
+      const float dc = dcarry + dh * k_dc;
+      float4 da = make_float4(dc * k_i, dc * k_f, dc * k_g, dh * k_o);
+      if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
+      dcarry = dc * k_cn;
+      unsigned p0[NT], p1[NT];
+      bfn_split2<NT>(da.x, da.y, p0);
+      bfn_split2<NT>(da.z, da.w, p1);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][s & 1][pj][4 * pu]) = make_uint2(p0[k], p1[k]);
+      if (prow_ok) {
+        st_da = da;
+        st_gp = gp;
+        dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
+      }
+    }
+    __syncthreads();                                                                                     // B
+    // ---------------------------------------------------------------- (3) partial dh of all units, publish
+    {
+      f32x4 acc[MTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // columns 8..15 of the batch side carry a second term (fold_halves): four MFMAs per tile and k-step
+        const u32x4 b1 = *reinterpret_cast<const u32x4*>(&dgs[ml >> 3][s & 1][ml & 7][32 * ks + 8 * kq]);
+        const u32x4 b2 = *reinterpret_cast<const u32x4*>(&dgs[2 + (ml >> 3)][s & 1][ml & 7][32 * ks + 8 * kq]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], b1, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][1], b1, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][0], b2, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma(wt[mt][ks][2], b1, acc[mt]);
+      }
+      {
+        const uint2 b1 = *reinterpret_cast<const uint2*>(&dgs[ml >> 3][s & 1][ml & 7][64 + 4 * kq]);
+        const uint2 b2 = *reinterpret_cast<const uint2*>(&dgs[2 + (ml >> 3)][s & 1][ml & 7][64 + 4 * kq]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma16(wtl[mt][0], b1, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma16(wtl[mt][1], b1, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma16(wtl[mt][0], b2, acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) acc[mt] = bf3_mfma16(wtl[mt][2], b1, acc[mt]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) fold_halves(acc[mt]);
+      // D: lane l holds units 16 tile + 4 (l >> 4) .. + 3 of batch row l & 15 -> one tagged quad to their owner's slot
+      if (ml < NR && s + 1 < T) {
+        const unsigned bit = tag_bit_of_step(s);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int ug = 16 * (MTW * wave + mt) + 4 * kq;
+          const int dest = ug / PUC, uo = ug - dest * PUC;
+          const unsigned doff = (unsigned)((xg - reinterpret_cast<float*>(a.xch)) + (s & 1) * PARSZ +
+                                           ((dest * 32 + slice) * PRG + ml) * PUC + uo) * 4u;
+          const u32x4 tq = {__float_as_uint(tag_word(acc[mt][0], bit)), __float_as_uint(tag_word(acc[mt][1], bit)),
+                            __float_as_uint(tag_word(acc[mt][2], bit)), __float_as_uint(tag_word(acc[mt][3], bit))};
+          __builtin_amdgcn_raw_buffer_store_b128(tq, xrs, doff, 0, 0);
+        }
+      }
+    }
+  }
+  // an abort raised by another workgroup during the last steps (the flag is sampled every 16th step inside the loop)
+  if (flag_load(a.ctrl + 8) != 0u) {
+    st_da.x = __builtin_nanf("");
+    dbacc.x = __builtin_nanf("");
+  }
+  if (st_gp) *st_gp = st_da;
+  if (a.db != nullptr) {        // one atomic per (unit, gate) and CU; the rows are summed through LDS
+    if (pw_lane) *reinterpret_cast<float4*>(&dbs[pj][4 * pu]) = dbacc;
+    __syncthreads();
+    if (tid < 4 * PUC) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < PRG; ++r) v += dbs[r][tid];
+      atomicAdd(a.db + (int64_t)d * 4 * PH + PUC * slice * 4 + tid, v);
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -1958,8 +2210,10 @@ bool persist_supported(int H) { return H == 128 || H == 256 || H == 320 || H == 
 // exchanged-partials backward: H with a multiple of 4 units per CU; H = 320 (10 units per CU in 12 slots) in the unfused
 // three-term kernel only
 bool rs_supported(int H, int arith) {
-  return H == 128 || H == 256 || H == 512 || (H == 320 && (arith & ASR_ARITH_MASK) == ASR_ARITH_BF16X6);
+  return H == 128 || H == 256 || H == 512 || ((H == 320 || H == 640) && (arith & ASR_ARITH_MASK) == ASR_ARITH_BF16X6);
 }
+// H = 640 (the judge LM): forward on the bf16 kernels, backward on lstm_persist_bwd_rs640_kernel (three terms) only
+bool bwd_persist_width(int H) { return persist_supported(H) || H == 640; }
 int rs_slots_per_cu(int H) { return (H / 32 + 3) / 4 * 4; }
 
 // rows per XCD group: 4 when the whole batch fits 4-row groups (half the MFMA work and gather per step), else 8
@@ -1989,16 +2243,27 @@ int dispatch_fwd(int H, int arith, const PersistArgs& a, hipStream_t stream) {
 // which backward kernel a call takes: 0 fp32 gathered-dG, 1 split gathered-dG, 2 split exchanged partials, -1 none
 int bwd_kernel_kind(int H, int arith) {
   const int ar = arith & ASR_ARITH_MASK;
+  if (H == 640) return (ar == ASR_ARITH_BF16X6 && !(arith & ASR_LSTM_BWD_GATHER)) ? 2 : -1;
   if (ar == ASR_ARITH_F32) return 0;
   if (rs_supported(H, arith) && !(arith & ASR_LSTM_BWD_GATHER)) return 2;
   // the gathered-dG kernel with three terms needs 171 KB of LDS at H = 512
   if (ar == ASR_ARITH_BF16X6 && H > 320) return -1;
   return 1;
 }
+template <int NR>
+int launch_bwd_rs640(const PersistArgs& a, hipStream_t stream) {
+  const size_t pad = 70 * 1024;                      // static (15 KB) + pad > 80 KB: one workgroup per CU
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_rs640_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((lstm_persist_bwd_rs640_kernel<NR>), dim3(256), dim3(PNT), pad, stream, a);
+  return 0;
+}
+
 template <int NR, int NT>
 int dispatch_bwd_split(int H, int kind, const PersistArgs& a, hipStream_t stream) {
   if (kind == 2) {
     if constexpr (NT == 3) {
+      if (H == 640) return launch_bwd_rs640<NR>(a, stream);
       if (H == 320) return launch_bwd_rs<320, NR, 3>(a, stream);
     }
     return H == 512 ? launch_bwd_rs<512, NR, NT>(a, stream) : H == 256 ? launch_bwd_rs<256, NR, NT>(a, stream)
@@ -2040,7 +2305,7 @@ bool asr_persist_device_ok() {
 // caller has to form it (the three-term exchanged-partials kernel: see lstm_persist_bwd_rs_kernel), -1 when no persistent
 // backward kernel applies.  The bias gradient is accumulated by every persistent backward kernel.
 extern "C" int asr_lstm_bwd_persist_fuses_dw(int H, int arith) {
-  if (!persist_supported(H)) return -1;
+  if (!bwd_persist_width(H)) return -1;
   const int kind = bwd_kernel_kind(H, arith);
   if (kind < 0) return -1;
   return (kind == 2 && (arith & ASR_ARITH_MASK) == ASR_ARITH_BF16X6) ? 0 : 1;
@@ -2087,7 +2352,7 @@ static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, floa
                                      float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || (!w_hhT && !w_hh_il) || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B || !arith_ok(arith)) return ASR_E_ARG;
-  if (!persist_supported(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
+  if (!bwd_persist_width(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   const int kind = bwd_kernel_kind(H, arith);
   if (kind < 0) return ASR_E_SHAPE;
   // the forward-layout weights are only read by the exchanged-partials kernel

@@ -493,7 +493,7 @@ DECODE_EARLY_STOP = os.environ.get("ASR_DECODE_EARLY_STOP", "1") != "0"
 _persist_scratch = {}
 # exchange area of the persistent kernels: the largest user is the LSTM backward with exchanged dh partials,
 # [8 groups][2 parities][32 dest][32 src][8 rows][H/32 units] floats = 8 MB at H = 512 (each launcher zeroes what it uses)
-XCH_BYTES = 8 * 2 * 32 * 32 * 8 * 16 * 4
+XCH_BYTES = 8 * 2 * 32 * 32 * 8 * 20 * 4      # the largest user: exchanged dh partials at H = 640 (20 units per CU), 10 MB
 
 # Which path every sequence operator actually took, per process: "<op>_persist" counts launches of the persistent
 # XCD-local kernels, "<op>_step" counts sequences that ran on the per-step kernels instead (persistent path switched off,

@@ -826,11 +826,12 @@ def test_arith_is_per_call_not_process_state():
         assert torch.equal(o, outs[(name, 0)])
 
 
-@pytest.mark.parametrize("B,T,ndir", [(32, 12, 1), (20, 7, 1), (8, 5, 2), (40, 3, 1)])
+@pytest.mark.parametrize("B,T,ndir", [(32, 12, 1), (20, 7, 1), (8, 5, 2), (40, 3, 1), (64, 105, 1), (3, 40, 2), (16, 31, 2)])
 def test_lstm_judge_width_h640(B, T, ndir):
     """H = 640 (the judge LM: config.yaml dis_hidden_dim, reference model.py:466-467): the forward recurrence runs on the
-    persistent split-bf16 kernel (20 units per CU = 5 M tiles), the backward on the per-step kernels; both against the
-    oracle, and the counters say which kernels ran."""
+    persistent split-bf16 kernel (20 units per CU = 5 M tiles), the backward - since round 3 - on its own
+    exchanged-partials kernel (lstm_persist_bwd_rs640_kernel: 80 local gate columns = two k-steps of 32 and one of 16, five
+    unit quads per row); both against the oracle, and the counters say which kernels ran."""
     dev = _gpu()
     import ops
     import hip_backend as hb
@@ -856,7 +857,8 @@ def test_lstm_judge_width_h640(B, T, ndir):
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
     got.backward(dy.transpose(0, 1).contiguous().to(dev))
-    assert hb.LAUNCHES["lstm_fwd_persist"] == 1 and hb.LAUNCHES["lstm_bwd_step"] == 1, dict(hb.LAUNCHES)
+    assert hb.LAUNCHES["lstm_fwd_persist"] == 1 and hb.LAUNCHES["lstm_bwd_persist"] == 1, dict(hb.LAUNCHES)
+    assert not hb.persist_aborted(dev)
     _close(xg.grad, xc.grad, rtol=1e-3, atol=1e-5, what="dx")
     for i, (a, b) in enumerate(zip(gp, cp)):
         _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)

@@ -2,7 +2,7 @@
 encoder, dec 320, batch 4, T=200), cfg-2 (the bench line), cfg-5 (T=1600, batch 8) and the semi-supervised generator
 step of cfg-4 at cfg-2's shape (labeled 32x800 + unlabeled 32x800, judge LM 2x640).  One line per workload.
 
-    python tools/workload_times.py [cfg1 cfg2 cfg5 ssl decode]
+    python tools/workload_times.py [cfg1 cfg2 cfg5 ssl decode judge]
 """
 import os
 import sys
@@ -40,7 +40,33 @@ def timed(step, warm=3, n=8):
     return (time.perf_counter() - t0) / n * 1e3, out
 
 
+def run_judge():
+    """judge_train_one_iteration (solver.py:288-301): the 2 x 640 LM on a text batch of 32 transcripts (cfg-2's label
+    lengths), loss, backward, clip + Adam."""
+    import hip_backend as hb
+    cfg = bench.CFG2
+    judge = M.LM(output_dim=cfg["output_dim"], embedding_dim=256, hidden_dim=640, dropout_rate=0.5, n_layers=2, bos=1,
+                 eos=2, pad=0, ls_weight=0.05, labeldist=synth.labeldist(cfg["output_dim"], 6)).to(dev).train()
+    opt = FlatAdam(judge, lr=1e-3, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0)
+    _, _, ys = bench.global_batch(32, 800, 77)
+    ys_d = [torch.from_numpy(y).to(dev) for y in ys]
+
+    def step():
+        _, lp, _ = judge(ys=ys_d, discrete_input=True)
+        loss = -judge.mask_and_cal_sum(lp, ys=ys_d, mask=None)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    hb.LAUNCHES.clear()
+    ms, loss = timed(step)
+    print("judge B=32 L=%d: %.2f ms/step (loss %.4f)  paths %s" % (max(len(y) for y in ys) + 5, ms, float(loss.detach()),
+          {k: v for k, v in hb.LAUNCHES.items() if "lstm" in k}), flush=True)
+
+
 def run(name):
+    if name == "judge":
+        return run_judge()
     cfg, B, T = WORK[name]
     torch.manual_seed(1000)
     net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 5), **cfg)
@@ -120,5 +146,5 @@ def run(name):
         name, B, B, T, ms, 2 * B / ms * 1e3, float(loss.detach()), det), flush=True)
 
 
-for w in (sys.argv[1:] or ["cfg1", "cfg2", "cfg5", "ssl", "decode"]):
+for w in (sys.argv[1:] or ["cfg1", "cfg2", "cfg5", "ssl", "decode", "judge"]):
     run(w)
