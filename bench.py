@@ -562,6 +562,9 @@ def main():
                        "parallelism": "dp%d" % world, "pad_mode": "global-exact", "launch_mode": "eager",
                        "persistent_kernels": bool(hb.USE_PERSIST), "sequence_op_paths_per_step": paths},
             "loss": final_loss, "allreduce_ms": allreduce_ms,
+            "allreduce": ("%d buckets issued from inside the backward pass (fixed order), awaited before the clip; "
+                          "allreduce_ms = the same bytes as one collective, alone" % len(opt.buf.buckets))
+            if opt.buf.overlap else "one collective over the flat gradient buffer after the backward pass",
             "model_tflops": value * f_train / 1e12,
             "model_tflops_incl_padded_frames": value * f_train_padded / 1e12,
         }

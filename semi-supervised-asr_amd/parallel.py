@@ -143,6 +143,7 @@ class FlatBuffers(object):
     floats so each view stays 16-byte aligned for the kernels."""
 
     NAUX = 4
+    BUCKET_FLOATS = 4 << 20          # 16 MB of gradients per overlapped all-reduce
 
     def __init__(self, params):
         self.params = []
@@ -167,10 +168,86 @@ class FlatBuffers(object):
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[o:o + n].view_as(p.data)
             p.grad = self.flat_g[o:o + n].view_as(p.data)
+        # Overlapped gradient exchange (enable_overlap): the flat buffer is cut into contiguous buckets counted from its END
+        # - autograd finishes the decoder's gradients first and encoder layer 0's last, module order is the reverse - and a
+        # bucket's all-reduce is issued from a post-accumulate hook as soon as its last gradient exists, while the backward
+        # of the layers below is still running.  Buckets are ISSUED IN A FIXED ORDER (0, 1, ...) whatever order they become
+        # ready in, and a rank without a backward (empty shard) issues the same sequence in reduce(): the collectives match
+        # across ranks by construction.
+        self.buckets = []            # (first param index, end param index, lo, hi) in issue order
+        hi_i, acc = len(self.params), 0
+        for i in range(len(self.params) - 1, -1, -1):
+            acc += self.params[i].numel()
+            if acc >= self.BUCKET_FLOATS or i == 0:
+                lo = self.offsets[i]
+                hi = self.offsets[hi_i] if hi_i < len(self.params) else self.total
+                self.buckets.append((i, hi_i, lo, hi))
+                hi_i, acc = i, 0
+        self.bucket_of = [0] * len(self.params)
+        for b, (i0, i1, _, _) in enumerate(self.buckets):
+            for i in range(i0, i1):
+                self.bucket_of[i] = b
+        self.overlap = False
+        self._group = None
+        self._hooks = []
+        self._reset_overlap_state()
+
+    # ---- overlapped exchange
+    def _reset_overlap_state(self):
+        self._pending = [i1 - i0 for (i0, i1, _, _) in self.buckets]
+        self._ready = [False] * len(self.buckets)
+        self._issued = 0
+        self._works = []
+
+    def enable_overlap(self, group=None, force=False):
+        """Issue each bucket's all-reduce from inside the backward pass (one backward per step; see __init__).  No-op in a
+        single process (force: also with a process group of one rank - the RCCL rehearsal a one-GPU box allows)."""
+        if self.overlap or not (dist.is_available() and dist.is_initialized()) or (world() <= 1 and not force):
+            return
+        self.overlap, self._group = True, group
+        for i, p in enumerate(self.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, i=i: self._on_grad(i)))
+
+    def _on_grad(self, i):
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] < 0:
+            raise RuntimeError("FlatBuffers overlap: a second backward pass reached a gradient of this step (one backward "
+                               "per zero_grad() with enable_overlap)")
+        if self._pending[b] == 0:
+            self._ready[b] = True
+            self._issue_ready()
+
+    def _issue_ready(self, force=False):
+        """Issue buckets in index order as far as they are ready (force: all that are left)."""
+        while self._issued < len(self.buckets) and (force or self._ready[self._issued]):
+            i0, i1, lo, hi = self.buckets[self._issued]
+            dst, src, missing = [], [], False
+            for i in range(i0, i1):
+                p, v = self.params[i], self._view(i)
+                if p.grad is None:
+                    missing = True
+                elif p.grad.data_ptr() != v.data_ptr():
+                    dst.append(v)
+                    src.append(p.grad)
+            if missing:                                   # a parameter without a gradient this step: its slice is zero
+                for i in range(i0, i1):
+                    if self.params[i].grad is None:
+                        self._view(i).zero_()
+            if dst:
+                torch._foreach_copy_(dst, src)
+            for i in range(i0, i1):
+                self.params[i].grad = self._view(i)
+            self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
+            self._issued += 1
 
     def zero_grad(self):
         """Detach every .grad: autograd then stores each gradient by reference instead of launching one add kernel per
         parameter into the flat buffer; collect() gathers them with a single multi-tensor copy before the step."""
+        if self.overlap:
+            for w in self._works:                        # a step that was abandoned after its backward
+                w.wait()
+            self._reset_overlap_state()
         for p in self.params:
             p.grad = None
 
@@ -203,7 +280,16 @@ class FlatBuffers(object):
             self.aux[:len(vals)].copy_(torch.stack([v.to(self.aux.device) for v in vals]))
 
     def allreduce_grads(self, group=None):
-        """THE collective of the step: one SUM all-reduce over the flat gradient buffer."""
+        """The gradient exchange of the step.  Default: ONE SUM all-reduce over the flat gradient buffer (+ aux scalars).
+        With enable_overlap(): the buckets not yet issued from the backward pass are issued now (same fixed order on every
+        rank), all are awaited, and the aux scalars travel in a 16-byte collective of their own."""
+        if self.overlap:
+            self._issue_ready(force=True)
+            for w in self._works:
+                w.wait()
+            self._works = []
+            dist.all_reduce(self.aux, op=dist.ReduceOp.SUM, group=self._group)
+            return
         self.collect()
         if world() > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
@@ -216,9 +302,16 @@ class FlatAdam(object):
     state_dict()/load_state_dict() use torch.optim.Adam's schema so `.opt` checkpoints interchange."""
 
     def __init__(self, module_or_params, lr, weight_decay=0.0, amsgrad=False, betas=(0.9, 0.999), eps=1e-8,
-                 max_grad_norm=None):
+                 max_grad_norm=None, overlap=None):
+        """overlap: issue the gradient all-reduce in buckets from inside the backward pass (FlatBuffers.enable_overlap);
+        None = when the process group has more than one rank (ASR_DP_OVERLAP=0 turns it off)."""
         params = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
         self.buf = FlatBuffers(list(params))
+        import os
+        if overlap is None:
+            overlap = os.environ.get("ASR_DP_OVERLAP", "1") != "0"
+        if overlap:
+            self.buf.enable_overlap(force=overlap == "force")
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad,
                                   params=list(range(len(self.buf.params))))]
         self.max_grad_norm = max_grad_norm

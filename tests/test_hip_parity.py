@@ -1513,11 +1513,13 @@ def _rccl_child(out_path):
     dev = torch.device("cuda", 0)
     cfg = dict(synth.TINY)
     res = {}
-    for tag in ("collective", "plain"):
+    parallel.FlatBuffers.BUCKET_FLOATS = 700         # tiny model: several buckets
+    for tag in ("collective", "overlapped", "plain"):
         net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 12), **cfg).to(dev)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.e2e_weights(cfg, 11).items()})
         net.train()
-        opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0)
+        opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0,
+                       overlap="force" if tag == "overlapped" else False)
         xs, ilens, ys = synth.batch(cfg["input_dim"], cfg["output_dim"], synth.TINY_ILENS, synth.TINY_YLENS, 13)
         np.random.seed(5)
         _, lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
@@ -1530,6 +1532,14 @@ def _rccl_child(out_path):
             res["aux"] = opt.buf.aux[:2].tolist()
             res["backend"] = dist.get_backend()
             opt.apply()
+        elif tag == "overlapped":
+            # the data-parallel default: bucket all-reduces issued by post-accumulate hooks from inside the backward pass
+            # (async RCCL collectives on slices of the flat buffer), awaited in reduce(); aux scalars in their own collective
+            assert opt.buf.overlap and len(opt.buf.buckets) >= 3 and opt.buf._issued >= 1, (opt.buf.overlap, opt.buf._issued)
+            opt.buf.set_aux([1.5, 2.5])
+            opt.reduce()
+            res["aux_overlapped"] = opt.buf.aux[:2].tolist()
+            opt.apply()
         else:
             opt.step()
         res[tag] = [float(p.detach().double().abs().sum()) for p in net.parameters()]
@@ -1540,8 +1550,9 @@ def _rccl_child(out_path):
 
 def test_rccl_allreduce_of_the_flat_gradient_buffer(tmp_path):
     """RCCL touched on hardware (world_size 1 is all a one-GPU box allows): a freshly spawned child initialises the `nccl`
-    backend before any other GPU call, pushes the flat gradient buffer (+ aux scalars) through dist.all_reduce and applies
-    the fused clip + Adam; the weights equal those of the non-distributed step."""
+    backend before any other GPU call, pushes the flat gradient buffer (+ aux scalars) through dist.all_reduce - once as ONE
+    collective, once as the overlapped bucket exchange of a data-parallel step (async collectives issued from autograd hooks)
+    - and applies the fused clip + Adam; the weights equal those of the non-distributed step."""
     _gpu()
     import json
     import subprocess
@@ -1554,6 +1565,7 @@ def test_rccl_allreduce_of_the_flat_gradient_buffer(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.load(open(out))
-    assert res["backend"] == "nccl" and res["aux"] == [1.5, 2.5]
-    for a, b in zip(res["collective"], res["plain"]):
-        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (a, b)
+    assert res["backend"] == "nccl" and res["aux"] == [1.5, 2.5] and res["aux_overlapped"] == [1.5, 2.5]
+    for tag in ("collective", "overlapped"):
+        for a, b in zip(res[tag], res["plain"]):
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (tag, a, b)

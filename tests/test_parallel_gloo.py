@@ -200,6 +200,70 @@ def test_two_ranks_equal_one_rank(tmp_path, tf_rate):
     assert err <= 1e-6 * max(scale, 1.0) + 1e-7, (err, scale)
 
 
+def _overlap_grads(rank, world, n_utts, overlap):
+    """Supervised step on the first n_utts utterances of the test batch; with `overlap` the flat buffer is cut into small
+    buckets whose all-reduces are issued from inside the backward pass (FlatBuffers.enable_overlap)."""
+    from oracle import asr_oracle as O
+    import parallel
+    cfg = dict(CFG, labeldist=synth.labeldist(CFG["output_dim"], 12))
+    sd = O.make_leaf_state(synth.e2e_weights(CFG, 11))
+    names = O.unique_param_names(sd)
+    parallel.FlatBuffers.BUCKET_FLOATS = 700              # tiny model: several buckets
+    buf = parallel.FlatBuffers([sd[n] for n in names])
+    assert len(buf.buckets) >= 3 and buf.buckets[0][3] == buf.total and buf.buckets[-1][2] == 0
+    if overlap:
+        buf.enable_overlap()
+        assert buf.overlap == (world > 1)
+    xs, ilens, ys = synth.batch(CFG["input_dim"], CFG["output_dim"], ILENS[:n_utts], YLENS[:n_utts], 13)
+    ys_t = [torch.from_numpy(y) for y in ys]
+    np.random.seed(4)
+    loss = parallel.sup_local_loss(_model_fwd(sd, cfg), xs, ilens, ys_t, 1.0, rank, world, CFG["enc_n_layers"], CFG["subsample"])
+    buf.zero_grad()
+    if loss is not None:
+        loss.backward()
+        if overlap and world > 1:
+            assert buf._issued >= 1, "no bucket was issued from inside the backward pass"
+    buf.set_aux([loss if loss is not None else 0.0])
+    buf.allreduce_grads()
+    assert all(p.grad is not None and p.grad.data_ptr() == buf._view(i).data_ptr() for i, p in enumerate(buf.params))
+    return buf
+
+
+def _worker_overlap(rank, world, port, n_utts, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    buf = _overlap_grads(rank, world, n_utts, True)
+    # a second step on the same buffers: the per-step bucket state is reset by zero_grad()
+    buf2 = _overlap_grads(rank, world, n_utts, True)
+    if rank == 0:
+        torch.save(dict(flat=buf.flat_g.clone(), flat2=buf2.flat_g.clone()), os.path.join(out_dir, "ov.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_utts", [(2, 6), (3, 2)])
+def test_overlapped_bucket_allreduce_equals_one_process(tmp_path, world, n_utts):
+    """The bucketed gradient exchange issued from inside the backward pass (FlatBuffers.enable_overlap: buckets counted from
+    the end of the flat buffer, issued in a fixed order) against the one-process gradients: 2 ranks, and 3 ranks of which
+    one has an empty shard - it runs no backward and issues the same sequence of collectives in allreduce_grads()."""
+    _setup_paths()
+    port = _free_port()
+    mp.spawn(_worker_overlap, args=(world, port, n_utts, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "ov.pt"))
+    import parallel
+    keep = parallel.FlatBuffers.BUCKET_FLOATS
+    try:
+        ref = _overlap_grads(0, 1, n_utts, False).flat_g
+    finally:
+        parallel.FlatBuffers.BUCKET_FLOATS = keep
+    scale = ref.abs().max().item()
+    for k in ("flat", "flat2"):
+        err = (got[k] - ref).abs().max().item()
+        assert scale > 0 and err <= 1e-6 * max(scale, 1.0) + 1e-7, (k, err, scale)
+
+
 def test_shard_is_strided_and_sorted():
     _setup_paths()
     import parallel
