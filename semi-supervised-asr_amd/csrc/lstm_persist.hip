@@ -11,7 +11,7 @@
 //     mantissa LSB is a validity tag, written with plain workgroup-scope stores (they stay in the XCD's L2) and read
 //     with 16-byte sc1 buffer loads that bypass L1.  The data is the flag: no fences, no separate counters, and
 //     correctness does not depend on which CU/XCD a workgroup landed on — only the speed does.  (The first version
-//     used 8-byte {tag = step+1, value} granules and agent-scope atomics: ASR_LSTM_FWD_WORDS 0.)
+//     used 8-byte {tag = step+1, value} granules and agent-scope atomics: 2.35 us per step against 2.05.)
 //   * the gate product runs on v_mfma_f32_4x4x1_16b_f32: its 16 blocks are this CU's 16 units, A = the 4 gates
 //     of a unit (one W register per k), B = 4 batch rows of h; K accumulates over instructions, so the 4 gate
 //     pre-activations of a (unit, row) land in one lane and the pointwise update needs no shuffles.  The 8
@@ -29,11 +29,6 @@
 #endif
 #ifndef ASR_LSTM_BWD_B128      /* hand-off rows of the backward read with one 16-byte sc1 buffer load each */
 #define ASR_LSTM_BWD_B128 1
-#endif
-#ifndef ASR_LSTM_FWD_WORDS
-#define ASR_LSTM_FWD_WORDS 2      /* forward hand-off: 0 = 8-byte {tag,value} granules + sentinel (2.35 us/step),
-                                     1 = single-stage LSB-tagged words read as 8-byte atomics (2.38-2.45),
-                                     2 = the same words read with 16-byte sc1 buffer loads (2.05) */
 #endif
 #ifndef ASR_LSTM_TOUCH
 #define ASR_LSTM_TOUCH 1
@@ -108,9 +103,6 @@ struct PersistArgs {
 template <int PH, int NR>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   static_assert(NR == 4 || NR == PRG, "rows per group");
-#if ASR_LSTM_FWD_WORDS == 1
-  static_assert(NR == PRG, "the 8-byte word protocol is only written for 8 rows");
-#endif
   constexpr int PKW = PH / PW;     // K columns per wave
   constexpr int PUC = PH / 32;     // hidden units per CU (<= 16 MFMA blocks)
   // this wave's K range of h_{t-1}; rows padded by 4 floats so the 4 rows a ds_read_b128 touches (the MFMA blocks
@@ -152,10 +144,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   u64* xch_g = a.xch + (int64_t)g * PRG * PH;          // + parity * 8*PRG*PH
   float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * PRG;   // word protocol: [parity][unit][row]
   const int64_t par_stride = (int64_t)8 * PRG * PH;
-#if ASR_LSTM_FWD_WORDS == 2
   typedef unsigned u4v __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
-#endif
   bool aborted = false;
   // The x-projection rows are fetched TWO steps ahead: they are HBM first-touch loads (~2 us under load, about one
   // forward step), vmcnt retires in order, and the row is consumed at the top of its step -- one step of distance
@@ -188,7 +178,6 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-#if ASR_LSTM_FWD_WORDS == 2
       // Single-stage hand-off, 16-byte reads: h_{t-1} travels as LSB-tagged fp32 words laid out [unit][row], so the rows
       // of a lane's unit are contiguous and one sc1 buffer load (two for 8 rows) is data and flag at once: no sentinel
       // round trip, and a quarter of the load instructions of the 8-byte granule protocol.
@@ -216,104 +205,16 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
         }
         __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
       }
-#elif ASR_LSTM_FWD_WORDS
-      // Single-stage hand-off: h_{t-1} travels as LSB-tagged fp32 words laid out [unit][row], so a lane's 8 rows are
-      // 32 contiguous bytes = four 8-byte L1-bypassing loads that are data and flag at once (no sentinel round trip:
-      // publish -> first seen is ~0.5 us, a second dependent round trip for the tile costs another ~0.55 us).
-      const bool gl = lane < PKW;
-      const u64* src = reinterpret_cast<const u64*>(xw_g + ((s - 1) & 1) * (PH * PRG) +
-                                                    (int64_t)(wave * PKW + (gl ? lane : 0)) * PRG);
-      const u64 tm = 0x0000000100000001ull, texp = tag_bit_of_step(s - 1) ? tm : 0ull;
-      u64 gr[PRG / 2];
-      unsigned spins = 0;
-      while (true) {
-#pragma unroll
-        for (int rr = 0; rr < PRG / 2; ++rr) gr[rr] = granule_load(src + rr);
-        bool ok = true;
-#pragma unroll
-        for (int rr = 0; rr < PRG / 2; ++rr) ok = ok && ((gr[rr] & tm) == texp);
-        LP_MARK(7);
-        if (__all(!gl || ok)) break;
-#ifdef ASR_NO_POLL
-        break;
-#endif
-        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) raise_abort(a.ctrl, 1u);
-          aborted = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
-      }
-#else
-      // gather this wave's K range of h_{t-1}: 8 rows x 64 units of granules tagged s
-      const u64* src = xch_g + ((s - 1) & 1) * par_stride + wave * PKW + (lane < PKW ? lane : 0);
-      const bool gl = lane < PKW;                       // lanes beyond the wave's K range re-read column 0
-      u64 gr[NR];
-      unsigned spins = 0;
-      while (true) {
-        bool done = false;
-        if (wave < ASR_LSTM_FULL_WAVES) {
-          // The pointwise waves reach this poll last (after the cell update), when the other CUs' rows have already
-          // landed (0 failed polls in tools/lstm_trace.py): all 8 rows are requested at once, one L2 round trip
-          // (~1 200 cycles under load) instead of sentinel + tile on the step's critical path.  Separate code path:
-          // written as `full || sentinel_ok` the compiler still waited for the sentinel before issuing the rest.
-#pragma unroll
-          for (int rr = 0; rr < NR; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
-          bool ok = true;
-#pragma unroll
-          for (int rr = 0; rr < NR; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
-          LP_MARK(7);
-          done = __all(!gl || ok);
-        } else {
-          // the other waves arrive early and spin: cheap sentinel read of the last row first (see backward)
-          gr[NR - 1] = granule_load(src + (int64_t)(NR - 1) * PH);
-#ifdef ASR_LP_TRACE3   /* ... and when lane 0 of (slice 0, wave 7) first sees that granule valid */
-          if (g == 0 && slice == 0 && tid == 448 && s - 1 < 64 && (unsigned)(gr[NR - 1] >> 32) == (unsigned)s &&
-              ((unsigned long long*)a.ctrl)[16 + 2 * (s - 1) + 1] == 0ull)
-            ((unsigned long long*)a.ctrl)[16 + 2 * (s - 1) + 1] = wall_clock64();
-#endif
-          if (__all(!gl || (unsigned)(gr[NR - 1] >> 32) == (unsigned)s)) {
-            LP_MARK(7);
-#pragma unroll
-            for (int rr = 0; rr < NR - 1; ++rr) gr[rr] = granule_load(src + (int64_t)rr * PH);
-            bool ok = true;
-#pragma unroll
-            for (int rr = 0; rr < NR - 1; ++rr) ok = ok && ((unsigned)(gr[rr] >> 32) == (unsigned)s);
-            done = __all(!gl || ok);
-          }
-        }
-        if (done) break;
-#ifdef ASR_NO_POLL
-        break;
-#endif
-        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
-          if (lane == 0) raise_abort(a.ctrl, 1u);
-          aborted = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
-      }
-#endif
       LP_MARK(1);
 #ifdef ASR_LP_TRACE
       if (tid == 0 && g == 0 && slice == 0 && s >= 8 && s < 16) ((unsigned long long*)(a.ctrl + 16))[(s - 8) * 16 + 8] = spins;
 #endif
-#if ASR_LSTM_FWD_WORDS == 2
 #pragma unroll
       for (int j = 0; j < NR / 4; ++j)
         if (gl) {
           hs[wave][4 * j][lane] = __uint_as_float(gw[j].x); hs[wave][4 * j + 1][lane] = __uint_as_float(gw[j].y);
           hs[wave][4 * j + 2][lane] = __uint_as_float(gw[j].z); hs[wave][4 * j + 3][lane] = __uint_as_float(gw[j].w);
         }
-#elif ASR_LSTM_FWD_WORDS
-#pragma unroll
-      for (int rr = 0; rr < PRG / 2; ++rr)
-        if (gl) { hs[wave][2 * rr][lane] = pair_lo(gr[rr]); hs[wave][2 * rr + 1][lane] = pair_hi(gr[rr]); }
-#else
-#pragma unroll
-      for (int rr = 0; rr < NR; ++rr)
-        if (gl) hs[wave][rr][lane] = __uint_as_float((unsigned)gr[rr]);
-#endif
       if (st_gp) {                    // previous step's outputs (see above)
         *st_gp = st_g;
         a.c[st_so] = st_c;
@@ -375,11 +276,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
       if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
       LP_MARK(5);
-#if ASR_LSTM_FWD_WORDS
       word_store(xw_g + (s & 1) * (PH * PRG) + (int64_t)punit * PRG + pj, hn, tag_bit_of_step(s));       // hand-off first
-#else
-      granule_store(xch_g + (s & 1) * par_stride + (int64_t)pj * PH + punit, (unsigned)(s + 1), hn);   // hand-off first
-#endif
 #ifdef ASR_LP_TRACE3   /* visibility probe: global 100 MHz clock at the publish of (slice 28, row 7, its first unit) ... */
       if (g == 0 && slice == 28 && tid == 7 && s < 64) ((unsigned long long*)a.ctrl)[16 + 2 * s] = wall_clock64();
 #endif
