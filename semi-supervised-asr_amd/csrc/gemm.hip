@@ -12,7 +12,7 @@
 #ifndef ASR_GEMM_BF3_TOUCH      /* L2 warm-up distance of the split-bf16 kernel in K tiles (2, 4, 6, 10 measured within 5 %: tools/gemm_cold_sweep.py; the kernel is bound by operand traffic at 32 flop/byte per 128x128 tile, not by latency) */
 #define ASR_GEMM_BF3_TOUCH 2
 #endif
-#ifndef ASR_GB_ABL               /* measurement only: 1 no products, 2 no operand loads after the first tile, 4 no LDS staging */
+#ifndef ASR_GB_ABL               /* measurement only: 1 no products, 2 no operand loads after the first tile, 4 no LDS staging, 8 no epilogue stores */
 #define ASR_GB_ABL 0
 #endif
 #ifndef ASR_GLDS_CLOBBER_M0
@@ -540,6 +540,17 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
     }
   }
 
+#if ASR_GB_ABL & 8   /* measurement: no epilogue stores (one lane keeps the accumulators alive) */
+  if (threadIdx.x + blockIdx.x + blockIdx.y != 0 || g.M != 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
+    return;
+  }
+#endif
   // epilogue (as gemm_f32_kernel: the C/D lane map of the 32x32 MFMAs does not depend on the input type)
   if (m0 + BM <= g.M && n0 + BN <= g.N) {
     const unsigned ldc = (unsigned)g.ldc;
