@@ -208,6 +208,15 @@ class FlatBuffers(object):
         for i, p in enumerate(self.params):
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, i=i: self._on_grad(i)))
 
+    def disable_overlap(self):
+        """Back to ONE collective after the backward pass (removes the hooks; outstanding collectives are awaited)."""
+        for w in self._works:
+            w.wait()
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.overlap = [], False
+        self._reset_overlap_state()
+
     def _on_grad(self, i):
         b = self.bucket_of[i]
         self._pending[b] -= 1

@@ -125,8 +125,15 @@ class Solver(object):
             att_odim=cfg["att_odim"], output_dim=len(self.vocab), embedding_dim=cfg["embedding_dim"],
             ls_weight=cfg["ls_weight"], labeldist=self.labeldist, pad=self.vocab["<PAD>"], bos=self.vocab["<BOS>"],
             eos=self.vocab["<EOS>"]))
+        # `dp_overlap` (not a reference key): issue the gradient all-reduce in buckets from inside the backward pass
+        # (parallel.FlatBuffers.enable_overlap).  Off by default HERE: an RCCL kernel that is resident while a persistent
+        # kernel is being placed could - if the two do not fit a CU together and a rank is late - hold that kernel's
+        # workgroups back until its bounded spins expire, and a data-parallel step cannot repair an abort locally
+        # (_dp_step raises).  bench.py turns it on and falls back by itself; turn it on here once a multi-GPU run has
+        # shown the latch stays clear.
+        overlap = bool(cfg.get("dp_overlap", False))
         self.gen_opt = FlatAdam(self.model, lr=cfg["learning_rate"], weight_decay=cfg["weight_decay"], amsgrad=True,
-                                max_grad_norm=cfg["max_grad_norm"])
+                                max_grad_norm=cfg["max_grad_norm"], overlap=overlap)
         if load_model:
             self.load_model(cfg["load_model_path"], cfg["load_optimizer"])
         self.judge = cc(LM(
@@ -134,7 +141,7 @@ class Solver(object):
             dropout_rate=cfg["dis_dropout_rate"], n_layers=cfg["dis_layers"], bos=self.vocab["<BOS>"],
             eos=self.vocab["<EOS>"], pad=self.vocab["<PAD>"], ls_weight=cfg["ls_weight"],
             labeldist=self.unlab_labeldist))
-        self.dis_opt = FlatAdam(self.judge, lr=cfg["d_learning_rate"], max_grad_norm=cfg["max_grad_norm"])
+        self.dis_opt = FlatAdam(self.judge, lr=cfg["d_learning_rate"], max_grad_norm=cfg["max_grad_norm"], overlap=overlap)
         if self.rank == 0:
             print(self.model)
             print(self.judge)
