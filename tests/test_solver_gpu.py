@@ -326,7 +326,9 @@ def _dp_worker(rank, world, port, root, out):
     try:
         torch.manual_seed(0)
         # per-GPU batch 3 on 2 ranks == batch 6 in one process; numpy_seed makes the single process draw like the ranks
-        solver, dev = _tiny_solver(root, mpatch, batch_size=6 // world, numpy_seed=0, shuffle=False)
+        # dp_overlap: the 2-rank run exchanges its gradients in buckets issued from inside the backward pass
+        solver, dev = _tiny_solver(root, mpatch, batch_size=6 // world, numpy_seed=0, shuffle=False, dp_overlap=True)
+        assert solver.gen_opt.buf.overlap == (world > 1)
         scalars = []
         data = next(iter(solver.train_lab_loader))
         from utils import to_gpu, cc
