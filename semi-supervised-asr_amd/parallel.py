@@ -111,7 +111,12 @@ def ssl_local_loss(model_fwd, judge_probs, lab, unlab, rank, world_size, eos, un
                                        total_length=padded_lengths(u_info["t_max"], n_layers, subsample))
         mask = (u_pred != eos).float()
         count += mask.sum()
-    work = global_sum_async(count, group)                 # 4 bytes; overlaps the judge and the labeled pass
+    # 4 bytes.  Awaited on the spot (a stream-level wait): an RCCL kernel left resident while the persistent kernels of
+    # the judge and the labeled pass are being placed would, with a late rank, hold their workgroups back
+    work = global_sum_async(count, group)
+    if work is not None:
+        work.wait()
+        work = None
     if u_il:
         num = -torch.sum(judge_probs(u_pred) * u_lp * mask)
     sup = sup_local_loss(model_fwd, lab_xs, lab_ilens, lab_ys, 1.0, rank, world_size, n_layers, subsample)
