@@ -533,6 +533,20 @@ def main():
     if rank == 0:
         note("timing %d steps (%s)" % (args.steps, args.arith))
     el, loss = timed(args.steps)
+    # the same check behind the timed steps: a number from NaN-poisoned steps is no number - fall back and time again
+    for _ in range(2):
+        if not any_abort():
+            break
+        if opt.buf.overlap:
+            note("persistent kernel aborted in the timed steps (code %d): again without the overlapped gradient exchange"
+                 % hb.persist_abort_code(dev))
+            hb.persist_clear_abort(dev)
+        else:
+            note("persistent kernel aborted in the timed steps (code %d): again on the per-step kernels" % hb.persist_abort_code(dev))
+            hb.disable_persistent(dev)
+        restart(False)
+        hb.LAUNCHES.clear()
+        el, loss = timed(args.steps)
     final_loss = float(loss.item()) * (world if world > 1 else 1)
     paths = {k: v // max(1, args.steps) for k, v in sorted(hb.LAUNCHES.items())}
     # the gradient all-reduce alone (68.7 MB at cfg-2), outside the timed region
