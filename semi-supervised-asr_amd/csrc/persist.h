@@ -16,7 +16,10 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-constexpr unsigned SPIN_LIMIT = 400000u;
+// ~1 us per attempt (round trip + s_sleep): a wait gives up after ~1-2 s.  Long enough for a workgroup of the same launch
+// that is still waiting for its CU (another kernel - e.g. a collective that waits for a late rank - holding resources
+// there), short enough that a placement that can never complete ends in an abort, not in a hang.
+constexpr unsigned SPIN_LIMIT = 2000000u;
 
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; }
 
