@@ -502,6 +502,10 @@ def main():
     # The persistent XCD-local kernels need one workgroup per CU (an exclusive, unpartitioned MI355X).  If one aborted
     # during the warm-up (NaN-poisoned outputs, sticky abort latch set) every rank falls back to the per-step HIP kernels
     # and the timed steps measure those; `config.persistent_kernels` says which path the number is for.
+    inject = os.environ.get("ASR_BENCH_INJECT_ABORT", "")      # rehearsal of the fallbacks below: "warmup" / "timed" sets the
+    if inject == "warmup":                                     # latch from the host once, as an aborting kernel would
+        hb.persist_abort_flag(dev).fill_(1)
+
     def any_abort():
         flag = torch.tensor([1.0 if hb.persist_aborted(dev) else 0.0], device=dev)
         if world > 1:
@@ -533,6 +537,8 @@ def main():
     if rank == 0:
         note("timing %d steps (%s)" % (args.steps, args.arith))
     el, loss = timed(args.steps)
+    if inject == "timed":
+        hb.persist_abort_flag(dev).fill_(1)
     # the same check behind the timed steps: a number from NaN-poisoned steps is no number - fall back and time again
     for _ in range(2):
         if not any_abort():
