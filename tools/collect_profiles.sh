@@ -9,6 +9,7 @@ grep -v "^[WE]20[0-9]* \|amdgpu.ids" $O/gemm_shapes.txt > profiles/${R}_gemm_sha
 grep -v "^[WE]20[0-9]* \|amdgpu.ids" $O/persist_bench.txt > profiles/${R}_persist_bench.txt
 grep -v "^[WE]20[0-9]* \|amdgpu.ids" $O/workload_times.log > profiles/${R}_workload_times.log
 tail -3 $O/tests.log > profiles/${R}_gpu_tests.txt
+[ -f $O/ssl_judge_kernel_stats.csv ] && cp $O/ssl_judge_kernel_stats.csv profiles/${R}_ssl_judge_kernel_stats.csv
 cp $O/r03_pmc_mfma.json profiles/${R}_pmc_mfma.json
 cp $O/r03_pmc_lstm_persist.json profiles/${R}_pmc_lstm_persist.json
 cp $O/r03_pmc_FETCH_SIZE_lstm_persist.csv profiles/${R}_pmc_FETCH_SIZE_lstm_persist.csv 2>/dev/null

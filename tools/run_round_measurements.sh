@@ -14,4 +14,5 @@ timeout -k 10 300 python bench.py --scaling strong --global-batch 256 --steps 5 
 (cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o r3 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-layer-gemms --no-also > $O/prof.log 2>&1; python3 tools/db_to_stats.py $O/prof/r3_results.db $O/kernel_stats.csv) &&
 (cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o f -- python3 tools/pmc_probe.py > $O/pmc_f.log 2>&1; timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o w -- python3 tools/pmc_probe.py > $O/pmc_w.log 2>&1; python3 tools/pmc_summary.py $O/pmc_f/f_counter_collection.csv $O/pmc_w/w_counter_collection.csv $O/r03_pmc_lstm_persist.json > $O/pmc_summary.log 2>&1; tail -3 $O/pmc_summary.log) &&
 (cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && for A in bf16x6 bf16x3 f32; do timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma_$A -o m -- python3 tools/pmc_mfma_probe.py $A > $O/mfma_$A.log 2>&1; python3 tools/pmc_mfma_summary.py $O/mfma_$A/m_counter_collection.csv $A $O/r03_pmc_mfma.json > $O/mfma_sum_$A.log 2>&1; tail -1 $O/mfma_$A.log; done) &&
-(python3 tools/timeline.py $O/prof/r3_results.db > $O/timeline.txt 2>&1; tail -1 $O/timeline.txt; timeout -k 10 300 python3 tools/gemm_shapes.py > $O/gemm_shapes.txt 2>&1; tail -1 $O/gemm_shapes.txt; timeout -k 10 200 python3 tools/persist_bench.py 400 > $O/persist_bench.txt 2>&1; tail -2 $O/persist_bench.txt; timeout -k 10 300 python3 tools/workload_times.py > $O/workload_times.log 2>&1; tail -8 $O/workload_times.log)
+(python3 tools/timeline.py $O/prof/r3_results.db > $O/timeline.txt 2>&1; tail -1 $O/timeline.txt; timeout -k 10 300 python3 tools/gemm_shapes.py > $O/gemm_shapes.txt 2>&1; tail -1 $O/gemm_shapes.txt; timeout -k 10 200 python3 tools/persist_bench.py 400 > $O/persist_bench.txt 2>&1; tail -2 $O/persist_bench.txt; timeout -k 10 300 python3 tools/workload_times.py > $O/workload_times.log 2>&1; tail -8 $O/workload_times.log) &&
+(cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_ssl -o ssl -- python3 tools/workload_times.py ssl judge > $O/prof_ssl.log 2>&1; python3 tools/db_to_stats.py $O/prof_ssl/ssl_results.db $O/ssl_judge_kernel_stats.csv | tail -1)
