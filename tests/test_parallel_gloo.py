@@ -200,7 +200,7 @@ def test_two_ranks_equal_one_rank(tmp_path, tf_rate):
     assert err <= 1e-6 * max(scale, 1.0) + 1e-7, (err, scale)
 
 
-def _overlap_grads(rank, world, n_utts, overlap):
+def _overlap_grads(rank, world, n_utts, overlap, then_disable=False):
     """Supervised step on the first n_utts utterances of the test batch; with `overlap` the flat buffer is cut into small
     buckets whose all-reduces are issued from inside the backward pass (FlatBuffers.enable_overlap)."""
     from oracle import asr_oracle as O
@@ -226,6 +226,20 @@ def _overlap_grads(rank, world, n_utts, overlap):
     buf.set_aux([loss if loss is not None else 0.0])
     buf.allreduce_grads()
     assert all(p.grad is not None and p.grad.data_ptr() == buf._view(i).data_ptr() for i, p in enumerate(buf.params))
+    if then_disable:
+        # bench.py's first fallback: back to ONE collective on the same buffers (hooks removed), same gradients
+        first = buf.flat_g.clone()
+        buf.disable_overlap()
+        assert not buf.overlap and not buf._hooks
+        np.random.seed(4)
+        loss = parallel.sup_local_loss(_model_fwd(sd, cfg), xs, ilens, ys_t, 1.0, rank, world, CFG["enc_n_layers"], CFG["subsample"])
+        buf.zero_grad()
+        if loss is not None:
+            loss.backward()
+            assert buf._issued == 0
+        buf.set_aux([loss if loss is not None else 0.0])
+        buf.allreduce_grads()
+        assert torch.allclose(buf.flat_g, first, rtol=0, atol=1e-7 * max(1.0, float(first.abs().max())))
     return buf
 
 
@@ -236,7 +250,7 @@ def _worker_overlap(rank, world, port, n_utts, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     buf = _overlap_grads(rank, world, n_utts, True)
     # a second step on the same buffers: the per-step bucket state is reset by zero_grad()
-    buf2 = _overlap_grads(rank, world, n_utts, True)
+    buf2 = _overlap_grads(rank, world, n_utts, True, then_disable=True)
     if rank == 0:
         torch.save(dict(flat=buf.flat_g.clone(), flat2=buf2.flat_g.clone()), os.path.join(out_dir, "ov.pt"))
     dist.barrier()
