@@ -496,6 +496,11 @@ def main():
 
     if rank == 0:
         note("%s, %d utterances per GPU x %d GPU(s), T=%d: warmup" % (args.config, b_local, world, t_frames))
+    if world > 1:
+        # communicator set-up (lazy in the first collective) and rank alignment before the first step, not inside its
+        # backward pass
+        dist.all_reduce(torch.zeros(1, device=dev))
+        fence()
     for _ in range(args.warmup):
         step()
     fence()
