@@ -62,6 +62,7 @@ int asr_abi_version(void);
 #define ASR_ARITH_MASK       0xff
 #define ASR_GEMM_TILE_NARROW 0x100
 #define ASR_GEMM_TILE_WIDE   0x200
+#define ASR_GEMM_TILE_SP     0x800
 #define ASR_LSTM_BWD_GATHER  0x400
 
 /* ---------------------------------------------------------------------------------------

@@ -101,6 +101,25 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
+
+// Tile id -> (tile row, tile column).  Consecutive ids walk down GM tile rows, then step one tile column (groups of GM
+// rows x all columns): the 32 workgroups an XCD runs at one time (its CUs take consecutive ids of the XCD's contiguous
+// chunk) then cover a GM x (32 / GM) block of tiles instead of one tile row x 32 columns, i.e. 32 / GM + GM operand
+// panels per K tile in the XCD's L2 instead of 33.  The operand fetch of the split-bf16 kernels runs at what ONE CU can
+// pull through its memory path (~11 B / cycle from the Infinity Cache, ~30 from L2; they need 16 - 21 B / cycle), so L2
+// hits are what the main loop's speed is made of.
+#ifndef ASR_GEMM_GM
+#define ASR_GEMM_GM 4
+#endif
+__device__ __forceinline__ void tile_coords(int tid, int tiles_m, int tiles_n, int gm_, int& tm, int& tn) {
+  const int per = gm_ * tiles_n;
+  const int grp = tid / per, in = tid - grp * per;
+  const int first = grp * gm_;
+  const int rows = tiles_m - first < gm_ ? tiles_m - first : gm_;
+  tm = first + in % rows;
+  tn = in / rows;
+}
+
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int SA = TileCfg<AKC>::S, SB = TileCfg<BKC>::S;
@@ -1196,6 +1215,422 @@ __global__ __launch_bounds__(512) void gemm_bf6w_kernel(GemmArgs g) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------ split-bf16, one wave per SIMD
+// gemm_bfs_kernel: 256 x 128 output tile per workgroup of FOUR waves - one per SIMD, up to 512 registers each - and the
+// whole pipeline of a K tile inside the instruction stream of every wave.  Why: two waves on one SIMD do not overlap one's
+// split arithmetic with the other's MFMAs (measured with a two-group ping-pong variant of gemm_bf3_kernel: the staging
+// phase takes 2 900 - 4 400 cycles beside the partner's matrix phase, 900 alone), while VALU / LDS / VMEM instructions of
+// the SAME wave hide in its own MFMA gaps as long as there are at most ~5 per 32-cycle MFMA.  So:
+//   * operands come in through registers (global_load_dwordx4, two K tiles ahead: 96 staging registers), are split ONCE
+//     per workgroup into NT bf16 images in LDS (5.5 VALU per element; per wave and K tile 264 VALU + 36 ds_write_b64 next
+//     to 96 MFMAs of 32 cycles = 3.6 fillers per MFMA gap, where the fragment-splitting wide kernel has 5.6 per gap and
+//     two waves per SIMD), and every wave reads its fragments (128 x 64 accumulator = 4 x 2 blocks of 32 x 32) by
+//     ds_read_b128 from the images;
+//   * images are double-buffered (2 x 72 KB with three terms), one s_barrier per K tile, in its middle:
+//       part A of K tile s: 48 MFMAs on k 0-15 (fragment set F0)  || read F1 = k 16-31 of image s
+//                                                                  || split + write units 6-11 of image s + 1, reload their registers with K tile s + 3
+//       barrier (image s + 1 complete; image s no longer read)
+//       part B:             48 MFMAs on k 16-31 (F1)               || read F0 = k 0-15 of image s + 1
+//                                                                  || split + write units 0-5 of image s + 2 (into image s's buffer), reload with K tile s + 4
+//   * image rows are 64 bytes (32 k), the 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3): fragment reads and
+//     8-byte writes are conflict-free without padding.
+// Shapes: K % 32 == 0, 16-byte aligned rows, M and N free (edge tiles clamp their source rows / columns and guard their
+// stores), row-contiguous operands need a multiple of 4 rows: the wide kernels' conditions.
+constexpr int SM = 256, SN = 128, SK = 32;
+constexpr int SP_A = SM * SK, SP_B = SN * SK;          // bf16 elements of one image
+#ifndef ASR_GS_ABL      /* measurement only: 1 no products, 2 no split arithmetic / image writes after the prologue, 4 no operand loads after the prologue, 8 no epilogue stores */
+#define ASR_GS_ABL 0
+#endif
+#ifndef ASR_GS_PAT      /* filler pattern inside a slot (measurement) */
+#define ASR_GS_PAT 0
+#endif
+#ifndef ASR_GS_NOBAR    /* measurement only (wrong results): no barrier in the K loop */
+#define ASR_GS_NOBAR 0
+#endif
+#ifndef ASR_GS_SCHED    /* 1: pin the MFMA / filler interleave with sched_group_barrier */
+#define ASR_GS_SCHED 3
+#endif
+
+typedef unsigned gu32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) gu32x2* lds_u2ptr;
+typedef __attribute__((address_space(3))) const gu32x4* lds_q4ptr;
+typedef __attribute__((address_space(3))) char* lds_cptr;
+
+// split four consecutive k of one row and store them into the NT images at LDS byte address a, a + plane, a + 2 plane
+template <int NT>
+__device__ __forceinline__ void bfs_write4(unsigned a, int plane, float x0, float x1, float x2, float x3) {
+  unsigned p0[NT], p1[NT];
+#if ASR_GS_ABL & 32      /* measurement: no split arithmetic (raw bits as terms) */
+  p0[0] = __float_as_uint(x0); p0[1] = __float_as_uint(x1); p1[0] = __float_as_uint(x2); p1[1] = __float_as_uint(x3);
+  if constexpr (NT > 2) { p0[2] = p0[0] ^ p1[1]; p1[2] = p0[1] ^ p1[0]; }
+#else
+  bfn_split2<NT>(x0, x1, p0);
+  bfn_split2<NT>(x2, x3, p1);
+#endif
+#if ASR_GS_ABL & 16      /* measurement: no image writes (the split stays) */
+  asm volatile("" ::"v"(p0[0]), "v"(p0[1]), "v"(p1[0]), "v"(p1[1]));
+  if constexpr (NT > 2) asm volatile("" ::"v"(p0[2]), "v"(p1[2]));
+  return;
+#endif
+  *(lds_u2ptr)(a) = gu32x2{p0[0], p1[0]};
+  *(lds_u2ptr)(a + plane) = gu32x2{p0[1], p1[1]};
+  if constexpr (NT > 2) *(lds_u2ptr)(a + 2 * plane) = gu32x2{p0[2], p1[2]};
+}
+
+template <bool AKC, bool BKC, int NT, bool KT>
+__global__ __launch_bounds__(256, 1) void gemm_bfs_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NT * (SP_A + SP_B)];
+  constexpr int PLA = 2 * SP_A, PLB = 2 * SP_B;        // bytes of one A / B image
+  constexpr int BUFB = NT * (PLA + PLB);               // bytes of one buffer: NT A images, then NT B images
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  int tid = blockIdx.x;
+  {
+    const int q = ntile >> 3, rmd = ntile & 7, xcd = tid & 7, idx = tid >> 3;
+    tid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
+  }
+  int tm, tn;
+  tile_coords(tid, g.tiles_m, g.tiles_n, ASR_GEMM_GM, tm, tn);
+  const int z = blockIdx.y;
+  const int bz = z / g.split_k, kz = z % g.split_k;
+  float* C = g.C + bz * g.sC;
+  const int64_t m0 = (int64_t)tm * SM, n0 = (int64_t)tn * SN;
+  const int64_t ktiles = KT ? (g.K + SK - 1) / SK : g.K / SK;         // KT: K % 32 != 0 (K % 4 == 0): the last K tile is masked
+  const int64_t per = (ktiles + g.split_k - 1) / g.split_k;
+  const int64_t kt_begin = kz * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int S = (int)(kt_end - kt_begin);
+  if (S <= 0) return;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  // ---- operands through buffer resources: wave-uniform base (batch element, first k of this K slice) + this thread's
+  // byte offset of each of its 8 + 4 float4 pieces (VGPR, computed once) + the K tile's byte offset (SGPR): no address
+  // arithmetic in the loop.  Rows and columns past the edge are clamped to the last valid ones (they only reach
+  // accumulators the guarded epilogue drops).
+  const int64_t lda = g.A.ld, ldb = g.B.ld;
+  const float* Ab = g.A.p + bz * g.sA + (AKC ? kt_begin * SK : kt_begin * SK * lda);
+  const float* Bb = g.B.p + bz * g.sB + (BKC ? kt_begin * SK : kt_begin * SK * ldb);
+  // the resources end with the operand: a fetch behind it (the K tail of a row-contiguous operand) returns zeros
+  const int64_t enda = ((AKC ? (g.M - 1) * lda + g.K : (g.K - 1) * lda + g.M) - (AKC ? kt_begin * SK : kt_begin * SK * lda)) * 4;
+  const int64_t endb = ((BKC ? (g.N - 1) * ldb + g.K : (g.K - 1) * ldb + g.N) - (BKC ? kt_begin * SK : kt_begin * SK * ldb)) * 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, (int)(enda < 0x7ffffff0 ? enda : 0x7ffffff0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, (int)(endb < 0x7ffffff0 ? endb : 0x7ffffff0), 0x00020000);
+  const int kloc = (int)(g.K - kt_begin * SK) - 4 * (t & 7);           // this lane's four k of K tile st are valid iff 32 st < kloc
+  unsigned offa[8], offb[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (AKC) {
+      const int r = (t >> 3) + 32 * i;
+      const int64_t row = m0 + r < g.M ? m0 + r : g.M - 1;
+      offa[i] = (unsigned)(row * lda + 4 * (t & 7)) * 4u;
+    } else {
+      const int64_t c0 = m0 + 128 * (i >> 2) + 4 * (t >> 3);
+      const int64_t col = c0 + 4 <= g.M ? c0 : g.M - 4;
+      offa[i] = (unsigned)((4 * (t & 7) + (i & 3)) * lda + col) * 4u;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (BKC) {
+      const int r = (t >> 3) + 32 * i;
+      const int64_t row = n0 + r < g.N ? n0 + r : g.N - 1;
+      offb[i] = (unsigned)(row * ldb + 4 * (t & 7)) * 4u;
+    } else {
+      const int64_t c0 = n0 + 4 * (t >> 3);
+      const int64_t col = c0 + 4 <= g.N ? c0 : g.N - 4;
+      offb[i] = (unsigned)((4 * (t & 7) + i) * ldb + col) * 4u;
+    }
+  }
+  const int stepa = (int)((AKC ? SK : SK * lda) * 4), stepb = (int)((BKC ? SK : SK * ldb) * 4);     // bytes per K tile
+
+  // ---- LDS addresses (bytes).  Image rows are 64 bytes; the 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3).
+  // One base per (buffer, operand, access kind) in a VGPR, everything else is an immediate offset of the DS instruction.
+  const int kq = t & 7;
+  const int woa = AKC ? (t >> 3) * 64 + ((((kq >> 1) ^ ((t >> 5) & 3))) << 4) + (kq & 1) * 8          // + 2048 i
+                      : 4 * (t >> 3) * 64 + ((((kq >> 1) ^ ((t >> 3) & 3))) << 4) + (kq & 1) * 8;     // + 64 j + 8192 h
+  const int wob = BKC ? (t >> 3) * 64 + ((((kq >> 1) ^ ((t >> 5) & 3))) << 4) + (kq & 1) * 8
+                      : 4 * (t >> 3) * 64 + ((((kq >> 1) ^ ((t >> 3) & 3))) << 4) + (kq & 1) * 8;
+  const int fsw = (l31 >> 2) & 3;       // fragment rows: wm*128 + 32 i + l31 (A), wn*64 + 32 j + l31 (B); chunk 2 ks + kh
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_cptr)smem;
+  unsigned wA[2], wB[2], rA[2][2], rB[2][2];           // [buffer], [buffer][k half]
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    wA[b] = lds0 + b * BUFB + woa;
+    wB[b] = lds0 + b * BUFB + NT * PLA + wob;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      rA[b][ks] = lds0 + b * BUFB + (wm * 128 + l31) * 64 + (((2 * ks + kh) ^ fsw) << 4);
+      rB[b][ks] = lds0 + b * BUFB + NT * PLA + (wn * 64 + l31) * 64 + (((2 * ks + kh) ^ fsw) << 4);
+      asm volatile("" : "+v"(rA[b][ks]), "+v"(rB[b][ks]));
+    }
+    asm volatile("" : "+v"(wA[b]), "+v"(wB[b]));
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  gu32x4 RA[2][8], RB[2][4];                 // staging registers (raw fp32 bits) of K tiles of even / odd parity
+  gu32x4 FA[2][4][NT], FB[2][2][NT];         // fragment sets F0 (k 0-15), F1 (k 16-31)
+
+  // load piece u (0-7: A, 8-11: B) of K tile st into register set Q
+  auto load_piece = [&](auto qtag, auto utag, int st) __attribute__((always_inline)) {
+    constexpr int Q = decltype(qtag)::value, U = decltype(utag)::value;
+    if (ASR_GS_ABL & 4) return;
+    if constexpr (U < 8) RA[Q][U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offa[U], st * stepa, 0);
+    else RB[Q][U - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offb[U - 8], st * stepb, 0);
+  };
+  // split + write unit u of the K tile held in register set Q into buffer BUF; units 0-5: A 0-3, B 0-1; 6-11: A 4-7, B 2-3
+  auto unit = [&](auto qtag, auto utag, auto btag, int stu) __attribute__((always_inline)) {
+    constexpr int Q = decltype(qtag)::value, U = decltype(utag)::value, BUF = decltype(btag)::value;
+    const bool kok = !KT || 32 * stu < kloc;
+#define BFS_F(v_, e_) (kok ? __uint_as_float((v_)[e_]) : 0.f)
+    constexpr bool isA = (U % 6) < 4;
+    constexpr int idx = isA ? (U / 6) * 4 + (U % 6) : (U / 6) * 2 + (U % 6) - 4;      // A piece 0-7 / B piece 0-3
+    if (ASR_GS_ABL & 2) return;
+    if constexpr (isA) {
+      if constexpr (AKC) {
+        const gu32x4 v = RA[Q][idx];
+        bfs_write4<NT>(wA[BUF] + 2048 * idx, PLA, BFS_F(v, 0), BFS_F(v, 1), BFS_F(v, 2), BFS_F(v, 3));
+      } else {
+        constexpr int h = idx >> 2, j = idx & 3;
+        bfs_write4<NT>(wA[BUF] + 64 * j + 8192 * h, PLA, BFS_F(RA[Q][4 * h], j), BFS_F(RA[Q][4 * h + 1], j), BFS_F(RA[Q][4 * h + 2], j),
+                       BFS_F(RA[Q][4 * h + 3], j));
+      }
+    } else {
+      if constexpr (BKC) {
+        const gu32x4 v = RB[Q][idx];
+        bfs_write4<NT>(wB[BUF] + 2048 * idx, PLB, BFS_F(v, 0), BFS_F(v, 1), BFS_F(v, 2), BFS_F(v, 3));
+      } else {
+        constexpr int j = idx;
+        bfs_write4<NT>(wB[BUF] + 64 * j, PLB, BFS_F(RB[Q][0], j), BFS_F(RB[Q][1], j), BFS_F(RB[Q][2], j), BFS_F(RB[Q][3], j));
+      }
+    }
+  };
+#undef BFS_F
+  // after unit u of set Q has been written: reload the registers it (and, for row-contiguous operands, its group) used
+  auto reload = [&](auto qtag, auto utag, int st) __attribute__((always_inline)) {
+    constexpr int Q = decltype(qtag)::value, U = decltype(utag)::value;
+    constexpr bool isA = (U % 6) < 4;
+    constexpr int idx = isA ? (U / 6) * 4 + (U % 6) : (U / 6) * 2 + (U % 6) - 4;
+    typedef std::integral_constant<int, Q> QT;
+    if constexpr (isA) {
+      if constexpr (AKC) load_piece(QT(), std::integral_constant<int, idx>(), st);
+      else if constexpr ((idx & 3) == 3) {
+        load_piece(QT(), std::integral_constant<int, idx - 3>(), st);
+        load_piece(QT(), std::integral_constant<int, idx - 2>(), st);
+        load_piece(QT(), std::integral_constant<int, idx - 1>(), st);
+        load_piece(QT(), std::integral_constant<int, idx>(), st);
+      }
+    } else {
+      if constexpr (BKC) load_piece(QT(), std::integral_constant<int, 8 + idx>(), st);
+      else if constexpr (idx == 3) {
+        load_piece(QT(), std::integral_constant<int, 8>(), st);
+        load_piece(QT(), std::integral_constant<int, 9>(), st);
+        load_piece(QT(), std::integral_constant<int, 10>(), st);
+        load_piece(QT(), std::integral_constant<int, 11>(), st);
+      }
+    }
+  };
+  // fragment reads of slot q (0-3: A block q, 4-5: B block q - 4) of k half KS from buffer BUF
+  auto frag_read = [&](auto kstag, auto qtag, auto btag) __attribute__((always_inline)) {
+    constexpr int KS = decltype(kstag)::value, Qs = decltype(qtag)::value, BUF = decltype(btag)::value;
+    if constexpr (Qs < 4) {
+      const unsigned a = rA[BUF][KS] + Qs * 2048;
+      FA[KS][Qs][0] = *(lds_q4ptr)(a);
+      FA[KS][Qs][1] = *(lds_q4ptr)(a + PLA);
+      if constexpr (NT > 2) FA[KS][Qs][2] = *(lds_q4ptr)(a + 2 * PLA);
+    } else {
+      const unsigned a = rB[BUF][KS] + (Qs - 4) * 2048;
+      FB[KS][Qs - 4][0] = *(lds_q4ptr)(a);
+      FB[KS][Qs - 4][1] = *(lds_q4ptr)(a + PLB);
+      if constexpr (NT > 2) FB[KS][Qs - 4][2] = *(lds_q4ptr)(a + 2 * PLB);
+    }
+  };
+#define BFS(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a_), __builtin_bit_cast(gbf16x8, b_), c_, 0, 0, 0)
+  // the 8 MFMAs of term pair number tp (in order of significance sum) of k half KS
+  auto products = [&](auto kstag, auto tptag) __attribute__((always_inline)) {
+    constexpr int KS = decltype(kstag)::value, TP = decltype(tptag)::value;
+    constexpr int o = TP == 0 ? 0 : TP < 3 ? 1 : 2, p = TP == 0 ? 0 : TP < 3 ? TP - 1 : TP - 3;
+    if (ASR_GS_ABL & 1) return;
+    if constexpr (o < NT) {
+      BFS(FA[KS][0][p], FB[KS][0][o - p], acc[0][0]); BFS(FA[KS][0][p], FB[KS][1][o - p], acc[0][1]);
+      BFS(FA[KS][1][p], FB[KS][0][o - p], acc[1][0]); BFS(FA[KS][1][p], FB[KS][1][o - p], acc[1][1]);
+      BFS(FA[KS][2][p], FB[KS][0][o - p], acc[2][0]); BFS(FA[KS][2][p], FB[KS][1][o - p], acc[2][1]);
+      BFS(FA[KS][3][p], FB[KS][0][o - p], acc[3][0]); BFS(FA[KS][3][p], FB[KS][1][o - p], acc[3][1]);
+    }
+  };
+  // One half of a K tile: 48 MFMAs of k half KS, slot by slot with the fragment reads of the other k half (from buffer RD),
+  // six split + write units (register set UQ, first unit U0 = 0 or 6, into buffer WR) and the reloads of their registers
+  // with K tile ld_st.  Each slot's instruction mix is pinned: 1 MFMA : 3 VALU, LDS reads early, LDS writes late.
+  auto half = [&](auto kstag, auto uqtag, auto u0tag, auto rdtag, bool do_rd, auto wrtag, bool do_wr, int stu, int ld_st, bool do_ld)
+      __attribute__((always_inline)) {
+    constexpr int KS = decltype(kstag)::value, UQ = decltype(uqtag)::value, U0 = decltype(u0tag)::value;
+    typedef std::integral_constant<int, KS> KST;
+    typedef std::integral_constant<int, 1 - KS> KSN;
+    typedef std::integral_constant<int, UQ> UQT;
+#define BFS_SLOT(q_)                                                                                     \
+    products(KST(), std::integral_constant<int, q_>());                                                  \
+    if (do_rd) frag_read(KSN(), std::integral_constant<int, q_>(), rdtag);                               \
+    if (do_wr) unit(UQT(), std::integral_constant<int, U0 + q_>(), wrtag, stu);                               \
+    if (do_ld) reload(UQT(), std::integral_constant<int, U0 + q_>(), ld_st);                             \
+    if (ASR_GS_SCHED & 2) {                                                                              \
+      _Pragma("unroll") for (int m_ = 0; m_ < 8; ++m_) {                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+        if (ASR_GS_PAT == 0) {                                                                           \
+          if (m_ < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                             \
+          if (m_ >= 5) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                \
+        } else if (ASR_GS_PAT == 1) {                                                                    \
+          if (m_ < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+          if (m_ < 6) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                 \
+          if (m_ >= 5) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                \
+        } else if (ASR_GS_PAT == 2) {                                                                    \
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                             \
+        } else if (ASR_GS_PAT == 3) {                                                                    \
+          if (m_ == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                \
+          if (m_ < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                             \
+          if (m_ >= 4 && m_ < 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                      \
+        }                                                                                                \
+      }                                                                                                  \
+      if (ASR_GS_PAT != 3) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                            \
+    }                                                                                                    \
+    if (ASR_GS_SCHED & 1) __builtin_amdgcn_sched_barrier(0);
+    BFS_SLOT(0) BFS_SLOT(1) BFS_SLOT(2) BFS_SLOT(3) BFS_SLOT(4) BFS_SLOT(5)
+#undef BFS_SLOT
+  };
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 6> I6;
+
+  // ---- prologue: K tiles 0 and 1 into the registers, image 0 whole, units 0-5 of image 1
+  {
+#define BFS_LD(q_, u_, st_) load_piece(std::integral_constant<int, q_>(), std::integral_constant<int, u_>(), st_)
+    BFS_LD(0, 0, 0); BFS_LD(0, 1, 0); BFS_LD(0, 2, 0); BFS_LD(0, 3, 0); BFS_LD(0, 4, 0); BFS_LD(0, 5, 0);
+    BFS_LD(0, 6, 0); BFS_LD(0, 7, 0); BFS_LD(0, 8, 0); BFS_LD(0, 9, 0); BFS_LD(0, 10, 0); BFS_LD(0, 11, 0);
+    if (S > 1) {
+      BFS_LD(1, 0, 1); BFS_LD(1, 1, 1); BFS_LD(1, 2, 1); BFS_LD(1, 3, 1); BFS_LD(1, 4, 1); BFS_LD(1, 5, 1);
+      BFS_LD(1, 6, 1); BFS_LD(1, 7, 1); BFS_LD(1, 8, 1); BFS_LD(1, 9, 1); BFS_LD(1, 10, 1); BFS_LD(1, 11, 1);
+    }
+#undef BFS_LD
+#define BFS_UN(q_, u_, st_) do { unit(std::integral_constant<int, q_>(), std::integral_constant<int, u_>(), std::integral_constant<int, q_>(), q_);   \
+      if ((st_) < S) reload(std::integral_constant<int, q_>(), std::integral_constant<int, u_>(), st_); } while (0)
+    BFS_UN(0, 0, 2); BFS_UN(0, 1, 2); BFS_UN(0, 2, 2); BFS_UN(0, 3, 2); BFS_UN(0, 4, 2); BFS_UN(0, 5, 2);
+    BFS_UN(0, 6, 2); BFS_UN(0, 7, 2); BFS_UN(0, 8, 2); BFS_UN(0, 9, 2); BFS_UN(0, 10, 2); BFS_UN(0, 11, 2);
+    if (S > 1) {
+      BFS_UN(1, 0, 3); BFS_UN(1, 1, 3); BFS_UN(1, 2, 3); BFS_UN(1, 3, 3); BFS_UN(1, 4, 3); BFS_UN(1, 5, 3);
+    }
+#undef BFS_UN
+    barrier();
+    frag_read(I0(), std::integral_constant<int, 0>(), I0()); frag_read(I0(), std::integral_constant<int, 1>(), I0());
+    frag_read(I0(), std::integral_constant<int, 2>(), I0()); frag_read(I0(), std::integral_constant<int, 3>(), I0());
+    frag_read(I0(), std::integral_constant<int, 4>(), I0()); frag_read(I0(), std::integral_constant<int, 5>(), I0());
+  }
+  // K tile st (parity P = st & 1; image st in buffer P): part A, barrier, part B
+  auto ktile = [&](int st, auto ptag, auto ftag) __attribute__((always_inline)) {
+    constexpr int P = decltype(ptag)::value;
+    constexpr bool FULL = decltype(ftag)::value;            // K tiles st + 1 ... st + 4 exist: no conditionals in the body
+    typedef std::integral_constant<int, P> PT;
+    typedef std::integral_constant<int, 1 - P> PN;
+    const bool n1 = FULL || st + 1 < S, n2 = FULL || st + 2 < S;
+    half(I0(), PN(), I6(), PT(), true, PN(), n1, st + 1, st + 3, FULL || st + 3 < S);
+    if (n1 && !ASR_GS_NOBAR) barrier();
+    half(I1(), PT(), I0(), PN(), n1, PT(), n2, st + 2, st + 4, FULL || st + 4 < S);
+  };
+  typedef std::integral_constant<bool, true> Full;
+  typedef std::integral_constant<bool, false> Tail;
+  int st = 0;
+  for (; st + 5 < S; st += 2) {
+    ktile(st, I0(), Full());
+    ktile(st + 1, I1(), Full());
+  }
+  for (; st < S; st += 2) {
+    ktile(st, I0(), Tail());
+    if (st + 1 < S) ktile(st + 1, I1(), Tail());
+  }
+#undef BFS
+
+#if ASR_GS_ABL & 8
+  if (threadIdx.x + blockIdx.x + blockIdx.y != 0 || g.M != 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
+    return;
+  }
+#endif
+  // ---- epilogue: lane owns column n, rows (e & 3) + 8 (e >> 2) + 4 kh of each 32 x 32 block
+  const int64_t mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
+  const unsigned ldc = (unsigned)g.ldc;
+  const bool split = g.split_k > 1, accum = g.accumulate != 0, relu = g.relu != 0;
+  const bool edge = !(m0 + SM <= g.M && n0 + SN <= g.N);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = ncol0 + j * 32 + l31;
+    const bool nok = !edge || n < g.N;
+    const float bv = (g.bias && nok) ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t mb = mrow0 + i * 32 + 4 * kh;
+      float* base = C + mb * g.ldc + n;
+      if (!edge) {
+        if (split) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) atomicAdd(base + (unsigned)((e & 3) + 8 * (e >> 2)) * ldc, acc[i][j][e]);
+        } else if (accum) {
+          float old[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) old[e] = base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv + old[e];
+            if (relu) v = fmaxf(v, 0.f);
+            base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][j][e] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            base[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = (e & 3) + 8 * (e >> 2);
+          if (!(nok && mb + r < g.M)) continue;
+          float* dst = base + (unsigned)r * ldc;
+          if (split) {
+            atomicAdd(dst, acc[i][j][e]);
+          } else {
+            float o = acc[i][j][e] + bv;
+            if (accum) o += *dst;
+            if (relu) o = fmaxf(o, 0.f);
+            *dst = o;
+          }
+        }
+      }
+    }
+  }
+}
+
 // bias (+ReLU) pass after a split-K product (the atomics cannot carry an epilogue)
 __global__ void bias_act_kernel(float* C, int64_t ldc, int64_t M, int64_t N, int64_t sC, const float* __restrict__ bias,
                                 int relu) {
@@ -1367,19 +1802,29 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   // kernels or worse on the wide one (one 8-wave workgroup per CU cannot hide its prologue and its 128 KB of output behind
   // another workgroup) and stay on the 128 x 128 kernel.  ASR_GEMM_TILE_WIDE sends every conforming shape there,
   // ASR_GEMM_TILE_NARROW none (tests, measurements).
-  const bool wide_shape = K % WK == 0 && g.A.vec && g.B.vec && (akc ? M : K) * lda < ((int64_t)1 << 31) &&
+  const bool base_shape = g.A.vec && g.B.vec && (akc ? M : K) * lda < ((int64_t)1 << 31) &&
                           (bkc ? N : K) * ldb < ((int64_t)1 << 31) && (akc || (M % 4 == 0 && M >= 4)) &&
                           (bkc || (N % 4 == 0 && N >= 4)) && M >= 64 && N >= 64;
+  const bool wide_shape = K % WK == 0 && base_shape;
   const int64_t wtiles = ((M + WM - 1) / WM) * ((N + WN - 1) / WN) * batch;
   const bool may_split = auto_split && !(epi && accumulate);
   const bool wide_pays = (!akc && !bkc && K >= 1024) || (K >= 2048 && ((may_split && !epi) || wtiles >= 150));
-  const bool wide = ar != ASR_ARITH_F32 && !(arith & ASR_GEMM_TILE_NARROW) && wide_shape &&
-                    (wide_pays || (arith & ASR_GEMM_TILE_WIDE)) && (auto_split || split_k == 1);
+  // The one-wave-per-SIMD kernel (gemm_bfs_kernel, same tile and K split policy): faster than both others on every shape
+  // with enough work to fill the chip a few times (tools/gemm_shapes.py: 256 x 128 tiles x K tiles >= ~5 000; below
+  // that its 4-wave workgroups cannot hide their prologue and the 128 x 128 kernel's two workgroups per CU win); its
+  // buffer addressing wants byte offsets below 2^31.  ASR_GEMM_TILE_SP forces it for conforming shapes.
+  const bool sp_shape = base_shape && (K % WK == 0 || (K % 4 == 0 && K > WK)) &&       // a K tail is masked (K = 80: the features)
+                        (akc ? M : K) * lda < ((int64_t)1 << 29) && (bkc ? N : K) * ldb < ((int64_t)1 << 29);
+  const bool sp_pays = K % WK == 0 && wtiles * (K / WK) >= 5000;      // (K = 80: 223 us against the 128 x 128 kernel's 195 - three K tiles are all prologue)
+  const bool use_sp = ar != ASR_ARITH_F32 && sp_shape && (auto_split || split_k == 1) &&
+                      ((arith & ASR_GEMM_TILE_SP) || (sp_pays && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_WIDE))));
+  const bool wide = use_sp || (ar != ASR_ARITH_F32 && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_SP)) && wide_shape &&
+                               (wide_pays || (arith & ASR_GEMM_TILE_WIDE)) && (auto_split || split_k == 1));
   if (wide) {
     // its own K split: 256 workgroup slots (one 8-wave workgroup per CU), cost in units of one stage = rounds x (stages
     // per slice + a fixed prologue / epilogue share) + what the atomics and the zero pass of a split cost per MB of output
     // (tools/gemm_wide_split.py: 12800 x 512 x 4096 takes 215 us unsplit on 200 of the 256 CUs, 256 us split in two)
-    const int64_t tiles = wtiles, stages = K / WK;
+    const int64_t tiles = wtiles, stages = (K + WK - 1) / WK;
     int best = 1;
     if (may_split && !epi) {
       double best_cost = 1e30;
@@ -1401,7 +1846,19 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
       hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
     }
     dim3 grid(g.tiles_m * g.tiles_n, batch * best, 1), block(512);
-    if (ar == ASR_ARITH_BF16X6) {
+    if (use_sp) {
+      const dim3 b4(256);
+#define SP_LAUNCH(nt_, kt_)                                                                                             \
+      do {                                                                                                              \
+        if (akc && bkc) hipLaunchKernelGGL((gemm_bfs_kernel<true, true, nt_, kt_>), grid, b4, 0, stream, g);            \
+        else if (akc && !bkc) hipLaunchKernelGGL((gemm_bfs_kernel<true, false, nt_, kt_>), grid, b4, 0, stream, g);     \
+        else if (!akc && bkc) hipLaunchKernelGGL((gemm_bfs_kernel<false, true, nt_, kt_>), grid, b4, 0, stream, g);     \
+        else hipLaunchKernelGGL((gemm_bfs_kernel<false, false, nt_, kt_>), grid, b4, 0, stream, g);                     \
+      } while (0)
+      if (ar == ASR_ARITH_BF16X6) { if (K % WK) SP_LAUNCH(3, true); else SP_LAUNCH(3, false); }
+      else { if (K % WK) SP_LAUNCH(2, true); else SP_LAUNCH(2, false); }
+#undef SP_LAUNCH
+    } else if (ar == ASR_ARITH_BF16X6) {
       if (akc && bkc) hipLaunchKernelGGL((gemm_bf6w_kernel<true, true>), grid, block, 0, stream, g);
       else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf6w_kernel<true, false>), grid, block, 0, stream, g);
       else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf6w_kernel<false, true>), grid, block, 0, stream, g);

@@ -47,7 +47,7 @@ for (ta, tb, M_, N, K, batch, bias, relu, acc, sk, lda, ldb, ldc), n in agg.item
     Av = A[:, :M_] if ta else A[:, :K]; Bv = B[:, :K] if tb else B[:, :N]
     res = []
     base = os.environ.get('GS_ARITH', 'bf16x6')
-    for mode in (base, base + '+narrow', base + '+wide'):
+    for mode in (base, base + '+narrow', base + '+wide', base + '+sp'):
         ts = []
         for _ in range(4):
             flush.fill_(1.0); torch.cuda.synchronize()
@@ -56,8 +56,8 @@ for (ta, tb, M_, N, K, batch, bias, relu, acc, sk, lda, ldb, ldc), n in agg.item
             ts.append(e0.elapsed_time(e1) * 1e3)
         res.append(sorted(ts)[1])
     wide = M_ % 256 == 0 and N % 128 == 0 and K % 32 == 0
-    rows.append((res[0] * n, '%s%s M%6d N%5d K%6d sk%2d %s%s%s x%d: %6.0f us policy / %6.0f narrow / %6.0f wide each  (%5.1f TF)%s' % (
-        'T' if ta else 'N', 'T' if tb else 'N', M_, N, K, sk, 'b' if bias else '-', 'r' if relu else '-', 'a' if acc else '-', n, res[0], res[1], res[2],
+    rows.append((res[0] * n, '%s%s M%6d N%5d K%6d sk%2d %s%s%s x%d: %6.0f us policy / %6.0f narrow / %6.0f wide / %6.0f sp each  (%5.1f TF)%s' % (
+        'T' if ta else 'N', 'T' if tb else 'N', M_, N, K, sk, 'b' if bias else '-', 'r' if relu else '-', 'a' if acc else '-', n, res[0], res[1], res[2], res[3],
         2.0 * M_ * N * K / res[0] / 1e6, '  [conforms]' if wide else '')))
 tot = sum(r[0] for r in rows)
 for t, s in sorted(rows, key=lambda r: -r[0]): print(s)
