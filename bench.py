@@ -333,8 +333,9 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     an = hb.arith_name()
     busy = mfma_busy_table()
     gpeak = arith_peak_tf(an)
-    gname = {"f32": "gemm_f32_kernel", "bf16x6": "gemm_bf6w_kernel", "bf16x3": "gemm_bf3w_kernel"}[an]
-    gemm = dict(bound="mfma", kernel="%s<false,false> (transA weight-gradient GEMMs of one step)" % gname,
+    gname = {"f32": "gemm_f32_kernel<false,false>", "bf16x6": "gemm_bfs_kernel<false,false,3,*> (one wave per SIMD; small shapes: gemm_bf3_kernel)",
+             "bf16x3": "gemm_bfs_kernel<false,false,2,*>"}[an]
+    gemm = dict(bound="mfma", kernel="%s (transA weight-gradient GEMMs of one step)" % gname,
                 achieved=gemm_flops / gemm_s / 1e12, peak=gpeak, unit="TFLOP/s",
                 peak_is="%s MFMA dense peak / %d products per product" % ("fp32-input" if an == "f32" else "bf16", PRODUCTS_PER_PRODUCT[an]),
                 frac=gemm_flops / gemm_s / 1e12 / gpeak, x_f32_mfma_peak=gemm_flops / gemm_s / 1e12 / MFMA_F32_PEAK_TF,
@@ -413,6 +414,47 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     return first
 
 
+VOCAB = ["<PAD>", "<BOS>", "<EOS>"] + ["c%02d" % i for i in range(29)] + ["<space>", "<NOISE>"]       # V = 34
+
+
+def make_solver(model_cfg, batch_per_gpu, frames, workdir, **overrides):
+    """The product's Solver (semi-supervised-asr_amd/solver.py) on a synthetic corpus written to `workdir`: the same
+    object main.py builds from config.yaml, with the benchmark's model sizes and the deterministic synthetic weights.
+    The corpus only feeds what the constructor derives from data (vocabulary, label distributions, length proportion);
+    the timed batches are the synthetic batches of this file, already resident in HBM."""
+    import contextlib
+    import pickle
+    import yaml
+    from dataset import synthetic_utterances
+    from solver import Solver
+    os.makedirs(workdir, exist_ok=True)
+    vocab = {sym: i for i, sym in enumerate(VOCAB)}
+    assert len(vocab) == model_cfg["output_dim"]
+    for name, n, seed in (("train", 16, 1), ("dev", 4, 2)):
+        with open(os.path.join(workdir, name + ".pkl"), "wb") as f:
+            pickle.dump(synthetic_utterances(n, model_cfg["input_dim"], len(vocab), max(64, frames // 4), seed), f)
+    with open(os.path.join(workdir, "vocab_dict.pkl"), "wb") as f:
+        pickle.dump(vocab, f)
+    with open(os.path.join(workdir, "non_lang_syms.pkl"), "wb") as f:
+        pickle.dump(["<NOISE>", "<PAD>", "<BOS>", "<EOS>"], f)
+    with open(os.path.join(ROOT, "semi-supervised-asr_amd", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update({k: v for k, v in model_cfg.items() if k in cfg})
+    cfg.update(logdir=os.path.join(workdir, "log"), model_dir=workdir, model_name="m", load_model_path=os.path.join(workdir, "m"),
+               load_judge_path=os.path.join(workdir, "m"), dataset_root_dir=workdir,
+               vocab_path=os.path.join(workdir, "vocab_dict.pkl"), non_lang_syms_path=os.path.join(workdir, "non_lang_syms.pkl"),
+               labeled_set="train", unlabeled_speech_set="train", unlabeled_text_set="train", dev_set="dev", test_set="dev",
+               min_feature_length=8, batch_size=batch_per_gpu, shuffle=False, learning_rate=5e-4, weight_decay=1e-6,
+               max_grad_norm=5)
+    cfg.update(overrides)
+    with contextlib.redirect_stdout(sys.stderr):             # the Solver prints its config and modules: stdout is the JSON line's
+        solver = Solver(cfg)
+    mcfg = dict(model_cfg)
+    solver.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.e2e_weights(mcfg, 99).items()})
+    solver.model.train()
+    return solver
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -425,17 +467,18 @@ def main():
     ap.add_argument("--global-batch", type=int, default=256, help="total utterances with --scaling strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-gemms", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the cfg-1 / cfg-5 / ssl / judge / decode sub-objects")
     ap.add_argument("--dropout", type=float, default=None)
     ap.add_argument("--arith", choices=["bf16x6", "f32", "bf16x3"], default="bf16x6",
                     help="product arithmetic of the MFMA kernels (default: bf16x6 = fp32-equivalent, see ARITH_TEXT)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra timings under the other arithmetics")
     args = ap.parse_args()
 
+    import contextlib
+    import tempfile
     import __graft_entry__ as entry
     entry.build()
     import parallel
-    import model as M
-    from parallel import FlatAdam
     import torch.distributed as dist
 
     import hip_backend as hb
@@ -455,113 +498,88 @@ def main():
     else:
         n_global = (args.batch_per_gpu or spec["batch"]) * world
     torch.manual_seed(1000 + rank)                     # per-rank dropout streams; weights below are shared
-    net = M.E2E(labeldist=synth.labeldist(cfg["output_dim"], 5), **cfg)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.e2e_weights(cfg, 99).items()})
-    net = net.to(dev).train()
-    opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0)
+    tmp = tempfile.mkdtemp(prefix="asr_bench_r%d_" % rank)
 
+    # ---- the timed object is the product's Solver: one step = Solver.sup_train_one_iteration on the (global) batch, i.e.
+    # forward on this rank's strided shard, loss, zero_grad, backward, ONE all-reduce of the flat gradient buffer, the
+    # host read of loss + abort latch (the reference's loss.item(), solver.py:379), clip + Adam
+    solver = make_solver(cfg, n_global // world, t_frames, os.path.join(tmp, "main"))
     xs, lens, ys = synth.ragged_batch(n_global, t_frames, cfg["input_dim"], cfg["output_dim"], 1234)
-    xs_r, lens_r, ys_r, info = parallel.shard_batch(xs, lens, ys, rank, world)
-    xs_d = torch.from_numpy(np.ascontiguousarray(xs_r)).to(dev)       # inputs resident in HBM before timing
-    ys_d = [torch.from_numpy(y).to(dev) for y in ys_r]
-    tl = M.padded_lengths(info["t_max"], cfg["enc_n_layers"], cfg["subsample"])
-    b_local = len(lens_r)
+    xs_d = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)        # inputs resident in HBM before timing (every rank
+    ys_d = [torch.from_numpy(y).to(dev) for y in ys]                  # holds the global batch, as the Solver's loaders give it)
+    info = dict(t_max=int(max(lens)), olength=max(int(y.shape[0]) for y in ys) + 1)
+    b_local = len(parallel.shard_indices(n_global, rank, world))
+    last = {}
 
     def step():
-        _, lp, _, _ = net(xs_d, lens_r, ys_d, tf_rate=1.0, total_length=tl, olength=info["olength"])
-        loss = parallel.local_loss(lp, info)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()                                    # one RCCL all-reduce -> clip -> Adam
-        return loss
-
-    def timed(n):
-        """n steps bracketed by barrier + synchronize on both sides; wall seconds, max over ranks."""
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            last = step()
-        fence()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, last
+        last["loss"] = solver.sup_train_one_iteration(xs_d, lens, ys_d, 1.0)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, fn=None):
+        """n steps bracketed by barrier + synchronize on both sides; wall seconds, max over ranks."""
+        fn = fn or step
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     if rank == 0:
         note("%s, %d utterances per GPU x %d GPU(s), T=%d: warmup" % (args.config, b_local, world, t_frames))
     if world > 1:
-        # communicator set-up (lazy in the first collective) and rank alignment before the first step, not inside its
-        # backward pass
+        # communicator set-up (lazy in the first collective) and rank alignment before the first step
         dist.all_reduce(torch.zeros(1, device=dev))
         fence()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # The persistent XCD-local kernels need one workgroup per CU (an exclusive, unpartitioned MI355X).  If one aborted
-    # during the warm-up (NaN-poisoned outputs, sticky abort latch set) every rank falls back to the per-step HIP kernels
-    # and the timed steps measure those; `config.persistent_kernels` says which path the number is for.
-    inject = os.environ.get("ASR_BENCH_INJECT_ABORT", "")      # rehearsal of the fallbacks below: "warmup" / "timed" sets the
-    if inject == "warmup":                                     # latch from the host once, as an aborting kernel would
-        hb.persist_abort_flag(dev).fill_(1)
-
-    def any_abort():
-        flag = torch.tensor([1.0 if hb.persist_aborted(dev) else 0.0], device=dev)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        return flag.item() > 0
-
-    def restart(overlap):
-        nonlocal opt
-        opt.buf.disable_overlap()
-        net.load_state_dict({k: torch.from_numpy(v).to(dev) for k, v in synth.e2e_weights(cfg, 99).items()})
-        opt = FlatAdam(net, lr=5e-4, weight_decay=1e-6, amsgrad=True, max_grad_norm=5.0, overlap=overlap)
-        for _ in range(max(1, args.warmup)):
+    # Rehearsal of the product's abort handling (Solver._backward_guarded in one process, parallel.dp_step's coordinated
+    # fallback under data parallelism): ASR_BENCH_INJECT_ABORT=warmup|timed sets the sticky latch from the host once, as an
+    # aborting persistent kernel would (on the last rank only).
+    inject = os.environ.get("ASR_BENCH_INJECT_ABORT", "")
+    for i in range(args.warmup):
+        if inject == "warmup" and i == 0 and rank == world - 1:
+            hb.persist_scratch(dev)
+            hb.persist_abort_flag(dev).fill_(1)
+        with contextlib.redirect_stdout(sys.stderr):
             step()
-        fence()
-
-    if any_abort() and opt.buf.overlap:
-        # first suspect under data parallelism: RCCL's kernels of the overlapped gradient exchange sharing CUs with a
-        # persistent kernel (never observed; the combination cannot be rehearsed on a one-GPU box) - retry with ONE
-        # collective after the backward pass, on every rank alike (the decision comes out of an all-reduce)
-        note("persistent kernel aborted in the warm-up (code %d): retrying without the overlapped gradient exchange"
-             % hb.persist_abort_code(dev))
-        hb.persist_clear_abort(dev)
-        restart(False)
-    if any_abort():
-        note("persistent kernel aborted in the warm-up (code %d): timing the per-step kernels" % hb.persist_abort_code(dev))
-        hb.disable_persistent(dev)
-        restart(False if not opt.buf.overlap else None)
+    fence()
     hb.LAUNCHES.clear()
     if rank == 0:
         note("timing %d steps (%s)" % (args.steps, args.arith))
-    el, loss = timed(args.steps)
-    if inject == "timed":
+    persist_before = bool(hb.USE_PERSIST)
+    if inject == "timed" and rank == world - 1:
+        hb.persist_scratch(dev)
         hb.persist_abort_flag(dev).fill_(1)
-    # the same check behind the timed steps: a number from NaN-poisoned steps is no number - fall back and time again
-    for _ in range(2):
-        if not any_abort():
-            break
-        if opt.buf.overlap:
-            note("persistent kernel aborted in the timed steps (code %d): again without the overlapped gradient exchange"
-                 % hb.persist_abort_code(dev))
-            hb.persist_clear_abort(dev)
-        else:
-            note("persistent kernel aborted in the timed steps (code %d): again on the per-step kernels" % hb.persist_abort_code(dev))
-            hb.disable_persistent(dev)
-        restart(False)
+    with contextlib.redirect_stdout(sys.stderr):
+        el = timed(args.steps)
+    retimed = False
+    if persist_before and not hb.USE_PERSIST:
+        # a persistent kernel aborted inside the timed steps and the Solver repeated that step on the per-step kernels
+        # (every rank alike): the number above mixes two paths - time again, on the path the run is on now
+        note("persistent kernels were left during the timed steps (abort handled by the Solver): timing again on the per-step kernels")
         hb.LAUNCHES.clear()
-        el, loss = timed(args.steps)
-    final_loss = float(loss.item()) * (world if world > 1 else 1)
+        with contextlib.redirect_stdout(sys.stderr):
+            el = timed(args.steps)
+        retimed = True
+    final_loss = float(last["loss"])
     paths = {k: v // max(1, args.steps) for k, v in sorted(hb.LAUNCHES.items())}
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([float(hb.persist_aborted(dev)), float(bool(hb.USE_PERSIST))], device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(rank=i, abort_latch=bool(t[0].item()), persistent_kernels=bool(t[1].item())) for i, t in enumerate(allr)]
     # the gradient all-reduce alone (68.7 MB at cfg-2), outside the timed region
     allreduce_ms = None
+    opt = solver.gen_opt
     if world > 1:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         dist.all_reduce(opt.buf.flat_g)
@@ -578,12 +596,29 @@ def main():
         for other in ("bf16x3", "f32"):
             if other == args.arith:
                 continue
-            with hb.arith(other):
+            with hb.arith(other), contextlib.redirect_stdout(sys.stderr):
                 step()
-                el_o, _ = timed(args.steps)
+                el_o = timed(args.steps)
             also[other] = dict(ms_per_step=el_o / args.steps * 1e3, value=n_global * args.steps / el_o,
                                unit="utterances/sec", arithmetic=ARITH_TEXT[other])
+    # N > 1: the bucketed exchange issued from inside the backward pass (opt-in in the product: config key dp_overlap /
+    # ASR_DP_OVERLAP=1), as a labelled sub-object next to the default (one collective)
+    also_overlapped = None
+    if world > 1 and not args.no_also:
+        opt.buf.enable_overlap()
+        with contextlib.redirect_stdout(sys.stderr):
+            step()
+            el_v = timed(args.steps)
+        also_overlapped = dict(ms_per_step=el_v / args.steps * 1e3, value=n_global * args.steps / el_v, unit="utterances/sec",
+                               exchange="%d buckets of >= 16 MB issued from inside the backward pass (fixed order), awaited "
+                                        "before the clip" % len(opt.buf.buckets),
+                               abort_latch_any_rank=None, persistent_kernels=bool(hb.USE_PERSIST))
+        flag = torch.tensor([float(hb.persist_aborted(dev))], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        also_overlapped["abort_latch_any_rank"] = bool(flag.item())
+        opt.buf.disable_overlap()
 
+    out = None
     if rank == 0:
         ms = el / args.steps * 1e3
         value = n_global * args.steps / el
@@ -601,19 +636,32 @@ def main():
                                                                            cfg["dropout_rate"]),
                        "config": args.config, "global_batch": n_global, "frames": t_frames,
                        "parallelism": "dp%d" % world, "pad_mode": "global-exact", "launch_mode": "eager",
-                       "persistent_kernels": bool(hb.USE_PERSIST), "sequence_op_paths_per_step": paths},
+                       "timed_call": "Solver.sup_train_one_iteration (semi-supervised-asr_amd/solver.py): forward, loss, zero_grad, "
+                                     "backward, gradient exchange, host read of loss + abort latch, clip + Adam; the (global) "
+                                     "batch is resident in HBM",
+                       "exchange": "one all-reduce of the flat gradient buffer after the backward pass (the Solver's default)"
+                                   if world > 1 else "none (one process)",
+                       "persistent_kernels": bool(hb.USE_PERSIST), "retimed_after_abort": retimed,
+                       "per_rank": per_rank, "sequence_op_paths_per_step": paths},
             "loss": final_loss, "allreduce_ms": allreduce_ms,
-            "allreduce": ("%d buckets issued from inside the backward pass (fixed order), awaited before the clip; "
-                          "allreduce_ms = the same bytes as one collective, alone" % len(opt.buf.buckets))
-            if opt.buf.overlap else "one collective over the flat gradient buffer after the backward pass",
+            "allreduce": "one collective over the flat gradient buffer after the backward pass",
             "model_tflops": value * f_train / 1e12,
             "model_tflops_incl_padded_frames": value * f_train_padded / 1e12,
         }
+        if also_overlapped is not None:
+            out["also_overlapped"] = also_overlapped
         if "bf16x3" in also:
             out["also_split_bf16_x3"] = also["bf16x3"]
         if "f32" in also:
             out["also_f32_mfma"] = also["f32"]
-        note("%.1f utt/s, %.2f ms/step; measuring dominant kernel" % (value, ms))
+        note("%.1f utt/s, %.2f ms/step" % (value, ms))
+    # ---- the other workloads of BASELINE.json through the same Solver methods (N = 1 only; ~2 s each)
+    del solver, opt
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_workloads and rank == 0:
+        out["workloads"] = other_workloads(dev, tmp, args.config, t_frames)
+    if rank == 0:
+        note("measuring dominant kernel")
         out["roofline"] = kernel_roofline(dev, cfg, b_local, t_frames, info["olength"])
         if not args.no_layer_gemms:
             out["encoder_gate_gemm"] = encoder_gate_gemms(dev, cfg, b_local, t_frames)
@@ -624,6 +672,75 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+def other_workloads(dev, tmp, main_config, main_frames):
+    """cfg-1, cfg-5 (cfg-2 when the headline is another one), the semi-supervised generator iteration of cfg-4, the judge
+    step and the validation decode - each through the Solver method the product runs (sup_train_one_iteration,
+    gen_train_one_iteration, judge_train_one_iteration, _greedy), 2 warm-up + 5 timed calls, with the sequence-operator paths
+    the calls took."""
+    import contextlib
+    import hip_backend as hb
+
+    def run(fn, warm=2, n=5):
+        with contextlib.redirect_stdout(sys.stderr):
+            for _ in range(warm):
+                fn()
+            hb.LAUNCHES.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = fn()
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        return ms, r, {k: v // n for k, v in sorted(hb.LAUNCHES.items())}
+
+    res = {}
+    for name in ("cfg1", "cfg2", "cfg5"):
+        spec = CONFIGS[name]
+        if name == main_config and main_frames == spec["frames"]:
+            continue
+        note("workload %s" % name)
+        c, B, T = dict(spec["model"]), spec["batch"], spec["frames"]
+        sv = make_solver(c, B, T, os.path.join(tmp, name))
+        xs, lens, ys = synth.ragged_batch(B, T, c["input_dim"], c["output_dim"], 1234)
+        xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+        ms, loss, paths = run(lambda: sv.sup_train_one_iteration(xs_d, lens, ys_d, 1.0))
+        res[name] = dict(call="Solver.sup_train_one_iteration", workload="%s, batch %d, 80x%d" % (spec["name"], B, T),
+                         ms_per_step=ms, value=B / ms * 1e3, unit="utterances/sec", loss=float(loss), sequence_op_paths=paths)
+        del sv, xs_d, ys_d
+        torch.cuda.empty_cache()
+    # cfg-4's iteration at cfg-2's shape: 32 labeled + 32 unlabeled utterances of T = 800, judge 2 x 640 (config.yaml).
+    # Random weights + random labels drift to an all-<EOS> hypothesis within a few steps (mask sum 0, the reference's 0 / 0):
+    # a negligible learning rate and an <EOS> bias keep the timed iterations in the regime a trained model is in.
+    note("workload ssl / judge / decode")
+    spec = CONFIGS["cfg2"]
+    c, B, T = dict(spec["model"]), spec["batch"], spec["frames"]
+    sv = make_solver(c, B, T, os.path.join(tmp, "ssl"), learning_rate=1e-8, g_learning_rate=1e-8)
+    sv.model.decoder.output_layer.bias.data[2] = -10.0
+    xs, lens, ys = synth.ragged_batch(B, T, c["input_dim"], c["output_dim"], 1234)
+    uxs, ulens, _ = synth.ragged_batch(B, T, c["input_dim"], c["output_dim"], 4321)
+    xs_d, ys_d, uxs_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys], torch.from_numpy(uxs).to(dev)
+    ms, meta, paths = run(lambda: sv.gen_train_one_iteration(xs_d, lens, ys_d, uxs_d, ulens))
+    res["ssl"] = dict(call="Solver.gen_train_one_iteration", workload="cfg-4 iteration: %d labeled + %d unlabeled utterances of 80x%d, "
+                      "smooth-embedding free-running decode of %d steps, judge 2x640" % (B, B, T, int(uxs.shape[1] * sv.proportion)),
+                      ms_per_step=ms, value=2 * B / ms * 1e3, unit="utterances/sec (labeled + unlabeled)",
+                      losses={k: float(v) for k, v in meta.items()}, sequence_op_paths=paths)
+    ms, meta, paths = run(lambda: sv.judge_train_one_iteration(ys_d))
+    res["judge"] = dict(call="Solver.judge_train_one_iteration", workload="2x640 LM, %d transcripts, %d steps" % (B, max(len(y) for y in ys) + 5),
+                        ms_per_step=ms, value=B / ms * 1e3, unit="transcripts/sec", losses={k: float(v) for k, v in meta.items()},
+                        sequence_op_paths=paths)
+    sv.model.eval()
+    ms, _, paths = run(lambda: sv._greedy(xs_d, lens))
+    sv.model.train()
+    res["decode"] = dict(call="Solver._greedy", workload="validation decode: cfg-2 model, %d utterances of 80x%d, greedy, max_dec_timesteps %d "
+                         "(random weights never emit <EOS>: no early stop)" % (B, T, sv.config["max_dec_timesteps"]),
+                         ms_per_batch=ms, value=B / ms * 1e3, unit="utterances/sec", sequence_op_paths=paths)
+    del sv
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

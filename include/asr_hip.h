@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 2
+#define ASR_ABI_VERSION 3
 
 #define ASR_E_ARG    (-1)  /* null pointer / non-positive size */
 #define ASR_E_SHAPE  (-2)  /* size not supported by the kernel (see each function) */
@@ -45,16 +45,23 @@ int asr_abi_version(void);
  * recurrences - there is no process-wide switch.  All operands, accumulators and results are fp32 in every mode; what
  * the mode selects is how a product x * y of two fp32 operands is formed:
  *   ASR_ARITH_F32     on the fp32-input MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1): the exact fp32 product, 157 TF peak.
+ *                     (In the persistent recurrences the RECURRENT operand - h_{t-1}, the exchanged partial sums - crosses
+ *                     CUs as fp32 words whose mantissa LSB carries the hand-off's validity tag (csrc/persist.h): the
+ *                     product is exact, that operand has 23 mantissa bits.  Worst cfg-2 / cfg-5 gradient element under
+ *                     this mode: 1.7e-4 / 4.6e-5 of its tensor's scale.)
  *   ASR_ARITH_BF16X6  fp32-equivalent on the bf16 MFMA: each operand is re-encoded LOSSLESSLY as three bf16 terms
  *                     (x = a + b + c exactly: 3 x 8 significand bits, every split rounded to nearest) and the six products
  *                     aa' + ab' + ba' + ac' + ca' + bb' are accumulated in fp32.  Dropped: bc' + cb' + cc' <= 2^-24 |x y|,
  *                     below the rounding of the fp32 product itself.  2.7x the fp32 pipe's MAC rate.  The host code's
  *                     default (hip_backend.ARITH).
- *   ASR_ARITH_BF16X3  two terms (16 significand bits), three products: <= 2^-15 relative per product.  Fastest; inside the
- *                     1e-3 parity gate but narrower than the reference's arithmetic - never the default.
+ *   ASR_ARITH_BF16X3  two terms (16 significand bits), three products: <= 2^-15 relative per product.  Fastest, and NOT a
+ *                     precision the reference has: OUTSIDE the 1e-3 parity gate on long recurrences (2.2e-3 on a sampled
+ *                     layer-0 dW_ih element at cfg-5, 6.8e-4 at cfg-2; tests/test_big_configs_gpu.py holds it to 5e-3) -
+ *                     never the default.
  * Flags OR-ed into `arith` select a kernel where several implement the same arithmetic (tests, measurements):
- *   ASR_GEMM_TILE_NARROW / ASR_GEMM_TILE_WIDE   asr_gemm_f32: never / always (for conforming shapes) the 256 x 128
- *                     LDS-DMA kernel; by default it is used for the shapes it pays on;
+ *   ASR_GEMM_TILE_NARROW / ASR_GEMM_TILE_WIDE / ASR_GEMM_TILE_SP   asr_gemm_f32: only the 128 x 128 kernel / the 256 x 128
+ *                     LDS-DMA kernel / the 256 x 128 one-wave-per-SIMD kernel for every conforming shape; by default
+ *                     each is used for the shapes it pays on (csrc/gemm.hip: asr_gemm_f32);
  *   ASR_LSTM_BWD_GATHER   asr_lstm_seq_bwd_persist: the gathered-dG kernel instead of the one with exchanged partials. */
 #define ASR_ARITH_F32        0
 #define ASR_ARITH_BF16X6     1
@@ -142,12 +149,16 @@ int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const 
  * XCD as LSB-tagged fp32 words.  Applies when H is 128, 256, 320, 512 (or 640 with a bf16 arithmetic) on an 8 x 32-CU
  * device, any nb (row blocks of 32 * (8 / ndir) run as consecutive launches); otherwise returns ASR_E_SHAPE and the
  * caller uses asr_lstm_seq_fwd.  `arith`: product arithmetic of h W_hh^T (ASR_ARITH_*, see above).
- * xch (>= 8 MB; 10 MB for the H = 640 backward) and ctrl (128 B) are caller-allocated scratch.  ctrl = [16 latch words | 16 per-launch words]: the
+ * xch and ctrl are caller-allocated scratch shared by ALL persistent entry points (LSTM and decoder): at least
+ * asr_persist_scratch_bytes() says (10 MB of exchange - the H = 640 backward's partial sums are the largest user - and a
+ * 128-byte control block); smaller buffers are silently overrun by the pre-launch zero fill and the kernels' atomics.
+ * ctrl = [16 latch words | 16 per-launch words]: the
  * per-launch words and the used part of xch are zeroed on the stream before every launch (one fill when ctrl sits exactly
  * 128 bytes in front of xch, else two).  A kernel that aborts (bounded spin expired / unexpected placement) poisons its
  * outputs with NaN and sets per-launch word 8 (code in word 9) AND latch word 0 (code in latch word 1).  The library
  * never clears the latch words: a sequence operator is several launches, and the caller looks once, after the last
  * one, and clears the latch itself. */
+int asr_persist_scratch_bytes(int64_t* xch_bytes, int64_t* ctrl_bytes);   /* minimum sizes of the scratch pair; returns 0 */
 int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
                              const int32_t* lens, float* y, float* c, void* xch, void* ctrl, int arith,
                              asr_stream_t stream);
@@ -280,8 +291,8 @@ int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, void* graphs
  * owns 4 utterances; W_cat, W_dec and the P slice stay in registers, exchanges stay in the XCD's L2).  Same results
  * except that Dproj is not written.  Returns ASR_E_SHAPE (-2) when it does not apply ((D,A,O,E) other than
  * (512,512,512,128) / (320,320,320,128), Tp > 128, C > 16, K > 100, not an 8 x 32-CU device): use asr_dec_seq_fwd.
- * xch >= 2 MB and ctrl >= 64 B are caller-allocated scratch (shared with the LSTM fast path); abort convention as
- * asr_lstm_seq_fwd_persist. */
+ * xch and ctrl: the scratch pair of asr_lstm_seq_fwd_persist (sizes: asr_persist_scratch_bytes(); the decoder kernels
+ * zero up to 3.6 MB of xch and use all 128 bytes of ctrl); abort convention as asr_lstm_seq_fwd_persist. */
 int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream);
 /* Free-running variant (greedy / smooth-embedding decode, model.py:334-341; solver.py:230-231,466-470): the embedding
  * input of step s >= 1 is made inside the kernel from the logits of step s-1: mode 1 = emb[argmax], mode 2 =

@@ -1738,7 +1738,7 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
 
 // Whole teacher-forced decoder sequence (steps 0..L-1) in one launch per block of 32 rows.  Same operands and
 // results as asr_dec_seq_fwd(p, 0, L) except that Dproj is not written.  Returns ASR_E_SHAPE when the fast path
-// does not apply (the caller then uses asr_dec_seq_fwd).  xch >= 2 MB, ctrl >= 64 B (zeroed here on the stream).
+// does not apply (the caller then uses asr_dec_seq_fwd).  xch / ctrl: asr_persist_scratch_bytes() (zeroed here on the stream: up to 3.6 MB and the 64 bytes of per-launch words).
 extern "C" int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream_) {
   return dec_fwd_persist_impl(p, nullptr, xch, ctrl, (hipStream_t)stream_);
 }

@@ -2216,8 +2216,14 @@ static bool arith_ok(int arith) {
 // Returns ASR_E_SHAPE when the fast path does not apply (caller falls back to asr_lstm_seq_fwd).  Batches larger
 // than 8 * (8 / ndir) rows run as consecutive launches over row blocks (rows are independent; any batch size: a
 // single-GPU batch of 256 is 8 launches per layer).
-// xch: >= 8 MB (the backward's exchanged partials at H = 512), ctrl: 128 B (persist.h: 16 latch words + 16 per-launch
-// words; the per-launch words and the exchange area are zeroed here on the stream before every launch).
+// xch / ctrl: at least asr_persist_scratch_bytes() (10 MB: the H = 640 backward's exchanged partials; 128 B: persist.h, 16
+// latch words + 16 per-launch words; the per-launch words and the exchange area are zeroed here on the stream before every
+// launch).
+extern "C" int asr_persist_scratch_bytes(int64_t* xch_bytes, int64_t* ctrl_bytes) {
+  if (xch_bytes) *xch_bytes = (int64_t)8 * 2 * 32 * 32 * 8 * 20 * 4;     // [8 groups][2 parities][32 dest][32 src][8 rows][20 units] floats
+  if (ctrl_bytes) *ctrl_bytes = 128;
+  return 0;
+}
 extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
                                         const int32_t* lens, float* y, float* c, void* xch, void* ctrl, int arith,
                                         asr_stream_t stream_) {

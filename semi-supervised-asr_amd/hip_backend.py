@@ -11,10 +11,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libasr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = (
-    "asr_abi_version", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
+    "asr_abi_version", "asr_persist_scratch_bytes", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_lstm_seq_bwd_persist_w", "asr_lstm_bwd_persist_fuses_dw", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
@@ -71,6 +71,7 @@ def load():
     lib.asr_graphs_destroy.restype = None
     lib.asr_graphs_destroy.argtypes = [c_p]
     lib.asr_graphs_stats.argtypes = [c_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
+    lib.asr_persist_scratch_bytes.argtypes = [ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
     lib.asr_gemm_f32.argtypes = [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_i,
                                  c_i, c_i64, c_i64, c_i64, c_i, c_i, c_p]
     lib.asr_gemm_skinny_f32.argtypes = [c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p,
@@ -494,6 +495,7 @@ _persist_scratch = {}
 # exchange area of the persistent kernels: the largest user is the LSTM backward with exchanged dh partials,
 # [8 groups][2 parities][32 dest][32 src][8 rows][H/32 units] floats = 8 MB at H = 512 (each launcher zeroes what it uses)
 XCH_BYTES = 8 * 2 * 32 * 32 * 8 * 20 * 4      # the largest user: exchanged dh partials at H = 640 (20 units per CU), 10 MB
+                                              # (= asr_persist_scratch_bytes(); persist_scratch checks it against the library)
 
 # Which path every sequence operator actually took, per process: "<op>_persist" counts launches of the persistent
 # XCD-local kernels, "<op>_step" counts sequences that ran on the per-step kernels instead (persistent path switched off,
@@ -537,7 +539,10 @@ def persist_scratch(device, trace=False):
         return _persist_scratch[tkey]
     key = str(device)
     if key not in _persist_scratch:
-        # one allocation: [128-byte control block | 8 MB exchange] so that the pre-launch reset is a single fill
+        xb, cb = c_i64(0), c_i64(0)
+        load().asr_persist_scratch_bytes(ctypes.byref(xb), ctypes.byref(cb))
+        assert xb.value <= XCH_BYTES and cb.value <= 128, "libasr_hip.so wants a larger persistent scratch than this host code allocates"
+        # one allocation: [128-byte control block | 10 MB exchange] so that the pre-launch reset is a single fill
         # (persist.h: persist_reset)
         base = torch.zeros(16 + XCH_BYTES // 8, dtype=torch.int64, device=device)
         _persist_scratch[key] = (base[16:], base[:16].view(torch.int32), base)

@@ -116,12 +116,9 @@ def ssl_local_loss(model_fwd, judge_probs, lab, unlab, rank, world_size, eos, un
     work = global_sum_async(count, group)
     if work is not None:
         work.wait()
-        work = None
     if u_il:
         num = -torch.sum(judge_probs(u_pred) * u_lp * mask)
     sup = sup_local_loss(model_fwd, lab_xs, lab_ilens, lab_ys, 1.0, rank, world_size, n_layers, subsample)
-    if work is not None:
-        work.wait()
     unsup = num / count[0] if num is not None else None   # 0/0 = nan for an all-<EOS> hypothesis, like the reference
     parts = [p for p in (sup, unsup_weight * unsup if unsup is not None else None) if p is not None]
     loss = sum(parts[1:], parts[0]) if parts else None
@@ -138,6 +135,38 @@ def judge_local_loss(judge_fwd, masked_sum, ys, rank, world_size):
     frac = float(sum(int(y.shape[0]) + 5 for y in ys_r)) / float(sum(int(y.shape[0]) + 5 for y in ys))
     log_probs, probs, _ = judge_fwd(ys_r)
     return -masked_sum(log_probs, ys_r) * frac, masked_sum(probs, ys_r) * frac
+
+
+def dp_step(make_loss, opt, n_aux, latch, leave_fast_path):
+    """One data-parallel optimiser step with a coordinated fallback (Solver._dp_step; no kernel code in here, so the gloo
+    tests run it on CPU).  make_loss() -> (local loss or None for an empty shard, [scalars]); opt: zero_grad() / buf
+    (FlatBuffers) / reduce() / apply().  latch() -> this rank's abort latch (0 = clean) as a float or 0-d tensor; it goes
+    into the last aux slot of the step's ONE all-reduce, so every rank reads the same sum between reduce() and apply().
+    If the sum is not zero nothing is applied and EVERY rank restores the numpy stream it had before the step (the
+    teacher-forcing draws), calls leave_fast_path(n_ranks_aborted) - which must also clear the latch - and repeats the
+    step; the collectives stay matched because the decision is identical on all ranks.  A second failure raises.
+    Returns the first n_aux scalars summed over the ranks."""
+    flag_slot = opt.buf.NAUX - 1
+    assert n_aux <= flag_slot
+    rng = np.random.get_state()
+    for attempt in (0, 1):
+        loss, scalars = make_loss()
+        opt.zero_grad()
+        if loss is not None:
+            loss.backward()
+        aux = [v if v is not None else 0.0 for v in scalars[:n_aux]] + [0.0] * (flag_slot - n_aux)
+        aux.append(latch())
+        opt.buf.set_aux(aux)
+        opt.reduce()
+        values = opt.buf.aux.tolist()                   # the step's one host sync, between the all-reduce and the update
+        if values[flag_slot] == 0.0:
+            opt.apply()
+            return values[:n_aux]
+        if attempt == 1:
+            raise RuntimeError("the abort latch is still set on %d rank(s) after a data-parallel step was repeated off the "
+                               "persistent kernels; nothing was applied" % int(values[flag_slot]))
+        np.random.set_state(rng)
+        leave_fast_path(int(values[flag_slot]))
 
 
 # ------------------------------------------------------------------------------ flat buffers
@@ -259,7 +288,11 @@ class FlatBuffers(object):
         """Detach every .grad: autograd then stores each gradient by reference instead of launching one add kernel per
         parameter into the flat buffer; collect() gathers them with a single multi-tensor copy before the step."""
         if self.overlap:
-            for w in self._works:                        # a step that was abandoned after its backward
+            # a step that was abandoned after (part of) its backward: ranks may have stopped at different buckets, so
+            # every rank issues the rest of the fixed sequence before waiting - the collectives stay matched
+            if 0 < self._issued < len(self.buckets):
+                self._issue_ready(force=True)
+            for w in self._works:
                 w.wait()
             self._reset_overlap_state()
         for p in self.params:
@@ -317,13 +350,15 @@ class FlatAdam(object):
 
     def __init__(self, module_or_params, lr, weight_decay=0.0, amsgrad=False, betas=(0.9, 0.999), eps=1e-8,
                  max_grad_norm=None, overlap=None):
-        """overlap: issue the gradient all-reduce in buckets from inside the backward pass (FlatBuffers.enable_overlap);
-        None = when the process group has more than one rank (ASR_DP_OVERLAP=0 turns it off)."""
+        """overlap: issue the gradient all-reduce in buckets from inside the backward pass (FlatBuffers.enable_overlap).
+        OPT-IN: None = only when ASR_DP_OVERLAP=1 is set.  The default exchange - of bench.py, the tools and the Solver
+        alike - is ONE all-reduce of the flat buffer after the backward pass (north_star), until a multi-GPU run has shown
+        that RCCL kernels resident beside the persistent kernels leave the abort latch clear and the overlap gains."""
         params = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
         self.buf = FlatBuffers(list(params))
         import os
         if overlap is None:
-            overlap = os.environ.get("ASR_DP_OVERLAP", "1") != "0"
+            overlap = os.environ.get("ASR_DP_OVERLAP", "0") == "1"
         if overlap:
             self.buf.enable_overlap(force=overlap == "force")
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad,

@@ -25,6 +25,7 @@ from utils import (Logger, adjust_learning_rate, calculate_cer, cc, infinite_ite
 class Solver(object):
     def __init__(self, config, load_model=False):
         self.config = config
+        self._paths_reported = False
         self.rank, self.world, _ = parallel.init_distributed()
         # The reference never seeds numpy (teacher-forcing draws model.py:328, input noise solver.py:370-373).  Data-parallel
         # ranks must draw identical streams, so `numpy_seed` (not a reference key) defaults to 0 there;
@@ -153,6 +154,19 @@ class Solver(object):
         refs = to_sents(all_ys, self.vocab, self.non_lang_syms)
         return calculate_cer(hyps, refs), hyps, refs
 
+    def _abort_seen(self, dev):
+        """True if a persistent kernel aborted on ANY rank since the latch was last cleared (synchronises).  Under data
+        parallelism the decision is collective (all-reduce MAX of the latch), so that all ranks leave the persistent
+        kernels together or none does - ranks on different kernel paths would still compute the same numbers, but a rank
+        that alone repeats a batch must not be the one the others wait for in the next collective."""
+        if dev.type != "cuda":
+            return False
+        flag = hb.persist_abort_flag(dev)[:1].float().clone()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return flag.item() != 0.0
+
     def _greedy(self, xs, ilens):
         """Greedy hypothesis ids for one batch.  No loss is read on this path, so the abort word of the persistent
         kernels is checked explicitly after the decode (the copy to the host has synchronised anyway): an aborted
@@ -163,9 +177,9 @@ class Solver(object):
                 _, _, prediction, _ = self.model(xs, ilens, ys=None, max_dec_timesteps=self.config["max_dec_timesteps"])
             return prediction.cpu().numpy().tolist()
         out = run()
-        if xs.is_cuda and hb.persist_aborted(xs.device):
-            print("persistent kernels aborted during greedy decoding (code %d): repeating the batch on the per-step "
-                  "kernels" % hb.persist_abort_code(xs.device))
+        if self._abort_seen(xs.device):
+            print("persistent kernels aborted during greedy decoding (this rank's code %d): repeating the batch on the "
+                  "per-step kernels" % hb.persist_abort_code(xs.device))
             hb.disable_persistent(xs.device)
             out = run()
         return out
@@ -179,7 +193,7 @@ class Solver(object):
             with torch.no_grad():
                 _, log_probs, _, _ = self.model(xs, ilens, ys=ys)
                 value = self.model.mask_and_cal_loss(log_probs, ys).item()
-                if not math.isfinite(value) and xs.is_cuda and hb.persist_aborted(xs.device):
+                if self._abort_seen(xs.device):             # the latch, not the loss: an abort need not reach the loss
                     hb.disable_persistent(xs.device)        # see _greedy
                     _, log_probs, _, _ = self.model(xs, ilens, ys=ys)
                     value = self.model.mask_and_cal_loss(log_probs, ys).item()
@@ -198,7 +212,12 @@ class Solver(object):
             ys.sort(key=lambda y: len(y), reverse=True)
             with torch.no_grad():
                 log_probs, _, _ = self.judge(ys)
-                total += -self.judge.mask_and_cal_sum(log_probs, ys).item()
+                value = -self.judge.mask_and_cal_sum(log_probs, ys).item()
+                if ys and self._abort_seen(ys[0].device):   # the H = 640 judge runs on the persistent kernels too: a latch
+                    hb.disable_persistent(ys[0].device)     # left here would fail the next (clean) training step
+                    log_probs, _, _ = self.judge(ys)
+                    value = -self.judge.mask_and_cal_sum(log_probs, ys).item()
+                total += value
         samples = self.judge.decode(n_samples=5, sample=True,
                                     max_dec_timesteps=int(self.config.get("lm_sample_steps", 100)))
         sents = to_sents(remove_pad_eos(samples.cpu().numpy(), eos=self.vocab["<EOS>"]), self.vocab,
@@ -257,38 +276,41 @@ class Solver(object):
         """One data-parallel step: zero_grad -> backward of this rank's local loss -> ONE all-reduce of the flat buffer
         (gradients + the per-rank partial scalars + this rank's abort latch in its aux slots) -> clip -> Adam.
         make_loss() -> (local loss or None for an empty shard, [scalars]); returns the scalars summed over ranks = the
-        single-process values.  Repeating a step locally (as _backward_guarded does after an aborted persistent kernel)
-        would desynchronise the collectives, so an abort is an error here - raised by EVERY rank, before the update is
-        applied: the abort latch rides in the last aux slot of the same all-reduce, so all ranks see the same sum and
-        none is left waiting in the next collective with NaN parameters."""
-        loss, scalars = make_loss()
-        opt.zero_grad()
-        if loss is not None:
-            loss.backward()
+        single-process values.
+        An aborted persistent kernel (NaN-poisoned outputs on ONE rank) cannot be repaired by that rank alone - its
+        repeat would be one collective the others do not take part in.  The abort latch therefore rides in the last aux
+        slot of the SAME all-reduce: every rank reads the same sum between reduce() and apply() (the step's one host
+        sync), and when it is not zero EVERY rank restores the numpy stream it had before the step (teacher-forcing
+        draws), switches to the per-step kernels and repeats the step - nothing of the poisoned attempt was applied, and
+        the collectives stay matched because the decision is identical everywhere.  A second failure raises."""
         dev = opt.buf.flat_g.device
-        flag_slot = opt.buf.NAUX - 1
-        assert n_aux <= flag_slot
-        aux = [v if v is not None else 0.0 for v in scalars[:n_aux]] + [0.0] * (flag_slot - n_aux)
-        aux.append(hb.persist_abort_flag(dev)[0].float() if dev.type == "cuda" else 0.0)
-        opt.buf.set_aux(aux)
-        opt.reduce()
-        values = opt.buf.aux.tolist()                   # the step's one host sync, between the all-reduce and the update
-        if values[flag_slot] != 0.0:
-            raise RuntimeError("persistent kernels aborted on %d rank(s) (this rank: %s, code %d) in a data-parallel "
-                               "step; nothing was applied - restart with ASR_PERSIST=0 on every rank to train on the "
-                               "per-step kernels" % (int(values[flag_slot]), hb.persist_aborted(dev),
-                                                     hb.persist_abort_code(dev)))
-        opt.apply()
-        return values[:n_aux]
+
+        def latch():
+            return hb.persist_abort_flag(dev)[0].float() if dev.type == "cuda" else 0.0
+
+        def leave_persistent(n_ranks):
+            print("rank %d: persistent kernels aborted on %d rank(s) (this rank: %s, code %d): every rank repeats the step "
+                  "on the per-step kernels" % (self.rank, n_ranks, hb.persist_aborted(dev), hb.persist_abort_code(dev)))
+            hb.disable_persistent(dev)                  # also clears this rank's latch
+        return parallel.dp_step(make_loss, opt, n_aux, latch, leave_persistent)
 
     def _step(self, make_local, opt, n_scalars):
         """Run one optimiser step on make_local() -> (local loss, [scalar tensors]); returns the scalars as floats,
         summed over the ranks of a data-parallel run (= the single-process values)."""
         if self.world > 1:
-            return self._dp_step(make_local, opt, n_scalars)
-        _, scalars, _ = self._backward_guarded(make_local, opt)
-        opt.step()                                       # clip -> Adam, no host sync
-        return [float(v.item()) for v in scalars[:n_scalars]]
+            out = self._dp_step(make_local, opt, n_scalars)
+        else:
+            _, scalars, _ = self._backward_guarded(make_local, opt)
+            opt.step()                                   # clip -> Adam, no host sync
+            out = [float(v.item()) for v in scalars[:n_scalars]]
+        if not self._paths_reported:
+            # which kernels the sequence operators of the first step ran on (hb.LAUNCHES: *_persist = the persistent
+            # XCD-local kernels, *_step = the per-step kernels, 3x slower: unsupported width, shared or partitioned GPU)
+            self._paths_reported = True
+            if self.rank == 0:
+                print("sequence-operator paths of the first step: %s (persistent kernels %s)"
+                      % (dict(sorted(hb.LAUNCHES.items())), "on" if hb.USE_PERSIST else "off"))
+        return out
 
     def judge_train_one_iteration(self, unlab_ys):
         """solver.py:288-301.  `unlab_ys` is the global text batch: every rank of a data-parallel run takes its strided
@@ -343,6 +365,16 @@ class Solver(object):
         return parallel.sup_local_loss(self.model, xs, ilens, ys, tf_rate, self.rank, self.world,
                                        cfg["enc_n_layers"], cfg["subsample"])
 
+    def sup_train_one_iteration(self, xs, ilens, ys, tf_rate):
+        """The body of the supervised loop (solver.py:375-385) for one (global) batch already on the device: forward on this
+        rank's shard, loss = -mean(log_probs), zero_grad, backward, (all-reduce,) loss + abort latch read on the host - the
+        reference's loss.item() - then clip + Adam.  bench.py times exactly this method."""
+        def make_local():
+            loss = self._sharded_forward(xs, ilens, ys, tf_rate)
+            return loss, [loss]
+        value, = self._step(make_local, self.gen_opt, 1)         # (all-reduce ->) clip -> Adam; local losses sum to the mean
+        return value
+
     def sup_train_one_epoch(self, epoch, tf_rate):
         cfg = self.config
         steps_per_epoch = len(self.train_lab_loader)
@@ -352,10 +384,7 @@ class Solver(object):
             if cfg["add_gaussian"] and epoch >= cfg["gaussian_epoch"]:
                 noise = np.random.normal(0, cfg["gaussian_std"], tuple(xs.shape)).astype(np.float32)
                 xs = xs + cc(torch.from_numpy(noise))
-            def make_local():
-                loss = self._sharded_forward(xs, ilens, ys, tf_rate)
-                return loss, [loss]
-            value, = self._step(make_local, self.gen_opt, 1)     # (all-reduce ->) clip -> Adam; local losses sum to the mean
+            value = self.sup_train_one_iteration(xs, ilens, ys, tf_rate)
             running += value
             if self.rank == 0:
                 print(f"epoch: {epoch}, [{it + 1}/{steps_per_epoch}], loss: {value:.3f}", end="\r")

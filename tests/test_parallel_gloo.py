@@ -312,3 +312,95 @@ def test_flat_buffers_alias_params_and_grads():
     buf.zero_grad()
     buf.collect()
     assert buf.flat_g.numel() == buf.total + buf.NAUX and buf.aux.tolist() == [1.5, 2.0, 0.0, 0.0]
+
+
+class _SgdOpt(object):
+    """Stand-in for FlatAdam on CPU (its apply() is a HIP kernel): the same zero_grad / buf / reduce / apply surface around
+    the product's FlatBuffers, with a plain SGD update."""
+
+    def __init__(self, params, lr):
+        import parallel
+        self.buf, self.lr, self.applied = parallel.FlatBuffers(params), lr, 0
+
+    def zero_grad(self):
+        self.buf.zero_grad()
+
+    def reduce(self):
+        self.buf.allreduce_grads()
+
+    def apply(self):
+        self.applied += 1
+        self.buf.flat_p -= self.lr * self.buf.flat_g[:self.buf.total]
+
+
+def _dp_steps(rank, world, abort_rank):
+    """Two optimiser steps through parallel.dp_step (what Solver._dp_step runs) with tf_rate 0.5 - the teacher-forcing
+    draws come from the numpy stream - where rank `abort_rank` reports an aborted persistent kernel (latch set, loss
+    poisoned) in the FIRST attempt of the FIRST step."""
+    from oracle import asr_oracle as O
+    import parallel
+    cfg = dict(CFG, labeldist=synth.labeldist(CFG["output_dim"], 12))
+    sd = O.make_leaf_state(synth.e2e_weights(CFG, 11))
+    opt = _SgdOpt([sd[n] for n in O.unique_param_names(sd)], 0.05)
+    xs, ilens, ys = synth.batch(CFG["input_dim"], CFG["output_dim"], ILENS, YLENS, 13)
+    ys_t = [torch.from_numpy(y) for y in ys]
+    state = dict(latch=0.0, fast=True, calls=0, left=[])
+
+    def make_loss():
+        state["calls"] += 1
+        loss = parallel.sup_local_loss(_model_fwd(sd, cfg), xs, ilens, ys_t, 0.5, rank, world, CFG["enc_n_layers"], CFG["subsample"])
+        if state["fast"] and rank == abort_rank and state["calls"] == 1:
+            state["latch"] = 1.0                          # what an aborting persistent kernel leaves behind:
+            loss = loss * float("nan")                    # the sticky latch and NaN-poisoned outputs
+        return loss, [loss]
+
+    def leave(n_ranks):
+        state["left"].append(n_ranks)
+        state["fast"], state["latch"] = False, 0.0        # hb.disable_persistent: off the fast path, latch cleared
+
+    np.random.seed(21)
+    losses = [parallel.dp_step(make_loss, opt, 1, lambda: state["latch"], leave)[0] for _ in range(2)]
+    return opt, losses, state
+
+
+def _worker_dp_abort(rank, world, port, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    opt, losses, state = _dp_steps(rank, world, abort_rank=1)
+    # every rank took the same decision: one repeat of step 1 (3 forward passes for 2 steps), 2 updates applied
+    assert state["calls"] == 3 and opt.applied == 2 and state["left"] == [1] and not state["fast"], (rank, state, opt.applied)
+    torch.save(dict(p=opt.buf.flat_p.clone(), losses=losses), os.path.join(out_dir, "dpabort%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_step_coordinated_fallback_after_an_abort_on_one_rank(tmp_path):
+    """An aborted persistent kernel on rank 1 only (latch set, NaN loss): the latch rides in the step's all-reduce, BOTH
+    ranks discard the attempt, restore the numpy stream, leave the fast path and repeat - the weights after two steps
+    equal the one-process run that never aborted, on both ranks."""
+    _setup_paths()
+    port = _free_port()
+    mp.spawn(_worker_dp_abort, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref_opt, ref_losses, ref_state = _dp_steps(0, 1, abort_rank=-1)
+    assert ref_state["calls"] == 2 and ref_state["left"] == []
+    ref = ref_opt.buf.flat_p
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), "dpabort%d.pt" % r))
+        assert all(np.isfinite(v) for v in got["losses"])
+        for a, b in zip(got["losses"], ref_losses):
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got["losses"], ref_losses)
+        err = (got["p"] - ref).abs().max().item()
+        assert err <= 1e-6 * max(1.0, ref.abs().max().item()), (r, err)
+
+
+def test_dp_step_raises_when_the_repeat_fails_too():
+    _setup_paths()
+    import parallel
+    lin = torch.nn.Linear(3, 2)
+    opt = _SgdOpt(list(lin.parameters()), 0.1)
+    before = opt.buf.flat_p.clone()
+    with pytest.raises(RuntimeError, match="nothing was applied"):
+        parallel.dp_step(lambda: ((lin(torch.ones(1, 3)).sum()),) * 1 + ([],), opt, 0, lambda: 1.0, lambda n: None)
+    assert opt.applied == 0 and torch.equal(opt.buf.flat_p, before)
