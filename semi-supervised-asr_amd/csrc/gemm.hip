@@ -1631,6 +1631,237 @@ __global__ __launch_bounds__(256, 1) void gemm_bfs_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------ split-bf16, short K, weights stationary
+// gemm_bfk_kernel: C[M, N] = A[M, K] B[N, K]^T (+ bias) for a SHORT contraction, K = 16 KS <= 96 - the layer-0 input
+// projection of the encoder (K = 80 features, M = T B = 25 600 rows, N = 8H = 4 096: 16.8 GFLOP against 420 MB of output,
+// i.e. bound by the OUTPUT STREAM - 64 KB per 128 x 128 tile at the ~10 B / cycle one CU stores - not by the matrix pipe).
+// The general kernels spend such a product on prologues: three K tiles, then the tile's output with nothing to overlap it.
+// Here a workgroup (8 waves = 2 (M) x 4 (N), two per SIMD: while one waits in the store queue the other issues) keeps ONE
+// 128-column tile of B for its whole life - split once, every wave's 32 x K slice of it as fragments in 12 KS registers -
+// and walks down the M tiles of its column: per tile of 128 rows the wave's 12 KS MFMAs (64 x 32 accumulator) run over
+// the stores of the PREVIOUS tile's accumulators (two accumulator sets), the split + image writes of the NEXT tile's A
+// rows (two LDS images of 128 x K) and the loads of the one after that; one barrier per tile.
+// Workgroup w: XCD w % 8 = group of M tiles (tiles g, g + G, ...), w / G = column tile: the 32 column tiles that read one
+// A tile run on one XCD at about the same time (one HBM read per XCD).  Image rows are padded to 2 K + 16 bytes:
+// 11 r mod 16 is a bijection, so a fragment read's 16 lanes hit 16 different bank quads.
+#ifndef ASR_GK_ABL      /* measurement only: 1 no products, 2 no split / image writes in the loop, 8 no output stores */
+#define ASR_GK_ABL 0
+#endif
+template <int KS> struct BfkDims {
+  static constexpr int K = 16 * KS, ROWB = 2 * K + 16, PLANE = 128 * ROWB, HP = K / 16;   // HP float4 pieces per thread and tile
+};
+
+// PLAIN: every tile is interior (M % 128 == 0, N % 128 == 0) and the epilogue is bias only - straight-line stores, no branches
+template <int NT, int KS, bool PLAIN>
+__global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
+  typedef BfkDims<KS> D;
+  constexpr int ROWB = D::ROWB, PLANE = D::PLANE, HP = D::HP, BUFB = NT * PLANE;
+  static_assert(KS >= 4 && KS <= 6, "the previous tile's accumulators are stored under k steps 0..3");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NT * D::PLANE];
+
+  const int grp = blockIdx.x % groups, tn = blockIdx.x / groups;
+  const int bz = blockIdx.y;
+  const int tiles_m = (int)((g.M + 127) / 128);
+  const int ntile = grp < tiles_m ? (tiles_m - grp + groups - 1) / groups : 0;
+  if (ntile <= 0) return;
+  const int64_t n0 = (int64_t)tn * 128;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;               // 2 (M) x 4 (N) waves: 64 rows x 32 columns each
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int64_t lda = g.A.ld, ldb = g.B.ld;
+  const float* Ab = g.A.p + bz * g.sA;
+  const float* Bb = g.B.p + bz * g.sB + n0 * ldb;
+  float* C = g.C + bz * g.sC;
+  // resources end with the operands: rows past M / N read as zeros
+  const int64_t enda = ((g.M - 1) * lda + g.K) * 4, endb = ((g.N - 1 - n0) * ldb + g.K) * 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, (int)(enda < 0x7ffffff0 ? enda : 0x7ffffff0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, (int)(endb < 0x7ffffff0 ? endb : 0x7ffffff0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7ffffff0, 0x00020000);
+  // piece u (of HP) of a tile: row t >> 2, float4 number (t & 3) HP + u of the row's K / 4: ONE base offset per operand in a
+  // VGPR, the rest are immediate offsets of the buffer / DS instructions
+  const unsigned pa0 = (unsigned)((t >> 2) * lda + 4 * (t & 3) * HP) * 4u;
+  const unsigned pb0 = (unsigned)((t >> 2) * ldb + 4 * (t & 3) * HP) * 4u;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_cptr)smem;
+  unsigned wimg[2], rimg[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    wimg[b] = lds0 + b * BUFB + (unsigned)((t >> 2) * ROWB + 8 * (t & 3) * HP);
+    rimg[b] = lds0 + b * BUFB + (wm * 64 + l31) * ROWB + 16 * kh;
+    asm volatile("" : "+v"(wimg[b]), "+v"(rimg[b]));
+  }
+  const int tile_step = (int)(128 * lda * 4);            // bytes between consecutive M tiles
+
+  gu32x4 RA[HP];                  // staging registers of one A tile
+  gu32x4 FB[KS][NT];              // this wave's B fragments (32 columns): [k step][term]
+  gu32x4 FA[2][2][NT];            // A fragments of one k step, double buffered: [slot][32-row block][term]
+  f32x16 acc[2][2];               // [set][row block]
+
+  auto load_a = [&](auto utag, int mt) __attribute__((always_inline)) {
+    constexpr int U = decltype(utag)::value;
+    RA[U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, pa0 + 16 * U, mt * tile_step, 0);
+  };
+  auto unit = [&](auto utag, auto btag) __attribute__((always_inline)) {       // split + write piece U of the staged tile
+    constexpr int U = decltype(utag)::value, BUF = decltype(btag)::value;
+    const gu32x4 v = RA[U];
+    bfs_write4<NT>(wimg[BUF] + 8 * U, PLANE, __uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  };
+  auto read_fa = [&](auto slottag, auto kstag, auto btag) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slottag)::value, KSI = decltype(kstag)::value, BUF = decltype(btag)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned a = rimg[BUF] + i * 32 * ROWB + 32 * KSI;
+      FA[SL][i][0] = *(lds_q4ptr)(a);
+      FA[SL][i][1] = *(lds_q4ptr)(a + PLANE);
+      if constexpr (NT > 2) FA[SL][i][2] = *(lds_q4ptr)(a + 2 * PLANE);
+    }
+  };
+#define BFK(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a_), __builtin_bit_cast(gbf16x8, b_), c_, 0, 0, 0)
+  auto products = [&](auto slottag, auto kstag, auto settag) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slottag)::value, KSI = decltype(kstag)::value, P = decltype(settag)::value;
+    if (ASR_GK_ABL & 1) return;
+#pragma unroll
+    for (int o = 0; o < NT; ++o)
+#pragma unroll
+      for (int p = 0; p <= o; ++p) {
+        BFK(FA[SL][0][p], FB[KSI][o - p], acc[P][0]);
+        BFK(FA[SL][1][p], FB[KSI][o - p], acc[P][1]);
+      }
+  };
+#undef BFK
+  const bool accum = g.accumulate != 0, relu = g.relu != 0;
+  const int64_t ncol = n0 + wn * 32 + l31;
+  const float bv = (g.bias && ncol < g.N) ? g.bias[ncol] : 0.f;
+  const unsigned cvo = (unsigned)((4 * kh) * g.ldc + ncol) * 4u;        // byte offset of (row 4 kh, this lane's column)
+  const int ldcb = (int)(g.ldc * 4);
+  // store half HF (accumulator elements 8 HF .. 8 HF + 7) of row block I of accumulator set P = tile mt's rows wm*64 + 32 I ..
+  auto store_half = [&](auto settag, auto itag, auto hftag, int mt) __attribute__((always_inline)) {
+    constexpr int P = decltype(settag)::value, I = decltype(itag)::value, HF = decltype(hftag)::value;
+    if (ASR_GK_ABL & 8) {
+#pragma unroll
+      for (int e = 8 * HF; e < 8 * HF + 8; ++e) asm volatile("" ::"v"(acc[P][I][e]));
+    } else if constexpr (PLAIN) {
+      // rows through the SGPR offset of the buffer store, this lane's column in the VGPR offset: no address arithmetic
+      const int row0 = (mt * 128 + wm * 64 + I * 32) * ldcb;
+#pragma unroll
+      for (int e = 8 * HF; e < 8 * HF + 8; ++e)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[P][I][e] + bv), rsC, cvo, row0 + ((e & 3) + 8 * (e >> 2)) * ldcb, 0);
+    } else {
+      const int64_t mb = (int64_t)mt * 128 + wm * 64 + I * 32 + 4 * kh;
+      float* base = C + mb * g.ldc + ncol;
+#pragma unroll
+      for (int e = 8 * HF; e < 8 * HF + 8; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2);
+        if (ncol < g.N && mb + r < g.M) {
+          float* dst = base + (unsigned)r * (unsigned)g.ldc;
+          float v = acc[P][I][e] + bv;
+          if (accum) v += *dst;
+          if (relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 8 * HF; e < 8 * HF + 8; ++e) acc[P][I][e] = 0.f;
+  };
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+#define BFK_FOR_PIECES(X) do { X(0); X(1); X(2); X(3); if constexpr (HP > 4) { X(4); } if constexpr (HP > 5) { X(5); } } while (0)
+
+  // ---- prologue: B tile -> image 1 -> fragments in registers; A tile 0 -> image 0; A tile 1 staged
+#define X_LDB(u_) RA[u_] = __builtin_amdgcn_raw_buffer_load_b128(rsB, pb0 + 16 * (u_), 0, 0)
+  BFK_FOR_PIECES(X_LDB);
+#undef X_LDB
+#define X_UNB(u_) unit(std::integral_constant<int, u_>(), I1())
+  BFK_FOR_PIECES(X_UNB);
+#undef X_UNB
+#define X_LDA0(u_) load_a(std::integral_constant<int, u_>(), grp)
+  BFK_FOR_PIECES(X_LDA0);
+#undef X_LDA0
+  barrier();
+  {
+    const unsigned bbase = lds0 + BUFB + (wn * 32 + l31) * ROWB + 16 * kh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const unsigned a = bbase + 32 * ks;
+      FB[ks][0] = *(lds_q4ptr)(a);
+      FB[ks][1] = *(lds_q4ptr)(a + PLANE);
+      if constexpr (NT > 2) FB[ks][2] = *(lds_q4ptr)(a + 2 * PLANE);
+    }
+  }
+#define X_UNA0(u_) unit(std::integral_constant<int, u_>(), I0())
+  BFK_FOR_PIECES(X_UNA0);
+#undef X_UNA0
+  if (ntile > 1) {
+#define X_LDA1(u_) load_a(std::integral_constant<int, u_>(), grp + groups)
+    BFK_FOR_PIECES(X_LDA1);
+#undef X_LDA1
+  }
+  barrier();                                            // image 0 complete; every wave has its B fragments (image 1 is free)
+  read_fa(I0(), I0(), I0());
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][i][e] = 0.f;
+
+  // ---- one M tile: k steps 0 .. KS-1 on accumulator set P / image P, around them the previous tile's stores (set 1 - P),
+  // the next tile's image (1 - P) and the loads of the tile after it
+  auto mtile = [&](int k, auto ptag) __attribute__((always_inline)) {
+    constexpr int P = decltype(ptag)::value;
+    typedef std::integral_constant<int, P> PT;
+    typedef std::integral_constant<int, 1 - P> PN;
+    const int mt = grp + k * groups;
+    const bool has_prev = k > 0, has_next = k + 1 < ntile, has_next2 = k + 2 < ntile;
+    // the HP units of the next tile are spread over k steps 0 .. KS-2; the barrier sits in front of the last k step
+#define BFK_UNIT(u_) { unit(std::integral_constant<int, u_>(), PN()); if (has_next2) load_a(std::integral_constant<int, u_>(), mt + 2 * groups); }
+#define BFK_STEP(ks_)                                                                                                   \
+    {                                                                                                                   \
+      typedef std::integral_constant<int, ((ks_) + P * KS) & 1> SL;      /* fragment slots alternate across tiles too (odd KS) */ \
+      typedef std::integral_constant<int, ((ks_) + 1 + P * KS) & 1> SN;                                                 \
+      if ((ks_) == KS - 1 && has_next) barrier();                                                                       \
+      products(SL(), std::integral_constant<int, ks_>(), PT());                                                         \
+      if ((ks_) + 1 < KS) read_fa(SN(), std::integral_constant<int, ((ks_) + 1 < KS ? (ks_) + 1 : 0)>(), PT());        \
+      else if (has_next) read_fa(SN(), I0(), PN());                                                                     \
+      if (has_next && (ks_) < KS - 1 && !(ASR_GK_ABL & 2)) {                                                            \
+        constexpr int u0 = (ks_) * HP / (KS - 1), u1 = ((ks_) + 1) * HP / (KS - 1);                                     \
+        if constexpr (u0 < u1) BFK_UNIT(u0)                                                                             \
+        if constexpr (u0 + 1 < u1) BFK_UNIT(u0 + 1)                                                                     \
+        if constexpr (u0 + 2 < u1) BFK_UNIT(u0 + 2)                                                                     \
+      }                                                                                                                 \
+      if (has_prev && (ks_) < 4) store_half(PN(), std::integral_constant<int, ((ks_) / 2)>(), std::integral_constant<int, (ks_) & 1>(), mt - groups); \
+      __builtin_amdgcn_sched_barrier(0);                                                                                \
+    }
+    BFK_STEP(0) BFK_STEP(1) BFK_STEP(2) BFK_STEP(3)
+    if constexpr (KS > 4) BFK_STEP(4)
+    if constexpr (KS > 5) BFK_STEP(5)
+#undef BFK_STEP
+#undef BFK_UNIT
+  };
+  int k = 0;
+  for (; k + 1 < ntile; k += 2) {
+    mtile(k, I0());
+    mtile(k + 1, I1());
+  }
+  if (k < ntile) mtile(k, I0());
+  // the last tile's accumulators
+  {
+    const int klast = ntile - 1, mt = grp + klast * groups;
+    if (klast & 1) {
+      store_half(I1(), I0(), I0(), mt); store_half(I1(), I0(), I1(), mt); store_half(I1(), I1(), I0(), mt); store_half(I1(), I1(), I1(), mt);
+    } else {
+      store_half(I0(), I0(), I0(), mt); store_half(I0(), I0(), I1(), mt); store_half(I0(), I1(), I0(), mt); store_half(I0(), I1(), I1(), mt);
+    }
+  }
+#undef BFK_FOR_PIECES
+}
+
 // bias (+ReLU) pass after a split-K product (the atomics cannot carry an epilogue)
 __global__ void bias_act_kernel(float* C, int64_t ldc, int64_t M, int64_t N, int64_t sC, const float* __restrict__ bias,
                                 int relu) {
@@ -1809,6 +2040,26 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   const int64_t wtiles = ((M + WM - 1) / WM) * ((N + WN - 1) / WN) * batch;
   const bool may_split = auto_split && !(epi && accumulate);
   const bool wide_pays = (!akc && !bkc && K >= 1024) || (K >= 2048 && ((may_split && !epi) || wtiles >= 150));
+  // Short contraction with k-contiguous operands (the layer-0 input projection, K = 80): the weights-stationary kernel
+  if (ar != ASR_ARITH_F32 && akc && bkc && K == 80 && g.A.vec && g.B.vec && M * lda < ((int64_t)1 << 29) && N * ldb < ((int64_t)1 << 29) &&
+      M >= 1024 && N >= 128 && (auto_split || split_k == 1) && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_WIDE | ASR_GEMM_TILE_SP))) {
+    const int tiles_n = (int)((N + 127) / 128);
+    if (tiles_n <= 256) {
+      const int groups = 8 * (tiles_n >= 32 ? 1 : 32 / tiles_n);
+      g.bias = bias; g.relu = relu; g.split_k = 1;
+      dim3 grid(tiles_n * groups, batch, 1), b4(512);
+      const bool plain = M % 128 == 0 && N % 128 == 0 && !relu && !accumulate && M * ldc < ((int64_t)1 << 29);
+      if (ar == ASR_ARITH_BF16X6) {
+        if (plain) hipLaunchKernelGGL((gemm_bfk_kernel<3, 5, true>), grid, b4, 0, stream, g, groups);
+        else hipLaunchKernelGGL((gemm_bfk_kernel<3, 5, false>), grid, b4, 0, stream, g, groups);
+      } else {
+        if (plain) hipLaunchKernelGGL((gemm_bfk_kernel<2, 5, true>), grid, b4, 0, stream, g, groups);
+        else hipLaunchKernelGGL((gemm_bfk_kernel<2, 5, false>), grid, b4, 0, stream, g, groups);
+      }
+      ASR_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   // The one-wave-per-SIMD kernel (gemm_bfs_kernel, same tile and K split policy): faster than both others on every shape
   // with enough work to fill the chip a few times (tools/gemm_shapes.py: 256 x 128 tiles x K tiles >= ~5 000; below
   // that its 4-wave workgroups cannot hide their prologue and the 128 x 128 kernel's two workgroups per CU win); its

@@ -181,6 +181,42 @@ def test_gemm_wide_tile(ta, tb, M, N, K, arith, rtol):
 
 
 @pytest.mark.parametrize("arith,rtol", [("bf16x6", 1e-5), ("bf16x3", 3e-5)])
+@pytest.mark.parametrize("M,N", [(1024, 128), (1100, 200), (3000, 4000), (2048, 130), (1025, 257), (12800, 512)])
+def test_gemm_short_k_weights_stationary(M, N, arith, rtol):
+    """gemm_bfk_kernel (K = 80, k-contiguous operands: the layer-0 input projection x W_ih^T + b): the weight tile stays in
+    registers, workgroups walk down the M tiles with the previous tile's stores under the current tile's MFMAs.  Interior
+    shapes take the branch-free epilogue (bias only), the rest the guarded one (edge tiles in M and N, relu, accumulate);
+    row-strided operands and output; batched.  Against a float64 product, and against the 128 x 128 kernel's numbers."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(M + N)
+    A, B = torch.randn(M, 80, generator=g), torch.randn(N, 80, generator=g)
+    bias, base = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = A.double() @ B.double().t()
+    tol = dict(rtol=rtol, atol=1e-4)
+    with hb.arith(arith):
+        _close(hb.gemm(A.to(dev), B.to(dev), trans_b=True), ref.float(), what="plain", **tol)
+        _close(hb.gemm(A.to(dev), B.to(dev), trans_b=True, bias=bias.to(dev)), (ref + bias).float(), what="bias", **tol)
+        _close(hb.gemm(A.to(dev), B.to(dev), trans_b=True, bias=bias.to(dev), relu=True), torch.relu(ref + bias).float(), what="bias+relu", **tol)
+        _close(hb.gemm(A.to(dev), B.to(dev), trans_b=True, out=base.clone().to(dev), accumulate=True), (ref + base).float(), what="accumulate", **tol)
+        o1 = hb.gemm(A.to(dev), B.to(dev), trans_b=True, bias=bias.to(dev))
+        o2 = hb.gemm(A.to(dev), B.to(dev), trans_b=True, bias=bias.to(dev), arith=arith + "+narrow", split_k=1)
+        _close(o1, o2, rtol=rtol, atol=1e-5, what="vs the 128 x 128 kernel")
+        wideA = torch.randn(M, 96, generator=g).to(dev)
+        wideB = torch.randn(N, 88, generator=g).to(dev)
+        outw = torch.zeros(M, N + 32, device=dev)
+        hb.gemm(wideA[:, 8:88], wideB[:, 4:84], trans_b=True, out=outw[:, 16:16 + N])
+        refv = wideA[:, 8:88].cpu().double() @ wideB[:, 4:84].cpu().double().t()
+        _close(outw[:, 16:16 + N], refv.float(), what="strided", **tol)
+        assert float(outw[:, :16].abs().max()) == 0.0 and float(outw[:, 16 + N:].abs().max()) == 0.0
+    if M <= 2048:
+        Ab, Bb = torch.randn(2, M, 80, generator=g).to(dev), torch.randn(2, N, 80, generator=g).to(dev)
+        C = torch.full((2, M, N), 3.0, device=dev)
+        hb.gemm_batched(Ab, Bb, C, False, True, M, N, 80, 80, 80, N, 2, M * 80, N * 80, M * N, arith=arith)
+        _close(C, torch.einsum("bmk,bnk->bmn", Ab.cpu().double(), Bb.cpu().double()).float(), what="batched", **tol)
+
+
+@pytest.mark.parametrize("arith,rtol", [("bf16x6", 1e-5), ("bf16x3", 3e-5)])
 def test_gemm_wide_tile_batched(arith, rtol):
     """The batched form (pointer + strides, one launch) through the 256 x 128 kernel: C[b] = A[:, b, :]^T B[:, b, :] with
     K % 32 == 0, edge tiles in M and N, batch folded into grid.y next to the kernel's own K split."""
