@@ -1692,18 +1692,18 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
   }
   const int tile_step = (int)(128 * lda * 4);            // bytes between consecutive M tiles
 
-  gu32x4 RA[HP];                  // staging registers of one A tile
+  gu32x4 RA[2][HP];               // staging registers of two A tiles (tile parity)
   gu32x4 FB[KS][NT];              // this wave's B fragments (32 columns): [k step][term]
   gu32x4 FA[2][2][NT];            // A fragments of one k step, double buffered: [slot][32-row block][term]
   f32x16 acc[2][2];               // [set][row block]
 
-  auto load_a = [&](auto utag, int mt) __attribute__((always_inline)) {
-    constexpr int U = decltype(utag)::value;
-    RA[U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, pa0 + 16 * U, mt * tile_step, 0);
+  auto load_a = [&](auto qtag, auto utag, int mt) __attribute__((always_inline)) {
+    constexpr int Q = decltype(qtag)::value, U = decltype(utag)::value;
+    RA[Q][U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, pa0 + 16 * U, mt * tile_step, 0);
   };
-  auto unit = [&](auto utag, auto btag) __attribute__((always_inline)) {       // split + write piece U of the staged tile
-    constexpr int U = decltype(utag)::value, BUF = decltype(btag)::value;
-    const gu32x4 v = RA[U];
+  auto unit = [&](auto qtag, auto utag, auto btag) __attribute__((always_inline)) {       // split + write piece U of staged tile Q into image BUF
+    constexpr int Q = decltype(qtag)::value, U = decltype(utag)::value, BUF = decltype(btag)::value;
+    const gu32x4 v = RA[Q][U];
     bfs_write4<NT>(wimg[BUF] + 8 * U, PLANE, __uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
   };
   auto read_fa = [&](auto slottag, auto kstag, auto btag) __attribute__((always_inline)) {
@@ -1774,13 +1774,13 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
 #define BFK_FOR_PIECES(X) do { X(0); X(1); X(2); X(3); if constexpr (HP > 4) { X(4); } if constexpr (HP > 5) { X(5); } } while (0)
 
   // ---- prologue: B tile -> image 1 -> fragments in registers; A tile 0 -> image 0; A tile 1 staged
-#define X_LDB(u_) RA[u_] = __builtin_amdgcn_raw_buffer_load_b128(rsB, pb0 + 16 * (u_), 0, 0)
+#define X_LDB(u_) RA[1][u_] = __builtin_amdgcn_raw_buffer_load_b128(rsB, pb0 + 16 * (u_), 0, 0)
   BFK_FOR_PIECES(X_LDB);
 #undef X_LDB
-#define X_UNB(u_) unit(std::integral_constant<int, u_>(), I1())
+#define X_UNB(u_) unit(I1(), std::integral_constant<int, u_>(), I1())
   BFK_FOR_PIECES(X_UNB);
 #undef X_UNB
-#define X_LDA0(u_) load_a(std::integral_constant<int, u_>(), grp)
+#define X_LDA0(u_) load_a(I0(), std::integral_constant<int, u_>(), grp)
   BFK_FOR_PIECES(X_LDA0);
 #undef X_LDA0
   barrier();
@@ -1794,11 +1794,11 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
       if constexpr (NT > 2) FB[ks][2] = *(lds_q4ptr)(a + 2 * PLANE);
     }
   }
-#define X_UNA0(u_) unit(std::integral_constant<int, u_>(), I0())
+#define X_UNA0(u_) unit(I0(), std::integral_constant<int, u_>(), I0())
   BFK_FOR_PIECES(X_UNA0);
 #undef X_UNA0
-  if (ntile > 1) {
-#define X_LDA1(u_) load_a(std::integral_constant<int, u_>(), grp + groups)
+  if (ntile > 1) {          // tile k's rows are staged in register set k & 1
+#define X_LDA1(u_) load_a(I1(), std::integral_constant<int, u_>(), grp + groups)
     BFK_FOR_PIECES(X_LDA1);
 #undef X_LDA1
   }
@@ -1819,8 +1819,16 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
     typedef std::integral_constant<int, 1 - P> PN;
     const int mt = grp + k * groups;
     const bool has_prev = k > 0, has_next = k + 1 < ntile, has_next2 = k + 2 < ntile;
+    // The loads of tile k + 2 go first, into the register set tile k's rows have left (the current tile's image was written
+    // during the previous tile): vmcnt retires loads and stores in issue order, so a wait for these loads also waits for
+    // every store issued before them - placed ahead of this tile's stores they only wait for stores of a tile ago.
+    if (has_next2 && !(ASR_GK_ABL & 2)) {
+#define X_LDA2(u_) load_a(PT(), std::integral_constant<int, u_>(), mt + 2 * groups)
+      BFK_FOR_PIECES(X_LDA2);
+#undef X_LDA2
+    }
     // the HP units of the next tile are spread over k steps 0 .. KS-2; the barrier sits in front of the last k step
-#define BFK_UNIT(u_) { unit(std::integral_constant<int, u_>(), PN()); if (has_next2) load_a(std::integral_constant<int, u_>(), mt + 2 * groups); }
+#define BFK_UNIT(u_) { unit(PN(), std::integral_constant<int, u_>(), PN()); }
 #define BFK_STEP(ks_)                                                                                                   \
     {                                                                                                                   \
       typedef std::integral_constant<int, ((ks_) + P * KS) & 1> SL;      /* fragment slots alternate across tiles too (odd KS) */ \
