@@ -64,7 +64,9 @@ ARITH_TEXT = {
               "under the exact fp32-input MFMA)",
     "bf16x3": "NOT the reference's precision: fp32 operands and accumulators, products on the bf16 pipe with two bf16 terms "
               "per operand (16 significand bits) and three products per product, <= 2^-15 relative each",
-    "f32": "fp32 operands, accumulators and results; products on the fp32-input MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1)",
+    "f32": "fp32 operands, accumulators and results; products on the fp32-input MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1) - except ONE "
+           "product of the decoder's backward, the embedding part of dX (dgates W_cat[:, D+O:], [L*B, 4D] x [4D, E]), which "
+           "asr_dec_seq_bwd_persist* always forms with the fp32-equivalent bf16x6 products",
 }
 CFG2 = CONFIGS["cfg2"]["model"]                 # used by tools/
 
@@ -501,8 +503,10 @@ def main():
     tmp = tempfile.mkdtemp(prefix="asr_bench_r%d_" % rank)
 
     # ---- the timed object is the product's Solver: one step = Solver.sup_train_one_iteration on the (global) batch, i.e.
-    # forward on this rank's strided shard, loss, zero_grad, backward, ONE all-reduce of the flat gradient buffer, the
-    # host read of loss + abort latch (the reference's loss.item(), solver.py:379), clip + Adam
+    # forward on this rank's strided shard, loss, zero_grad, backward, ONE all-reduce of the flat gradient buffer, clip + Adam,
+    # and the host read of loss + abort latch (the reference's loss.item(), solver.py:379).  In one process that read is
+    # pipelined: the Adam kernel checks the latch on the device, the host reads step i's record while step i + 1 runs
+    # (Solver._step); under data parallelism it sits between the all-reduce and the update (parallel.dp_step)
     solver = make_solver(cfg, n_global // world, t_frames, os.path.join(tmp, "main"))
     xs, lens, ys = synth.ragged_batch(n_global, t_frames, cfg["input_dim"], cfg["output_dim"], 1234)
     xs_d = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)        # inputs resident in HBM before timing (every rank
@@ -526,6 +530,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
+        solver.flush()                                # the host record (loss + abort latch) of the last step too
         fence()
         el = time.perf_counter() - t0
         if world > 1:
@@ -540,7 +545,7 @@ def main():
         # communicator set-up (lazy in the first collective) and rank alignment before the first step
         dist.all_reduce(torch.zeros(1, device=dev))
         fence()
-    # Rehearsal of the product's abort handling (Solver._backward_guarded in one process, parallel.dp_step's coordinated
+    # Rehearsal of the product's abort handling (Solver._recover in one process, parallel.dp_step's coordinated
     # fallback under data parallelism): ASR_BENCH_INJECT_ABORT=warmup|timed sets the sticky latch from the host once, as an
     # aborting persistent kernel would (on the last rank only).
     inject = os.environ.get("ASR_BENCH_INJECT_ABORT", "")
@@ -637,8 +642,10 @@ def main():
                        "config": args.config, "global_batch": n_global, "frames": t_frames,
                        "parallelism": "dp%d" % world, "pad_mode": "global-exact", "launch_mode": "eager",
                        "timed_call": "Solver.sup_train_one_iteration (semi-supervised-asr_amd/solver.py): forward, loss, zero_grad, "
-                                     "backward, gradient exchange, host read of loss + abort latch, clip + Adam; the (global) "
-                                     "batch is resident in HBM",
+                                     "backward, gradient exchange, clip + Adam (device-side check of the abort latch), host read of "
+                                     "loss + abort latch %s; the (global) batch is resident in HBM"
+                                     % ("between the all-reduce and the update" if world > 1 else
+                                        "one step late (pipeline_steps = 1), the last one inside the timed region"),
                        "exchange": "one all-reduce of the flat gradient buffer after the backward pass (the Solver's default)"
                                    if world > 1 else "none (one process)",
                        "persistent_kernels": bool(hb.USE_PERSIST), "retimed_after_abort": retimed,
@@ -684,7 +691,7 @@ def other_workloads(dev, tmp, main_config, main_frames):
     import contextlib
     import hip_backend as hb
 
-    def run(fn, warm=2, n=5):
+    def run(fn, flush, warm=2, n=5):
         with contextlib.redirect_stdout(sys.stderr):
             for _ in range(warm):
                 fn()
@@ -693,6 +700,7 @@ def other_workloads(dev, tmp, main_config, main_frames):
             t0 = time.perf_counter()
             for _ in range(n):
                 r = fn()
+            flush()
             torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         return ms, r, {k: v // n for k, v in sorted(hb.LAUNCHES.items())}
@@ -707,7 +715,7 @@ def other_workloads(dev, tmp, main_config, main_frames):
         sv = make_solver(c, B, T, os.path.join(tmp, name))
         xs, lens, ys = synth.ragged_batch(B, T, c["input_dim"], c["output_dim"], 1234)
         xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
-        ms, loss, paths = run(lambda: sv.sup_train_one_iteration(xs_d, lens, ys_d, 1.0))
+        ms, loss, paths = run(lambda: sv.sup_train_one_iteration(xs_d, lens, ys_d, 1.0), sv.flush)
         res[name] = dict(call="Solver.sup_train_one_iteration", workload="%s, batch %d, 80x%d" % (spec["name"], B, T),
                          ms_per_step=ms, value=B / ms * 1e3, unit="utterances/sec", loss=float(loss), sequence_op_paths=paths)
         del sv, xs_d, ys_d
@@ -723,17 +731,17 @@ def other_workloads(dev, tmp, main_config, main_frames):
     xs, lens, ys = synth.ragged_batch(B, T, c["input_dim"], c["output_dim"], 1234)
     uxs, ulens, _ = synth.ragged_batch(B, T, c["input_dim"], c["output_dim"], 4321)
     xs_d, ys_d, uxs_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys], torch.from_numpy(uxs).to(dev)
-    ms, meta, paths = run(lambda: sv.gen_train_one_iteration(xs_d, lens, ys_d, uxs_d, ulens))
+    ms, meta, paths = run(lambda: sv.gen_train_one_iteration(xs_d, lens, ys_d, uxs_d, ulens), sv.flush)
     res["ssl"] = dict(call="Solver.gen_train_one_iteration", workload="cfg-4 iteration: %d labeled + %d unlabeled utterances of 80x%d, "
                       "smooth-embedding free-running decode of %d steps, judge 2x640" % (B, B, T, int(uxs.shape[1] * sv.proportion)),
                       ms_per_step=ms, value=2 * B / ms * 1e3, unit="utterances/sec (labeled + unlabeled)",
                       losses={k: float(v) for k, v in meta.items()}, sequence_op_paths=paths)
-    ms, meta, paths = run(lambda: sv.judge_train_one_iteration(ys_d))
+    ms, meta, paths = run(lambda: sv.judge_train_one_iteration(ys_d), sv.flush)
     res["judge"] = dict(call="Solver.judge_train_one_iteration", workload="2x640 LM, %d transcripts, %d steps" % (B, max(len(y) for y in ys) + 5),
                         ms_per_step=ms, value=B / ms * 1e3, unit="transcripts/sec", losses={k: float(v) for k, v in meta.items()},
                         sequence_op_paths=paths)
     sv.model.eval()
-    ms, _, paths = run(lambda: sv._greedy(xs_d, lens))
+    ms, _, paths = run(lambda: sv._greedy(xs_d, lens), sv.flush)
     sv.model.train()
     res["decode"] = dict(call="Solver._greedy", workload="validation decode: cfg-2 model, %d utterances of 80x%d, greedy, max_dec_timesteps %d "
                          "(random weights never emit <EOS>: no early stop)" % (B, T, sv.config["max_dec_timesteps"]),

@@ -48,7 +48,9 @@ int asr_abi_version(void);
  *                     (In the persistent recurrences the RECURRENT operand - h_{t-1}, the exchanged partial sums - crosses
  *                     CUs as fp32 words whose mantissa LSB carries the hand-off's validity tag (csrc/persist.h): the
  *                     product is exact, that operand has 23 mantissa bits.  Worst cfg-2 / cfg-5 gradient element under
- *                     this mode: 1.7e-4 / 4.6e-5 of its tensor's scale.)
+ *                     this mode: 1.7e-4 / 4.6e-5 of its tensor's scale.  asr_dec_seq_bwd_persist* take no arith argument: the
+ *                     decoder kernels are exact fp32 throughout except the embedding part of dX, dgates W_cat[:, D+O:],
+ *                     which they always form with bf16x6 products.)
  *   ASR_ARITH_BF16X6  fp32-equivalent on the bf16 MFMA: each operand is re-encoded LOSSLESSLY as three bf16 terms
  *                     (x = a + b + c exactly: 3 x 8 significand bits, every split rounded to nearest) and the six products
  *                     aa' + ab' + ba' + ac' + ca' + bb' are accumulated in fp32.  Dropped: bc' + cb' + cc' <= 2^-24 |x y|,
@@ -461,12 +463,14 @@ int asr_dec_feedback_bwd(int B, int V, int E, int DO, const float* demb, float* 
  * weight_decay).step).  asr_sumsq_f32 adds sum(g^2) into the device scalar out[0] (caller zeroes
  * it); asr_adam_clip_f32 scales g by min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) (skipped when
  * gnorm_sq is NULL), folds weight_decay*p into g, updates m, v, the AMSGrad max (skipped when vmax
- * is NULL) and p.  bias_c1 = 1-beta1^t, bias_c2 = 1-beta2^t are passed by the host.
+ * is NULL) and p.  bias_c1 = 1-beta1^t, bias_c2 = 1-beta2^t are passed by the host.  skip_if_nonzero (may be
+ * NULL): a 4-byte device word; when it is not zero at the time the kernel runs, nothing is updated - the abort latch
+ * of the persistent kernels (or its all-reduced sum), so that the step can be enqueued before the host has read it.
  * ------------------------------------------------------------------------------------- */
 int asr_sumsq_f32(int64_t n, const float* g, float* out, asr_stream_t stream);
 int asr_adam_clip_f32(int64_t n, float* p, const float* g, float* m, float* v, float* vmax,
-                      const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2,
-                      float eps, float weight_decay, float bias_c1, float bias_c2,
+                      const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float bias_c1, float bias_c2, const void* skip_if_nonzero,
                       asr_stream_t stream);
 
 #ifdef __cplusplus

@@ -63,9 +63,23 @@ _POOL = _Pool()
 
 
 # --------------------------------------------------------------------------------------
+def _with_saved_arith(bwd):
+    """The backward of a sequence operator runs under the product arithmetic its FORWARD ran under (ctx.arith), not under
+    whatever the host default is when .backward() happens to be called: a forward inside `with hb.arith("f32")` followed by
+    a backward outside the block would otherwise mix arithmetics (and the fused-dW_hh decision with them)."""
+    import functools
+
+    @functools.wraps(bwd)
+    def wrapped(ctx, *grads):
+        with hb.arith(ctx.arith):
+            return bwd(ctx, *grads)
+    return wrapped
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu, drop):
+        ctx.arith = hb.current_arith()
         x2 = x.reshape(-1, x.shape[-1])
         y = hb.gemm(x2, weight, trans_b=True, bias=bias, relu=relu)
         seeded = isinstance(drop, hb.SeededMask)
@@ -80,6 +94,7 @@ class _Linear(torch.autograd.Function):
         return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
+    @_with_saved_arith
     def backward(ctx, dy):
         x2, weight, y = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -124,6 +139,7 @@ class _LstmLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lens, ndir, pooled, *params):
+        ctx.arith = hb.current_arith()
         T, B, I = x.shape
         H = params[1].shape[1]
         dev = x.device
@@ -147,6 +163,7 @@ class _LstmLayer(torch.autograd.Function):
         return ws["y"].detach()      # fresh tensor object aliasing the workspace (no stale autograd metadata)
 
     @staticmethod
+    @_with_saved_arith
     def backward(ctx, dy):
         x2, w_ih = ctx.saved_tensors
         T, B, I, H, ndir = ctx.dims
@@ -287,6 +304,7 @@ class _DecoderSeq(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, P, Q, emb_w, w_ih, w_hh, b_ih, b_hh, wdec, convw, watt, gvec, bo, w_out, b_out, w0, opts):
+        ctx.arith = hb.current_arith()
         dev = P.device
         B, Tp, A = P.shape
         O = Q.shape[2]
@@ -482,6 +500,7 @@ class _DecoderSeq(torch.autograd.Function):
         return logits, ws["ws"].clone(), pred
 
     @staticmethod
+    @_with_saved_arith
     def backward(ctx, dlogits, dws, _dpred):
         wdec, watt, bo, fed, probs_saved, w_out, emb_w = ctx.keep
         B, Tp, A, O, D, E, V, C, K, L, KX = ctx.dims

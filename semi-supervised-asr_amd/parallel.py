@@ -380,9 +380,11 @@ class FlatAdam(object):
         update (Solver._dp_step: the abort flag of the persistent kernels) calls reduce(), reads, then apply()."""
         self.buf.allreduce_grads(group)
 
-    def apply(self, max_grad_norm=None):
+    def apply(self, max_grad_norm=None, skip_if=None):
         """Second half: global grad norm -> clip + Adam on the (reduced) flat buffer.  Returns the device scalar holding
-        ||g||^2 (read it with .item() only if you need the number)."""
+        ||g||^2 (read it with .item() only if you need the number).  skip_if: a 1-element device tensor (4 bytes); if it is
+        not zero when the kernel runs the update is a no-op on the device - the caller that finds it set later takes the
+        step count back with unapply()."""
         import hip_backend as hb
         clip = self.max_grad_norm if max_grad_norm is None else max_grad_norm
         g = self.param_groups[0]
@@ -400,8 +402,13 @@ class FlatAdam(object):
                                        hb.ptr(self.v), hb.ptr(self.vmax), gptr,
                                        float(clip if clip is not None else 0.0), float(g["lr"]), float(b1),
                                        float(b2), float(g["eps"]), float(g["weight_decay"]),
-                                       1.0 - b1 ** self.t, 1.0 - b2 ** self.t, hb.stream()), "asr_adam_clip_f32")
+                                       1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
+                                       None if skip_if is None else hb.c_p(skip_if.data_ptr()), hb.stream()), "asr_adam_clip_f32")
         return self.gnorm_sq
+
+    def unapply(self, n=1):
+        """n apply() calls were no-ops on the device (skip_if was set): take the step count back."""
+        self.t -= int(n)
 
     def step(self, max_grad_norm=None, group=None):
         """all-reduce (if distributed) -> global grad norm -> clip + Adam; no host sync."""

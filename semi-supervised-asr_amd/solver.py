@@ -22,10 +22,50 @@ from utils import (Logger, adjust_learning_rate, calculate_cer, cc, infinite_ite
                    to_sents)
 
 
+class StepScalar(object):
+    """A scalar of a train step (loss, ...) whose host copy may still be on its way: the step's kernels, its optimiser
+    update included, are enqueued without waiting for it (Solver._step).  float() / format() / arithmetic resolve it -
+    which waits for that step and deals with an abort latch it may carry."""
+    __slots__ = ("_rec", "_i")
+
+    def __init__(self, rec, i):
+        self._rec, self._i = rec, i
+
+    def __float__(self):
+        if self._rec["values"] is None:
+            self._rec["solver"]._resolve_through(self._rec)
+        return float(self._rec["values"][self._i])
+
+    item = __float__
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return repr(float(self))
+
+    def __reduce__(self):                               # pickles (torch.save of a log) as the plain float
+        return (float, (float(self),))
+
+
+def _float_op(name):
+    def op(self, *args):
+        return getattr(float(self), name)(*[float(a) if isinstance(a, StepScalar) else a for a in args])
+    return op
+
+
+for _name in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__neg__",
+              "__abs__", "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__", "__pow__", "__bool__"):
+    setattr(StepScalar, _name, _float_op(_name))
+StepScalar.__hash__ = lambda self: hash(float(self))
+
+
 class Solver(object):
     def __init__(self, config, load_model=False):
         self.config = config
         self._paths_reported = False
+        self._pending = []                 # train steps whose host read (scalars + abort latch) is outstanding, oldest first
+        self._pinned = None                # their landing slots in pinned host memory
         self.rank, self.world, _ = parallel.init_distributed()
         # The reference never seeds numpy (teacher-forcing draws model.py:328, input noise solver.py:370-373).  Data-parallel
         # ranks must draw identical streams (SURVEY 8e-iii), so `numpy_seed` (not a reference key) defaults to 0 there;
@@ -45,11 +85,13 @@ class Solver(object):
 
     # ------------------------------------------------------------------ checkpoints (.ckpt/.opt/.judge.*)
     def save_model(self, model_path):
+        self.flush()
         if self.rank == 0:
             torch.save(self.model.state_dict(), f"{model_path}.ckpt")
             torch.save(self.gen_opt.state_dict(), f"{model_path}.opt")
 
     def save_judge(self, model_path):
+        self.flush()
         if self.rank == 0:
             torch.save(self.judge.state_dict(), f"{model_path}.judge.ckpt")
             torch.save(self.dis_opt.state_dict(), f"{model_path}.judge.opt")
@@ -186,6 +228,7 @@ class Solver(object):
 
     def validation(self):
         """Teacher-forced dev loss + greedy CER (solver.py:212-242); greedy pass runs without autograd."""
+        self.flush()
         self.model.eval()
         preds, refs, total = [], [], 0.0
         for data in self.dev_loader:
@@ -205,6 +248,7 @@ class Solver(object):
         return total / len(self.dev_loader), cer, hyp_sents, ref_sents
 
     def lm_validation(self):
+        self.flush()
         self.judge.eval()
         total = 0.0
         for data in self.dev_loader:
@@ -247,31 +291,6 @@ class Solver(object):
         return cer
 
     # ------------------------------------------------------------------ judge (LM) pre-training
-    def _backward_guarded(self, make_loss, opt):
-        """zero_grad -> backward, then look at the loss BEFORE the optimiser step (the reference reads loss.item() every
-        step anyway, solver.py:379).  The persistent XCD-local kernels poison their output with NaN when they abort (a
-        workgroup placement other than one per CU, or a bounded spin expiring, e.g. on a shared or partitioned GPU):
-        in that case this process switches to the per-step HIP kernels for good and repeats the step, so an abort costs
-        one step instead of the run.  A non-finite loss without the abort word set is the model's own and passes through
-        unchanged, as in the reference.  -> (loss, aux, float(loss))"""
-        def run():
-            loss, aux = make_loss()
-            opt.zero_grad()
-            loss.backward()
-            if not loss.is_cuda:
-                return loss, aux, loss.item(), False
-            # the loss and the abort latch of the persistent kernels in ONE read.  The latch is sticky across launches
-            # (csrc/persist.h): it also catches an abort in the backward kernels, after a finite loss was formed.
-            both = torch.stack([loss.detach().reshape(()), hb.persist_abort_flag(loss.device)[0].float()]).tolist()
-            return loss, aux, both[0], both[1] != 0.0
-        loss, aux, value, aborted = run()
-        if aborted:
-            print("persistent kernels aborted (code %d): continuing on the per-step kernels"
-                  % hb.persist_abort_code(loss.device))
-            hb.disable_persistent(loss.device)          # also clears the latch
-            loss, aux, value, _ = run()
-        return loss, aux, value
-
     def _dp_step(self, make_loss, opt, n_aux):
         """One data-parallel step: zero_grad -> backward of this rank's local loss -> ONE all-reduce of the flat buffer
         (gradients + the per-rank partial scalars + this rank's abort latch in its aux slots) -> clip -> Adam.
@@ -294,15 +313,58 @@ class Solver(object):
             hb.disable_persistent(dev)                  # also clears this rank's latch
         return parallel.dp_step(make_loss, opt, n_aux, latch, leave_persistent)
 
+    # Number of train steps whose host read may be outstanding when the next one is enqueued.  1 (default): the host looks
+    # at step i's loss and abort latch while step i + 1 runs - no GPU idle time between steps.  0: the reference's order,
+    # loss.item() inside every step (solver.py:379).  Config key `pipeline_steps` (not a reference key).
+    PIPELINE_STEPS = 1
+
     def _step(self, make_local, opt, n_scalars):
-        """Run one optimiser step on make_local() -> (local loss, [scalar tensors]); returns the scalars as floats,
-        summed over the ranks of a data-parallel run (= the single-process values)."""
+        """Run one optimiser step on make_local() -> (local loss, [scalar tensors]); returns the scalars, summed over the
+        ranks of a data-parallel run (= the single-process values): floats under data parallelism, StepScalars in one
+        process.
+
+        One process: nothing in the step waits for the host.  zero_grad -> backward -> gradients into the flat buffer ->
+        [loss scalars + abort latch -> pinned host memory, asynchronously] -> clip + Adam, whose kernel checks the abort latch
+        ON THE DEVICE and does nothing when it is set (asr_adam_clip_f32: skip_if_nonzero).  The host reads a step's record
+        while the NEXT step runs (the reference's per-step loss.item(), one step late).  The persistent XCD-local kernels
+        poison their outputs with NaN and set the sticky latch when they abort (a workgroup placement other than one per CU,
+        a bounded spin expiring: a shared or partitioned GPU); the latch stays set, so the update of the aborted step AND of
+        every step enqueued behind it was skipped on the device - _recover switches this process to the per-step kernels
+        and runs those steps again from the numpy stream (teacher-forcing draws) the first of them started with.  A
+        non-finite loss without the latch is the model's own and is applied, as in the reference."""
         if self.world > 1:
             out = self._dp_step(make_local, opt, n_scalars)
-        else:
-            _, scalars, _ = self._backward_guarded(make_local, opt)
-            opt.step()                                   # clip -> Adam, no host sync
-            out = [float(v.item()) for v in scalars[:n_scalars]]
+            self._report_paths()
+            return out
+        rec = dict(solver=self, opt=opt, make_local=make_local, n=n_scalars, rng=np.random.get_state(), values=None,
+                   event=None, slot=None)
+        loss, scalars = make_local()
+        opt.zero_grad()
+        loss.backward()
+        opt.reduce()                                     # gradients -> flat buffer (no collective in one process)
+        if not loss.is_cuda:                             # CPU tensors (tests of the host logic): nothing to pipeline
+            opt.apply()
+            rec["values"] = [float(v) for v in scalars[:n_scalars]]
+            return [StepScalar(rec, i) for i in range(n_scalars)]
+        dev = loss.device
+        latch = hb.persist_abort_flag(dev)
+        if self._pinned is None:
+            self._pinned = torch.zeros(8, 8, dtype=torch.float32).pin_memory()
+        busy = set(r["slot"] for r in self._pending)
+        rec["slot"] = next(i for i in range(self._pinned.shape[0]) if i not in busy)
+        stage = torch.stack([v.detach().reshape(()).float() for v in scalars[:n_scalars]] + [latch[0].float()])
+        self._pinned[rec["slot"], :n_scalars + 1].copy_(stage, non_blocking=True)
+        rec["event"] = torch.cuda.Event()
+        rec["event"].record()
+        opt.apply(skip_if=latch)                         # clip -> Adam; a no-op on the device if the latch is set
+        self._pending.append(rec)
+        depth = int(self.config.get("pipeline_steps", self.PIPELINE_STEPS))
+        while len(self._pending) > depth:
+            self._resolve_through(self._pending[0])
+        self._report_paths()
+        return [StepScalar(rec, i) for i in range(n_scalars)]
+
+    def _report_paths(self):
         if not self._paths_reported:
             # which kernels the sequence operators of the first step ran on (hb.LAUNCHES: *_persist = the persistent
             # XCD-local kernels, *_step = the per-step kernels, 3x slower: unsupported width, shared or partitioned GPU)
@@ -310,7 +372,65 @@ class Solver(object):
             if self.rank == 0:
                 print("sequence-operator paths of the first step: %s (persistent kernels %s)"
                       % (dict(sorted(hb.LAUNCHES.items())), "on" if hb.USE_PERSIST else "off"))
-        return out
+
+    def _resolve_through(self, rec):
+        """Read the host records of every outstanding step up to and including `rec` (oldest first)."""
+        while self._pending and rec["values"] is None:
+            first = self._pending[0]
+            first["event"].synchronize()
+            vals = self._pinned[first["slot"], :first["n"] + 1].tolist()
+            if vals[-1] != 0.0:
+                self._recover()
+            else:
+                first["values"] = vals[:first["n"]]
+                self._pending.pop(0)
+
+    def _lagged(self, log):
+        """-> (push, done): push(item) reports the PREVIOUS item through log(item) - its step's host record has landed by
+        then, so printing its loss does not make the host wait for the step that was just enqueued - and done() reports
+        the last one (the reference prints every step's loss inside the step, solver.py:379-381)."""
+        held = []
+
+        def push(item):
+            if held:
+                log(held.pop())
+            held.append(item)
+
+        def done():
+            if held:
+                log(held.pop())
+        return push, done
+
+    def flush(self):
+        """Wait for the host records of all outstanding train steps (before validation, checkpoints, the end of a loop)."""
+        while self._pending:
+            self._resolve_through(self._pending[-1])
+
+    def _recover(self):
+        """The oldest outstanding step found the abort latch set: neither its update nor that of any step enqueued behind it
+        was applied (the latch is sticky and the Adam kernel checks it on the device).  Leave the persistent kernels for
+        good, take the optimisers' step counts back and run those steps again, in order, from the numpy stream the first
+        of them started with."""
+        torch.cuda.synchronize()
+        redo, self._pending = self._pending, []
+        dev = redo[0]["opt"].buf.flat_g.device
+        print("persistent kernels aborted (code %d): continuing on the per-step kernels, repeating %d step(s)"
+              % (hb.persist_abort_code(dev), len(redo)))
+        hb.disable_persistent(dev)                       # also clears the latch
+        for rec in redo:
+            rec["opt"].unapply()
+        np.random.set_state(redo[0]["rng"])
+        for rec in redo:
+            loss, scalars = rec["make_local"]()
+            rec["opt"].zero_grad()
+            loss.backward()
+            both = torch.stack([v.detach().reshape(()).float() for v in scalars[:rec["n"]]] +
+                               [hb.persist_abort_flag(dev)[0].float()]).tolist()
+            if both[-1] != 0.0:
+                raise RuntimeError("the abort latch is set (code %d) after a step on the per-step kernels"
+                                   % hb.persist_abort_code(dev))
+            rec["opt"].step()
+            rec["values"] = both[:rec["n"]]
 
     def judge_train_one_iteration(self, unlab_ys):
         """solver.py:288-301.  `unlab_ys` is the global text batch: every rank of a data-parallel run takes its strided
@@ -334,15 +454,21 @@ class Solver(object):
             # MultiStepLR(milestones=[dis_change_learning_rate_epoch], gamma) stepped at epoch start (solver.py:308-315)
             adjust_learning_rate(self.dis_opt, base_lr * (cfg["lr_gamma"] if epoch + 1 >= cfg[
                 "dis_change_learning_rate_epoch"] else 1.0))
-            running = 0.0
-            for it, data in enumerate(self.train_unlab_y_loader):
-                meta = self.judge_train_one_iteration([cc(y) for y in data])
-                running += meta["loss"]
+            total = [0.0]
+
+            def log(item):
+                it, meta = item
+                total[0] += float(meta["loss"])
                 print(f"epoch: {epoch}, [{it + 1}/{steps_per_epoch}], loss: {meta['loss']:.3f}, "
                       f"prob: {meta['avg_prob']:.3f}", end="\r")
                 for key, val in meta.items():
-                    self.logger.scalar_summary(f"{cfg['tag']}/judge_pretrain/{key}", val,
+                    self.logger.scalar_summary(f"{cfg['tag']}/judge_pretrain/{key}", float(val),
                                                epoch * steps_per_epoch + it + 1)
+            push, done = self._lagged(log)
+            for it, data in enumerate(self.train_unlab_y_loader):
+                push((it, self.judge_train_one_iteration([cc(y) for y in data])))
+            done()
+            running = total[0]
             val_loss, samples = self.lm_validation()
             print(f"epoch: {epoch}, train_loss={running / steps_per_epoch:.3f}, valid_loss={val_loss:.3f}")
             for i, s in enumerate(samples):
@@ -378,19 +504,24 @@ class Solver(object):
     def sup_train_one_epoch(self, epoch, tf_rate):
         cfg = self.config
         steps_per_epoch = len(self.train_lab_loader)
-        running = 0.0
+        running = [0.0]
+
+        def log(item):
+            it, value = item
+            running[0] += float(value)
+            if self.rank == 0:
+                print(f"epoch: {epoch}, [{it + 1}/{steps_per_epoch}], loss: {value:.3f}", end="\r")
+            self.logger.scalar_summary(tag=f"{cfg['tag']}/train_loss", value=float(value),
+                                       step=epoch * steps_per_epoch + it + 1)
+        push, done = self._lagged(log)
         for it, data in enumerate(self.train_lab_loader):
             xs, ilens, ys = to_gpu(data)
             if cfg["add_gaussian"] and epoch >= cfg["gaussian_epoch"]:
                 noise = np.random.normal(0, cfg["gaussian_std"], tuple(xs.shape)).astype(np.float32)
                 xs = xs + cc(torch.from_numpy(noise))
-            value = self.sup_train_one_iteration(xs, ilens, ys, tf_rate)
-            running += value
-            if self.rank == 0:
-                print(f"epoch: {epoch}, [{it + 1}/{steps_per_epoch}], loss: {value:.3f}", end="\r")
-            self.logger.scalar_summary(tag=f"{cfg['tag']}/train_loss", value=value,
-                                       step=epoch * steps_per_epoch + it + 1)
-        return running / steps_per_epoch
+            push((it, self.sup_train_one_iteration(xs, ilens, ys, tf_rate)))
+        done()
+        return running[0] / steps_per_epoch
 
     def sup_pretrain(self):
         cfg = self.config
@@ -452,10 +583,7 @@ class Solver(object):
         lab_data, unlab_data = next(self.lab_iter), next(self.unlab_x_iter)
         lab_xs, lab_ilens, lab_ys = to_gpu(lab_data)
         unlab_xs, unlab_ilens = unlab_data
-        meta = self.gen_train_one_iteration(lab_xs, lab_ilens, lab_ys, cc(unlab_xs), unlab_ilens)
-        for key, val in meta.items():
-            self.logger.scalar_summary(f"{self.config['tag']}/ssl_generator/{key}", val, iteration + 1)
-        return meta
+        return self.gen_train_one_iteration(lab_xs, lab_ilens, lab_ys, cc(unlab_xs), unlab_ilens)
 
     def ssl_train(self):
         cfg = self.config
@@ -466,11 +594,17 @@ class Solver(object):
         path = os.path.join(cfg["model_dir"], cfg["model_name"])
         if not hasattr(self, "lab_iter"):
             self.get_infinite_iter()
-        for step in range(total):
-            meta = self.ssl_train_one_iteration(iteration=step)
-            print(f"[{step + 1}/{total}], sup_loss: {meta['sup_loss']:.3f}, unsup_loss: {meta['unsup_loss']:.3f}, "
+        def log(item):
+            it, meta = item
+            print(f"[{it + 1}/{total}], sup_loss: {meta['sup_loss']:.3f}, unsup_loss: {meta['unsup_loss']:.3f}, "
                   f"loss: {meta['loss']:.3f}", end="\r")
+            for key, val in meta.items():
+                self.logger.scalar_summary(f"{cfg['tag']}/ssl_generator/{key}", float(val), it + 1)
+        push, done = self._lagged(log)
+        for step in range(total):
+            push((step, self.ssl_train_one_iteration(iteration=step)))
             if (step + 1) % cfg["summary_steps"] == 0 or step + 1 == total:
+                done()
                 val_loss, cer, hyps, refs = self.validation()
                 print(f"Iter: [{step + 1}/{total}], valid_loss={val_loss:.4f}, CER={cer:.4f}")
                 self.logger.scalar_summary(f"{cfg['tag']}/ssl/cer", cer, step + 1)

@@ -112,7 +112,9 @@ def test_solver_recovers_from_aborted_persistent_kernel(tmp_path, monkeypatch, p
         hb.persist_clear_abort(dev)
         mean_loss = solver.sup_train_one_epoch(0, 1.0)
         steps = len(solver.train_lab_loader)
-        assert state["calls"] == steps + 1, "the aborted step is repeated once"
+        # the host reads a step's record while the next step runs (Solver._step): the abort of step 2 is found after
+        # step 3 was enqueued; neither was applied (the Adam kernel checks the sticky latch on the device), both are repeated
+        assert state["calls"] == steps + 2, "the aborted step and the one enqueued behind it are repeated once"
         assert np.isfinite(mean_loss)
         assert not (hb.USE_PERSIST or hb.USE_PERSIST_DEC or hb.USE_PERSIST_DEC_BWD)
         assert not hb.persist_aborted(dev), "the latch is cleared once the abort has been dealt with"
@@ -345,7 +347,7 @@ def _dp_worker(rank, world, port, root, out):
         meta = solver.gen_train_one_iteration(xs, ilens, ys, cc(uxs), uilens)
         scalars += [meta["unsup_loss"], meta["sup_loss"], meta["loss"]]
         if rank == 0:
-            torch.save(dict(scalars=scalars, model={n: p.detach().cpu() for n, p in solver.model.named_parameters()},
+            torch.save(dict(scalars=[float(v) for v in scalars], model={n: p.detach().cpu() for n, p in solver.model.named_parameters()},
                             judge={n: p.detach().cpu() for n, p in solver.judge.named_parameters()}), out)
         if world > 1:
             import torch.distributed as dist
