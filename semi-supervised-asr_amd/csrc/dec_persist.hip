@@ -863,10 +863,11 @@ __host__ __device__ inline BwdLds bwd_lds_plan(int Tp, int C, int K, int fbV = 0
 //   (g3) slice 0 sums the 32 shares, runs the softmax backward with the saved probabilities,
 //        dl = k p (dp - sum_u p_u dp_u), stores dl (-> dlfb) and publishes it;
 //   (g4) every CU adds dl W_out for its 16 z / 16 ctx columns (W_out slice in LDS) to the dX it hands to step s - 1.
-// Two more hand-offs per step; written for the 4-row geometry (T' <= 100 with 10 channels: the LDS plan is full).
+// Two more hand-offs per step.  The row axis of every feedback buffer keeps 4 slots in both geometries: with 2 rows per
+// group (T' <= 256) rows 2, 3 alias rows 0, 1 and are never stored.
 template <int DD, int AA, int OO, int EE, int RG = 4, int TPM = DP_TPM, bool FB = false>
 __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArgs a) {
-  static_assert(!FB || (RG == 4 && EE == 128), "the feedback backward is written for 4 rows per group and E = 128");
+  static_assert(!FB || EE == 128, "the feedback backward is written for E = 128");
   using BM = DecBwdDims<DD, AA, OO>;
   using GEO = DecGeo<RG, TPM>;
   using BX = BwdX<TPM>;
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       const int mrow = tid_ & 3, mb = r0 + mrow;
       if (drop && tid_ < 16)
         fb_mask = a.xmask[((int64_t)s * B + (mb < nb ? mb : r0)) * (OO + EE) + OO + 4 * slice + (tid_ >> 2)];
-      if (slice == 0 && wave < 4) {
+      if (slice == 0 && wave < RG) {
         const int pb2 = r0 + wave;
         fb_prob = (lane_ < a.V && pb2 < nb) ? a.probs[((int64_t)(s - 1) * B + pb2) * a.V + lane_] : 0.f;
       }
@@ -1449,7 +1450,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float4 x = *reinterpret_cast<const float4*>(dg + r * GS + 4 * i);
+            const float4 x = *reinterpret_cast<const float4*>(dg + (r % RG) * GS + 4 * i);      // rows >= RG alias (never stored)
             pr[r] += wfe[i].x * x.x + wfe[i].y * x.y + wfe[i].z * x.z + wfe[i].w * x.w;
           }
 #pragma unroll
@@ -1462,7 +1463,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       if (tid_ < 16) {
         const int row = tid_ & 3, ec = tid_ >> 2, b = r0 + row;
         const float v = (fbr[ec * 4 + row] + fbr[(ec + 4) * 4 + row]) * fb_mask;
-        if (b < nb) a.G[((int64_t)s * B + b) * KX + DD + OO + 4 * slice + ec] = v;
+        if (row < RG && b < nb) a.G[((int64_t)s * B + b) * KX + DD + OO + 4 * slice + ec] = v;
         fbr[32 + row * 4 + ec] = v;
       }
       __syncthreads();
@@ -1484,7 +1485,11 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
           off[i] = pbase + (unsigned)(q < 32 * 36 ? q : 0) * 16u;
         }
         poll_quads<NPQ, true>(xrs, off, bit, v, a.ctrl, aborted, 25u);
-        __syncthreads();                       // every thread is done with the gathered dgates: dgs becomes scratch
+        // every thread is done with the gathered dgates: dgs becomes scratch for the 32 x 144 shares - with two rows per
+        // group that is more than the two gathered rows hold (4 608 > 4 104 floats) and the tail lands in `part`, which
+        // follows dgs in the LDS plan and is idle here (its K-partials of the dX product were summed before (g2))
+        static_assert(32 * 144 <= RG * BM::GS + 8 * 64 * 5, "scratch of the feedback shares");
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NPQ; ++i) {
           const int q = tid_ + DP_NT * i;
@@ -1502,7 +1507,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
           const float pdot = wave_sum_dpp(fb_prob * dp);
           const float dl = a.fb_scale * fb_prob * (dp - pdot);          // 0 beyond V and for rows beyond the batch
           const int b = r0 + wave;
-          if (lane_ < a.V && b < nb) a.dlfb[((int64_t)(s - 1) * B + b) * a.V + lane_] = dl;
+          if (lane_ < a.V && wave < RG && b < nb) a.dlfb[((int64_t)(s - 1) * B + b) * a.V + lane_] = dl;
           if (lane_ < 36) word_store(xg + BX_L + slot * 144 + wave * 36 + lane_, dl, bit);
         }
       }
@@ -1778,7 +1783,7 @@ static int dec_bwd_persist_impl(const asr_dec_bwd_t* q, const asr_dec_feedback_b
   // geometry as in the forward: 4 utterances per group while the per-thread prefetch registers cover the conv features
   // and M of 4 rows (T' <= 102 at 10 channels), else 2 utterances per group on 16 CUs each (T' <= 256)
   const bool geo4 = p->Tp <= DP_TPM && p->C * TpP <= 2 * DP_NT && 4 * p->C * TpP <= 8 * DP_NT;
-  const bool geo2 = !geo4 && !fb && p->Tp <= 256 && p->C * TpP <= 5 * DP_NT && 2 * p->C * TpP <= 10 * DP_NT;
+  const bool geo2 = !geo4 && p->Tp <= 256 && p->C * TpP <= 5 * DP_NT && 2 * p->C * TpP <= 10 * DP_NT;
   if (!geo4 && !geo2) return ASR_E_SHAPE;
   if (!asr_persist_device_ok()) return ASR_E_SHAPE;
   const int B = p->B, Tp = p->Tp, A = p->A, D = p->D, O = p->O, E = p->E, C = p->C, KX = D + O + E;
@@ -1811,8 +1816,10 @@ static int dec_bwd_persist_impl(const asr_dec_bwd_t* q, const asr_dec_feedback_b
     if (fb) {
       a.V = fb->V; a.fb_scale = fb->scaling; a.w_out = fb->w_out; a.emb = fb->emb;
       a.probs = fb->probs + (int64_t)rb * fb->V; a.dlfb = fb->dlfb + (int64_t)rb * fb->V;
-      rc = cfg2 ? launch_dec_bwd<512, 512, 512, 128, 4, DP_TPM, true>(a, stream)
-                : launch_dec_bwd<320, 320, 320, 128, 4, DP_TPM, true>(a, stream);
+      rc = geo4 ? (cfg2 ? launch_dec_bwd<512, 512, 512, 128, 4, DP_TPM, true>(a, stream)
+                        : launch_dec_bwd<320, 320, 320, 128, 4, DP_TPM, true>(a, stream))
+                : (cfg2 ? launch_dec_bwd<512, 512, 512, 128, 2, 256, true>(a, stream)
+                        : launch_dec_bwd<320, 320, 320, 128, 2, 256, true>(a, stream));
     } else {
       rc = geo4 ? (cfg2 ? launch_dec_bwd<512, 512, 512, 128>(a, stream) : launch_dec_bwd<320, 320, 320, 128>(a, stream))
                 : (cfg2 ? launch_dec_bwd<512, 512, 512, 128, 2, 256>(a, stream)
@@ -1850,8 +1857,9 @@ extern "C" int asr_dec_seq_bwd_persist(const asr_dec_bwd_t* q, float* mbuf, void
 // Backward of a FREE-RUNNING sequence with the smooth-embedding feedback (asr_dec_seq_fwd_persist_free, mode 2): as
 // asr_dec_seq_bwd_persist, plus the gradient that every step sends into the previous step's logits through
 // emb_s = softmax(k logit_{s-1}) @ E (kernel template FB).  fb->dlfb [L][B][V] (zero-filled by the caller) receives that
-// gradient per step; G[s][:, D+O:] holds d(emb_s) for every s.  4-row geometry only (T' <= 100 at 10 channels): otherwise
-// ASR_E_SHAPE and the caller uses the per-step kernels + asr_dec_feedback_bwd.
+// gradient per step; G[s][:, D+O:] holds d(emb_s) for every s.  Both geometries (4 rows per group for T' <= 100 at 10
+// channels, 2 rows per group up to T' = 256); beyond that ASR_E_SHAPE and the caller uses the per-step kernels +
+// asr_dec_feedback_bwd.
 extern "C" int asr_dec_seq_bwd_persist_free(const asr_dec_bwd_t* q, const asr_dec_feedback_bwd_t* fb, float* mbuf, void* xch,
                                             void* ctrl, asr_stream_t stream) {
   if (!fb) return ASR_E_ARG;

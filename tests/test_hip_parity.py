@@ -1138,6 +1138,8 @@ def test_decoder_feedback_kernels(B, V, E, DO):
                                                   # T' > 102: the free-running kernel in the 2-rows-per-group geometry
                                                   (512, 9, 200, 6, False, "greedy"), (512, 12, 130, 5, True, "smooth"),
                                                   (320, 5, 256, 4, False, "smooth"), (512, 19, 200, 3, True, "greedy"),
+                                                  (512, 8, 200, 7, True, "smooth"), (512, 21, 200, 4, False, "smooth"),
+                                                  (320, 16, 150, 6, True, "smooth"),
                                                   # longer smooth sequences: the feedback path through many steps
                                                   (512, 32, 100, 12, True, "smooth"), (512, 7, 50, 9, False, "smooth"),
                                                   (320, 10, 64, 8, True, "smooth"),
@@ -1196,9 +1198,9 @@ def test_free_running_decode_fused_feedback(dim, B, Tp, L, drop, kind):
                 # scheduled sampling: the host's per-step draws travel with the launch, both directions persistent
                 assert hb.LAUNCHES["dec_bwd_persist" if persist else "dec_bwd_step"] == 1, (persist, dict(hb.LAUNCHES))
             if fused and kind == "smooth" and L > 1:
-                # the backward of the smooth free-running sequence: persistent (feedback carried inside the kernel) in the
-                # 4-row geometry, per-step kernels + feedback kernel otherwise
-                want = "dec_bwd_persist" if (persist and Tp <= 100) else "dec_bwd_step"
+                # the backward of the smooth free-running sequence: persistent (feedback carried inside the kernel) in both
+                # geometries (4 rows per group up to T' = 100, 2 rows per group up to T' = 256: cfg-5's T' = 200)
+                want = "dec_bwd_persist" if persist else "dec_bwd_step"
                 assert hb.LAUNCHES[want] == 1, (persist, Tp, dict(hb.LAUNCHES))
             return logits.detach(), ws.detach(), pred.clone(), {k: par[k].grad.detach() for k in names}
         finally:
