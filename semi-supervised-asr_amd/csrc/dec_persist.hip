@@ -22,7 +22,12 @@
 // the same buffers as the per-step path, so asr_dec_seq_bwd runs unchanged on the result.
 #include "persist.h"
 // measurement only: per-phase shader-clock stamps of workgroup (group 0, slice 0), steps 8..15, into ctrl[16..]
-#ifdef ASR_DP_TRACE
+#if defined(ASR_DP_TRACE2)
+// every slice of group 0, steps 8..15, on the chip-wide 100 MHz clock (comparable across CUs): [slice][step][mark] in a
+// 32 KB trace buffer behind the control words (tools/dec_trace2.py: who waits for whom)
+#define DP_MARK(k) do { if (tid == 0 && g == 0 && TRS >= 8 && TRS < 16) \
+    ((unsigned long long*)(a.ctrl + 16))[(slice * 8 + (TRS - 8)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#elif defined(ASR_DP_TRACE)
 #define DP_MARK(k) do { if (tid == 0 && g == 0 && slice == 0 && TRS >= 8 && TRS < 16) \
     ((unsigned long long*)(a.ctrl + 16))[(TRS - 8) * 16 + (k)] = clock64(); } while (0)
 #else

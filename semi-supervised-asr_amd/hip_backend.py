@@ -534,7 +534,7 @@ def persist_scratch(device, trace=False):
         tkey = str(device) + "/trace"
         if tkey not in _persist_scratch:
             _persist_scratch[tkey] = (torch.zeros(XCH_BYTES // 8, dtype=torch.int64, device=device),
-                                      torch.zeros(1024, dtype=torch.int32, device=device))
+                                      torch.zeros(16384, dtype=torch.int32, device=device))     # 64 KB: tools/dec_trace2.py
         return _persist_scratch[tkey]
     key = str(device)
     if key not in _persist_scratch:
