@@ -508,9 +508,9 @@ def main():
 
     # ---- the timed object is the product's Solver: one step = Solver.sup_train_one_iteration on the (global) batch, i.e.
     # forward on this rank's strided shard, loss, zero_grad, backward, ONE all-reduce of the flat gradient buffer, clip + Adam,
-    # and the host read of loss + abort latch (the reference's loss.item(), solver.py:379).  In one process that read is
-    # pipelined: the Adam kernel checks the latch on the device, the host reads step i's record while step i + 1 runs
-    # (Solver._step); under data parallelism it sits between the all-reduce and the update (parallel.dp_step)
+    # and the host read of loss + abort latch (the reference's loss.item(), solver.py:379).  That read is pipelined: the
+    # Adam kernel checks the latch on the device - under data parallelism the latch summed over the ranks by the step's
+    # all-reduce - and the host reads step i's record while step i + 1 runs (Solver._step, parallel.DpPipeline)
     solver = make_solver(cfg, n_global // world, t_frames, os.path.join(tmp, "main"))
     xs, lens, ys = synth.ragged_batch(n_global, t_frames, cfg["input_dim"], cfg["output_dim"], 1234)
     xs_d = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)        # inputs resident in HBM before timing (every rank
@@ -549,8 +549,8 @@ def main():
         # communicator set-up (lazy in the first collective) and rank alignment before the first step
         dist.all_reduce(torch.zeros(1, device=dev))
         fence()
-    # Rehearsal of the product's abort handling (Solver._recover in one process, parallel.dp_step's coordinated
-    # fallback under data parallelism): ASR_BENCH_INJECT_ABORT=warmup|timed sets the sticky latch from the host once, as an
+    # Rehearsal of the product's abort handling (Solver._recover in one process, parallel.DpPipeline's coordinated
+    # repeat under data parallelism): ASR_BENCH_INJECT_ABORT=warmup|timed sets the sticky latch from the host once, as an
     # aborting persistent kernel would (on the last rank only).
     inject = os.environ.get("ASR_BENCH_INJECT_ABORT", "")
     for i in range(args.warmup):
@@ -647,9 +647,9 @@ def main():
                        "parallelism": "dp%d" % world, "pad_mode": "global-exact", "launch_mode": "eager",
                        "timed_call": "Solver.sup_train_one_iteration (semi-supervised-asr_amd/solver.py): forward, loss, zero_grad, "
                                      "backward, gradient exchange, clip + Adam (device-side check of the abort latch), host read of "
-                                     "loss + abort latch %s; the (global) batch is resident in HBM"
-                                     % ("between the all-reduce and the update" if world > 1 else
-                                        "one step late (pipeline_steps = 1), the last one inside the timed region"),
+                                     "loss + abort latch %sone step late (pipeline_steps = 1), the last one inside the timed "
+                                     "region; the (global) batch is resident in HBM"
+                                     % ("(summed over the ranks by the all-reduce) " if world > 1 else ""),
                        "exchange": "one all-reduce of the flat gradient buffer after the backward pass (the Solver's default)"
                                    if world > 1 else "none (one process)",
                        "persistent_kernels": bool(hb.USE_PERSIST), "retimed_after_abort": retimed,

@@ -169,6 +169,79 @@ def dp_step(make_loss, opt, n_aux, latch, leave_fast_path):
         leave_fast_path(int(values[flag_slot]))
 
 
+class DpPipeline(object):
+    """Data-parallel optimiser steps with NO host wait inside the step (Solver._step under data parallelism; no kernel
+    code in here, so the gloo tests run it on CPU).  dp_step reads the reduced abort latch on the host between the
+    all-reduce and the update - a GPU that idles for the length of a host round trip plus the launch of the update, every
+    step.  Here the update is enqueued behind the all-reduce at once, PREDICATED ON THE DEVICE on the reduced latch (the
+    last aux slot of the flat buffer: opt.apply(skip_if=...); the sum is the same word on every rank, so all ranks skip or
+    none does), the reduced aux slots travel to the host asynchronously (stage), and the host looks at step i while step
+    i + 1 .. i + depth run.  A rank's latch is sticky until leave_fast_path() clears it, so every step enqueued behind an
+    aborted one carries a non-zero sum too and was skipped as well; the first record found set makes EVERY rank (the
+    values are identical) take the step counts back, restore the numpy stream that step started with, leave the fast
+    path and run the skipped steps again through dp_step, in order.  Every rank has to resolve records at the same points
+    of its program (the Solver's loops do: they run the same code on all ranks) - the replay is a sequence of collectives.
+      latch()              -> this rank's abort latch (0 = clean), float or 0-d tensor
+      leave_fast_path(n)   -> switch to the fallback path AND clear the latch (n = ranks that reported an abort)
+      stage(aux)           -> (host tensor, wait): start copying the reduced aux slots to the host; wait() blocks until
+                              they have landed.  Default: a clone (CPU tensors)."""
+
+    def __init__(self, depth, latch, leave_fast_path, stage=None):
+        self.depth, self.latch, self.leave = max(1, int(depth)), latch, leave_fast_path
+        self.stage = stage if stage is not None else (lambda aux: (aux.clone(), lambda: None))
+        self.pending = []
+
+    def step(self, make_loss, opt, n_aux):
+        """Enqueue one step; -> its record (rec["values"]: the first n_aux scalars summed over ranks once resolve(rec) /
+        flush() has run, None before)."""
+        flag_slot = opt.buf.NAUX - 1
+        assert n_aux <= flag_slot
+        rec = dict(make_loss=make_loss, opt=opt, n=n_aux, rng=np.random.get_state(), values=None, resolve=self.resolve)
+        loss, scalars = make_loss()
+        opt.zero_grad()
+        if loss is not None:
+            loss.backward()
+        aux = [v if v is not None else 0.0 for v in scalars[:n_aux]] + [0.0] * (flag_slot - n_aux)
+        aux.append(self.latch())
+        opt.buf.set_aux(aux)
+        opt.reduce()
+        rec["host"], rec["wait"] = self.stage(opt.buf.aux)
+        opt.apply(skip_if=opt.buf.aux[flag_slot:flag_slot + 1])      # a no-op on the device if any rank's latch was set
+        self.pending.append(rec)
+        while len(self.pending) > self.depth:
+            self.resolve(self.pending[0])
+        return rec
+
+    def resolve(self, rec):
+        """Read the host records of every outstanding step up to and including `rec` (oldest first)."""
+        while self.pending and rec["values"] is None:
+            first = self.pending[0]
+            first["wait"]()
+            vals = first["host"].tolist()
+            if vals[-1] != 0.0:
+                self._recover(int(vals[-1]))
+            else:
+                first["values"] = vals[:first["n"]]
+                self.pending.pop(0)
+
+    def flush(self):
+        while self.pending:
+            self.resolve(self.pending[-1])
+
+    def _recover(self, n_ranks):
+        redo, self.pending = self.pending, []
+        for r in redo:
+            r["opt"].unapply()
+        np.random.set_state(redo[0]["rng"])
+        self.leave(n_ranks)
+
+        def again(n):
+            raise RuntimeError("the abort latch is set on %d rank(s) after a data-parallel step off the fast path; nothing "
+                               "was applied" % n)
+        for r in redo:
+            r["values"] = dp_step(r["make_loss"], r["opt"], r["n"], self.latch, again)
+
+
 # ------------------------------------------------------------------------------ flat buffers
 class FlatBuffers(object):
     """Re-home every parameter (and its .grad) of a module into two flat fp32 buffers so that the

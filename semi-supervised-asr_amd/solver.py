@@ -33,7 +33,7 @@ class StepScalar(object):
 
     def __float__(self):
         if self._rec["values"] is None:
-            self._rec["solver"]._resolve_through(self._rec)
+            self._rec["resolve"](self._rec)
         return float(self._rec["values"][self._i])
 
     item = __float__
@@ -66,6 +66,7 @@ class Solver(object):
         self._paths_reported = False
         self._pending = []                 # train steps whose host read (scalars + abort latch) is outstanding, oldest first
         self._pinned = None                # their landing slots in pinned host memory
+        self._dp_pipe = None               # the same for data-parallel steps (parallel.DpPipeline)
         self.rank, self.world, _ = parallel.init_distributed()
         # The reference never seeds numpy (teacher-forcing draws model.py:328, input noise solver.py:370-373).  Data-parallel
         # ranks must draw identical streams, so `numpy_seed` (not a reference key) defaults to 0 there;
@@ -320,8 +321,8 @@ class Solver(object):
 
     def _step(self, make_local, opt, n_scalars):
         """Run one optimiser step on make_local() -> (local loss, [scalar tensors]); returns the scalars, summed over the
-        ranks of a data-parallel run (= the single-process values): floats under data parallelism, StepScalars in one
-        process.
+        ranks of a data-parallel run (= the single-process values), as StepScalars (plain floats from the synchronous
+        data-parallel step, `pipeline_steps: 0`).
 
         One process: nothing in the step waits for the host.  zero_grad -> backward -> gradients into the flat buffer ->
         [loss scalars + abort latch -> pinned host memory, asynchronously] -> clip + Adam, whose kernel checks the abort latch
@@ -331,13 +332,23 @@ class Solver(object):
         a bounded spin expiring: a shared or partitioned GPU); the latch stays set, so the update of the aborted step AND of
         every step enqueued behind it was skipped on the device - _recover switches this process to the per-step kernels
         and runs those steps again from the numpy stream (teacher-forcing draws) the first of them started with.  A
-        non-finite loss without the latch is the model's own and is applied, as in the reference."""
+        non-finite loss without the latch is the model's own and is applied, as in the reference.
+
+        Data parallel: the same, with the latch SUMMED OVER THE RANKS in the step's one all-reduce (last aux slot of the flat
+        buffer) as the device-side predicate - every rank skips or none does - and the coordinated repeat of _dp_step one
+        step late (parallel.DpPipeline).  Every rank resolves its StepScalars at the same points of the program (the loops
+        below run the same code on all ranks): a recovery is a sequence of collectives."""
+        depth = int(self.config.get("pipeline_steps", self.PIPELINE_STEPS))
         if self.world > 1:
-            out = self._dp_step(make_local, opt, n_scalars)
+            if depth <= 0 or opt.buf.flat_g.device.type != "cuda":
+                out = self._dp_step(make_local, opt, n_scalars)        # the host reads between all-reduce and update
+            else:
+                rec = self._dp_pipeline(depth).step(make_local, opt, n_scalars)
+                out = [StepScalar(rec, i) for i in range(n_scalars)]
             self._report_paths()
             return out
-        rec = dict(solver=self, opt=opt, make_local=make_local, n=n_scalars, rng=np.random.get_state(), values=None,
-                   event=None, slot=None)
+        rec = dict(resolve=self._resolve_through, opt=opt, make_local=make_local, n=n_scalars, rng=np.random.get_state(),
+                   values=None, event=None, slot=None)
         loss, scalars = make_local()
         opt.zero_grad()
         loss.backward()
@@ -348,21 +359,54 @@ class Solver(object):
             return [StepScalar(rec, i) for i in range(n_scalars)]
         dev = loss.device
         latch = hb.persist_abort_flag(dev)
-        if self._pinned is None:
-            self._pinned = torch.zeros(8, 8, dtype=torch.float32).pin_memory()
-        busy = set(r["slot"] for r in self._pending)
-        rec["slot"] = next(i for i in range(self._pinned.shape[0]) if i not in busy)
+        rec["slot"] = self._free_slot()
         stage = torch.stack([v.detach().reshape(()).float() for v in scalars[:n_scalars]] + [latch[0].float()])
         self._pinned[rec["slot"], :n_scalars + 1].copy_(stage, non_blocking=True)
         rec["event"] = torch.cuda.Event()
         rec["event"].record()
         opt.apply(skip_if=latch)                         # clip -> Adam; a no-op on the device if the latch is set
         self._pending.append(rec)
-        depth = int(self.config.get("pipeline_steps", self.PIPELINE_STEPS))
         while len(self._pending) > depth:
             self._resolve_through(self._pending[0])
         self._report_paths()
         return [StepScalar(rec, i) for i in range(n_scalars)]
+
+    def _free_slot(self):
+        """A row of the pinned landing buffer that no outstanding step uses."""
+        if self._pinned is None:
+            self._pinned = torch.zeros(8, 8, dtype=torch.float32).pin_memory()
+        busy = set(r["slot"] for r in self._pending)
+        if self._dp_pipe is not None:
+            row = self._pinned.stride(0) * self._pinned.element_size()
+            busy |= set((r["host"].data_ptr() - self._pinned.data_ptr()) // row for r in self._dp_pipe.pending)
+        return next(i for i in range(self._pinned.shape[0]) if i not in busy)
+
+    def _dp_pipeline(self, depth):
+        """The data-parallel step without a host wait (parallel.DpPipeline): the reduced abort latch predicates the update on
+        the device, the reduced scalars land in pinned host memory behind an event; on an abort every rank leaves the
+        persistent kernels and repeats what was skipped (the decision of _dp_step, one step late)."""
+        if self._dp_pipe is None:
+            def stage(aux):
+                host = self._pinned[self._free_slot(), :aux.numel()]
+                host.copy_(aux, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record()
+                return host, event.synchronize
+
+            def latch():
+                return hb.persist_abort_flag(torch.device("cuda", torch.cuda.current_device()))[0].float()
+
+            def leave_persistent(n_ranks):
+                dev = torch.device("cuda", torch.cuda.current_device())
+                torch.cuda.synchronize()
+                print("rank %d: persistent kernels aborted on %d rank(s) (this rank: %s, code %d): every rank repeats the "
+                      "skipped step(s) on the per-step kernels" % (self.rank, n_ranks, hb.persist_aborted(dev),
+                                                                   hb.persist_abort_code(dev)))
+                hb.disable_persistent(dev)              # also clears this rank's latch
+            self._free_slot()                           # allocates the pinned buffer
+            self._dp_pipe = parallel.DpPipeline(depth, latch, leave_persistent, stage)
+        self._dp_pipe.depth = max(1, int(depth))
+        return self._dp_pipe
 
     def _report_paths(self):
         if not self._paths_reported:
@@ -405,6 +449,8 @@ class Solver(object):
         """Wait for the host records of all outstanding train steps (before validation, checkpoints, the end of a loop)."""
         while self._pending:
             self._resolve_through(self._pending[-1])
+        if self._dp_pipe is not None:
+            self._dp_pipe.flush()
 
     def _recover(self):
         """The oldest outstanding step found the abort latch set: neither its update nor that of any step enqueued behind it

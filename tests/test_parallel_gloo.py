@@ -320,7 +320,7 @@ class _SgdOpt(object):
 
     def __init__(self, params, lr):
         import parallel
-        self.buf, self.lr, self.applied = parallel.FlatBuffers(params), lr, 0
+        self.buf, self.lr, self.applied, self.t = parallel.FlatBuffers(params), lr, 0, 0
 
     def zero_grad(self):
         self.buf.zero_grad()
@@ -328,15 +328,24 @@ class _SgdOpt(object):
     def reduce(self):
         self.buf.allreduce_grads()
 
-    def apply(self):
+    def apply(self, skip_if=None):
+        """skip_if: a 1-element tensor; not zero = the update is a no-op (FlatAdam: checked by the kernel on the device)
+        that still counts as a step until unapply() takes it back."""
+        self.t += 1
+        if skip_if is not None and float(skip_if) != 0.0:
+            return
         self.applied += 1
         self.buf.flat_p -= self.lr * self.buf.flat_g[:self.buf.total]
 
+    def unapply(self, n=1):
+        self.t -= n
 
-def _dp_steps(rank, world, abort_rank):
+
+def _dp_steps(rank, world, abort_rank, pipelined=0):
     """Two optimiser steps through parallel.dp_step (what Solver._dp_step runs) with tf_rate 0.5 - the teacher-forcing
     draws come from the numpy stream - where rank `abort_rank` reports an aborted persistent kernel (latch set, loss
-    poisoned) in the FIRST attempt of the FIRST step."""
+    poisoned) in the FIRST attempt of the FIRST step.  pipelined = depth > 0: three steps through parallel.DpPipeline
+    (the Solver's default under data parallelism) instead."""
     from oracle import asr_oracle as O
     import parallel
     cfg = dict(CFG, labeldist=synth.labeldist(CFG["output_dim"], 12))
@@ -359,6 +368,13 @@ def _dp_steps(rank, world, abort_rank):
         state["fast"], state["latch"] = False, 0.0        # hb.disable_persistent: off the fast path, latch cleared
 
     np.random.seed(21)
+    if pipelined:
+        pipe = parallel.DpPipeline(pipelined, lambda: state["latch"], leave)
+        recs = [pipe.step(make_loss, opt, 1) for _ in range(3)]
+        state["outstanding"] = [r["values"] is None for r in recs]
+        pipe.flush()
+        assert not pipe.pending and opt.t == 3
+        return opt, [r["values"][0] for r in recs], state
     losses = [parallel.dp_step(make_loss, opt, 1, lambda: state["latch"], leave)[0] for _ in range(2)]
     return opt, losses, state
 
@@ -388,6 +404,41 @@ def test_dp_step_coordinated_fallback_after_an_abort_on_one_rank(tmp_path):
     ref = ref_opt.buf.flat_p
     for r in range(2):
         got = torch.load(os.path.join(str(tmp_path), "dpabort%d.pt" % r))
+        assert all(np.isfinite(v) for v in got["losses"])
+        for a, b in zip(got["losses"], ref_losses):
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got["losses"], ref_losses)
+        err = (got["p"] - ref).abs().max().item()
+        assert err <= 1e-6 * max(1.0, ref.abs().max().item()), (r, err)
+
+
+def _worker_dp_pipeline(rank, world, port, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    opt, losses, state = _dp_steps(rank, world, abort_rank=1, pipelined=1)
+    # step 1 aborted on rank 1, step 2 was enqueued behind it with the latch still set (both skipped on BOTH ranks), the
+    # record of step 1 was read after step 2: both repeated off the fast path, then step 3: 5 forward passes, 3 updates
+    assert state["calls"] == 5 and opt.applied == 3 and state["left"] == [1] and not state["fast"], (rank, state, opt.applied)
+    assert state["outstanding"] == [False, False, True]      # the last step's record is read by flush()
+    torch.save(dict(p=opt.buf.flat_p.clone(), losses=losses), os.path.join(out_dir, "dppipe%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_pipeline_skips_on_every_rank_and_repeats_one_step_late(tmp_path):
+    """The data-parallel step without a host wait: the update is predicated on the all-reduced latch, the host reads a
+    step's record while the next one runs.  Rank 1 aborts in step 1: neither step 1 nor step 2 (enqueued behind it) is
+    applied on either rank; both ranks repeat them in order from the numpy stream of step 1 - weights and losses after
+    three steps equal the one-process run that never aborted."""
+    _setup_paths()
+    port = _free_port()
+    mp.spawn(_worker_dp_pipeline, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref_opt, ref_losses, ref_state = _dp_steps(0, 1, abort_rank=-1, pipelined=1)
+    assert ref_state["calls"] == 3 and ref_state["left"] == [] and ref_opt.applied == 3
+    ref = ref_opt.buf.flat_p
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), "dppipe%d.pt" % r))
         assert all(np.isfinite(v) for v in got["losses"])
         for a, b in zip(got["losses"], ref_losses):
             assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got["losses"], ref_losses)
