@@ -64,6 +64,8 @@ int asr_abi_version(void);
  *   ASR_GEMM_TILE_NARROW / ASR_GEMM_TILE_WIDE / ASR_GEMM_TILE_SP   asr_gemm_f32: only the 128 x 128 kernel / the 256 x 128
  *                     LDS-DMA kernel / the 256 x 128 one-wave-per-SIMD kernel for every conforming shape; by default
  *                     each is used for the shapes it pays on (csrc/gemm.hip: asr_gemm_f32);
+ *   ASR_GEMM_TILE_SMALL   asr_gemm_f32: 64 x 64 tiles on the 128 x 128 kernel's code (by default for products whose large tiles,
+ *                     K split included, would be at most one workgroup per CU: decoder-side projections, output layer);
  *   ASR_LSTM_BWD_GATHER   asr_lstm_seq_bwd_persist: the gathered-dG kernel instead of the one with exchanged partials. */
 #define ASR_ARITH_F32        0
 #define ASR_ARITH_BF16X6     1
@@ -72,6 +74,7 @@ int asr_abi_version(void);
 #define ASR_GEMM_TILE_NARROW 0x100
 #define ASR_GEMM_TILE_WIDE   0x200
 #define ASR_GEMM_TILE_SP     0x800
+#define ASR_GEMM_TILE_SMALL  0x1000
 #define ASR_LSTM_BWD_GATHER  0x400
 
 /* ---------------------------------------------------------------------------------------

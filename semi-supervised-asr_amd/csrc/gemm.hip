@@ -356,34 +356,49 @@ __device__ __forceinline__ void bfn_split2(float x, float y, unsigned (&t)[NT]) 
   }
 }
 
-// this thread's 4 float4 pieces of a 128 (rows) x 32 (k) operand tile; MC mapping: k block t & 7, rows 4 (t >> 3) .. + 3
-template <bool KC>
-__device__ __forceinline__ void tile_fetch_bf3(const MatView& m, int64_t row0, int64_t k0, float4 (&v)[4]) {
+// this thread's TS / 32 float4 pieces of a TS (rows) x 32 (k) operand tile, TS = 128 or 64.  KC (k-contiguous rows):
+// piece i = 4 k of row (t + 256 i) >> 3.  MC (row-contiguous): k block t & 7, rows 4 (t >> 3) .. + 3 - at TS = 128 all four
+// k of the block, at TS = 64 (16 row quads x 8 k blocks = 128 threads' worth) the two k 2 (t >> 7), + 1 of it
+template <bool KC, int TS>
+__device__ __forceinline__ void tile_fetch_bf3(const MatView& m, int64_t row0, int64_t k0, float4 (&v)[TS / 32]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TS / 32; ++i) {
     if (KC) {
       const int f = t + 256 * i;
       v[i] = load4_guard(m, row0 + (f >> 3), k0 + 4 * (f & 7));
-    } else {
+    } else if (TS == 128) {
       v[i] = load4_guard(m, k0 + 4 * (t & 7) + i, row0 + 4 * (t >> 3));
+    } else {
+      v[i] = load4_guard(m, k0 + 4 * (t & 7) + 2 * (t >> 7) + i, row0 + 4 * ((t >> 3) & 15));
     }
   }
 }
 
-template <bool KC, int NT>
-__device__ __forceinline__ void tile_store_bf3(unsigned short* img, const float4 (&v)[4]) {   // NT images, BM * BS apart
+template <bool KC, int NT, int TS>
+__device__ __forceinline__ void tile_store_bf3(unsigned short* img, const float4 (&v)[TS / 32]) {   // NT images, TS * BS apart
   const int t = threadIdx.x;
   if (KC) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TS / 32; ++i) {
       const int f = t + 256 * i;
       const int o = (f >> 3) * BS + 4 * (f & 7);
       unsigned p0[NT], p1[NT];
       bfn_split2<NT>(v[i].x, v[i].y, p0);
       bfn_split2<NT>(v[i].z, v[i].w, p1);
 #pragma unroll
-      for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(img + k * BM * BS + o) = make_uint2(p0[k], p1[k]);
+      for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(img + k * TS * BS + o) = make_uint2(p0[k], p1[k]);
+    }
+  } else if constexpr (TS == 64) {
+    // two consecutive k of four rows: one packed split and a 4-byte store per row and term
+    const int o = 4 * ((t >> 3) & 15) * BS + 4 * (t & 7) + 2 * (t >> 7);
+    const float r[4][2] = {{v[0].x, v[1].x}, {v[0].y, v[1].y}, {v[0].z, v[1].z}, {v[0].w, v[1].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned p0[NT];
+      bfn_split2<NT>(r[j][0], r[j][1], p0);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) *reinterpret_cast<unsigned*>(img + k * TS * BS + o + j * BS) = p0[k];
     }
   } else {
     const int o = 4 * (t >> 3) * BS + 4 * (t & 7);
@@ -395,14 +410,19 @@ __device__ __forceinline__ void tile_store_bf3(unsigned short* img, const float4
       bfn_split2<NT>(r[j][0], r[j][1], p0);
       bfn_split2<NT>(r[j][2], r[j][3], p1);
 #pragma unroll
-      for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(img + k * BM * BS + o + j * BS) = make_uint2(p0[k], p1[k]);
+      for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(img + k * TS * BS + o + j * BS) = make_uint2(p0[k], p1[k]);
     }
   }
 }
 
-template <bool AKC, bool BKC, int NT>
+// TS = 128: the 128 x 128 tile (a wave owns 64 x 64).  TS = 64: a 64 x 64 tile (a wave owns one 32 x 32 block) for the
+// products too small to fill the chip with 128 x 128 tiles - the decoder-side projections, their gradients, the output
+// layer: [3 200, 512] outputs are 100 large tiles, each a serial walk of 16-64 K tiles alone on its CU; as 400 small tiles
+// every CU holds one or two workgroups whose K tiles cost a quarter (tools/gemm_shapes.py).
+template <bool AKC, bool BKC, int NT, int TS = 128>
 __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
-  // NT images (split terms, most significant first) per operand: 40 KB for two terms, 60 KB for three
+  // NT images (split terms, most significant first) per operand: 40 KB for two terms, 60 KB for three (TS = 128)
+  constexpr int BM = TS, BN = TS, NP = TS / 32, NB = TS / 64;      // tile, float4 pieces per thread and operand, blocks per wave and side
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NT * BM * BS];
   unsigned short* Ai = smem;
   unsigned short* Bi = smem + NT * BM * BS;
@@ -432,11 +452,11 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, kh = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[NB][NB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -444,17 +464,18 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   const bool fast_a = A.vec && (AKC ? (m0 + BM <= A.R) : (m0 + BM <= A.Cn)) && A.R * A.ld < (int64_t)1 << 30;
   const bool fast_b = B.vec && (BKC ? (n0 + BN <= B.R) : (n0 + BN <= B.Cn)) && B.R * B.ld < (int64_t)1 << 30;
   const bool fast = fast_a && fast_b;
-  unsigned offa[4], offb[4];
+  unsigned offa[NP], offb[NP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NP; ++i) {
     const int f = threadIdx.x + 256 * i;
     const int t = threadIdx.x;
-    offa[i] = AKC ? (unsigned)((f >> 3) * A.ld + 4 * (f & 7)) : (unsigned)((4 * (t & 7) + i) * A.ld + 4 * (t >> 3));
-    offb[i] = BKC ? (unsigned)((f >> 3) * B.ld + 4 * (f & 7)) : (unsigned)((4 * (t & 7) + i) * B.ld + 4 * (t >> 3));
+    const int krow = TS == 128 ? 4 * (t & 7) + i : 4 * (t & 7) + 2 * (t >> 7) + i, rq = TS == 128 ? (t >> 3) : ((t >> 3) & 15);
+    offa[i] = AKC ? (unsigned)((f >> 3) * A.ld + 4 * (f & 7)) : (unsigned)(krow * A.ld + 4 * rq);
+    offb[i] = BKC ? (unsigned)((f >> 3) * B.ld + 4 * (f & 7)) : (unsigned)(krow * B.ld + 4 * rq);
   }
   const float* basea = AKC ? A.p + m0 * A.ld : A.p + m0;     // + k0 (KC) or + k0*ld (MC)
   const float* baseb = BKC ? B.p + n0 * B.ld : B.p + n0;
-  float4 ra[4], rb[4];
+  float4 ra[NP], rb[NP];
   // Two copies of the K loop, chosen once per workgroup.  With the bare loads and the guarded loads as two branches of
   // one fetch, hipcc loads into temporaries and copies them into (ra, rb) at the end of the branch - an s_waitcnt vmcnt
   // right behind the loads, i.e. a full memory round trip exposed on every K tile (the kernel ran at 150 TF-equivalent
@@ -464,19 +485,19 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
     const float* pa = basea + (AKC ? k0 : k0 * A.ld);
     const float* pb = baseb + (BKC ? k0 : k0 * B.ld);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + offa[i]);
+    for (int i = 0; i < NP; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + offa[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + offb[i]);
+    for (int i = 0; i < NP; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + offb[i]);
   };
   auto fetch_guard = [&](int64_t kt2) {
     const int64_t k0 = kt2 * BK;
-    tile_fetch_bf3<AKC>(A, m0, k0, ra);
-    tile_fetch_bf3<BKC>(B, n0, k0, rb);
+    tile_fetch_bf3<AKC, TS>(A, m0, k0, ra);
+    tile_fetch_bf3<BKC, TS>(B, n0, k0, rb);
   };
   const int tt = threadIdx.x & 127;
   const bool touch_a = threadIdx.x < 128;
   float touched = 0.f;
-  const bool do_touch = kt_end - kt_begin > 2 * ASR_GEMM_BF3_TOUCH;
+  const bool do_touch = TS == 128 && kt_end - kt_begin > 2 * ASR_GEMM_BF3_TOUCH;   // (the small tiles run several workgroups per CU instead)
   auto touch_tile = [&](int64_t ktt) {
     const MatView& m = touch_a ? A : B;
     const bool kc = touch_a ? AKC : BKC;
@@ -489,13 +510,13 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
     touched = m.p[rr * m.ld + cc];
   };
   // fragment of row tile i at k-step ks: row wm*64 + 32 i + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7
-  const int ao = (wm * 64 + l31) * BS + 8 * kh, bo = (wn * 64 + l31) * BS + 8 * kh;
+  const int ao = (wm * (TS / 2) + l31) * BS + 8 * kh, bo = (wn * (TS / 2) + l31) * BS + 8 * kh;
   auto multiply = [&]() {
 #pragma unroll
     for (int ks = 0; ks < ((ASR_GB_ABL & 1) ? 0 : BK / 16); ++ks) {
-      gu32x4 af[2][NT], bf[2][NT];
+      gu32x4 af[NB][NT], bf[NB][NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
           af[i][k] = *reinterpret_cast<const gu32x4*>(Ai + k * BM * BS + ao + 32 * i * BS + 16 * ks);
@@ -508,9 +529,9 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
 #pragma unroll
         for (int p = 0; p <= o; ++p)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < NB; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) BF3G(af[i][p], bf[j][o - p], acc[i][j]);
+            for (int j = 0; j < NB; ++j) BF3G(af[i][p], bf[j][o - p], acc[i][j]);
 #undef BF3G
     }
   };
@@ -518,20 +539,67 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   // workgroups take the guarded loop, which does not overlap its loads (one tile in the K = 80 case)
   const int64_t kt_full = g.K / BK < kt_end ? g.K / BK : kt_end;
   const int64_t kt_fast_end = (fast && kt_full > kt_begin) ? kt_full : kt_begin;
-  if (kt_begin < kt_fast_end) {
+  if constexpr (TS == 64) {
+    // Small tiles: a K tile's 12 MFMAs per wave (384 cycles) cannot cover a memory round trip, so the operands of PD = 3
+    // K tiles are in flight in registers (12 float4 per thread).  The steady state runs in groups of PD tiles with
+    // unconditional fetches - a conditional one makes hipcc wait for ALL outstanding loads (vmcnt(0)) at the next store -
+    // and the last < 2 PD tiles take the conditional form.
+    constexpr int PD = 3;
+    float4 qa[PD][NP], qb[PD][NP];
+    auto fetch_set = [&](int64_t kt2, float4 (&xa)[NP], float4 (&xb)[NP]) __attribute__((always_inline)) {
+      const int64_t k0 = kt2 * BK;
+      const float* pa = basea + (AKC ? k0 : k0 * A.ld);
+      const float* pb = baseb + (BKC ? k0 : k0 * B.ld);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) xa[i] = *reinterpret_cast<const float4*>(pa + offa[i]);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) xb[i] = *reinterpret_cast<const float4*>(pb + offb[i]);
+    };
+    int64_t kt = kt_begin;
+    if (kt < kt_fast_end) {
+#pragma unroll
+      for (int d = 0; d < PD; ++d)
+        if (kt + d < kt_fast_end) fetch_set(kt + d, qa[d], qb[d]);
+      for (; kt + 2 * PD <= kt_fast_end; kt += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          __builtin_amdgcn_sched_barrier(0);        // (keeps the split of a later set - and the wait for its loads - out of this step)
+          tile_store_bf3<AKC, NT, TS>(Ai, qa[d]);
+          tile_store_bf3<BKC, NT, TS>(Bi, qb[d]);
+          __syncthreads();
+          fetch_set(kt + d + PD, qa[d], qb[d]);
+          multiply();
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // tail: PD .. 2 PD - 1 tiles (or fewer than PD when the whole slice is short); tile kt + d sits in set d % PD
+#pragma unroll
+      for (int d = 0; d < 2 * PD - 1; ++d) {
+        if (kt + d < kt_fast_end) {
+          tile_store_bf3<AKC, NT, TS>(Ai, qa[d % PD]);
+          tile_store_bf3<BKC, NT, TS>(Bi, qb[d % PD]);
+          __syncthreads();
+          if (kt + d + PD < kt_fast_end) fetch_set(kt + d + PD, qa[d % PD], qb[d % PD]);
+          multiply();
+          __syncthreads();
+        }
+      }
+    }
+  } else if (kt_begin < kt_fast_end) {
     fetch_fast(kt_begin);
     for (int64_t kt = kt_begin; kt < kt_fast_end; ++kt) {
 #if ASR_GB_ABL & 4
       if (kt == kt_begin) {
-        tile_store_bf3<AKC, NT>(Ai, ra);
-        tile_store_bf3<BKC, NT>(Bi, rb);
+        tile_store_bf3<AKC, NT, TS>(Ai, ra);
+        tile_store_bf3<BKC, NT, TS>(Bi, rb);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w), "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+        for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w), "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
       }
 #else
-      tile_store_bf3<AKC, NT>(Ai, ra);
-      tile_store_bf3<BKC, NT>(Bi, rb);
+      tile_store_bf3<AKC, NT, TS>(Ai, ra);
+      tile_store_bf3<BKC, NT, TS>(Bi, rb);
 #endif
       __syncthreads();
       if (kt + 1 < kt_fast_end && !(ASR_GB_ABL & 2)) fetch_fast(kt + 1);
@@ -546,8 +614,8 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
   if (kt_fast_end < kt_end) {
     fetch_guard(kt_fast_end);
     for (int64_t kt = kt_fast_end; kt < kt_end; ++kt) {
-      tile_store_bf3<AKC, NT>(Ai, ra);
-      tile_store_bf3<BKC, NT>(Bi, rb);
+      tile_store_bf3<AKC, NT, TS>(Ai, ra);
+      tile_store_bf3<BKC, NT, TS>(Bi, rb);
       __syncthreads();
       if (kt + 1 < kt_end) fetch_guard(kt + 1);
 #if ASR_GEMM_TOUCH
@@ -562,9 +630,9 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
 #if ASR_GB_ABL & 8   /* measurement: no epilogue stores (one lane keeps the accumulators alive) */
   if (threadIdx.x + blockIdx.x + blockIdx.y != 0 || g.M != 1) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
     return;
@@ -575,12 +643,12 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
     const unsigned ldc = (unsigned)g.ldc;
     const bool split = g.split_k > 1, accum = g.accumulate != 0, relu = g.relu != 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NB; ++j) {
+      const int64_t n = n0 + wn * (TS / 2) + j * 32 + l31;
       const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float* base = C + (m0 + wm * 64 + i * 32 + 4 * kh) * g.ldc + n;
+      for (int i = 0; i < NB; ++i) {
+        float* base = C + (m0 + wm * (TS / 2) + i * 32 + 4 * kh) * g.ldc + n;
         if (split) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) atomicAdd(base + (unsigned)((e & 3) + 8 * (e >> 2)) * ldc, acc[i][j][e]);
@@ -607,15 +675,15 @@ __global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
     return;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t n = n0 + wn * 64 + j * 32 + l31;
+  for (int j = 0; j < NB; ++j) {
+    const int64_t n = n0 + wn * (TS / 2) + j * 32 + l31;
     if (n >= g.N) continue;
     const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NB; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int64_t m = m0 + wm * (TS / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         if (m >= g.M) continue;
         float v = acc[i][j][e];
         float* dst = C + m * g.ldc + n;
@@ -1992,24 +2060,25 @@ extern "C" int asr_gw_trace_read(void* dst) {
 // bias / ReLU epilogue then needs a second pass over C).  256 CUs hold two 128 x 128 workgroups each, so the target is
 // ~512 workgroups: floor(512 / tiles), at most 8 (16 for <= 32 tiles), every K slice at least 256 long.  Measured with
 // cold operands (tools/gemm_cold_split_sweep.py): 400 tiles -> 1, 200 -> 2, 144 -> 3, 128 -> 4, 64 -> 8.
-static int narrow_split_k(int64_t M, int64_t N, int64_t K, int batch, bool epilogue) {
-  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
-  if (tiles >= 512 || K < 512) return 1;
+static int narrow_split_k(int64_t M, int64_t N, int64_t K, int batch, bool epilogue, int ts = 128) {
+  const int64_t tiles = ((M + ts - 1) / ts) * ((N + ts - 1) / ts) * batch;
+  const int64_t target = 512;       // (64 x 64 tiles, tools/gemm_small_sweep.py: 400 tiles unsplit 28 us, split in two 41)
+  if (tiles >= target || K < 512) return 1;
   int64_t sk = tiles <= 32 ? 16 : 8;
-  if (512 / tiles < sk) sk = 512 / tiles;
+  if (target / tiles < sk) sk = target / tiles;
   if (K / 256 < sk) sk = K / 256;
   if (sk < 1) sk = 1;
-  if (epilogue && sk > 1 && tiles > 64) return 1;
+  if (epilogue && sk > 1 && tiles > 64 && K < 2048) return 1;     // (K >= 2048: 100 tiles x 64 serial K tiles 134 us, split in 4-5 + the two passes 80)
   return (int)sk;
 }
 
-template <int NT>
+template <int NT, int TS = 128>
 static void launch_narrow_split(bool akc, bool bkc, dim3 grid, hipStream_t stream, const GemmArgs& g) {
   const dim3 block(256);
-  if (akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, true, NT>), grid, block, 0, stream, g);
-  else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, false, NT>), grid, block, 0, stream, g);
-  else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<false, true, NT>), grid, block, 0, stream, g);
-  else hipLaunchKernelGGL((gemm_bf3_kernel<false, false, NT>), grid, block, 0, stream, g);
+  if (akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, true, NT, TS>), grid, block, 0, stream, g);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, false, NT, TS>), grid, block, 0, stream, g);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<false, true, NT, TS>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_bf3_kernel<false, false, NT, TS>), grid, block, 0, stream, g);
 }
 
 extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -2050,7 +2119,7 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   const bool wide_pays = (!akc && !bkc && K >= 1024) || (K >= 2048 && ((may_split && !epi) || wtiles >= 150));
   // Short contraction with k-contiguous operands (the layer-0 input projection, K = 80): the weights-stationary kernel
   if (ar != ASR_ARITH_F32 && akc && bkc && K == 80 && g.A.vec && g.B.vec && M * lda < ((int64_t)1 << 29) && N * ldb < ((int64_t)1 << 29) &&
-      M >= 1024 && N >= 128 && (auto_split || split_k == 1) && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_WIDE | ASR_GEMM_TILE_SP))) {
+      M >= 1024 && N >= 128 && (auto_split || split_k == 1) && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_WIDE | ASR_GEMM_TILE_SP | ASR_GEMM_TILE_SMALL))) {
     const int tiles_n = (int)((N + 127) / 128);
     if (tiles_n <= 256) {
       const int groups = 8 * (tiles_n >= 32 ? 1 : 32 / tiles_n);
@@ -2068,35 +2137,51 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
       return 0;
     }
   }
+  // Products too small to fill the chip with 128 x 128 tiles take 64 x 64 tiles (gemm_bf3_kernel<..., 64>): at most
+  // ASR_GEMM_SMALL_MAX workgroups of large tiles (the decoder-side projections and their gradients, the output layer); ASR_GEMM_TILE_SMALL
+  // forces them (tests, measurements), ASR_GEMM_TILE_NARROW the 128 x 128 tile.
+  static const int64_t small_max = [] { const char* f = getenv("ASR_GEMM_SMALL_MAX"); return f ? (int64_t)atoll(f) : (int64_t)256; }();   // measurement
+  const int64_t tiles128 = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+  // ... i.e. when the large tiles, K split included, would be at most one workgroup per CU (tools/gemm_small_sweep.py:
+  // [3 200 x 512] x K 512 28-31 us against 42-47, the output layer 31-37 against 46-48; a long K on 64 large tiles -
+  // 512 workgroups after the split - stays on the large tiles: 76 against 83)
+  const int64_t wgs128 = tiles128 * (auto_split ? ((epi && accumulate) ? 1 : narrow_split_k(M, N, K, batch, epi, 128)) : (split_k > 0 ? split_k : 1));
+  const bool small = ar != ASR_ARITH_F32 && ((arith & ASR_GEMM_TILE_SMALL) || (wgs128 <= small_max && !(arith & ASR_GEMM_TILE_NARROW)));
   // The one-wave-per-SIMD kernel (gemm_bfs_kernel, same tile and K split policy): faster than both others on every shape
   // with enough work to fill the chip a few times (tools/gemm_shapes.py: 256 x 128 tiles x K tiles >= ~5 000; below
   // that its 4-wave workgroups cannot hide their prologue and the 128 x 128 kernel's two workgroups per CU win); its
   // buffer addressing wants byte offsets below 2^31.  ASR_GEMM_TILE_SP forces it for conforming shapes.
   const bool sp_shape = base_shape && (K % WK == 0 || (K % 4 == 0 && K > WK)) &&       // a K tail is masked (K = 80: the features)
                         (akc ? M : K) * lda < ((int64_t)1 << 29) && (bkc ? N : K) * ldb < ((int64_t)1 << 29);
-  const bool sp_pays = K % WK == 0 && wtiles * (K / WK) >= 5000;      // (K = 80: 223 us against the 128 x 128 kernel's 195 - three K tiles are all prologue)
-  const bool use_sp = ar != ASR_ARITH_F32 && sp_shape && (auto_split || split_k == 1) &&
-                      ((arith & ASR_GEMM_TILE_SP) || (sp_pays && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_WIDE))));
-  const bool wide = use_sp || (ar != ASR_ARITH_F32 && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_SP)) && wide_shape &&
-                               (wide_pays || (arith & ASR_GEMM_TILE_WIDE)) && (auto_split || split_k == 1));
+  static const int64_t sp_min_units = [] { const char* f = getenv("ASR_GEMM_SP_MIN"); return f ? (int64_t)atoll(f) : (int64_t)5000; }();   // measurement
+  const bool sp_pays = K % WK == 0 && wtiles * (K / WK) >= sp_min_units;      // (K = 80: 223 us against the 128 x 128 kernel's 195 - three K tiles are all prologue)
+  const bool use_sp = ar != ASR_ARITH_F32 && sp_shape && (auto_split || split_k == 1) && (!small || (arith & ASR_GEMM_TILE_SP)) &&
+                      ((arith & ASR_GEMM_TILE_SP) || (sp_pays && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_WIDE | ASR_GEMM_TILE_SMALL))));
+  const bool wide = use_sp || (ar != ASR_ARITH_F32 && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_SP | ASR_GEMM_TILE_SMALL)) && wide_shape &&
+                               ((wide_pays && !small) || (arith & ASR_GEMM_TILE_WIDE)) && (auto_split || split_k == 1));
   if (wide) {
     // its own K split: 256 workgroup slots (one 8-wave workgroup per CU), cost in units of one stage = rounds x (stages
     // per slice + a fixed prologue / epilogue share) + what the atomics and the zero pass of a split cost per MB of output
     // (tools/gemm_wide_split.py: 12800 x 512 x 4096 takes 215 us unsplit on 200 of the 256 CUs, 256 us split in two)
     const int64_t tiles = wtiles, stages = (K + WK - 1) / WK;
+    // A product with a bias / ReLU epilogue may be split as well: the atomics cannot carry the epilogue, so it becomes a
+    // pass of its own over C (bias_act_kernel, as on the 128 x 128 kernels) - worth it where few tiles walk a long K
+    // (the [T B / 4, 2048] x [2048, 512] projection of the top encoder layer: 52 tiles x 64 K tiles; tools/gemm_epi_split_sweep.py)
     int best = 1;
-    if (may_split && !epi) {
+    if (may_split) {
       double best_cost = 1e30;
       for (int sk = 1; sk <= 16 && stages / sk >= 8; ++sk) {
         const int64_t wgs = tiles * sk, rounds = (wgs + 255) / 256;
         const double out_mb = (double)M * N * batch * 4.0 / 1048576.0;
-        const double cost = (double)rounds * ((double)((stages + sk - 1) / sk) + 6.0) + (sk > 1 ? 0.47 * sk * out_mb : 0.0);
+        const double cost = (double)rounds * ((double)((stages + sk - 1) / sk) + 6.0) +
+                            (sk > 1 ? 0.47 * sk * out_mb + (epi ? 3.0 + 0.6 * out_mb : 0.0) : 0.0);
         if (cost < best_cost) { best_cost = cost; best = sk; }
       }
     }
     static const int forced_sk = [] { const char* f = getenv("ASR_GEMM_WIDE_SK"); return f ? atoi(f) : 0; }();   // measurement
-    if (forced_sk >= 1 && forced_sk <= stages && may_split && !epi) best = forced_sk;
-    g.bias = bias; g.relu = relu;
+    if (forced_sk >= 1 && forced_sk <= stages && may_split) best = forced_sk;
+    const bool late_epi = best > 1 && epi;
+    g.bias = late_epi ? nullptr : bias; g.relu = late_epi ? 0 : relu;
     g.split_k = best;
     g.tiles_m = (int)((M + WM - 1) / WM);
     g.tiles_n = (int)((N + WN - 1) / WN);
@@ -2128,17 +2213,22 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
       else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<false, true>), grid, block, 0, stream, g);
       else hipLaunchKernelGGL((gemm_bf3w_kernel<false, false>), grid, block, 0, stream, g);
     }
+    if (late_epi) {
+      dim3 eg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
+      hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, bias, relu);
+    }
     ASR_CHECK_LAUNCH();
     return 0;
   }
-  if (auto_split) split_k = (epi && accumulate) ? 1 : narrow_split_k(M, N, K, batch, epi);
+  const int ts = small ? 64 : 128;
+  if (auto_split) split_k = (epi && accumulate) ? 1 : narrow_split_k(M, N, K, batch, epi, ts);
   // split-K with an epilogue: the product is formed without it (atomics) and a second pass applies bias / ReLU
   const bool late_epilogue = split_k > 1 && epi;
   if (late_epilogue && accumulate) return ASR_E_SHAPE;
   g.bias = late_epilogue ? nullptr : bias;
   g.relu = late_epilogue ? 0 : relu;
-  g.tiles_m = (int)((M + BM - 1) / BM);
-  g.tiles_n = (int)((N + BN - 1) / BN);
+  g.tiles_m = (int)((M + ts - 1) / ts);
+  g.tiles_n = (int)((N + ts - 1) / ts);
   const int64_t ktiles = (K + BK - 1) / BK;
   if (split_k > ktiles) split_k = (int)ktiles;
   g.split_k = split_k;
@@ -2147,7 +2237,9 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
     hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
   }
   dim3 grid(g.tiles_m * g.tiles_n, batch * split_k, 1), block(256);
-  if (ar == ASR_ARITH_BF16X6) launch_narrow_split<3>(akc, bkc, grid, stream, g);
+  if (ar == ASR_ARITH_BF16X6 && small) launch_narrow_split<3, 64>(akc, bkc, grid, stream, g);
+  else if (ar == ASR_ARITH_BF16X3 && small) launch_narrow_split<2, 64>(akc, bkc, grid, stream, g);
+  else if (ar == ASR_ARITH_BF16X6) launch_narrow_split<3>(akc, bkc, grid, stream, g);
   else if (ar == ASR_ARITH_BF16X3) launch_narrow_split<2>(akc, bkc, grid, stream, g);
   else if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
   else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);

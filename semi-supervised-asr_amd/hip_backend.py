@@ -124,7 +124,7 @@ def load():
 # This module only holds the host code's DEFAULT for calls that do not name one: bf16x6 (three-term split, six products:
 # fp32-equivalent), overridable with ASR_ARITH=f32|bf16x6|bf16x3 or `with hb.arith("f32"):`.
 ARITH_F32, ARITH_BF16X6, ARITH_BF16X3 = 0, 1, 2
-GEMM_TILE_NARROW, GEMM_TILE_WIDE, LSTM_BWD_GATHER, GEMM_TILE_SP = 0x100, 0x200, 0x400, 0x800
+GEMM_TILE_NARROW, GEMM_TILE_WIDE, LSTM_BWD_GATHER, GEMM_TILE_SP, GEMM_TILE_SMALL = 0x100, 0x200, 0x400, 0x800, 0x1000
 ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "bf16x3": ARITH_BF16X3}
 ARITH_LABEL = {ARITH_F32: "f32", ARITH_BF16X6: "bf16x6", ARITH_BF16X3: "bf16x3"}
 
@@ -133,7 +133,8 @@ def _arith_code(a):
     if isinstance(a, str):
         code = 0
         for part in a.lower().split("+"):
-            code |= {"narrow": GEMM_TILE_NARROW, "wide": GEMM_TILE_WIDE, "gather": LSTM_BWD_GATHER, "sp": GEMM_TILE_SP}.get(part, 0) or \
+            code |= {"narrow": GEMM_TILE_NARROW, "wide": GEMM_TILE_WIDE, "gather": LSTM_BWD_GATHER, "sp": GEMM_TILE_SP,
+                     "small": GEMM_TILE_SMALL}.get(part, 0) or \
                     ARITH_NAMES[part]
         return code
     return int(a)

@@ -109,7 +109,8 @@ def test_gemm_bf16x6_is_fp32_equivalent(ta, tb, M, N, K):
         return float((out.double().cpu() - ref).abs().max()) / scale
     e32 = err(arith="f32", split_k=1)
     for kw in (dict(arith="bf16x6"), dict(arith="bf16x6", split_k=1), dict(arith="bf16x6+narrow", split_k=1),
-               dict(arith="bf16x6+wide", split_k=1), dict(arith="bf16x6+sp", split_k=1), dict(arith="bf16x6+sp")):
+               dict(arith="bf16x6+wide", split_k=1), dict(arith="bf16x6+sp", split_k=1), dict(arith="bf16x6+sp"),
+               dict(arith="bf16x6+small", split_k=1), dict(arith="bf16x6+small")):
         e6 = err(**kw)
         assert e6 <= 2.0 * e32 + 2e-8, "bf16x6 %s: error %.3g vs fp32 kernel %.3g" % (kw, e6, e32)
     e3 = err(arith="bf16x3", split_k=1)
@@ -139,7 +140,8 @@ def test_gemm_split_terms_are_lossless():
                                    (300, 80, 64), (1000, 200, 512), (64, 64, 32), (4096, 80, 3200), (3232, 1152, 2048),
                                    (2560, 512, 80), (260, 132, 100)])
 def test_gemm_wide_tile(ta, tb, M, N, K, arith, rtol):
-    """The 256 x 128 kernels - LDS-DMA (gemm_bf6w_kernel / gemm_bf3w_kernel: K % 32 == 0) and one wave per SIMD with the
+    """(Also "+small": the 64 x 64 tiles of the 128 x 128 kernel's code, the default for products whose large tiles would not fill the chip.)
+    The 256 x 128 kernels - LDS-DMA (gemm_bf6w_kernel / gemm_bf3w_kernel: K % 32 == 0) and one wave per SIMD with the
     split once per workgroup (gemm_bfs_kernel, "+sp": also a masked K tail, K = 80 / 100) - of the bf16 arithmetics in
     the four operand layouts: 1, 2, 3 and many ring stages, their own K split (long K on few tiles), edge tiles in M and N
     (clamped DMA sources, guarded stores; the thin N = 80 weight gradient and the decoder's M = 3232), epilogue,
@@ -154,7 +156,7 @@ def test_gemm_wide_tile(ta, tb, M, N, K, arith, rtol):
     base = torch.randn(M, N, generator=g)
     ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
     tol = dict(rtol=rtol, atol=1e-4)
-    for mode in (arith + "+wide", arith + "+sp", arith, arith + "+narrow"):
+    for mode in (arith + "+wide", arith + "+sp", arith, arith + "+narrow", arith + "+small"):
         with hb.arith(mode):
             out = hb.gemm(A.to(dev), B.to(dev), trans_a=ta, trans_b=tb)
             _close(out, ref.float(), what="plain/%s" % mode, **tol)
@@ -172,7 +174,7 @@ def test_gemm_wide_tile(ta, tb, M, N, K, arith, rtol):
     wideA = torch.randn((K, M + 64) if ta else (M, K + 64), generator=g).to(dev)
     Av = wideA[:, 32:32 + M] if ta else wideA[:, 32:32 + K]
     refv = (Av.cpu().double().t() if ta else Av.cpu().double()) @ (B.double().t() if tb else B.double())
-    for flag in ("+wide", "+sp"):
+    for flag in ("+wide", "+sp", "+small"):
         outw = torch.zeros(M, N + 32, device=dev)
         with hb.arith(arith + flag):
             hb.gemm(Av, B.to(dev), trans_a=ta, trans_b=tb, out=outw[:, 16:16 + N])
@@ -227,7 +229,7 @@ def test_gemm_wide_tile_batched(arith, rtol):
     A = torch.randn(L, Bn, Tp, generator=g).to(dev)
     Bm = torch.randn(L, Bn, Od, generator=g).to(dev)
     want = torch.einsum("lbt,lbo->bto", A.cpu().double(), Bm.cpu().double()).float()
-    for mode in (arith + "+wide", arith + "+sp", arith + "+narrow"):
+    for mode in (arith + "+wide", arith + "+sp", arith + "+narrow", arith + "+small"):
         C = torch.full((Bn, Tp, Od), 3.0, device=dev)
         hb.gemm_batched(A, Bm, C, True, False, Tp, Od, L, Bn * Tp, Bn * Od, Od, Bn, Tp, Od, Tp * Od, arith=mode)
         _close(C, want, rtol=rtol, atol=1e-4, what="batched/%s" % mode)
