@@ -1702,7 +1702,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bfs_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------ split-bf16, short K, weights stationary
 // gemm_bfk_kernel: C[M, N] = A[M, K] B[N, K]^T (+ bias) for a SHORT contraction, K = 16 KS <= 96 - the layer-0 input
 // projection of the encoder (K = 80 features, M = T B = 25 600 rows, N = 8H = 4 096: 16.8 GFLOP against 420 MB of output,
-// i.e. bound by the OUTPUT STREAM - 64 KB per 128 x 128 tile at the ~10 B / cycle one CU stores - not by the matrix pipe).
+// i.e. bound by the OUTPUT STREAM - the chip stores 6.3-7.2 TB/s, ~10-13 B / cycle and CU when all 256 store at once (tools/store_probe.hip) - not by the matrix pipe).
 // The general kernels spend such a product on prologues: three K tiles, then the tile's output with nothing to overlap it.
 // Here a workgroup (8 waves = 2 (M) x 4 (N), two per SIMD: while one waits in the store queue the other issues) keeps ONE
 // 128-column tile of B for its whole life - split once, every wave's 32 x K slice of it as fragments in 12 KS registers -
