@@ -316,7 +316,10 @@ class FlatBuffers(object):
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, i=i: self._on_grad(i)))
 
     def disable_overlap(self):
-        """Back to ONE collective after the backward pass (removes the hooks; outstanding collectives are awaited)."""
+        """Back to ONE collective after the backward pass (removes the hooks; outstanding collectives are awaited, and a
+        step abandoned between two buckets issues the rest of the fixed sequence first, as zero_grad does)."""
+        if self.overlap and 0 < self._issued < len(self.buckets):
+            self._issue_ready(force=True)
         for w in self._works:
             w.wait()
         for h in self._hooks:
