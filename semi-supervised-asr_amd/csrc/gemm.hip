@@ -24,6 +24,9 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef ASR_GEMM_SMALL_OCC      /* waves per SIMD the 64 x 64-tile kernel is compiled for (= workgroups per CU) */
+#define ASR_GEMM_SMALL_OCC 1      /* (3: 168 registers with 11-21 spilled, 4: 52-113 spilled; left to itself hipcc takes 195-229 = two workgroups per CU) */
+#endif
 #ifndef ASR_GEMM_TOUCH
 #define ASR_GEMM_TOUCH 2      /* L2 warm-up distance in K tiles (0 = off); 2 measured best of 2,3,5,8 */
 #endif
@@ -420,7 +423,7 @@ __device__ __forceinline__ void tile_store_bf3(unsigned short* img, const float4
 // layer: [3 200, 512] outputs are 100 large tiles, each a serial walk of 16-64 K tiles alone on its CU; as 400 small tiles
 // every CU holds one or two workgroups whose K tiles cost a quarter (tools/gemm_shapes.py).
 template <bool AKC, bool BKC, int NT, int TS = 128>
-__global__ __launch_bounds__(256) void gemm_bf3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, TS == 64 ? ASR_GEMM_SMALL_OCC : 1) void gemm_bf3_kernel(GemmArgs g) {
   // NT images (split terms, most significant first) per operand: 40 KB for two terms, 60 KB for three (TS = 128)
   constexpr int BM = TS, BN = TS, NP = TS / 32, NB = TS / 64;      // tile, float4 pieces per thread and operand, blocks per wave and side
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NT * BM * BS];
