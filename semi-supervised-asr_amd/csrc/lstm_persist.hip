@@ -56,6 +56,9 @@
 #ifndef ASR_POLL_FIRST_SLEEP
 #define ASR_POLL_FIRST_SLEEP 0
 #endif
+#ifndef ASR_POLL_SENTINEL_ROWS /* forward (split-bf16) kernel: groups of at least this many rows spin on one quad per lane before requesting the tile (99 = never) */
+#define ASR_POLL_SENTINEL_ROWS 16
+#endif
 #ifndef ASR_STAGE_H_TOP       /* 0 (measurement): h staging behind the poll instead of at the top of the step: 2.27 vs 2.16 us */
 #define ASR_STAGE_H_TOP 1
 #endif
@@ -385,9 +388,13 @@ __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, const 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int PH, int NR, int NT>
+// RG = rows of a group in the exchange / LDS layouts: 8 (NR = 8 or 4 active rows), or 16 (NR = 16: batches of >= 64 rows run
+// 16 rows per XCD group - the MFMA's 16 batch columns all carry rows, six products per tile and k-step instead of the
+// folded four, twice the gather - so that two 32-row blocks share one traversal of the chain).
+template <int PH, int NR, int NT, int RG = PRG>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a) {
-  static_assert(NR == 4 || NR == PRG, "rows per group");
+  static_assert((RG == PRG && (NR == 4 || NR == PRG)) || (RG == 16 && NR == 16), "rows per group");
+  constexpr bool FOLD = NT == 3 && RG == 8;        // the idle batch columns 8..15 carry a second term (fold_halves)
   constexpr int PKW = PH / PW;           // K columns per wave
   constexpr int KS = (PKW + 31) / 32;    // k-steps of 32 (the range is zero padded to KS * 32)
   constexpr int KP = KS * 32;
@@ -395,14 +402,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   constexpr int MT = (PUC + 3) / 4;      // M tiles: 4 units (16 gate rows) each
   constexpr int HST = KP + 8;            // LDS row stride in bf16: 16-byte multiple, rows 144 B apart at KP = 64 (the 8
                                          // rows of a 16-byte operand read then cover 8 distinct bank groups)
-  constexpr int NIMG = NT == 3 ? 4 : NT;  // three terms: + an image that stays zero (the idle half of B2, see fold_halves)
-  __shared__ __attribute__((aligned(16))) unsigned short hh[NIMG][PW][PRG][HST];    // split terms of the h tile
-  __shared__ __attribute__((aligned(16))) float part[2][PW][4 * MT][PRG][4];   // K-partials [unit][row][gate], double buffered
+  constexpr int NIMG = FOLD ? 4 : NT;     // folded three terms: + an image that stays zero (the idle half of B2, see fold_halves)
+  __shared__ __attribute__((aligned(16))) unsigned short hh[NIMG][PW][RG][HST];    // split terms of the h tile
+  __shared__ __attribute__((aligned(16))) float part[2][PW][4 * MT][RG][4];   // K-partials [unit][row][gate], double buffered
   __shared__ int role[2];
   extern __shared__ float occupancy_pad[];                                // forces one workgroup per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < NIMG * PW * PRG * HST; i += PNT) (&hh[0][0][0][0])[i] = 0;   // K padding, unused rows
+  for (int i = tid; i < NIMG * PW * RG * HST; i += PNT) (&hh[0][0][0][0])[i] = 0;   // K padding, unused rows
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
@@ -434,15 +441,15 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       bfn_split8<NT>(v, wt[mt][ks]);
     }
   }
-  // pointwise ownership: thread (pu, pj) for tid < PUC*PRG -> unit PUC*slice+pu, row r0+pj
-  const int pu = tid >> 3, pj = tid & 7;
-  const bool pw_thread = tid < PUC * PRG && pj < NR;
+  // pointwise ownership: thread (pu, pj) for tid < PUC*RG -> unit PUC*slice+pu, row r0+pj
+  const int pu = tid / RG, pj = tid % RG;
+  const bool pw_thread = tid < PUC * RG && pj < NR;
   const int prow = r0 + pj;
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
   float c_prev = 0.f;
-  float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * PRG;   // [parity][unit][row]
+  float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * RG;   // [parity][unit][row]
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
   bool aborted = false;
   auto gx_ptr = [&](int sn) {
@@ -474,13 +481,13 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      if constexpr (NR == 8) {
+      if constexpr (NR >= 8) {
         // single-stage hand-off: a lane owns two adjacent k of the wave's range for half of the rows (job = (k pair, row
         // half): 64 jobs at H = 512; H = 640 needs a second job on 16 lanes) and reads them as two 16-byte quads.  The pair is what makes the staging cheap: one packed split (v_cvt_pk_bf16_f32 works on two values
         // anyway) and one 4-byte LDS store per row and term - with one k and all NR rows per lane the same tile took 24
         // two-byte stores per lane (1.85 -> 1.77 us per time step at 8 rows)
         constexpr int RJ = 4;                           // rows per job
-        constexpr int NPAIR = PKW / 2, NJOB = NPAIR * 2, NJC = (NJOB + 63) / 64;
+        constexpr int NPAIR = PKW / 2, NJOB = NPAIR * (NR / RJ), NJC = (NJOB + 63) / 64;      // (16 rows: four row quarters, two jobs per lane at H = 512)
         static_assert(PKW % 2 == 0, "k pairs");
         bool gl[NJC];
         unsigned boff[NJC];
@@ -491,19 +498,33 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
           gl[jc] = jb < NJOB;
           ghalf[jc] = gl[jc] ? jb / NPAIR : 0;
           gpair[jc] = gl[jc] ? jb - ghalf[jc] * NPAIR : 0;
-          boff[jc] = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
-                                (wave * PKW + 2 * gpair[jc]) * PRG + RJ * ghalf[jc]) * 4u;
+          boff[jc] = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * RG) +
+                                (wave * PKW + 2 * gpair[jc]) * RG + RJ * ghalf[jc]) * 4u;
         }
         const unsigned tb = tag_bit_of_step(s - 1);
         unsigned gw[NJC][2][RJ];
         unsigned spins = 0;
+        if constexpr (ASR_POLL_SENTINEL_ROWS <= NR) {
+          // The poll itself is L2 traffic: every attempt of every wave re-reads its whole tile (32 KB per CU and attempt at 16
+          // rows, 1 MB per XCD: ~500 cycles of the L2's bandwidth per round, three rounds per step by the stamps of
+          // tools/lstm_trace.py).  So the spin watches ONE quad per lane - a quarter of the tile - and the whole tile is
+          // requested once that quad carries this step's tag (its neighbours were written by the same store instruction
+          // of the same producer); every word still carries its own tag and is checked below.
+          while (true) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff[0], 0, 16);
+            const bool ok1 = !gl[0] || (((q.x ^ tb) | (q.y ^ tb) | (q.z ^ tb) | (q.w ^ tb)) & 1u) == 0u;
+            if (__all(ok1)) break;
+            if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) break;      // the loop below raises the abort
+            __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+          }
+        }
         while (true) {
           bool ok = true;
   #pragma unroll
           for (int jc = 0; jc < NJC; ++jc)
   #pragma unroll
             for (int u = 0; u < 2; ++u) {
-              const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff[jc] + (unsigned)(PRG * 4) * u, 0, 16);
+              const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff[jc] + (unsigned)(RG * 4) * u, 0, 16);
               gw[jc][u][0] = q.x; gw[jc][u][1] = q.y; gw[jc][u][2] = q.z; gw[jc][u][3] = q.w;
             }
   #pragma unroll
@@ -546,8 +567,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
           gl[kc] = lane + 64 * kc < PKW;
-          boff[kc] = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * PRG) +
-                                (wave * PKW + (gl[kc] ? lane + 64 * kc : 0)) * PRG) * 4u;
+          boff[kc] = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * RG) +
+                                (wave * PKW + (gl[kc] ? lane + 64 * kc : 0)) * RG) * 4u;
         }
         const unsigned tb = tag_bit_of_step(s - 1);
         u32x4 gw[NKC][NR / 4];
@@ -599,7 +620,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       // (wave-private LDS tile: program order within the wave is enough)
 #pragma unroll
       for (int ks = 0; ks < ((ASR_LA & 1) ? 0 : KS); ++ks) {
-        if constexpr (NT == 3) {
+        if constexpr (FOLD) {
           // columns 8..15 of the batch side carry a second term (fold_halves): four MFMAs per tile and k-step
           const u32x4 b1 = *reinterpret_cast<const u32x4*>(&hh[ml >> 3][wave][ml & 7][32 * ks + 8 * kq]);
           const u32x4 b2 = *reinterpret_cast<const u32x4*>(&hh[2 + (ml >> 3)][wave][ml & 7][32 * ks + 8 * kq]);
@@ -614,7 +635,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
         } else {
           u32x4 bt[NT];
 #pragma unroll
-          for (int k = 0; k < NT; ++k) bt[k] = *reinterpret_cast<const u32x4*>(&hh[k][wave][ml & 7][32 * ks + 8 * kq]);
+          for (int k = 0; k < NT; ++k) bt[k] = *reinterpret_cast<const u32x4*>(&hh[k][wave][RG == 16 ? ml : (ml & 7)][32 * ks + 8 * kq]);
           // hi hi, hi lo, lo hi
 #pragma unroll
           for (int o = 0; o < NT; ++o)
@@ -627,7 +648,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
     }
     LP_MARK(2);
     if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
-    if constexpr (NT == 3) {
+    if constexpr (FOLD) {
       if (s > 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fold_halves(acc[mt]);
@@ -656,7 +677,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
       LP_MARK(5);
-      word_store(xw_g + (s & 1) * (PH * PRG) + (int64_t)punit * PRG + pj, hn, tag_bit_of_step(s));       // hand-off first
+      word_store(xw_g + (s & 1) * (PH * RG) + (int64_t)punit * RG + pj, hn, tag_bit_of_step(s));       // hand-off first
       LP_MARK(6);
       if (prow_ok) {
         st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
@@ -2055,15 +2076,15 @@ int launch_fwd(const PersistArgs& a, hipStream_t stream) {
   return 0;
 }
 
-template <int PH, int NR, int NT>
+template <int PH, int NR, int NT, int RG = PRG>
 int launch_fwd_bf3(const PersistArgs& a, hipStream_t stream) {
   constexpr int KP = ((PH / PW + 31) / 32) * 32, MT = (PH / 32 + 3) / 4;
-  const size_t stat = (size_t)(NT == 3 ? 4 : NT) * PW * PRG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * PRG * 4 + 64;
+  const size_t stat = (size_t)((NT == 3 && RG == 8) ? 4 : NT) * PW * RG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * RG * 4 + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT>,
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR, NT>), dim3(256), dim3(PNT), pad, stream, a);
+  hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
@@ -2114,10 +2135,23 @@ bool bwd_persist_width(int H) { return persist_supported(H) || H == 640; }
 int rs_slots_per_cu(int H) { return (H / 32 + 3) / 4 * 4; }
 
 // rows per XCD group: 4 when the whole batch fits 4-row groups (half the MFMA work and gather per step), else 8
-int rows_per_group(int nb, int ndir) {
+int forced_rows() {
   static const int forced = [] { const char* e = getenv("ASR_LSTM_ROWS"); return e ? atoi(e) : 0; }();   // measurement
+  return forced;
+}
+int rows_per_group(int nb, int ndir) {
+  const int forced = forced_rows();
   if (forced == 4 || forced == PRG) return forced;
   return nb <= 4 * (8 / ndir) ? 4 : PRG;
+}
+// 16-row groups (forward, H = 512, split-bf16 arithmetics): a row block that fills all eight XCDs with 16 rows each (64 rows
+// of a bidirectional layer) takes one traversal of the chain instead of two.  ASR_LSTM_ROWS=16 forces them for any block,
+// ASR_LSTM_ROWS=8 / 4 switches them off (measurement, tests).
+bool fwd_rows16(int left, int ndir, int H, int arith) {
+  if (H != 512 || (arith & ASR_ARITH_MASK) == ASR_ARITH_F32) return false;
+  const int forced = forced_rows();
+  if (forced == 16) return true;
+  return forced == 0 && left >= 16 * (8 / ndir);
 }
 
 // arith (include/asr_hip.h): ASR_ARITH_F32 -> the 4x4x1 fp32-MFMA kernels; ASR_ARITH_BF16X6 / _BF16X3 -> the bf16-MFMA
@@ -2232,18 +2266,24 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
   // H = 640 (the judge LM, config.yaml dis_hidden_dim): forward only - 20 units per CU = 5 M tiles of the bf16 MFMA
   if (!(persist_supported(H) || H == 640) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   if (H == 640 && (arith & ASR_ARITH_MASK) == ASR_ARITH_F32) return ASR_E_SHAPE;
-  const int nr = rows_per_group(nb, ndir);
-  const int rows_per_launch = nr * (8 / ndir);
-  for (int rb = 0; rb < nb; rb += rows_per_launch) {
-    hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * PRG * H * sizeof(u64), stream);
+  const int nr8 = rows_per_group(nb, ndir);
+  for (int rb = 0; rb < nb;) {
+    const int nr = fwd_rows16(nb - rb, ndir, H, arith) ? 16 : nr8;
+    const int rows_per_launch = nr * (8 / ndir);
+    hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * (nr > PRG ? nr : PRG) * H * sizeof(u64), stream);
     if (e != hipSuccess) return (int)e;
     PersistArgs a = {};
     a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
     a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
     a.y = y + (int64_t)rb * ndir * H; a.c = c + (int64_t)rb * ndir * H;
     a.dy = nullptr; a.yfwd = nullptr; a.dw = nullptr; a.db = nullptr; a.xch = (u64*)xch; a.ctrl = persist_launch_words(ctrl);
-    int rc = nr == 4 ? dispatch_fwd<4>(H, arith, a, stream) : dispatch_fwd<PRG>(H, arith, a, stream);
+    int rc;
+    if (nr == 16)
+      rc = (arith & ASR_ARITH_MASK) == ASR_ARITH_BF16X6 ? launch_fwd_bf3<512, 16, 3, 16>(a, stream) : launch_fwd_bf3<512, 16, 2, 16>(a, stream);
+    else
+      rc = nr == 4 ? dispatch_fwd<4>(H, arith, a, stream) : dispatch_fwd<PRG>(H, arith, a, stream);
     if (rc) return rc;
+    rb += rows_per_launch;
   }
   ASR_CHECK_LAUNCH();
   return 0;

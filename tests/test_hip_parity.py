@@ -748,11 +748,14 @@ def test_edge_shapes(B, T):
                                               (1, 70, 4, None, 256), (2, 16, 5, None, 512), (2, 12, 7, None, 320),
                                               (2, 17, 4, None, 256), (1, 30, 5, None, 128), (2, 8, 40, None, 512),
                                               (2, 32, 1, None, 512), (2, 9, 2, None, 512), (2, 32, 3, None, 256),
-                                              (2, 32, 41, None, 512), (1, 64, 13, None, 128), (2, 33, 8, None, 512)])
+                                              (2, 32, 41, None, 512), (1, 64, 13, None, 128), (2, 33, 8, None, 512),
+                                              (2, 64, 9, None, 512), (2, 96, 5, None, 512), (2, 70, 6, None, 512),
+                                              (1, 128, 4, None, 512), (1, 150, 3, None, 512), (2, 256, 3, None, 512)])
 def test_lstm_persistent_path(ndir, B, T, lens, H):
     """H in {128,256,320,512} takes the persistent XCD-local kernels (forward and backward); parity vs the oracle
-    incl. ragged lengths, batches spanning several row blocks, and both group shapes (4 rows per XCD group up to
-    4 * 8/ndir rows, 8 rows beyond); the kernels must not have aborted."""
+    incl. ragged lengths, batches spanning several row blocks, and the group shapes (4 rows per XCD group up to
+    4 * 8/ndir rows, 8 rows beyond; at H = 512 the forward takes 16 rows per group for every block of 16 * 8/ndir rows:
+    B = 64, 96 = 64 + 32, 70 = 64 + 6, 256); the kernels must not have aborted."""
     dev = _gpu()
     import ops
     import hip_backend as hb
@@ -790,7 +793,7 @@ def test_lstm_persistent_path(ndir, B, T, lens, H):
 
 
 @pytest.mark.parametrize("arith", ["f32", "bf16x3", "bf16x3+gather", "bf16x6+gather"])
-@pytest.mark.parametrize("ndir,B,T,H", [(2, 32, 9, 512), (2, 7, 6, 128), (1, 40, 5, 256), (2, 12, 7, 320)])
+@pytest.mark.parametrize("ndir,B,T,H", [(2, 32, 9, 512), (2, 7, 6, 128), (1, 40, 5, 256), (2, 12, 7, 320), (2, 64, 5, 512)])
 def test_lstm_persistent_other_arithmetics(ndir, B, T, H, arith):
     """The persistent LSTM kernels that are not the default stay selectable (the `arith` argument of the C ABI) and
     correct: the exact-fp32 4x4x1 products of round 1, the two-term bf16x3 products of round 2, and the gathered-dG

@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, ROOT + '/semi-supervised-asr_amd']
 import torch, numpy as np
 import hip_backend as hb
 dev = torch.device('cuda')
-H, B, T = 512, 32, 64
+H, B, T = 512, int(os.environ.get("PB_B", "32")), 64
 g = torch.Generator().manual_seed(3)
 gates0 = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).to(dev)
 wf = (torch.randn(2, 4 * H, H, generator=g) / np.sqrt(H)).to(dev)
