@@ -152,7 +152,8 @@ int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const 
 /* Persistent fast path of asr_lstm_seq_fwd (same arguments and results; csrc/lstm_persist.hip): ONE launch runs
  * all T steps, each XCD owns a (direction, 8- or 4-row) group, W_hh stays in registers, h_t is exchanged inside the
  * XCD as LSB-tagged fp32 words.  Applies when H is 128, 256, 320, 512 (or 640 with a bf16 arithmetic) on an 8 x 32-CU
- * device, any nb (row blocks of 32 * (8 / ndir) run as consecutive launches); otherwise returns ASR_E_SHAPE and the
+ * device, any nb (row blocks of 32 * (8 / ndir) run as consecutive launches; at H = 512 under the bf16 arithmetics every
+ * block of 64 * (8 / ndir) rows runs 16 rows per group in one launch); otherwise returns ASR_E_SHAPE and the
  * caller uses asr_lstm_seq_fwd.  `arith`: product arithmetic of h W_hh^T (ASR_ARITH_*, see above).
  * xch and ctrl are caller-allocated scratch shared by ALL persistent entry points (LSTM and decoder): at least
  * asr_persist_scratch_bytes() says (10 MB of exchange - the H = 640 backward's partial sums are the largest user - and a
