@@ -34,6 +34,18 @@ def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
 
+_SHARD_INDEX = {}
+
+
+def _shard_index_tensor(n, rank, world, device):
+    """The strided row indices as a tensor on `device`, built once per (batch size, rank, world): indexing with a Python
+    list uploads a fresh index tensor from pageable memory every step."""
+    key = (n, rank, world, str(device))
+    if key not in _SHARD_INDEX:
+        _SHARD_INDEX[key] = torch.arange(rank, n, world, device=device)
+    return _SHARD_INDEX[key]
+
+
 def shard_batch(xs, ilens, ys, rank, world):
     """(xs [B,T,D] zero-padded to the global T_max, ilens desc, ys list) -> this rank's rows.
     xs keeps the global padded length; returns (xs_r, ilens_r, ys_r, info) where info carries the
@@ -43,7 +55,7 @@ def shard_batch(xs, ilens, ys, rank, world):
     if world == 1:
         return xs, list(ilens), ys, info
     idx = shard_indices(len(ilens), rank, world)
-    xs_r = xs[idx]
+    xs_r = xs[_shard_index_tensor(len(ilens), rank, world, xs.device)] if torch.is_tensor(xs) else xs[idx]
     return xs_r, [ilens[i] for i in idx], ([ys[i] for i in idx] if ys is not None else None), info
 
 
@@ -396,11 +408,24 @@ class FlatBuffers(object):
             p.grad = self._view(i)
 
     def set_aux(self, values):
-        """Scalars (tensors or floats, at most NAUX) that should come out of the step's all-reduce summed over ranks."""
-        vals = [v.detach().reshape(()).float() if torch.is_tensor(v) else torch.tensor(float(v)) for v in values]
+        """Scalars (tensors or floats, at most NAUX) that should come out of the step's all-reduce summed over ranks.
+        Nothing here moves host memory to the device (a pageable copy would make the host wait for the stream - the wait the
+        pipelined data-parallel step exists to avoid): device tensors are copied on the device, host values are kernel
+        arguments of a fill."""
         self.aux.zero_()
-        if vals:
-            self.aux[:len(vals)].copy_(torch.stack([v.to(self.aux.device) for v in vals]))
+        on_dev, where = [], []
+        for i, v in enumerate(values):
+            if torch.is_tensor(v) and v.device == self.aux.device:
+                on_dev.append(v.detach().reshape(()).float())
+                where.append(i)
+            elif float(v) != 0.0:
+                self.aux[i].fill_(float(v))
+        if on_dev:
+            if where == list(range(where[0], where[0] + len(where))):
+                self.aux[where[0]:where[0] + len(where)].copy_(torch.stack(on_dev))
+            else:
+                for i, v in zip(where, on_dev):
+                    self.aux[i].copy_(v)
 
     def allreduce_grads(self, group=None):
         """The gradient exchange of the step.  Default: ONE SUM all-reduce over the flat gradient buffer (+ aux scalars).
