@@ -439,7 +439,7 @@ class FlatBuffers(object):
             dist.all_reduce(self.aux, op=dist.ReduceOp.SUM, group=self._group)
             return
         self.collect()
-        if world() > 1:
+        if world() > 1 or (FORCE_DP and dist.is_initialized()):
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
 
 
@@ -545,11 +545,22 @@ class FlatAdam(object):
             self.t = int(float(ent["step"]))
 
 
+# Rehearsal switch (measurement): ASR_FORCE_DP=1 makes a single process take the data-parallel step - process group of one
+# rank on RCCL, the flat buffer all-reduced, the update predicated on the reduced latch - so that the step's timeline can be
+# looked at on a one-GPU box (tools/profile_step.sh).
+import os as _os
+FORCE_DP = _os.environ.get("ASR_FORCE_DP", "0") == "1"
+
+
 def init_distributed():
     """One process per GPU (torch.distributed.run env).  Returns (rank, world, local_rank)."""
     import os
     w = int(os.environ.get("WORLD_SIZE", "1"))
     if w <= 1:
+        if FORCE_DP and torch.cuda.is_available() and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend=os.environ.get("ASR_DIST_BACKEND", "nccl"), rank=0, world_size=1)
         return 0, 1, int(os.environ.get("LOCAL_RANK", "0"))
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", str(rank)))

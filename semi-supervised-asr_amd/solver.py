@@ -339,7 +339,7 @@ class Solver(object):
         step late (parallel.DpPipeline).  Every rank resolves its StepScalars at the same points of the program (the loops
         below run the same code on all ranks): a recovery is a sequence of collectives."""
         depth = int(self.config.get("pipeline_steps", self.PIPELINE_STEPS))
-        if self.world > 1:
+        if self.world > 1 or parallel.FORCE_DP:
             if depth <= 0 or opt.buf.flat_g.device.type != "cuda":
                 out = self._dp_step(make_local, opt, n_scalars)        # the host reads between all-reduce and update
             else:
