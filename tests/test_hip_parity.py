@@ -41,7 +41,7 @@ GEMM_ARITH = [("bf16x6", 1e-5), ("f32", 1e-5), ("bf16x3", 3e-5)]
 
 @pytest.mark.parametrize("arith,rtol", GEMM_ARITH)
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 130, 70), (33, 34, 9), (1000, 96, 513)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 130, 70), (33, 34, 9), (1000, 96, 513), (1, 1, 1), (7, 5, 3)])
 def test_gemm_variants(ta, tb, M, N, K, arith, rtol):
     """asr_gemm_f32 in its four operand layouts, with epilogue / split-K / accumulate, in its three product arithmetics:
     bf16x6 (default: three bf16 terms per operand, six MFMA products, fp32-equivalent), the fp32-input MFMA, and bf16x3
