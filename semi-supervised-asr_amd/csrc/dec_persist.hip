@@ -1620,10 +1620,14 @@ __global__ __launch_bounds__(256) void att_m_kernel(int B, int nb, int L, int Tp
   }
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
-  for (int pair = blockIdx.x; pair < nb * L; pair += gridDim.x) {
+  // work items = (pair, 16-frame tile), dealt to the WAVES of the grid: with the tiles of one pair dealt to the four waves of
+  // a workgroup, T' = 100 (seven tiles) ran 2 : 2 : 2 : 1
+  const int ntile = (Tp + 15) / 16;
+  for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < (int64_t)nb * L * ntile; item += (int64_t)gridDim.x * 4) {
+    const int pair = (int)(item / ntile), tile = (int)(item - (int64_t)pair * ntile);
     const int s = pair / nb, b = pair - s * nb;
     const float* Sb = S + ((int64_t)s * B + b) * Tp * AA;
-    for (int tile = wave; 16 * tile < Tp; tile += 4) {
+    {
       const int t = 16 * tile + r;
       const float* row = Sb + (int64_t)(t < Tp ? t : Tp - 1) * AA + 4 * q;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};
