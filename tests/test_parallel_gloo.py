@@ -446,6 +446,21 @@ def test_dp_pipeline_skips_on_every_rank_and_repeats_one_step_late(tmp_path):
         assert err <= 1e-6 * max(1.0, ref.abs().max().item()), (r, err)
 
 
+def test_dp_pipeline_depth_two_repeats_everything_enqueued_behind_the_abort():
+    """One process, two records outstanding: the abort of step 1 is found after steps 2 and 3 have been enqueued (all three
+    skipped: the latch is sticky), the three are repeated in order from the numpy stream of step 1 - same weights and
+    losses as the run that never aborted."""
+    _setup_paths()
+    ref_opt, ref_losses, ref_state = _dp_steps(0, 1, abort_rank=-1, pipelined=2)
+    opt, losses, state = _dp_steps(0, 1, abort_rank=0, pipelined=2)
+    assert ref_state["calls"] == 3 and state["calls"] == 6 and opt.applied == 3 and state["left"] == [1], (state, opt.applied)
+    assert ref_state["outstanding"] == [False, True, True]       # step 3's enqueue resolved step 1; two records stay in flight
+    assert state["outstanding"] == [False, False, False]         # ... and with the abort it resolved all three (the replay is synchronous)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (losses, ref_losses)
+    assert (opt.buf.flat_p - ref_opt.buf.flat_p).abs().max().item() <= 1e-6 * max(1.0, ref_opt.buf.flat_p.abs().max().item())
+
+
 def test_dp_step_raises_when_the_repeat_fails_too():
     _setup_paths()
     import parallel
