@@ -7,4 +7,5 @@ mkdir -p $O
 python3 tools/timeline.py $O/prof/r4_results.db > $O/timeline.txt 2>&1; tail -1 $O/timeline.txt
 python3 tools/small_launches.py $O/prof/r4_results.db > $O/small_launches.txt; tail -1 $O/small_launches.txt
 python3 tools/db_to_stats.py $O/prof/r4_results.db $O/kernel_stats.csv | tail -1
+python3 tools/step_kernels.py $O/prof/r4_results.db > $O/step_kernels.txt
 rm -f $O/prof/*.db
