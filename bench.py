@@ -479,6 +479,12 @@ def main():
                     help="product arithmetic of the MFMA kernels (default: bf16x6 = fp32-equivalent, see ARITH_TEXT)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra timings under the other arithmetics")
     args = ap.parse_args()
+    # stdout carries ONE line, the JSON record.  Libraries write there too - RCCL prints a five-line version banner from C when a
+    # communicator comes up, on every rank - so file descriptor 1 is pointed at stderr for the whole run and the record goes
+    # out through a private duplicate of the original descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import contextlib
     import tempfile
@@ -679,7 +685,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, xs, lens, ys, args.config + " T=%d" % t_frames,
                                                3 if args.config == "cfg1" else 1)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
