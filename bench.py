@@ -478,6 +478,8 @@ def main():
     ap.add_argument("--arith", choices=["bf16x6", "f32", "bf16x3"], default="bf16x6",
                     help="product arithmetic of the MFMA kernels (default: bf16x6 = fp32-equivalent, see ARITH_TEXT)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra timings under the other arithmetics")
+    ap.add_argument("--epoch-only", type=int, default=0, metavar="STEPS",
+                    help="only the epoch workload (Solver.sup_train_one_epoch through the input pipeline), for profiling")
     args = ap.parse_args()
     # stdout carries ONE line, the JSON record.  Libraries write there too - RCCL prints a five-line version banner from C when a
     # communicator comes up, on every rank - so file descriptor 1 is pointed at stderr for the whole run and the record goes
@@ -511,6 +513,12 @@ def main():
         n_global = (args.batch_per_gpu or spec["batch"]) * world
     torch.manual_seed(1000 + rank)                     # per-rank dropout streams; weights below are shared
     tmp = tempfile.mkdtemp(prefix="asr_bench_r%d_" % rank)
+    if args.epoch_only:
+        assert world == 1
+        res = epoch_workload(dev, tmp, args.epoch_only, args.config)
+        note("epoch: %.2f ms/step" % res["ms_per_step"])
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+        return
 
     # ---- the timed object is the product's Solver: one step = Solver.sup_train_one_iteration on the (global) batch, i.e.
     # forward on this rank's strided shard, loss, zero_grad, backward, ONE all-reduce of the flat gradient buffer, clip + Adam,
@@ -677,6 +685,11 @@ def main():
     torch.cuda.empty_cache()
     if world == 1 and not args.no_workloads and rank == 0:
         out["workloads"] = other_workloads(dev, tmp, args.config, t_frames)
+        if args.config == "cfg2" and t_frames == spec["frames"] and args.scaling == "weak" and not args.batch_per_gpu:
+            note("workload epoch")
+            ep = epoch_workload(dev, tmp)
+            ep["vs_resident_batch"] = ep["ms_per_step"] / out["ms_per_step"]
+            out["workloads"]["epoch"] = ep
     if rank == 0:
         note("measuring dominant kernel")
         out["roofline"] = kernel_roofline(dev, cfg, b_local, t_frames, info["olength"])
@@ -691,6 +704,53 @@ def main():
         dist.destroy_process_group()
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
+
+
+def epoch_workload(dev, tmp, steps=40, config="cfg2"):
+    """The product's own training loop, input pipeline included: Solver.sup_train_one_epoch over a loader of `steps` batches
+    whose utterances have exactly the lengths of the headline batch (ragged 0.6T..T, seed 1234; features and labels differ
+    from batch to batch), so that its ms/step is comparable with the resident-batch `ms_per_step`.  Every batch is collated
+    one step ahead into pinned memory and uploaded on a side stream (feed.DeviceFeed); per-step logging as in the
+    product.  One warm-up epoch of 3 batches, then the timed epoch (its first batch's collate + upload is inside)."""
+    import contextlib
+    import hip_backend as hb
+    from dataset import DictDataset
+    spec = CONFIGS[config]
+    c, B, T = dict(spec["model"]), spec["batch"], spec["frames"]
+    sv = make_solver(c, B, T, os.path.join(tmp, "epoch"))
+    _, lens, ys = synth.ragged_batch(B, T, c["input_dim"], c["output_dim"], 1234)
+    rs = np.random.RandomState(77)
+    feats = [[rs.normal(0.0, 1.0, size=(l, c["input_dim"])).astype(np.float32) for l in lens] for _ in range(4)]
+
+    def corpus(n_batches):
+        data = {}
+        for i in range(n_batches):
+            for j, l in enumerate(lens):
+                data["b%03du%02d" % (i, j)] = dict(feature=feats[i % 4][j],
+                                                    token_ids=rs.randint(3, c["output_dim"], size=(len(ys[j]),)).tolist())
+        return DictDataset(data, config=None, sort=False)
+
+    def loop(n_batches, epoch):
+        sv.train_lab_dataset = corpus(n_batches)
+        sv.train_lab_loader = sv._loader(sv.train_lab_dataset, B, False, False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(sys.stderr):
+            mean_loss = sv.sup_train_one_epoch(epoch, 1.0)
+            sv.flush()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n_batches * 1e3, mean_loss
+
+    loop(3, 0)
+    hb.LAUNCHES.clear()
+    ms, mean_loss = loop(steps, 1)
+    paths = {k: v // steps for k, v in sorted(hb.LAUNCHES.items())}
+    return dict(call="Solver.sup_train_one_epoch", steps=steps, ms_per_step=ms, value=B / ms * 1e3, unit="utterances/sec",
+                workload="%s: an epoch of %d batches of %d utterances with the headline batch's lengths, through the product's "
+                         "loader -> feed.DeviceFeed (collated one step ahead into pinned memory by a background thread, "
+                         "uploaded on a side stream, labels as one packed int64 tensor) -> sup_train_one_iteration, per-step "
+                         "logging on" % (spec["name"], steps, B),
+                mean_loss=float(mean_loss), sequence_op_paths=paths)
 
 
 def other_workloads(dev, tmp, main_config, main_frames):

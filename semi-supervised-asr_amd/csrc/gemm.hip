@@ -1385,7 +1385,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bfs_kernel(GemmArgs g) {
   const int64_t lda = g.A.ld, ldb = g.B.ld;
   const float* Ab = g.A.p + bz * g.sA + (AKC ? kt_begin * SK : kt_begin * SK * lda);
   const float* Bb = g.B.p + bz * g.sB + (BKC ? kt_begin * SK : kt_begin * SK * ldb);
-  // the resources end with the operand: a fetch behind it (the K tail of a row-contiguous operand) returns zeros
+  // the resources end with the operand: a fetch behind it (the K tail of the KT instantiations) returns zeros - the range
+  // check covers the VGPR offset only, so those instantiations carry the K tile's offset there (load_piece)
   const int64_t enda = ((AKC ? (g.M - 1) * lda + g.K : (g.K - 1) * lda + g.M) - (AKC ? kt_begin * SK : kt_begin * SK * lda)) * 4;
   const int64_t endb = ((BKC ? (g.N - 1) * ldb + g.K : (g.K - 1) * ldb + g.N) - (BKC ? kt_begin * SK : kt_begin * SK * ldb)) * 4;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, (int)(enda < 0x7ffffff0 ? enda : 0x7ffffff0), 0x00020000);
@@ -1456,8 +1457,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bfs_kernel(GemmArgs g) {
   auto load_piece = [&](auto qtag, auto utag, int st) __attribute__((always_inline)) {
     constexpr int Q = decltype(qtag)::value, U = decltype(utag)::value;
     if (ASR_GS_ABL & 4) return;
-    if constexpr (U < 8) RA[Q][U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offa[U], st * stepa, 0);
-    else RB[Q][U - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offb[U - 8], st * stepb, 0);
+    if constexpr (KT) {          // the last K tile reaches behind the operand: offset in the VGPR, where the range check sees it
+      if constexpr (U < 8) RA[Q][U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offa[U] + (unsigned)(st * stepa), 0, 0);
+      else RB[Q][U - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offb[U - 8] + (unsigned)(st * stepb), 0, 0);
+    } else {                     // every K tile is inside the operand (rows / columns are clamped in offa / offb)
+      if constexpr (U < 8) RA[Q][U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offa[U], st * stepa, 0);
+      else RB[Q][U - 8] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offb[U - 8], st * stepb, 0);
+    }
   };
   // split + write unit u of the K tile held in register set Q into buffer BUF; units 0-5: A 0-3, B 0-1; 6-11: A 4-7, B 2-3
   auto unit = [&](auto qtag, auto utag, auto btag, int stu) __attribute__((always_inline)) {
@@ -1744,7 +1750,9 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
   const float* Ab = g.A.p + bz * g.sA;
   const float* Bb = g.B.p + bz * g.sB + n0 * ldb;
   float* C = g.C + bz * g.sC;
-  // resources end with the operands: rows past M / N read as zeros
+  // resources end with the operands: rows past M / N read as zeros.  The hardware's range check covers the VGPR offset
+  // plus the instruction offset only - NOT the SGPR offset - so everything that can leave the operand (the M tile of A)
+  // goes into the VGPR offset (load_a); B's rows past N are inside pb0.
   const int64_t enda = ((g.M - 1) * lda + g.K) * 4, endb = ((g.N - 1 - n0) * ldb + g.K) * 4;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, (int)(enda < 0x7ffffff0 ? enda : 0x7ffffff0), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, (int)(endb < 0x7ffffff0 ? endb : 0x7ffffff0), 0x00020000);
@@ -1770,7 +1778,7 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
 
   auto load_a = [&](auto qtag, auto utag, int mt) __attribute__((always_inline)) {
     constexpr int Q = decltype(qtag)::value, U = decltype(utag)::value;
-    RA[Q][U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, pa0 + 16 * U, mt * tile_step, 0);
+    RA[Q][U] = __builtin_amdgcn_raw_buffer_load_b128(rsA, pa0 + (unsigned)(mt * tile_step) + 16 * U, 0, 0);
   };
   auto unit = [&](auto qtag, auto utag, auto btag) __attribute__((always_inline)) {       // split + write piece U of staged tile Q into image BUF
     constexpr int Q = decltype(qtag)::value, U = decltype(utag)::value, BUF = decltype(btag)::value;

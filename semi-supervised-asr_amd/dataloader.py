@@ -60,9 +60,23 @@ def padded_fraction(lengths, batches):
     return 1.0 - real / float(padded)
 
 
+def _raw_items(batch):
+    """Collation deferred to the DeviceFeed: the utterances in the reference's batch order (frame count descending), as the
+    (feature, token_ids) pairs the dataset holds - no padding, no copy."""
+    return _by_frames(batch)
+
+
+def _raw_texts(batch):
+    return sorted(batch, key=lambda item: len(item[1]), reverse=True)
+
+
 def get_data_loader(dataset, batch_size, shuffle, drop_last, speech_only=False, text_only=False, generator=None,
-                    bucket=False):
+                    bucket=False, raw=False):
+    """raw=True: batches are lists of (feature, token_ids) in the collated ORDER but not padded - the input of a DeviceFeed,
+    which pads them straight into pinned memory (this rank's rows only under data parallelism)."""
     fn = _speech_collate_fn if speech_only else (_text_collate_fn if text_only else _collate_fn)
+    if raw:
+        fn = _raw_texts if text_only else _raw_items
     if bucket:
         sampler = BucketBatchSampler(len(dataset), batch_size, shuffle, drop_last, generator=generator)
         return DataLoader(dataset, batch_sampler=sampler, collate_fn=fn, num_workers=0)

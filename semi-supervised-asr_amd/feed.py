@@ -1,0 +1,228 @@
+"""Input pipeline of the training loops.
+
+The reference feeds a step with `for data in loader: xs, ilens, ys = to_gpu(data)` (solver.py:365-367, utils.py:154-158,
+dataloader.py:6-12): collate on the host, then one synchronous pageable upload for the features and one per label tensor,
+on the compute stream.  With every other host wait gone from the step (Solver._step) that upload was the last one: the
+host could not enqueue step i + 1 before step i had drained.  `DeviceFeed` keeps the reference's batch (same order, same
+zero padding, `ilens` a host list, `ys` a list of int64 tensors) and changes how it reaches HBM:
+
+  * batches are collated ONE STEP AHEAD, straight into a ring of pinned host buffers (no intermediate padded tensor), by
+    a background thread (or inline, `thread=False`);
+  * the labels of a batch travel as ONE packed int64 tensor; the `ys` list handed to the model are views of it;
+  * the upload runs on a side stream; the compute stream only waits for its event - which has long fired;
+  * under data parallelism every rank pads and uploads ITS strided rows only (parallel.shard_indices) and takes the
+    global constants the exact-parity rules need (B_global, T_max, olength, the judge's normaliser) from the
+    lengths of the whole batch, which every rank sees (the samplers are seeded identically): a `parallel.LocalShard`.
+
+The optional Gaussian input noise (solver.py:370-373) is drawn here, for the GLOBAL batch from a numpy stream of its own
+(seeded from the process's numpy stream when the feed is built, so data-parallel ranks agree), and added on the host
+before the upload.
+"""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+import parallel
+
+
+class Batch(object):
+    """One batch in HBM.  Unpacks like the reference's to_gpu(data): `xs, ilens, ys = batch` (speech-only: xs, ilens;
+    text-only: iterating gives the label tensors).  Under data parallelism `xs` is a parallel.LocalShard (this rank's rows
+    + the global constants), which the Solver's step methods accept wherever they accept the global tensor.
+    `ys_host`: the labels as host lists (validation's references: no read back from the device)."""
+    __slots__ = ("kind", "xs", "ilens", "ys", "ys_host")
+
+    def __init__(self, kind, xs, ilens, ys, ys_host):
+        self.kind, self.xs, self.ilens, self.ys, self.ys_host = kind, xs, ilens, ys, ys_host
+
+    def __iter__(self):
+        if self.kind == "text":
+            return iter(self.ys)
+        return iter((self.xs, self.ilens) if self.kind == "speech" else (self.xs, self.ilens, self.ys))
+
+    def __len__(self):
+        return len(self.ys) if self.kind == "text" else (2 if self.kind == "speech" else 3)
+
+
+def _round_up(n, q):
+    return (int(n) + q - 1) // q * q
+
+
+class _Slot(object):
+    """Pinned staging of one batch in flight: a float32 area (features) and an int64 area (labels), grown on demand."""
+
+    def __init__(self, pin):
+        self.pin, self.f, self.i, self.event = pin, None, None, None
+
+    def _area(self, old, n, dtype, quantum):
+        if old is not None and old.numel() >= n:
+            return old
+        t = torch.empty(_round_up(max(n, 1), quantum), dtype=dtype)
+        return t.pin_memory() if self.pin else t
+
+    def floats(self, n):
+        self.f = self._area(self.f, n, torch.float32, 1 << 18)
+        return self.f[:n]
+
+    def ints(self, n):
+        self.i = self._area(self.i, n, torch.int64, 1 << 10)
+        return self.i[:n]
+
+
+class DeviceFeed(object):
+    """Iterate `source` (batches of raw utterances: lists of (feature [T, D] float32, token_ids), in the collated order -
+    dataloader.get_data_loader(raw=True), or any iterable of such lists) and yield `Batch`es on `device`, prepared `depth`
+    batches ahead.
+
+      kind        "labeled" (features + labels), "speech" (features only), "text" (labels only)
+      rank/world  data-parallel position: world > 1 yields this rank's strided rows as a parallel.LocalShard
+      noise_std   > 0: add N(0, noise_std) noise to the features (drawn for the global batch, see the module docstring)
+      thread      collate + upload in a background thread (default) or inline in next()
+    """
+
+    def __init__(self, source, device, kind="labeled", rank=0, world=1, depth=2, noise_std=0.0, thread=True):
+        assert kind in ("labeled", "speech", "text")
+        self.source, self.kind, self.rank, self.world = source, kind, int(rank), int(world)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        if self.cuda and self.device.index is None:      # the producer thread needs the index (set_device)
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.depth = max(1, int(depth))
+        self.noise_std = float(noise_std)
+        # the noise stream: seeded from the process's numpy stream HERE (the consumer's thread), so that identically
+        # seeded data-parallel ranks draw identical noise whatever the interleaving of the threads
+        self.noise_rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1)) if self.noise_std > 0 else None
+        self.thread = bool(thread)
+        self._slots = [_Slot(self.cuda) for _ in range(self.depth + 2)]
+        self._side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._n = 0
+
+    def __len__(self):
+        return len(self.source)
+
+    # ---------------------------------------------------------------- one batch: host lists -> pinned -> device
+    def _prepare(self, items):
+        """-> (Batch, copy-done event or None).  Runs in the producer (thread or inline)."""
+        slot = self._slots[self._n % len(self._slots)]
+        self._n += 1
+        if slot.event is not None:
+            slot.event.synchronize()                    # the upload that last read this pinned area has finished
+            slot.event = None
+        rows = parallel.shard_indices(len(items), self.rank, self.world)
+        sharded = self.world > 1
+        xs_h = ys_h = None
+        ilens = ys_lens = ys_host = None
+        info = dict(b_global=len(items))
+        if self.kind != "text":
+            lens_all = [int(f.shape[0]) for f, _ in items]
+            t_max = max(lens_all)
+            dim = int(items[0][0].shape[1])
+            ilens = [lens_all[i] for i in rows]
+            xs_h = slot.floats(len(rows) * t_max * dim).view(len(rows), t_max, dim)
+            for r, i in enumerate(rows):
+                n = lens_all[i]
+                xs_h[r, :n].copy_(torch.from_numpy(np.asarray(items[i][0], dtype=np.float32)))
+                xs_h[r, n:].zero_()
+            if self.noise_rng is not None:
+                noise = self.noise_rng.normal(0.0, self.noise_std, (len(items), t_max, dim)).astype(np.float32)
+                if rows:
+                    xs_h.add_(torch.from_numpy(noise[self.rank::self.world] if sharded else noise))
+            info.update(t_max=t_max, olength=None)
+        if self.kind != "speech":
+            tok_all = [items[i][1] for i in range(len(items))]
+            len_all = [len(t) for t in tok_all]
+            ys_lens = [len_all[i] for i in rows]
+            ys_host = [list(tok_all[i]) for i in rows]
+            ys_h = slot.ints(sum(ys_lens))
+            off = 0
+            for t, n in zip(ys_host, ys_lens):
+                ys_h[off:off + n].copy_(torch.from_numpy(np.asarray(t, dtype=np.int64)))
+                off += n
+            info.update(olength=max(len_all) + 1, text_norm=float(sum(n + 5 for n in len_all)))
+        event = None
+        if self.cuda:
+            with torch.cuda.stream(self._side):
+                xs_d = xs_h.to(self.device, non_blocking=True) if xs_h is not None else None
+                ys_d = ys_h.to(self.device, non_blocking=True) if ys_h is not None else None
+                event = torch.cuda.Event()
+                event.record(self._side)
+            slot.event = event
+        else:
+            xs_d = xs_h.clone() if xs_h is not None else None
+            ys_d = ys_h.clone() if ys_h is not None else None
+        ys = list(torch.split(ys_d, ys_lens)) if ys_d is not None else None       # views of the one label tensor
+        flat = (xs_d, ys_d)
+        if sharded:
+            xs_out = parallel.LocalShard(xs_d, ilens, ys, info)
+        else:
+            xs_out = xs_d
+        return Batch(self.kind, xs_out, ilens, ys, ys_host), event, flat
+
+    def _hand_over(self, prepared):
+        """Consumer side: order the compute stream behind the upload and tell the allocator who uses the memory."""
+        batch, event, flat = prepared
+        if event is not None:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(event)
+            for t in flat:
+                if t is not None:
+                    t.record_stream(main)
+        return batch
+
+    # ---------------------------------------------------------------- iteration
+    def __iter__(self):
+        if not self.thread:
+            return self._iter_inline()
+        return self._iter_threaded()
+
+    def _iter_inline(self):
+        ahead = []
+        it = iter(self.source)
+        for items in it:
+            ahead.append(self._prepare(items))
+            if len(ahead) > self.depth - 1:
+                yield self._hand_over(ahead.pop(0))
+        while ahead:
+            yield self._hand_over(ahead.pop(0))
+
+    def _iter_threaded(self):
+        q = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+        done = object()
+
+        def put(x):
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def produce():
+            try:
+                if self.cuda:
+                    torch.cuda.set_device(self.device)
+                for items in self.source:
+                    if not put(self._prepare(items)):
+                        return
+                put(done)
+            except BaseException as exc:                 # surfaces in the consumer
+                put(exc)
+
+        worker = threading.Thread(target=produce, name="asr-device-feed", daemon=True)
+        worker.start()
+        try:
+            while True:
+                item = q.get()
+                if item is done:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield self._hand_over(item)
+        finally:
+            stop.set()                                   # the consumer left early (break / exception): release the producer
+            # the producer may be inside _prepare; let it finish so that no upload is in flight from a slot we drop
+            worker.join(timeout=5.0)

@@ -42,14 +42,34 @@ def _shard_index_tensor(n, rank, world, device):
     list uploads a fresh index tensor from pageable memory every step."""
     key = (n, rank, world, str(device))
     if key not in _SHARD_INDEX:
-        _SHARD_INDEX[key] = torch.arange(rank, n, world, device=device)
+        _SHARD_INDEX[key] = torch.arange(rank, max(n, rank), world, device=device)      # empty for rank >= n
     return _SHARD_INDEX[key]
+
+
+class LocalShard(object):
+    """This rank's rows of a global batch together with the global constants the exact-parity rules need - what
+    shard_batch() returns, made by the input pipeline (feed.DeviceFeed) instead of on the device: under data parallelism
+    a rank then pads and uploads ITS rows only.  Accepted wherever a step takes the global batch tensor.
+      xs     [b_local, T_max_global, D] (None for a text batch), ilens / ys: this rank's rows (lists; ys None for speech)
+      info   b_global, t_max (global padded length), olength (global max label length + 1), text_norm (global sum of
+             len + 5: the judge's normaliser)"""
+    __slots__ = ("xs", "ilens", "ys", "info")
+
+    def __init__(self, xs, ilens, ys, info):
+        self.xs, self.ilens, self.ys, self.info = xs, ilens, ys, info
+
+    @property
+    def device(self):
+        t = self.xs if self.xs is not None else (self.ys[0] if self.ys else None)
+        return t.device if t is not None else None
 
 
 def shard_batch(xs, ilens, ys, rank, world):
     """(xs [B,T,D] zero-padded to the global T_max, ilens desc, ys list) -> this rank's rows.
     xs keeps the global padded length; returns (xs_r, ilens_r, ys_r, info) where info carries the
-    global constants every rank needs (B_global, T_max, olength)."""
+    global constants every rank needs (B_global, T_max, olength).  A LocalShard passes through."""
+    if isinstance(xs, LocalShard):
+        return xs.xs, list(xs.ilens), xs.ys, xs.info
     info = dict(b_global=len(ilens), t_max=int(max(ilens)),
                 olength=(max(int(y.shape[0]) for y in ys) + 1) if ys is not None else None)
     if world == 1:
@@ -112,9 +132,10 @@ def ssl_local_loss(model_fwd, judge_probs, lab, unlab, rank, world_size, eos, un
     the single-process values, and the all-reduced gradient of the local losses is the single-process gradient."""
     lab_xs, lab_ilens, lab_ys = lab
     unlab_xs, unlab_ilens = unlab
-    steps = int(unlab_xs.shape[1] * proportion)           # global padded length (solver.py:467)
     u_xs, u_il, _, u_info = shard_batch(unlab_xs, unlab_ilens, None, rank, world_size)
-    dev = unlab_xs.device if torch.is_tensor(unlab_xs) else None
+    t_pad = u_info["t_max"] if isinstance(unlab_xs, LocalShard) else unlab_xs.shape[1]
+    steps = int(t_pad * proportion)                       # global padded length (solver.py:467)
+    dev = unlab_xs.device if (torch.is_tensor(unlab_xs) or isinstance(unlab_xs, LocalShard)) else None
     count = torch.zeros(1, dtype=torch.float32, device=dev)
     num = None
     if u_il:
@@ -139,12 +160,16 @@ def ssl_local_loss(model_fwd, judge_probs, lab, unlab, rank, world_size, eos, un
 
 def judge_local_loss(judge_fwd, masked_sum, ys, rank, world_size):
     """Judge (LM) step (solver.py:288-291): NLL normalised by the GLOBAL sum of (len + 5), known on the host.
-    -> (local loss, local avg_prob) or (None, None) for an empty shard."""
-    idx = shard_indices(len(ys), rank, world_size)
-    if not idx:
+    -> (local loss, local avg_prob) or (None, None) for an empty shard.  ys: the global text batch, or this rank's
+    LocalShard of it."""
+    if isinstance(ys, LocalShard):
+        ys_r, total = ys.ys, ys.info["text_norm"]
+    else:
+        ys_r = [ys[i] for i in shard_indices(len(ys), rank, world_size)]
+        total = float(sum(int(y.shape[0]) + 5 for y in ys))
+    if not ys_r:
         return None, None
-    ys_r = [ys[i] for i in idx]
-    frac = float(sum(int(y.shape[0]) + 5 for y in ys_r)) / float(sum(int(y.shape[0]) + 5 for y in ys))
+    frac = float(sum(int(y.shape[0]) + 5 for y in ys_r)) / total
     log_probs, probs, _ = judge_fwd(ys_r)
     return -masked_sum(log_probs, ys_r) * frac, masked_sum(probs, ys_r) * frac
 
@@ -234,6 +259,7 @@ class DpPipeline(object):
                 self._recover(int(vals[-1]))
             else:
                 first["values"] = vals[:first["n"]]
+                first["make_loss"] = first["opt"] = None
                 self.pending.pop(0)
 
     def flush(self):
@@ -244,14 +270,17 @@ class DpPipeline(object):
         redo, self.pending = self.pending, []
         for r in redo:
             r["opt"].unapply()
-        np.random.set_state(redo[0]["rng"])
+        resume = np.random.get_state()
         self.leave(n_ranks)
 
         def again(n):
             raise RuntimeError("the abort latch is set on %d rank(s) after a data-parallel step off the fast path; nothing "
                                "was applied" % n)
         for r in redo:
+            np.random.set_state(r["rng"])                # every step again from the stream state it started with
             r["values"] = dp_step(r["make_loss"], r["opt"], r["n"], self.latch, again)
+            r["make_loss"] = r["opt"] = None
+        np.random.set_state(resume)                      # draws per step do not depend on the poisoned values
 
 
 # ------------------------------------------------------------------------------ flat buffers

@@ -2,8 +2,10 @@
 names, config keys, loss formulas and op order (zero_grad -> backward -> [all-reduce] -> clip -> step).
 Differences, all MI355X-first: the optimiser is the fused flat-buffer FlatAdam (one HIP kernel for
 clip+Adam(amsgrad)), gradients of a data-parallel run are exchanged with ONE RCCL all-reduce, and
-under torch.distributed every rank collates the same global batch and keeps its strided shard padded
-to the global extents (parallel.py), which reproduces the single-process numbers exactly.
+under torch.distributed every rank draws the same global batch (identically seeded samplers), pads and uploads
+only its strided shard - at the global extents (parallel.py), which reproduces the single-process numbers
+exactly.  Batches reach HBM through feed.DeviceFeed: collated one step ahead into pinned memory and uploaded on
+a side stream, so that the loops below never wait for a copy (the reference: to_gpu(data), utils.py:154-158).
 """
 import math
 import os
@@ -14,12 +16,12 @@ import torch
 
 import hip_backend as hb
 import parallel
-from dataloader import get_data_loader
+from dataloader import get_data_loader, _raw_items, _raw_texts
 from dataset import PickleDataset
+from feed import DeviceFeed
 from model import E2E, LM
 from parallel import FlatAdam
-from utils import (Logger, adjust_learning_rate, calculate_cer, cc, infinite_iter, remove_pad_eos, to_gpu,
-                   to_sents)
+from utils import Logger, adjust_learning_rate, calculate_cer, cc, infinite_iter, remove_pad_eos, to_sents
 
 
 class StepScalar(object):
@@ -154,10 +156,23 @@ class Solver(object):
         self.dev_dataset = self._dataset(cfg["dev_set"], None)
         self.dev_loader = self._loader(self.dev_dataset, cfg["batch_size"] // 2, False, False)
 
+    def _feed(self, loader, kind="labeled", sharded=True, noise_std=0.0, endless=False):
+        """The device-side view of a loader: the same batches in the same order (the loader's own batch sampler), collated
+        one step ahead into pinned memory and uploaded on a side stream (feed.DeviceFeed) - this rank's strided rows only
+        when `sharded` and the run is data parallel.  Config keys (not reference keys): `prefetch_batches` (default 2),
+        `prefetch_thread` (default true: collate in a background thread)."""
+        from torch.utils.data import DataLoader
+        raw = DataLoader(loader.dataset, batch_sampler=loader.batch_sampler, num_workers=0,
+                         collate_fn=_raw_texts if kind == "text" else _raw_items)
+        rank, world = (self.rank, self.world) if sharded else (0, 1)
+        return DeviceFeed(infinite_iter(raw) if endless else raw, "cuda" if torch.cuda.is_available() else "cpu", kind=kind,
+                          rank=rank, world=world, depth=int(self.config.get("prefetch_batches", 2)), noise_std=noise_std,
+                          thread=bool(self.config.get("prefetch_thread", True)))
+
     def get_infinite_iter(self):
-        self.lab_iter = infinite_iter(self.train_lab_loader)
-        self.unlab_x_iter = infinite_iter(self.train_unlab_x_loader)
-        self.unlab_y_iter = infinite_iter(self.train_unlab_y_loader)
+        self.lab_iter = iter(self._feed(self.train_lab_loader, endless=True))
+        self.unlab_x_iter = iter(self._feed(self.train_unlab_x_loader, kind="speech", endless=True))
+        self.unlab_y_iter = iter(self._feed(self.train_unlab_y_loader, kind="text", endless=True))
 
     # ------------------------------------------------------------------ model + optimisers
     def build_model(self, load_model=False):
@@ -232,8 +247,8 @@ class Solver(object):
         self.flush()
         self.model.eval()
         preds, refs, total = [], [], 0.0
-        for data in self.dev_loader:
-            xs, ilens, ys = to_gpu(data)
+        for batch in self._feed(self.dev_loader, sharded=False):
+            xs, ilens, ys = batch
             with torch.no_grad():
                 _, log_probs, _, _ = self.model(xs, ilens, ys=ys)
                 value = self.model.mask_and_cal_loss(log_probs, ys).item()
@@ -243,7 +258,7 @@ class Solver(object):
                     value = self.model.mask_and_cal_loss(log_probs, ys).item()
                 total += value
             preds += self._greedy(xs, ilens)
-            refs += [y.cpu().numpy().tolist() for y in ys]
+            refs += batch.ys_host
         self.model.train()
         cer, hyp_sents, ref_sents = self.ind2sent(preds, refs)
         return total / len(self.dev_loader), cer, hyp_sents, ref_sents
@@ -252,9 +267,8 @@ class Solver(object):
         self.flush()
         self.judge.eval()
         total = 0.0
-        for data in self.dev_loader:
-            _, _, ys = to_gpu(data)
-            ys.sort(key=lambda y: len(y), reverse=True)
+        for batch in self._feed(self.dev_loader, kind="text", sharded=False):     # transcripts, longest first
+            ys = list(batch)
             with torch.no_grad():
                 log_probs, _, _ = self.judge(ys)
                 value = -self.judge.mask_and_cal_sum(log_probs, ys).item()
@@ -280,10 +294,10 @@ class Solver(object):
                                  drop_last=False)
         self.model.eval()
         preds, refs = [], []
-        for data in loader:
-            xs, ilens, ys = to_gpu(data)
+        for batch in self._feed(loader, sharded=False):
+            xs, ilens, _ = batch
             preds += self._greedy(xs, ilens)
-            refs += [y.cpu().numpy().tolist() for y in ys]
+            refs += batch.ys_host
         self.model.train()
         cer, hyp_sents, _ = self.ind2sent(preds, refs)
         with open(f"{test_set}.txt", "w") as f:
@@ -318,6 +332,7 @@ class Solver(object):
     # at step i's loss and abort latch while step i + 1 runs - no GPU idle time between steps.  0: the reference's order,
     # loss.item() inside every step (solver.py:379).  Config key `pipeline_steps` (not a reference key).
     PIPELINE_STEPS = 1
+    PINNED_ROWS = 8                    # landing rows for the host records of outstanding steps: pipeline_steps <= PINNED_ROWS - 2
 
     def _step(self, make_local, opt, n_scalars):
         """Run one optimiser step on make_local() -> (local loss, [scalar tensors]); returns the scalars, summed over the
@@ -338,7 +353,7 @@ class Solver(object):
         buffer) as the device-side predicate - every rank skips or none does - and the coordinated repeat of _dp_step one
         step late (parallel.DpPipeline).  Every rank resolves its StepScalars at the same points of the program (the loops
         below run the same code on all ranks): a recovery is a sequence of collectives."""
-        depth = int(self.config.get("pipeline_steps", self.PIPELINE_STEPS))
+        depth = min(int(self.config.get("pipeline_steps", self.PIPELINE_STEPS)), self.PINNED_ROWS - 2)   # one landing row each
         if self.world > 1 or parallel.FORCE_DP:
             if depth <= 0 or opt.buf.flat_g.device.type != "cuda":
                 out = self._dp_step(make_local, opt, n_scalars)        # the host reads between all-reduce and update
@@ -374,7 +389,7 @@ class Solver(object):
     def _free_slot(self):
         """A row of the pinned landing buffer that no outstanding step uses."""
         if self._pinned is None:
-            self._pinned = torch.zeros(8, 8, dtype=torch.float32).pin_memory()
+            self._pinned = torch.zeros(self.PINNED_ROWS, 8, dtype=torch.float32).pin_memory()
         busy = set(r["slot"] for r in self._pending)
         if self._dp_pipe is not None:
             row = self._pinned.stride(0) * self._pinned.element_size()
@@ -427,6 +442,7 @@ class Solver(object):
                 self._recover()
             else:
                 first["values"] = vals[:first["n"]]
+                first["make_local"] = first["opt"] = None   # a StepScalar kept in a log must not keep the batch alive
                 self._pending.pop(0)
 
     def _lagged(self, log):
@@ -465,8 +481,12 @@ class Solver(object):
         hb.disable_persistent(dev)                       # also clears the latch
         for rec in redo:
             rec["opt"].unapply()
-        np.random.set_state(redo[0]["rng"])
+        resume = np.random.get_state()                   # where the stream stands now: behind every draw made so far
         for rec in redo:
+            # each step again from the stream state IT started with: draws made between the steps (none in the loops of
+            # this file - the input noise has a stream of its own, feed.DeviceFeed - but a caller may make some) are not
+            # part of a step and must not shift the teacher-forcing draws of the repeats
+            np.random.set_state(rec["rng"])
             loss, scalars = rec["make_local"]()
             rec["opt"].zero_grad()
             loss.backward()
@@ -477,10 +497,13 @@ class Solver(object):
                                    % hb.persist_abort_code(dev))
             rec["opt"].step()
             rec["values"] = both[:rec["n"]]
+            rec["make_local"] = rec["opt"] = None
+        np.random.set_state(resume)                      # a step draws the same number of values whatever its outputs were
 
     def judge_train_one_iteration(self, unlab_ys):
-        """solver.py:288-301.  `unlab_ys` is the global text batch: every rank of a data-parallel run takes its strided
-        shard and normalises by the global sum of (len + 5) (parallel.judge_local_loss; the identity for one process)."""
+        """solver.py:288-301.  `unlab_ys` is the global text batch - every rank of a data-parallel run takes its strided
+        shard and normalises by the global sum of (len + 5) (parallel.judge_local_loss; the identity for one process) - or
+        this rank's parallel.LocalShard of it (the loops below: only the shard was uploaded)."""
         def make_local():
             loss, avg_prob = parallel.judge_local_loss(
                 lambda ys: self.judge(ys=ys, discrete_input=True),
@@ -511,8 +534,8 @@ class Solver(object):
                     self.logger.scalar_summary(f"{cfg['tag']}/judge_pretrain/{key}", float(val),
                                                epoch * steps_per_epoch + it + 1)
             push, done = self._lagged(log)
-            for it, data in enumerate(self.train_unlab_y_loader):
-                push((it, self.judge_train_one_iteration([cc(y) for y in data])))
+            for it, batch in enumerate(self._feed(self.train_unlab_y_loader, kind="text")):
+                push((it, self.judge_train_one_iteration(batch.xs if self.world > 1 else batch.ys)))
             done()
             running = total[0]
             val_loss, samples = self.lm_validation()
@@ -538,7 +561,8 @@ class Solver(object):
                                        cfg["enc_n_layers"], cfg["subsample"])
 
     def sup_train_one_iteration(self, xs, ilens, ys, tf_rate):
-        """The body of the supervised loop (solver.py:375-385) for one (global) batch already on the device: forward on this
+        """The body of the supervised loop (solver.py:375-385) for one batch already on the device - the global batch, or this
+        rank's parallel.LocalShard of it as `xs` (what the epoch loop's feed uploads under data parallelism): forward on this
         rank's shard, loss = -mean(log_probs), zero_grad, backward, (all-reduce,) loss + abort latch read on the host - the
         reference's loss.item() - then clip + Adam.  bench.py times exactly this method."""
         def make_local():
@@ -560,11 +584,9 @@ class Solver(object):
             self.logger.scalar_summary(tag=f"{cfg['tag']}/train_loss", value=float(value),
                                        step=epoch * steps_per_epoch + it + 1)
         push, done = self._lagged(log)
-        for it, data in enumerate(self.train_lab_loader):
-            xs, ilens, ys = to_gpu(data)
-            if cfg["add_gaussian"] and epoch >= cfg["gaussian_epoch"]:
-                noise = np.random.normal(0, cfg["gaussian_std"], tuple(xs.shape)).astype(np.float32)
-                xs = xs + cc(torch.from_numpy(noise))
+        # input noise (solver.py:370-373) is added by the feed, on the host, before the upload
+        noise = float(cfg["gaussian_std"]) if cfg["add_gaussian"] and epoch >= cfg["gaussian_epoch"] else 0.0
+        for it, (xs, ilens, ys) in enumerate(self._feed(self.train_lab_loader, noise_std=noise)):
             push((it, self.sup_train_one_iteration(xs, ilens, ys, tf_rate)))
         done()
         return running[0] / steps_per_epoch
@@ -603,8 +625,8 @@ class Solver(object):
         """The LM-judge auxiliary loss (solver.py:460-495): greedy smooth-embedding decode of unlabeled
         speech WITH grad, judge probabilities of the hypothesis, unsup = -sum(p_LM * log p_model * mask)/sum(mask);
         loss = sup + unsup_weight * unsup; only the generator is stepped.
-        lab_* / unlab_* are the GLOBAL batches (the loaders draw batch_size * world utterances): every rank works on its
-        strided shards at the global padded extents and normalises the auxiliary loss by the global hypothesis-token
+        lab_* / unlab_* are the GLOBAL batches (the loaders draw batch_size * world utterances) or this rank's
+        parallel.LocalShards of them as lab_xs / unlab_xs: every rank works on its strided shards at the global padded extents and normalises the auxiliary loss by the global hypothesis-token
         count (parallel.ssl_local_loss: one 4-byte all-reduce next to the gradient all-reduce; nothing in one process)."""
         cfg = self.config
 
@@ -626,10 +648,9 @@ class Solver(object):
         return {"unsup_loss": unsup, "sup_loss": sup, "loss": value}
 
     def ssl_train_one_iteration(self, iteration):
-        lab_data, unlab_data = next(self.lab_iter), next(self.unlab_x_iter)
-        lab_xs, lab_ilens, lab_ys = to_gpu(lab_data)
-        unlab_xs, unlab_ilens = unlab_data
-        return self.gen_train_one_iteration(lab_xs, lab_ilens, lab_ys, cc(unlab_xs), unlab_ilens)
+        lab_xs, lab_ilens, lab_ys = next(self.lab_iter)
+        unlab_xs, unlab_ilens = next(self.unlab_x_iter)
+        return self.gen_train_one_iteration(lab_xs, lab_ilens, lab_ys, unlab_xs, unlab_ilens)
 
     def ssl_train(self):
         cfg = self.config

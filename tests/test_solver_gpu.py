@@ -310,10 +310,12 @@ def test_judge_train_one_iteration_against_golden(tmp_path, monkeypatch):
         assert float((p.detach().cpu() - torch.from_numpy(want)).abs().max()) <= 1e-4 * float(np.abs(want).max()) + 2e-6, n
 
 
-def _dp_worker(rank, world, port, root, out):
+def _dp_worker(rank, world, port, root, out, use_feed=False):
     """One rank of a 2-rank rehearsal that SHARES the one GPU (gloo for the collectives; init_distributed switches a
     shared card to the per-step kernels): supervised step with scheduled sampling (tf_rate 0.5, numpy RNG seeded by the
-    Solver), judge step, semi-supervised step -> rank 0 saves the resulting weights and the reported scalars."""
+    Solver), judge step, semi-supervised step -> rank 0 saves the resulting weights and the reported scalars.
+    use_feed: the batches come from the Solver's input pipeline (feed.DeviceFeed: every rank pads and uploads ITS rows
+    only, parallel.LocalShard) instead of the global batch uploaded by every rank."""
     import sys
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (here, os.path.join(here, "semi-supervised-asr_amd"), os.path.join(here, "tests", "golden"),
@@ -332,20 +334,32 @@ def _dp_worker(rank, world, port, root, out):
         solver, dev = _tiny_solver(root, mpatch, batch_size=6 // world, numpy_seed=0, shuffle=False, dp_overlap=True)
         assert solver.gen_opt.buf.overlap == (world > 1)
         scalars = []
-        data = next(iter(solver.train_lab_loader))
         from utils import to_gpu, cc
-        xs, ilens, ys = to_gpu(data)
-        assert len(ilens) == 6
+        if use_feed:
+            import parallel
+            xs, ilens, ys = next(iter(solver._feed(solver.train_lab_loader)))
+            texts = next(iter(solver._feed(solver.train_unlab_y_loader, kind="text")))
+            texts = texts.xs if world > 1 else texts.ys
+            uxs, uilens = next(iter(solver._feed(solver.train_unlab_x_loader, kind="speech")))
+            if world > 1:
+                assert isinstance(xs, parallel.LocalShard) and xs.xs.shape[0] == 3 and xs.info["b_global"] == 6
+                assert isinstance(uxs, parallel.LocalShard) and isinstance(texts, parallel.LocalShard)
+        else:
+            xs, ilens, ys = to_gpu(next(iter(solver.train_lab_loader)))
+            assert len(ilens) == 6
+            texts = [cc(y) for y in next(iter(solver.train_unlab_y_loader))]
+            uxs, uilens = next(iter(solver.train_unlab_x_loader))
+            uxs = cc(uxs)
 
         def make_local():
             loss = solver._sharded_forward(xs, ilens, ys, 0.5)
             return loss, [loss]
         scalars += solver._step(make_local, solver.gen_opt, 1)
-        meta = solver.judge_train_one_iteration([cc(y) for y in next(iter(solver.train_unlab_y_loader))])
+        meta = solver.judge_train_one_iteration(texts)
         scalars += [meta["loss"], meta["avg_prob"]]
-        uxs, uilens = next(iter(solver.train_unlab_x_loader))
-        meta = solver.gen_train_one_iteration(xs, ilens, ys, cc(uxs), uilens)
+        meta = solver.gen_train_one_iteration(xs, ilens, ys, uxs, uilens)
         scalars += [meta["unsup_loss"], meta["sup_loss"], meta["loss"]]
+        solver.flush()        # every rank resolves its lazy scalars at the same point (a recovery is a sequence of collectives)
         if rank == 0:
             torch.save(dict(scalars=[float(v) for v in scalars], model={n: p.detach().cpu() for n, p in solver.model.named_parameters()},
                             judge={n: p.detach().cpu() for n, p in solver.judge.named_parameters()}), out)
@@ -357,9 +371,12 @@ def _dp_worker(rank, world, port, root, out):
         mpatch.undo()
 
 
-def test_solver_steps_two_ranks_equal_one_process(tmp_path):
+@pytest.mark.parametrize("use_feed", [False, True])
+def test_solver_steps_two_ranks_equal_one_process(tmp_path, use_feed):
     """supervised (tf_rate 0.5 through the Solver's seeded numpy stream), judge and semi-supervised
-    steps of the product Solver on 2 data-parallel ranks == the same steps in one process on the global batches."""
+    steps of the product Solver on 2 data-parallel ranks == the same steps in one process on the global batches.
+    use_feed: the 2 ranks take rank-local batches from the input pipeline (each pads and uploads its 3 of
+    the 6 utterances), the one process the global batch through the reference's to_gpu."""
     import socket
     import torch.multiprocessing as mp
     import __graft_entry__ as entry
@@ -370,7 +387,7 @@ def test_solver_steps_two_ranks_equal_one_process(tmp_path):
     s.close()
     r2, r1 = str(tmp_path / "w2"), str(tmp_path / "w1")
     os.makedirs(r2), os.makedirs(r1)
-    mp.spawn(_dp_worker, args=(2, port, r2, os.path.join(r2, "out.pt")), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, r2, os.path.join(r2, "out.pt"), use_feed), nprocs=2, join=True)
     mp.spawn(_dp_worker, args=(1, 0, r1, os.path.join(r1, "out.pt")), nprocs=1, join=True)
     got, ref = torch.load(os.path.join(r2, "out.pt")), torch.load(os.path.join(r1, "out.pt"))
     for a, b in zip(got["scalars"], ref["scalars"]):
@@ -379,3 +396,36 @@ def test_solver_steps_two_ranks_equal_one_process(tmp_path):
         for n, want in ref[part].items():
             err = float((got[part][n] - want).abs().max())
             assert err <= 1e-5 * float(want.abs().max()) + 2e-6, (part, n, err)
+
+
+@pytest.mark.parametrize("thread", [True, False])
+def test_epoch_through_the_input_pipeline_equals_the_to_gpu_loop(tmp_path, monkeypatch, thread):
+    """Solver.sup_train_one_epoch takes its batches from feed.DeviceFeed (collated one step ahead into pinned
+    memory, uploaded on a side stream, labels as one packed tensor) - same batches, same order, same numbers as the
+    reference's loop `for data in loader: to_gpu(data)` (solver.py:365-367) around the same step; judge_pretrain's and
+    validation's loops read through the same pipeline."""
+    import __graft_entry__ as entry
+    entry.build()
+    from utils import to_gpu
+    results = []
+    for mode in ("feed", "to_gpu"):
+        root = str(tmp_path / (mode + str(thread)))
+        os.makedirs(root)
+        torch.manual_seed(0)
+        solver, dev = _tiny_solver(root, monkeypatch, batch_size=5, shuffle=True, numpy_seed=3, prefetch_thread=thread)
+        if mode == "feed":
+            mean = solver.sup_train_one_epoch(0, 0.7)
+        else:
+            losses = []
+            for data in solver.train_lab_loader:
+                xs, ilens, ys = to_gpu(data)
+                losses.append(float(solver.sup_train_one_iteration(xs, ilens, ys, 0.7)))
+            mean = sum(losses) / len(losses)
+        solver.flush()
+        val = solver.validation()
+        results.append((mean, val[0], val[1], {n: p.detach().cpu().clone() for n, p in solver.model.named_parameters()}))
+    (m1, v1, c1, w1), (m2, v2, c2, w2) = results
+    # (not bitwise: the split-K products accumulate with atomics, run-to-run order differs)
+    assert abs(m1 - m2) <= 1e-5 * abs(m2) and abs(v1 - v2) <= 1e-5 * abs(v2) and abs(c1 - c2) <= 0.05
+    for n in w2:
+        assert float((w1[n] - w2[n]).abs().max()) <= 1e-5 * float(w2[n].abs().max()) + 1e-6, n

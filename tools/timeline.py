@@ -5,7 +5,8 @@ from collections import Counter
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end from kernels order by start"))
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
-step = rows[adam[-3] + 1:adam[-2] + 1]
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # consecutive steps to print (default: one)
+step = rows[adam[-2 - nsteps] + 1:adam[-2] + 1]
 big = ('lstm_persist', 'gemm_f32', 'gemm_bf3', 'gemm_bf6', 'dec_persist', 'att_m', 'pyramid', 'colsum', 'adam', 'sumsq')
 t0 = step[0][1]; prev_end = t0; groups = []; cur = []
 for nm, st, en in step:
