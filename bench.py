@@ -706,7 +706,7 @@ def main():
     shutil.rmtree(tmp, ignore_errors=True)
 
 
-def epoch_workload(dev, tmp, steps=40, config="cfg2"):
+def epoch_workload(dev, tmp, steps=60, config="cfg2"):
     """The product's own training loop, input pipeline included: Solver.sup_train_one_epoch over a loader of `steps` batches
     whose utterances have exactly the lengths of the headline batch (ragged 0.6T..T, seed 1234; features and labels differ
     from batch to batch), so that its ms/step is comparable with the resident-batch `ms_per_step`.  Every batch is collated

@@ -98,6 +98,12 @@ struct PersistArgs {
   float* db;            // bwd: bias gradient [ndir][4H] gate-interleaved (sum of dG over time and rows), or NULL
   u64* xch;             // fwd: [2][8][PRG][H] granules;  bwd: [2][8][PRG][4H]
   unsigned* ctrl;       // [0..7] tickets per XCC, [8] abort, [9] error code
+  // Row addressing of gates / y / c / dy.  NULL: time-major, row (t, b) = t * B + b, every row has all T times.  Otherwise
+  // PACKED rows (include/asr_hip.h): batch row b owns rows rowbase[b] .. rowbase[b] + rowext[b] - 1, time t at rowbase[b] + t;
+  // lens[b] < rowext[b], the rows lens[b] .. rowext[b] - 1 are written as padding (zeros), times >= rowext[b] do not exist
+  // (nothing is stored; loads are clamped to the last row of the block, their values are dead).
+  const int32_t* rowbase;
+  const int32_t* rowext;
 };
 
 // ---------------------------------------------------------------------------------------------------- forward
@@ -143,6 +149,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
+  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
+  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
+  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
   float c_prev = 0.f;
   u64* xch_g = a.xch + (int64_t)g * PRG * PH;          // + parity * 8*PRG*PH
   float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * PRG;   // word protocol: [parity][unit][row]
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   // left the pointwise waves waiting ~1 300 cycles there (tools/lstm_trace.py).
   auto gx_ptr = [&](int sn) {
     const int tt = d == 0 ? sn : T - 1 - sn;
-    return reinterpret_cast<const float4*>(a.gates + (((int64_t)tt * B + prow) * ndir + d) * 4 * PH + punit * 4);
+    return reinterpret_cast<const float4*>(a.gates + (row_at(tt) * ndir + d) * 4 * PH + punit * 4);
   };
   float4 gx_n1 = make_float4(0.f, 0.f, 0.f, 0.f), gx_n2 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (prow_ok) {
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     const float4 gx = gx_n1;
     gx_n1 = gx_n2;
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (row_at(t) * ndir + d) * 4 * PH + punit * 4);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       // Single-stage hand-off, 16-byte reads: h_{t-1} travels as LSB-tagged fp32 words laid out [unit][row], so the rows
@@ -283,10 +292,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
 #ifdef ASR_LP_TRACE3   /* visibility probe: global 100 MHz clock at the publish of (slice 28, row 7, its first unit) ... */
       if (g == 0 && slice == 28 && tid == 7 && s < 64) ((unsigned long long*)a.ctrl)[16 + 2 * s] = wall_clock64();
 #endif
-      if (prow_ok) {
+      if (prow_ok && t < pext) {
         st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
         st_gp = gp;
-        st_so = ((int64_t)t * B + prow) * ldy + d * PH + punit;
+        st_so = row_at(t) * ldy + d * PH + punit;
       }
       LP_MARK(6);
     }
@@ -448,13 +457,16 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
+  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
+  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
+  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
   float c_prev = 0.f;
   float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * RG;   // [parity][unit][row]
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
   bool aborted = false;
   auto gx_ptr = [&](int sn) {
     const int tt = d == 0 ? sn : T - 1 - sn;
-    return reinterpret_cast<const float4*>(a.gates + (((int64_t)tt * B + prow) * ndir + d) * 4 * PH + punit * 4);
+    return reinterpret_cast<const float4*>(a.gates + (row_at(tt) * ndir + d) * 4 * PH + punit * 4);
   };
   float4 gx_n1 = make_float4(0.f, 0.f, 0.f, 0.f), gx_n2 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (prow_ok) {
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
     const float4 gx = gx_n1;
     gx_n1 = gx_n2;
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (((int64_t)t * B + prow) * ndir + d) * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (row_at(t) * ndir + d) * 4 * PH + punit * 4);
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -679,10 +691,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       LP_MARK(5);
       word_store(xw_g + (s & 1) * (PH * RG) + (int64_t)punit * RG + pj, hn, tag_bit_of_step(s));       // hand-off first
       LP_MARK(6);
-      if (prow_ok) {
+      if (prow_ok && t < pext) {
         st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
         st_gp = gp;
-        st_so = ((int64_t)t * B + prow) * ldy + d * PH + punit;
+        st_so = row_at(t) * ldy + d * PH + punit;
       }
     }
   }
@@ -755,6 +767,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   const bool touch_ok = ASR_LSTM_TOUCH && tid >= 384 && mt < PUC * PRG && pj < NR && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
+  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
+  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
+  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of this thread's (unit, row): sum of dG over time
   float* xch_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * PRG * 4 * PH;   // + parity * 8*PRG*4H
@@ -778,11 +793,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     const int tt = (ASR_LP_ABL & 8) ? 1 : (d == 0 ? T - 1 - sn : sn);      // bit 8 (measurement): always the same, cached row
     const int ttp = d == 0 ? tt - 1 : tt + 1;
     const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
-    const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
+    const int64_t so = row_at(tt) * ldy + d * PH + punit;
     n_dy = a.dy[so];
-    n_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    n_av = *reinterpret_cast<const float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
     n_ct = a.c[so];
-    n_cp = hp ? a.c[((int64_t)ttp * B + prow) * ldy + d * PH + punit] : 0.f;
+    n_cp = hp ? a.c[row_at(ttp) * ldy + d * PH + punit] : 0.f;
     if (fuse_dw) n_y = a.yfwd[so];
   };
   if (prow_ok) fetch_step(0);
@@ -793,7 +808,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     const float dyv = n_dy, ct = n_ct, cp = n_cp;
     const float4 av = n_av;
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + row_at(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
     if (fuse_dw && pw_thread) ysl[s & 1][pj][pu] = prow_ok ? n_y : 0.f;     // h_t of this CU's units (read after the barrier)
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
@@ -942,7 +957,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
                          __HIP_MEMORY_SCOPE_WORKGROUP);
       LP_MARK(11);
       if (prow_ok) {     // after the hand-off: the bulk store and the bias-gradient sum are off the serial chain
-        if (!(ASR_LP_ABL & 16)) *gp = da;
+        if (!(ASR_LP_ABL & 16) && t < pext) *gp = da;
         dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
       }
     }
@@ -1067,6 +1082,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
   const bool touch_ok = ASR_LSTM_TOUCH && tid >= 384 && mt < PUC * PRG && pj < NR && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
+  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
+  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
+  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of this thread's (unit, row): sum of dG over time
   float* xch_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * PRG * 4 * PH;   // + parity * 8*PRG*4H
@@ -1090,11 +1108,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
     const int tt = (ASR_LP_ABL & 8) ? 1 : (d == 0 ? T - 1 - sn : sn);      // bit 8 (measurement): always the same, cached row
     const int ttp = d == 0 ? tt - 1 : tt + 1;
     const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
-    const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
+    const int64_t so = row_at(tt) * ldy + d * PH + punit;
     n_dy = a.dy[so];
-    n_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    n_av = *reinterpret_cast<const float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
     n_ct = a.c[so];
-    n_cp = hp ? a.c[((int64_t)ttp * B + prow) * ldy + d * PH + punit] : 0.f;
+    n_cp = hp ? a.c[row_at(ttp) * ldy + d * PH + punit] : 0.f;
     if (fuse_dw) n_y = a.yfwd[so];
   };
   if (prow_ok) fetch_step(0);
@@ -1105,7 +1123,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
     const float dyv = n_dy, ct = n_ct, cp = n_cp;
     const float4 av = n_av;
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + row_at(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
     if (fuse_dw && pw_thread) ysl[s & 1][pj][pu] = prow_ok ? n_y : 0.f;     // h_t of this CU's units (read after the barrier)
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
@@ -1239,7 +1257,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
                          __HIP_MEMORY_SCOPE_WORKGROUP);
       LP_MARK(11);
       if (prow_ok) {     // after the hand-off: the bulk store and the bias-gradient sum are off the serial chain
-        if (!(ASR_LP_ABL & 16)) *gp = da;
+        if (!(ASR_LP_ABL & 16) && t < pext) *gp = da;
         dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
       }
     }
@@ -1436,6 +1454,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUR * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
+  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
+  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
+  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
   float* xg = reinterpret_cast<float*>(a.xch) + (int64_t)g * RD::group_floats;
@@ -1461,9 +1482,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   auto time_of = [&](int sn) { return d == 0 ? T - 1 - sn : sn; };
   auto fetch_step = [&](int sn, float& o_dy, float& o_ct, float4& o_av) {
     const int tt = time_of(sn);
-    const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
+    const int64_t so = row_at(tt) * ldy + d * PH + punit;
     o_dy = a.dy[so];
-    o_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    o_av = *reinterpret_cast<const float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
     o_ct = a.c[so];
   };
   // forward hidden state at the time that fed step sn's time.  Bare loads from clamped addresses: nothing may touch a
@@ -1584,7 +1605,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     if (h_lane && s + 1 < T && !(ASR_RA & 256)) stage_h((s + 1) & 3, s + 1);
 #endif
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + row_at(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
     // ---------------------------------------------------------------- (1) gather the partials addressed to this CU
     float dh_rec = 0.f;
     if (s > 0) {
@@ -1660,7 +1681,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         }
         if (prow_ok) {
           st_da = da;
-          st_gp = gp;
+          st_gp = t < pext ? gp : nullptr;
           dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
         }
       }
@@ -1872,6 +1893,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
+  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
+  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
+  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
   float* xg = reinterpret_cast<float*>(a.xch) + (int64_t)g * (2 * PARSZ);
@@ -1882,9 +1906,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
   auto time_of = [&](int sn) { return d == 0 ? T - 1 - sn : sn; };
   auto fetch_step = [&](int sn, float& o_dy, float& o_ct, float4& o_av) {
     const int tt = time_of(sn);
-    const int64_t so = ((int64_t)tt * B + prow) * ldy + d * PH + punit;
+    const int64_t so = row_at(tt) * ldy + d * PH + punit;
     o_dy = a.dy[so];
-    o_av = *reinterpret_cast<const float4*>(a.gates + ((int64_t)tt * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    o_av = *reinterpret_cast<const float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
     o_ct = a.c[so];
   };
   // gather descriptors: DPP row rr sums the 32 sources of (row = wave, unit quad rr), two sources per lane; row 0 also quad 4
@@ -1935,7 +1959,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
       asm volatile("" : "+v"(k_dc), "+v"(k_i), "+v"(k_f), "+v"(k_g), "+v"(k_o), "+v"(k_cn));
     }
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ((int64_t)t * B + prow) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + row_at(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
     // ---------------------------------------------------------------- (1) gather the partials addressed to this CU
     float dh_rec = 0.f;
     if (s > 0) {
@@ -1989,7 +2013,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
       for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][s & 1][pj][4 * pu]) = make_uint2(p0[k], p1[k]);
       if (prow_ok) {
         st_da = da;
-        st_gp = gp;
+        st_gp = t < pext ? gp : nullptr;
         dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
       }
     }
@@ -2258,11 +2282,22 @@ extern "C" int asr_persist_scratch_bytes(int64_t* xch_bytes, int64_t* ctrl_bytes
   if (ctrl_bytes) *ctrl_bytes = 128;
   return 0;
 }
+// Steps a row block of PACKED rows has to run: the largest extent of its rows when the caller gave a host copy of rowext
+// (times >= rowext[b] do not exist, so this is exact), else T.
+static int block_steps(int T, const int32_t* rowext_host, int rb, int rows) {
+  if (!rowext_host) return T;
+  int m = 1;
+  for (int r = 0; r < rows; ++r) m = rowext_host[rb + r] > m ? rowext_host[rb + r] : m;
+  return m < T ? m : T;
+}
+
 extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
-                                        const int32_t* lens, float* y, float* c, void* xch, void* ctrl, int arith,
+                                        const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
+                                        const int32_t* rowext_host, float* y, float* c, void* xch, void* ctrl, int arith,
                                         asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B || !arith_ok(arith)) return ASR_E_ARG;
+  if ((rowbase == nullptr) != (rowext == nullptr) || (rowext_host && !rowbase)) return ASR_E_ARG;
   // H = 640 (the judge LM, config.yaml dis_hidden_dim): forward only - 20 units per CU = 5 M tiles of the bf16 MFMA
   if (!(persist_supported(H) || H == 640) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   if (H == 640 && (arith & ASR_ARITH_MASK) == ASR_ARITH_F32) return ASR_E_SHAPE;
@@ -2273,9 +2308,13 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
     hipError_t e = persist_reset(xch, ctrl, (size_t)2 * 8 * (nr > PRG ? nr : PRG) * H * sizeof(u64), stream);
     if (e != hipSuccess) return (int)e;
     PersistArgs a = {};
-    a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
-    a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
-    a.y = y + (int64_t)rb * ndir * H; a.c = c + (int64_t)rb * ndir * H;
+    a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
+    a.T = block_steps(T, rowext_host, rb, a.nb);
+    // time-major: the row block starts rb rows into every time slab; packed rows: rowbase is absolute
+    const int64_t ro = rowbase ? 0 : rb;
+    a.gates = gates + ro * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
+    a.rowbase = rowbase ? rowbase + rb : nullptr; a.rowext = rowext ? rowext + rb : nullptr;
+    a.y = y + ro * ndir * H; a.c = c + ro * ndir * H;
     a.dy = nullptr; a.yfwd = nullptr; a.dw = nullptr; a.db = nullptr; a.xch = (u64*)xch; a.ctrl = persist_launch_words(ctrl);
     int rc;
     if (nr == 16)
@@ -2291,10 +2330,13 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
 
 // Persistent fast path of asr_lstm_seq_bwd (same arguments and results except that no dcarry scratch is needed).
 static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT, const float* w_hh_il,
-                                     const int32_t* lens, const float* dy, const float* c, const float* y,
+                                     const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
+                                     const int32_t* rowext_host, const float* dy, const float* c, const float* y,
                                      float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || (!w_hhT && !w_hh_il) || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B || !arith_ok(arith)) return ASR_E_ARG;
+  if ((rowbase == nullptr) != (rowext == nullptr) || (rowext_host && !rowbase)) return ASR_E_ARG;
+  if (rowbase) { y = nullptr; dw_hh = nullptr; }     // packed rows: dW_hh is the caller's (one product over all rows, see asr_hip.h)
   if (!bwd_persist_width(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   const int kind = bwd_kernel_kind(H, arith);
   if (kind < 0) return ASR_E_SHAPE;
@@ -2309,10 +2351,13 @@ static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, floa
     hipError_t e = persist_reset(xch, ctrl, xbytes, stream);
     if (e != hipSuccess) return (int)e;
     PersistArgs a = {};
-    a.T = T; a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
-    a.gates = gates + (int64_t)rb * ndir * 4 * H; a.w = w_hhT; a.w_il = w_hhT ? nullptr : w_hh_il; a.lens = lens + rb; a.y = nullptr;
-    a.c = const_cast<float*>(c) + (int64_t)rb * ndir * H; a.dy = dy + (int64_t)rb * ndir * H;
-    a.yfwd = (y && dw_hh) ? y + (int64_t)rb * ndir * H : nullptr; a.dw = (y && dw_hh) ? dw_hh : nullptr;
+    a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
+    a.T = block_steps(T, rowext_host, rb, a.nb);
+    const int64_t ro = rowbase ? 0 : rb;
+    a.gates = gates + ro * ndir * 4 * H; a.w = w_hhT; a.w_il = w_hhT ? nullptr : w_hh_il; a.lens = lens + rb; a.y = nullptr;
+    a.rowbase = rowbase ? rowbase + rb : nullptr; a.rowext = rowext ? rowext + rb : nullptr;
+    a.c = const_cast<float*>(c) + ro * ndir * H; a.dy = dy + ro * ndir * H;
+    a.yfwd = (y && dw_hh) ? y + ro * ndir * H : nullptr; a.dw = (y && dw_hh) ? dw_hh : nullptr;
     a.db = db;
     a.xch = (u64*)xch; a.ctrl = persist_launch_words(ctrl);
     int rc = nr == 4 ? dispatch_bwd<4>(H, arith, a, stream) : dispatch_bwd<PRG>(H, arith, a, stream);
@@ -2323,10 +2368,12 @@ static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, floa
 }
 
 extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
-                                        const int32_t* lens, const float* dy, const float* c, const float* y,
+                                        const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
+                                        const int32_t* rowext_host, const float* dy, const float* c, const float* y,
                                         float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream) {
   if (!w_hhT) return ASR_E_ARG;
-  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, w_hhT, nullptr, lens, dy, c, y, dw_hh, db, xch, ctrl, arith, stream);
+  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, w_hhT, nullptr, lens, rowbase, rowext, rowext_host, dy, c, y,
+                                   dw_hh, db, xch, ctrl, arith, stream);
 }
 
 // Same, taking W_hh in the FORWARD layout ([ndir][4H][H], what asr_lstm_seq_fwd_persist consumed): the exchanged-partials
@@ -2334,8 +2381,10 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
 // does not apply (H not in {128, 256, 512}, fp32-MFMA arithmetic, ASR_LSTM_BWD_GATHER): the caller then transposes and uses
 // asr_lstm_seq_bwd_persist.
 extern "C" int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh_il,
-                                          const int32_t* lens, const float* dy, const float* c, const float* y,
+                                          const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
+                                          const int32_t* rowext_host, const float* dy, const float* c, const float* y,
                                           float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream) {
   if (!w_hh_il) return ASR_E_ARG;
-  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, nullptr, w_hh_il, lens, dy, c, y, dw_hh, db, xch, ctrl, arith, stream);
+  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, nullptr, w_hh_il, lens, rowbase, rowext, rowext_host, dy, c, y,
+                                   dw_hh, db, xch, ctrl, arith, stream);
 }

@@ -59,8 +59,7 @@ class _Slot(object):
     def _area(self, old, n, dtype, quantum):
         if old is not None and old.numel() >= n:
             return old
-        t = torch.empty(_round_up(max(n, 1), quantum), dtype=dtype)
-        return t.pin_memory() if self.pin else t
+        return torch.empty(_round_up(max(n, 1), quantum), dtype=dtype, pin_memory=self.pin)
 
     def floats(self, n):
         self.f = self._area(self.f, n, torch.float32, 1 << 18)
@@ -69,6 +68,29 @@ class _Slot(object):
     def ints(self, n):
         self.i = self._area(self.i, n, torch.int64, 1 << 10)
         return self.i[:n]
+
+
+# Pinning host memory is slow (hipHostMalloc: of the order of 100 ms for the 8 MB of a cfg-2 batch), so the staging slots
+# outlive the feed that first needed them: a feed borrows its slots for the length of one iteration (an epoch) and hands them
+# back, and the next epoch's feed finds them pinned and large enough.
+_SLOT_POOL = {True: [], False: []}
+_SLOT_LOCK = threading.Lock()
+
+
+def _borrow_slots(n, pin):
+    with _SLOT_LOCK:
+        free = _SLOT_POOL[pin]
+        out = [free.pop() for _ in range(min(n, len(free)))]
+    return out + [_Slot(pin) for _ in range(n - len(out))]
+
+
+def _return_slots(slots):
+    for slot in slots:
+        if slot.event is not None:
+            slot.event.synchronize()                    # its last upload has left the pinned area
+            slot.event = None
+    with _SLOT_LOCK:
+        _SLOT_POOL[slots[0].pin].extend(slots)
 
 
 class DeviceFeed(object):
@@ -95,7 +117,7 @@ class DeviceFeed(object):
         # seeded data-parallel ranks draw identical noise whatever the interleaving of the threads
         self.noise_rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1)) if self.noise_std > 0 else None
         self.thread = bool(thread)
-        self._slots = [_Slot(self.cuda) for _ in range(self.depth + 2)]
+        self._slots = None                               # borrowed for the length of one iteration
         self._side = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._n = 0
 
@@ -121,10 +143,11 @@ class DeviceFeed(object):
             dim = int(items[0][0].shape[1])
             ilens = [lens_all[i] for i in rows]
             xs_h = slot.floats(len(rows) * t_max * dim).view(len(rows), t_max, dim)
-            for r, i in enumerate(rows):
+            xs_n = xs_h.numpy()                          # (numpy row assignments: a third less host time than tensor copies,
+            for r, i in enumerate(rows):                 #  and they release the GIL)
                 n = lens_all[i]
-                xs_h[r, :n].copy_(torch.from_numpy(np.asarray(items[i][0], dtype=np.float32)))
-                xs_h[r, n:].zero_()
+                xs_n[r, :n] = items[i][0]
+                xs_n[r, n:] = 0.0
             if self.noise_rng is not None:
                 noise = self.noise_rng.normal(0.0, self.noise_std, (len(items), t_max, dim)).astype(np.float32)
                 if rows:
@@ -136,10 +159,8 @@ class DeviceFeed(object):
             ys_lens = [len_all[i] for i in rows]
             ys_host = [list(tok_all[i]) for i in rows]
             ys_h = slot.ints(sum(ys_lens))
-            off = 0
-            for t, n in zip(ys_host, ys_lens):
-                ys_h[off:off + n].copy_(torch.from_numpy(np.asarray(t, dtype=np.int64)))
-                off += n
+            if ys_lens:
+                ys_h.numpy()[:] = np.concatenate([np.asarray(t, dtype=np.int64) for t in ys_host]) if sum(ys_lens) else 0
             info.update(olength=max(len_all) + 1, text_norm=float(sum(n + 5 for n in len_all)))
         event = None
         if self.cuda:
@@ -150,7 +171,7 @@ class DeviceFeed(object):
                 event.record(self._side)
             slot.event = event
         else:
-            xs_d = xs_h.clone() if xs_h is not None else None
+            xs_d = xs_h.clone() if xs_h is not None else None      # (CPU: tests of the host logic)
             ys_d = ys_h.clone() if ys_h is not None else None
         ys = list(torch.split(ys_d, ys_lens)) if ys_d is not None else None       # views of the one label tensor
         flat = (xs_d, ys_d)
@@ -179,13 +200,17 @@ class DeviceFeed(object):
 
     def _iter_inline(self):
         ahead = []
-        it = iter(self.source)
-        for items in it:
-            ahead.append(self._prepare(items))
-            if len(ahead) > self.depth - 1:
+        self._slots = _borrow_slots(self.depth + 2, self.cuda)
+        try:
+            for items in self.source:
+                ahead.append(self._prepare(items))
+                if len(ahead) > self.depth - 1:
+                    yield self._hand_over(ahead.pop(0))
+            while ahead:
                 yield self._hand_over(ahead.pop(0))
-        while ahead:
-            yield self._hand_over(ahead.pop(0))
+        finally:
+            slots, self._slots = self._slots, None
+            _return_slots(slots)
 
     def _iter_threaded(self):
         q = queue.Queue(maxsize=self.depth)
@@ -212,6 +237,7 @@ class DeviceFeed(object):
             except BaseException as exc:                 # surfaces in the consumer
                 put(exc)
 
+        self._slots = _borrow_slots(self.depth + 2, self.cuda)
         worker = threading.Thread(target=produce, name="asr-device-feed", daemon=True)
         worker.start()
         try:
@@ -226,3 +252,6 @@ class DeviceFeed(object):
             stop.set()                                   # the consumer left early (break / exception): release the producer
             # the producer may be inside _prepare; let it finish so that no upload is in flight from a slot we drop
             worker.join(timeout=5.0)
+            slots, self._slots = self._slots, None
+            if not worker.is_alive():                    # (a producer stuck in its source keeps its slots: they are dropped)
+                _return_slots(slots)

@@ -162,7 +162,9 @@ class Solver(object):
         when `sharded` and the run is data parallel.  Config keys (not reference keys): `prefetch_batches` (default 2),
         `prefetch_thread` (default true: collate in a background thread)."""
         from torch.utils.data import DataLoader
-        raw = DataLoader(loader.dataset, batch_sampler=loader.batch_sampler, num_workers=0,
+        # (the loader's generator too: iterating a DataLoader draws a base seed from it before the sampler draws its
+        # permutation - the batches are then the ones `for data in loader` would have produced)
+        raw = DataLoader(loader.dataset, batch_sampler=loader.batch_sampler, num_workers=0, generator=loader.generator,
                          collate_fn=_raw_texts if kind == "text" else _raw_items)
         rank, world = (self.rank, self.world) if sharded else (0, 1)
         return DeviceFeed(infinite_iter(raw) if endless else raw, "cuda" if torch.cuda.is_available() else "cpu", kind=kind,
