@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 3
+#define ASR_ABI_VERSION 4
 
 #define ASR_E_ARG    (-1)  /* null pointer / non-positive size */
 #define ASR_E_SHAPE  (-2)  /* size not supported by the kernel (see each function) */
@@ -145,9 +145,21 @@ int asr_colsum_f32(int64_t M, int64_t N, const float* X, int64_t ldx, float* out
  * 4 gates = 16 gate rows) x (<=32 batch rows); h_{t-1} W_hh^T on the 16x16x4 f32 MFMA
  * with K split over the 4 waves, partials reduced through LDS, then sigmoid/tanh/state
  * update.  H % 16 == 0.
+ *
+ * PACKED ROWS (ABI 4; rowbase / rowext, both NULL = the time-major layout above).  pack_padded_sequence spares the
+ * reference's LSTM the padded frames (model.py:79-81); here the whole encoder runs without them: batch row b owns the
+ * rows rowbase[b] .. rowbase[b] + rowext[b] - 1 of gates / y / c / dy (then [R][ndir][4H] and [R][ndir*H], R = the sum
+ * of the extents), time t at row rowbase[b] + t.  lens[b] < rowext[b]: the rows lens[b] .. rowext[b] - 1 are padding
+ * INSIDE the block - the kernels write y = c = 0 (forward) and dG = 0 (backward) there, as they do for the padded times
+ * of the time-major layout - and times >= rowext[b] do not exist (nothing is read into a result or written).  With at
+ * least one padding row behind every utterance the products that pair a row with its time neighbour (dW_hh = sum_t
+ * dG_t^T h_{t-1}) stay ONE row-shifted GEMM over all R rows: the neighbour across a block boundary is a zero row.
+ * Blocks whose extents halve from layer to layer (rowext_l = 2 rowext_{l+1}) make the pyramid's pair-concat the
+ * B = 1 case of asr_pyramid_concat_* over the R rows.  rowbase / rowext: int32 [B] on the device.
  * ------------------------------------------------------------------------------------- */
 int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
-                     const int32_t* lens, float* y, float* c, void* graphs, asr_stream_t stream);
+                     const int32_t* lens, const int32_t* rowbase, const int32_t* rowext, float* y, float* c,
+                     void* graphs, asr_stream_t stream);
 
 /* Persistent fast path of asr_lstm_seq_fwd (same arguments and results; csrc/lstm_persist.hip): ONE launch runs
  * all T steps, each XCD owns a (direction, 8- or 4-row) group, W_hh stays in registers, h_t is exchanged inside the
@@ -165,8 +177,12 @@ int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const 
  * never clears the latch words: a sequence operator is several launches, and the caller looks once, after the last
  * one, and clears the latch itself. */
 int asr_persist_scratch_bytes(int64_t* xch_bytes, int64_t* ctrl_bytes);   /* minimum sizes of the scratch pair; returns 0 */
+/* rowbase / rowext: packed rows (see asr_lstm_seq_fwd), NULL = time-major.  rowext_host: optional HOST copy of rowext
+ * (packed rows only): every row block then runs max(rowext of its rows) steps instead of T - exact, since later times
+ * do not exist for any of its rows (a batch of 256 length-sorted utterances on one GPU: the later blocks are shorter). */
 int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
-                             const int32_t* lens, float* y, float* c, void* xch, void* ctrl, int arith,
+                             const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
+                             const int32_t* rowext_host, float* y, float* c, void* xch, void* ctrl, int arith,
                              asr_stream_t stream);
 
 /* Backward through the same recurrence.
@@ -178,8 +194,8 @@ int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates
  * dW_hh is NOT produced here: the caller forms sum_t dG_t^T h_{t-1} with one asr_gemm_f32
  * (transA=1) over the whole sequence after this call. */
 int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
-                     const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
-                     asr_stream_t stream);
+                     const int32_t* lens, const int32_t* rowbase, const int32_t* rowext, const float* dy, const float* c,
+                     float* dcarry, void* graphs, asr_stream_t stream);
 /* Persistent fast path of asr_lstm_seq_bwd (same conditions / scratch / abort convention as asr_lstm_seq_fwd_persist;
  * H in {128, 256, 320, 512}, and 640 under ASR_ARITH_BF16X6).  With a bf16 arithmetic and H in {128, 256, 512} - and
  * H = 320 (10 units per CU in 12 slots) / H = 640 (20 units per CU, its own kernel) under ASR_ARITH_BF16X6 - the CUs of a
@@ -191,9 +207,12 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
  * If y (forward hidden states) and dw_hh ([ndir][4H][H], gate-interleaved, zero-filled or holding a running sum)
  * are given, the recurrent weight gradient sum_t dG_t^T h_{t-1} is accumulated into dw_hh inside the kernel
  * (fp32 atomics across the row groups) and the caller skips that GEMM.  If db ([ndir][4H], gate-interleaved,
- * zero-filled) is given, the bias gradient sum_{t,b} dG is accumulated into it as well. */
+ * zero-filled) is given, the bias gradient sum_{t,b} dG is accumulated into it as well.
+ * With packed rows (rowbase / rowext / rowext_host as in asr_lstm_seq_fwd_persist) y / dw_hh are ignored: dW_hh is the
+ * caller's row-shifted product over all R rows. */
 int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
-                             const int32_t* lens, const float* dy, const float* c, const float* y,
+                             const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
+                             const int32_t* rowext_host, const float* dy, const float* c, const float* y,
                              float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
 /* Does asr_lstm_seq_bwd_persist(_w) with this (H, arith) accumulate dW_hh itself when given y and dw_hh?  1 yes; 0 no -
  * the ASR_ARITH_BF16X6 exchanged-partials kernels (H in {128, 256, 320, 512, 640}) leave dW_hh = sum_t dG_t^T h_{t-1} to the caller
@@ -206,8 +225,30 @@ int asr_lstm_bwd_persist_fuses_dw(int H, int arith);
  * launch.  Returns ASR_E_SHAPE where that kernel does not apply; the caller then forms w_hhT and calls
  * asr_lstm_seq_bwd_persist / asr_lstm_seq_bwd. */
 int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh_il,
-                               const int32_t* lens, const float* dy, const float* c, const float* y, float* dw_hh,
+                               const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
+                               const int32_t* rowext_host, const float* dy, const float* c, const float* y, float* dw_hh,
                                float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The two ends of the packed-row encoder (csrc/rows.hip).  C % 4 == 0; lens / rowbase / rowext int32 [B] on the device;
+ * ext_max = max_b rowext[b] (host).
+ *   asr_rows_pack_f32        x [B][T][C], the collated batch (dataloader.py:6-12) -> rows [R][C]: row rowbase[b] + t =
+ *                            x[b][t] for t < lens[b], zeros for lens[b] <= t < rowext[b]
+ *   asr_rows_unpack_fwd_f32  rows [R][C] -> out [B][T][C] (the encoder output the decoder reads, model.py:109-112):
+ *                            out[b][t] = rows[rowbase[b] + t] for t < lens[b]; the frames behind an utterance hold what the
+ *                            reference's last projection makes of an all-zero frame, dropout(relu(bias)) (model.py:93-95,
+ *                            SURVEY F2): fill [C] (NULL = zeros) times the dropout mask - `mask` [B][T][C] given, or
+ *                            regenerated from (seed, p) over the element index of out (asr_dropout_seeded_f32; p = 0: none)
+ *   asr_rows_unpack_bwd_f32  drows[rowbase[b] + t] = dout[b][t] for t < lens[b], zeros on the block's padding rows;
+ *                            dfill [C] (NULL, or zero-filled by the caller) += sum of dout * mask over the padded frames
+ * ------------------------------------------------------------------------------------- */
+int asr_rows_pack_f32(int B, int T, int C, const float* x, const int32_t* lens, const int32_t* rowbase,
+                      const int32_t* rowext, int ext_max, float* rows, asr_stream_t stream);
+int asr_rows_unpack_fwd_f32(int B, int T, int C, const float* rows, const int32_t* lens, const int32_t* rowbase,
+                            const float* fill, const float* mask, uint64_t seed, float p, float* out, asr_stream_t stream);
+int asr_rows_unpack_bwd_f32(int B, int T, int C, const float* dout, const int32_t* lens, const int32_t* rowbase,
+                            const int32_t* rowext, int ext_max, const float* mask, uint64_t seed, float p, float* drows,
+                            float* dfill, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pyramidal pair-concat (model.py:85-92), time-major:

@@ -183,11 +183,13 @@ __device__ __forceinline__ void skinny_mma_any(const SkinnyRegs<MT>& rg, int i0,
   else skinny_mma<MT, false>(rg, i0, nmine, acc);
 }
 
+// skinny_partial_rows: the rows of A are given per lane - arow[m] = the row of A that feeds tile row m * 16 + (lane & 15)
+// (any rows: the packed-row layout of the LSTM kernels has no common stride between batch rows).
 template <int MT, int NW = 4>
-__device__ __forceinline__ void skinny_partial(const float* __restrict__ A, int64_t lda, int64_t row0,
-                                               int64_t nrows, const float* __restrict__ Bt, int64_t ldb,
-                                               int64_t bt_row0, int64_t bt_nrows, int K,
-                                               float* red /* [NW][MT*16][17] */) {
+__device__ __forceinline__ void skinny_partial_rows(const float* __restrict__ A, int64_t lda, const int64_t (&arow)[MT],
+                                                    const float* __restrict__ Bt, int64_t ldb,
+                                                    int64_t bt_row0, int64_t bt_nrows, int K,
+                                                    float* red /* [NW][MT*16][17] */) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -196,12 +198,6 @@ __device__ __forceinline__ void skinny_partial(const float* __restrict__ A, int6
   for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int64_t br = bt_row0 + r < bt_nrows ? bt_row0 + r : bt_nrows - 1;  // clamp; caller masks the store
   const float* brow = Bt + br * ldb;
-  int64_t arow[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    int64_t rr = row0 + m * 16 + r;
-    arow[m] = rr < nrows ? rr : nrows - 1;
-  }
   const int nchunk = K >> 4;
   const int nmine = (nchunk - wave + NW - 1) / NW;   // this wave owns chunks wave, wave+NW, ...
   const int cbase = nmine > 0 ? (int)((blockIdx.x * 5u + blockIdx.y * 3u + blockIdx.z * 7u) % (unsigned)nmine) : 0;
@@ -221,6 +217,21 @@ __device__ __forceinline__ void skinny_partial(const float* __restrict__ A, int6
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int i = 0; i < 4; ++i) mine[(m * 16 + q * 4 + i) * SK_LDS_STRIDE + r] = acc[m][i];
+}
+
+template <int MT, int NW = 4>
+__device__ __forceinline__ void skinny_partial(const float* __restrict__ A, int64_t lda, int64_t row0,
+                                               int64_t nrows, const float* __restrict__ Bt, int64_t ldb,
+                                               int64_t bt_row0, int64_t bt_nrows, int K,
+                                               float* red /* [NW][MT*16][17] */) {
+  const int r = threadIdx.x & 15;
+  int64_t arow[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int64_t rr = row0 + m * 16 + r;
+    arow[m] = rr < nrows ? rr : nrows - 1;               // clamp; caller masks the store
+  }
+  skinny_partial_rows<MT, NW>(A, lda, arow, Bt, ldb, bt_row0, bt_nrows, K, red);
 }
 
 // sum of the NW waves' partials for (row, col) after a __syncthreads()

@@ -21,7 +21,12 @@ __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int nb,
                                                            float* __restrict__ gates,
                                                            const float* __restrict__ w_hh,
                                                            const int32_t* __restrict__ lens, float* __restrict__ y,
-                                                           float* __restrict__ c, int s) {
+                                                           float* __restrict__ c, int s,
+                                                           const int32_t* __restrict__ rowbase,
+                                                           const int32_t* __restrict__ rowext) {
+  // rowbase / rowext: NULL = time-major rows (t * B + b); else packed rows, batch row b at rowbase[b] + t for t < rowext[b]
+  // (include/asr_hip.h): times >= rowext[b] do not exist - loads are clamped to the block's last row (dead values), nothing
+  // is stored
   __shared__ float red[4 * MT * 16 * SK_LDS_STRIDE];
   const int j = blockIdx.x, d = blockIdx.y;
   const int64_t row0 = (int64_t)blockIdx.z * (MT * 16);
@@ -38,16 +43,29 @@ __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int nb,
   int len = 0;
   float4* gp = nullptr;
   int64_t so = 0;
+  bool exists = false;
+  auto row_of = [&](int64_t bb, int tt) -> int64_t {
+    if (!rowbase) return (int64_t)tt * B + bb;
+    const int ext = rowext[bb];
+    return (int64_t)rowbase[bb] + (tt < ext ? tt : ext - 1);
+  };
   if (mine) {
-    gp = reinterpret_cast<float4*>(gates + (((int64_t)t * B + b) * ndir + d) * 4 * H + unit * 4);
-    so = ((int64_t)t * B + b) * ldy + d * H + unit;
+    exists = !rowbase || t < rowext[b];
+    const int64_t rt = row_of(b, t);
+    gp = reinterpret_cast<float4*>(gates + (rt * ndir + d) * 4 * H + unit * 4);
+    so = rt * ldy + d * H + unit;
     gx = *gp;
     len = lens[b];
-    if (s > 0) cp = c[((int64_t)tp * B + b) * ldy + d * H + unit];
+    if (s > 0) cp = c[row_of(b, tp) * ldy + d * H + unit];
   }
   if (s > 0) {
-    skinny_partial<MT>(y + (int64_t)tp * B * ldy + d * H, ldy, row0, nb, w_hh + (int64_t)d * 4 * H * H, H,
-                       (int64_t)16 * j, (int64_t)4 * H, H, red);
+    int64_t arow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int64_t rr = row0 + m * 16 + (threadIdx.x & 15);
+      arow[m] = row_of(rr < nb ? rr : nb - 1, tp);
+    }
+    skinny_partial_rows<MT>(y + d * H, ldy, arow, w_hh + (int64_t)d * 4 * H * H, H, (int64_t)16 * j, (int64_t)4 * H, H, red);
   }
   __syncthreads();
   if (mine) {
@@ -61,9 +79,11 @@ __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int nb,
     float cn = gf * cp + gi * gg;
     float hn = go * tanhf(cn);
     if (t >= len) { cn = 0.f; hn = 0.f; }
-    *gp = make_float4(gi, gf, gg, go);
-    c[so] = cn;
-    y[so] = hn;
+    if (exists) {
+      *gp = make_float4(gi, gf, gg, go);
+      c[so] = cn;
+      y[so] = hn;
+    }
   }
 }
 
@@ -78,8 +98,15 @@ __global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int
                                                            const float* __restrict__ w_hhT,
                                                            const int32_t* __restrict__ lens,
                                                            const float* __restrict__ dy, const float* __restrict__ c,
-                                                           float* __restrict__ dcarry, int s) {
+                                                           float* __restrict__ dcarry, int s,
+                                                           const int32_t* __restrict__ rowbase,
+                                                           const int32_t* __restrict__ rowext) {
   __shared__ float red[NW * MT * 16 * SK_LDS_STRIDE];
+  auto row_of = [&](int64_t bb, int tt) -> int64_t {     // see enc_step_fwd_kernel
+    if (!rowbase) return (int64_t)tt * B + bb;
+    const int ext = rowext[bb];
+    return (int64_t)rowbase[bb] + (tt < ext ? tt : ext - 1);
+  };
   constexpr int NT = NW * 64;
   constexpr int NE = (MT * 16 * UNITS + NT - 1) / NT;   // pointwise elements per thread
   const int j = blockIdx.x, d = blockIdx.y;
@@ -105,19 +132,25 @@ __global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int
     lenv[i] = 0;
     if (live[i]) {
       const int unit = UNITS * j + u;
-      const int64_t so = ((int64_t)t * B + b) * ldy + d * H + unit;
+      const int64_t rt = row_of(b, t);
+      const int64_t so = rt * ldy + d * H + unit;
       dyv[i] = dy[so];
-      av[i] = *reinterpret_cast<const float4*>(gates + ((int64_t)t * B + b) * ldg + (int64_t)d * 4 * H + unit * 4);
+      av[i] = *reinterpret_cast<const float4*>(gates + rt * ldg + (int64_t)d * 4 * H + unit * 4);
       ctv[i] = c[so];
-      if (has_prev) cpv[i] = c[((int64_t)tp * B + b) * ldy + d * H + unit];
+      if (has_prev) cpv[i] = c[row_of(b, tp) * ldy + d * H + unit];
       dcv[i] = dcarry[b * ldy + d * H + unit];
       lenv[i] = lens[b];
     }
   }
   if (s > 0) {
-    skinny_partial<MT, NW>(gates + (int64_t)tn * B * ldg + (int64_t)d * 4 * H, ldg, row0, nb,
-                       w_hhT + (int64_t)d * H * 4 * H, (int64_t)4 * H, (int64_t)UNITS * j,
-                       (int64_t)UNITS * (j + 1), 4 * H, red);
+    int64_t arow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int64_t rr = row0 + m * 16 + (threadIdx.x & 15);
+      arow[m] = row_of(rr < nb ? rr : nb - 1, tn);
+    }
+    skinny_partial_rows<MT, NW>(gates + (int64_t)d * 4 * H, ldg, arow, w_hhT + (int64_t)d * H * 4 * H, (int64_t)4 * H,
+                                (int64_t)UNITS * j, (int64_t)UNITS * (j + 1), 4 * H, red);
   }
   __syncthreads();
 #pragma unroll
@@ -139,7 +172,8 @@ __global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int
     da.w = dh * tc * a.w * (1.f - a.w);
     float dcn = dc * a.y;
     if (t >= lenv[i]) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
-    *reinterpret_cast<float4*>(gates + ((int64_t)t * B + b) * ldg + (int64_t)d * 4 * H + unit * 4) = da;
+    if (!rowbase || t < rowext[b])
+      *reinterpret_cast<float4*>(gates + row_of(b, t) * ldg + (int64_t)d * 4 * H + unit * 4) = da;
     dcarry[b * ldy + d * H + unit] = dcn;
   }
 }
@@ -236,21 +270,23 @@ int asr_cell_bwd_launch(int B, int D, int KX, const float* Gnext, const float* g
 }
 
 extern "C" int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
-                                const int32_t* lens, float* y, float* c, void* graphs, asr_stream_t stream_) {
+                                const int32_t* lens, const int32_t* rowbase, const int32_t* rowext, float* y, float* c,
+                                void* graphs, asr_stream_t stream_) {
   hipStream_t stream0 = (hipStream_t)stream_;
   if (!gates || !w_hh || !lens || !y || !c || T <= 0 || B <= 0 || H <= 0 || nb <= 0 || nb > B) return ASR_E_ARG;
+  if ((rowbase == nullptr) != (rowext == nullptr)) return ASR_E_ARG;
   if (H % 16 || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
   if (!asr_aligned16(gates) || !asr_aligned16(w_hh) || !asr_aligned16(y)) return ASR_E_ALIGN;
-  struct { int kind, T, B, nb, H, ndir; const void *a, *b, *c, *d, *e; } key = {1, T, B, nb, H, ndir, gates, w_hh,
-                                                                             lens, y, c};
+  struct { int kind, T, B, nb, H, ndir; const void *a, *b, *c, *d, *e, *f, *g; } key = {1, T, B, nb, H, ndir, gates, w_hh,
+                                                                                     lens, y, c, rowbase, rowext};
   return asr_graph_run((AsrGraphCache*)graphs, &key, sizeof(key), stream0, [&](hipStream_t stream) -> int {
     for (int s = 0; s < T; ++s) {
       if (nb <= 16)
         hipLaunchKernelGGL((enc_step_fwd_kernel<1>), dim3(H / 4, ndir, 1), dim3(256), 0, stream, T, B, nb, H, ndir,
-                           gates, w_hh, lens, y, c, s);
+                           gates, w_hh, lens, y, c, s, rowbase, rowext);
       else
         hipLaunchKernelGGL((enc_step_fwd_kernel<2>), dim3(H / 4, ndir, (nb + 31) / 32), dim3(256), 0, stream, T, B, nb,
-                           H, ndir, gates, w_hh, lens, y, c, s);
+                           H, ndir, gates, w_hh, lens, y, c, s, rowbase, rowext);
     }
     ASR_CHECK_LAUNCH();
     return 0;
@@ -268,20 +304,21 @@ extern "C" int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* ga
 #endif
 
 extern "C" int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
-                                const int32_t* lens, const float* dy, const float* c, float* dcarry, void* graphs,
-                                asr_stream_t stream_) {
+                                const int32_t* lens, const int32_t* rowbase, const int32_t* rowext, const float* dy,
+                                const float* c, float* dcarry, void* graphs, asr_stream_t stream_) {
   hipStream_t stream0 = (hipStream_t)stream_;
   if (!gates || !w_hhT || !lens || !dy || !c || !dcarry || T <= 0 || B <= 0 || H <= 0 || nb <= 0 || nb > B)
     return ASR_E_ARG;
+  if ((rowbase == nullptr) != (rowext == nullptr)) return ASR_E_ARG;
   if (H % 16 || (ndir != 1 && ndir != 2)) return ASR_E_SHAPE;
   if (!asr_aligned16(gates) || !asr_aligned16(w_hhT)) return ASR_E_ALIGN;
   constexpr int U = ASR_BWD_UNITS, MTB = ASR_BWD_MT, NWB = ASR_BWD_NW;
-  struct { int kind, T, B, nb, H, ndir; const void *a, *b, *c, *d, *e, *f; } key = {2, T, B, nb, H, ndir, gates, w_hhT,
-                                                                                 lens, dy, c, dcarry};
+  struct { int kind, T, B, nb, H, ndir; const void *a, *b, *c, *d, *e, *f, *g, *h; } key = {2, T, B, nb, H, ndir, gates, w_hhT,
+                                                                                         lens, dy, c, dcarry, rowbase, rowext};
   return asr_graph_run((AsrGraphCache*)graphs, &key, sizeof(key), stream0, [&](hipStream_t stream) -> int {
     for (int s = 0; s < T; ++s) {
       hipLaunchKernelGGL((enc_step_bwd_kernel<MTB, U, NWB>), dim3(H / U, ndir, (nb + MTB * 16 - 1) / (MTB * 16)),
-                         dim3(NWB * 64), 0, stream, T, B, nb, H, ndir, gates, w_hhT, lens, dy, c, dcarry, s);
+                         dim3(NWB * 64), 0, stream, T, B, nb, H, ndir, gates, w_hhT, lens, dy, c, dcarry, s, rowbase, rowext);
     }
     ASR_CHECK_LAUNCH();
     return 0;

@@ -11,12 +11,12 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libasr_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
     "asr_abi_version", "asr_persist_scratch_bytes", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_lstm_seq_bwd_persist_w", "asr_lstm_bwd_persist_fuses_dw", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
-    "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
+    "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_rows_pack_f32", "asr_rows_unpack_fwd_f32", "asr_rows_unpack_bwd_f32", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
@@ -77,12 +77,16 @@ def load():
     lib.asr_gemm_skinny_f32.argtypes = [c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p,
                                         c_i64, c_i64, c_p]
     lib.asr_colsum_f32.argtypes = [c_i64, c_i64, c_p, c_i64, c_p, c_i, c_p]
-    lib.asr_lstm_seq_fwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
-    lib.asr_lstm_seq_fwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]
-    lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]
+    lib.asr_lstm_seq_fwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_fwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]
+    lib.asr_lstm_seq_bwd_persist.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                             c_i, c_p]
     lib.asr_lstm_seq_bwd_persist_w.argtypes = lib.asr_lstm_seq_bwd_persist.argtypes
     lib.asr_lstm_bwd_persist_fuses_dw.argtypes = [c_i, c_i]
-    lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_rows_pack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]
+    lib.asr_rows_unpack_fwd_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, ctypes.c_uint64, c_f, c_p, c_p]
+    lib.asr_rows_unpack_bwd_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, ctypes.c_uint64, c_f, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     c_u64 = ctypes.c_uint64
@@ -483,6 +487,8 @@ def _off(t, elems):
     return c_p(_dev(t).data_ptr() + 4 * int(elems))
 
 
+# the encoder on packed rows (RowLayout below; model.pBLSTM) - "padded": the time-major padded tensors (measurement)
+USE_PACKED_ROWS = os.environ.get("ASR_ENCODER_ROWS", "packed") != "padded"
 USE_PERSIST = os.environ.get("ASR_PERSIST", "1") != "0"
 USE_PERSIST_DEC = USE_PERSIST and os.environ.get("ASR_PERSIST_DEC", "1") != "0"   # persistent decoder forward
 USE_PERSIST_DEC_BWD = USE_PERSIST and os.environ.get("ASR_PERSIST_DEC_BWD", "1") != "0"   # ... and backward
@@ -586,13 +592,79 @@ def persist_abort_flag(device):
     return persist_scratch(device)[1][:1]
 
 
-def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
+class RowLayout(object):
+    """Packed rows of the encoder (include/asr_hip.h, "PACKED ROWS"): per layer l = 0 .. n (n = the encoder output), batch
+    row b owns ext[l][b] rows starting at base[l][b]; time t of utterance b sits at row base[l][b] + t.  The extents halve
+    with the pyramid (ext[l] = 2 ext[l + 1] where layer l subsamples), so the pair-concat is a reshape of the row matrix,
+    and every block ends with at least one padding row (ext > len).  Built on the host from the utterance lengths and
+    uploaded once per batch (one non-blocking copy): `dev` [n + 1][3][B] int32 = (lens, base, ext) per layer."""
+
+    def __init__(self, ilens, subsample, device, t_pad=None):
+        import numpy as np
+        n = len(subsample)
+        lens = [np.asarray([int(v) for v in ilens], dtype=np.int64)]
+        pads = [int(max(ilens)) if t_pad is None else int(t_pad[0])]
+        for i in range(n):
+            lens.append((lens[-1] + 1) // 2 if subsample[i] > 1 else lens[-1].copy())
+            pads.append(((pads[-1] + 1) // 2 if subsample[i] > 1 else pads[-1]) if t_pad is None else int(t_pad[i + 1]))
+        ext = [None] * (n + 1)
+        ext[n] = lens[n] + 1
+        for i in range(n - 1, -1, -1):
+            ext[i] = ext[i + 1] * 2 if subsample[i] > 1 else ext[i + 1].copy()
+        self.B, self.n = len(ilens), n
+        self.lens = [l.astype(np.int32) for l in lens]          # host copies (the launchers take rowext_host)
+        self.ext = [np.ascontiguousarray(e.astype(np.int32)) for e in ext]
+        self.base = [np.concatenate([[0], np.cumsum(e)[:-1]]).astype(np.int32) for e in ext]
+        self.rows = [int(e.sum()) for e in ext]                 # R per layer
+        self.steps = [int(e.max()) for e in ext]                # time steps the recurrence of layer l has to run
+        self.t_pad = pads                                       # padded time extent per layer (the global one of a shard)
+        table = np.stack([np.stack([self.lens[i], self.base[i], self.ext[i]]) for i in range(n + 1)])
+        self.dev = to_device_i32(table, device)                 # [n + 1][3][B]
+
+    def lens_dev(self, l):
+        return self.dev[l, 0]
+
+    def base_dev(self, l):
+        return self.dev[l, 1]
+
+    def ext_dev(self, l):
+        return self.dev[l, 2]
+
+    def replicated_rows(self, l):
+        """Output rows of layer l's pair-concat whose second half is the reference's replicate-padded frame (model.py:85-88:
+        an odd padded length T; only utterances of exactly that length see a non-zero replica): [(row of the pair)]."""
+        import numpy as np
+        T = self.t_pad[l]
+        if T % 2 == 0:
+            return []
+        return [int((self.base[l][b] + T - 1) // 2) for b in np.nonzero(self.lens[l] == T)[0]]
+
+
+class LayerRows(object):
+    """One layer's view of a RowLayout: what the LSTM launchers need."""
+
+    def __init__(self, layout, l):
+        self.layout, self.l = layout, l
+        self.B, self.R, self.T = layout.B, layout.rows[l], layout.steps[l]
+        self.lens, self.base, self.ext = layout.lens_dev(l), layout.base_dev(l), layout.ext_dev(l)
+        self.ext_host = layout.ext[l]
+
+    def host_ptr(self):
+        return c_p(self.ext_host.ctypes.data)
+
+
+def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True, rows=None):
+    """rows: a LayerRows - gates / y / c are then row matrices [R, 1, ...] in the packed layout (lens = rows.lens)."""
     T, B, ndir, H4 = gates.shape
     H = H4 // 4
     lib = load()
+    rb, re, rh = (ptr(rows.base), ptr(rows.ext), rows.host_ptr()) if rows is not None else (None, None, None)
+    if rows is not None:
+        assert B == 1 and T == rows.R
+        T, B = rows.T, rows.B
     if USE_PERSIST:
         xch, ctrl = persist_scratch(gates.device)
-        rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(y), ptr(c),
+        rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), rb, re, rh, ptr(y), ptr(c),
                                           c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ARITH[0], stream())
         if rc == 0:
             count_path("lstm_fwd", True)
@@ -605,13 +677,17 @@ def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True):
 
     def one(gi, grp, st):
         b0, nb = grp
-        check(lib.asr_lstm_seq_fwd(T, B, nb, H, ndir, _off(gates, b0 * ndir * H4), ptr(w_hh), _off(lens, b0),
+        if rows is not None:                               # packed rows: the row maps are absolute, only they advance
+            check(lib.asr_lstm_seq_fwd(T, B, nb, H, ndir, ptr(gates), ptr(w_hh), _off(lens, b0), _off(rows.base, b0),
+                                       _off(rows.ext, b0), ptr(y), ptr(c), gh[gi], st), "asr_lstm_seq_fwd")
+            return
+        check(lib.asr_lstm_seq_fwd(T, B, nb, H, ndir, _off(gates, b0 * ndir * H4), ptr(w_hh), _off(lens, b0), None, None,
                                    _off(y, b0 * ndir * H), _off(c, b0 * ndir * H), gh[gi], st), "asr_lstm_seq_fwd")
 
     run_grouped(groups, one)
 
 
-def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None, w_hh=None):
+def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None, w_hh=None, rows=None):
     """-> (fused_dw, fused_db): whether dW_hh and the bias gradient `db` were accumulated by the persistent kernel itself
     (db: by every persistent backward kernel; dW_hh: by all of them except the bf16x6 exchanged-partials kernel, see
     asr_lstm_bwd_persist_fuses_dw - the caller then forms it with a GEMM).
@@ -622,11 +698,15 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None,
     H = H4 // 4
     lib = load()
     ar = ARITH[0]
-    fuses = USE_PERSIST and lib.asr_lstm_bwd_persist_fuses_dw(H, ar) == 1 and y is not None and dw_hh is not None
+    rb, re, rh = (ptr(rows.base), ptr(rows.ext), rows.host_ptr()) if rows is not None else (None, None, None)
+    if rows is not None:                                   # packed rows (see lstm_seq_fwd): dW_hh is always the caller's
+        assert B == 1 and T == rows.R
+        T, B = rows.T, rows.B
+    fuses = USE_PERSIST and rows is None and lib.asr_lstm_bwd_persist_fuses_dw(H, ar) == 1 and y is not None and dw_hh is not None
     yk, dwk = (y, dw_hh) if fuses else (None, None)
     if USE_PERSIST and w_hh is not None:
         xch, ctrl = persist_scratch(gates.device)
-        rc = lib.asr_lstm_seq_bwd_persist_w(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), ptr(dy), ptr(c),
+        rc = lib.asr_lstm_seq_bwd_persist_w(T, B, B, H, ndir, ptr(gates), ptr(w_hh), ptr(lens), rb, re, rh, ptr(dy), ptr(c),
                                             ptr(yk), ptr(dwk), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ar, stream())
         if rc == 0:
             count_path("lstm_bwd", True)
@@ -637,7 +717,7 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None,
         w_hhT = w_hhT()
     if USE_PERSIST:
         xch, ctrl = persist_scratch(gates.device)
-        rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hhT), ptr(lens), ptr(dy), ptr(c),
+        rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, ndir, ptr(gates), ptr(w_hhT), ptr(lens), rb, re, rh, ptr(dy), ptr(c),
                                           ptr(yk), ptr(dwk), ptr(db), c_p(xch.data_ptr()), c_p(ctrl.data_ptr()), ar, stream())
         if rc == 0:
             count_path("lstm_bwd", True)
@@ -650,7 +730,12 @@ def lstm_seq_bwd(gates, w_hhT, lens, dy, c, dcarry, y=None, dw_hh=None, db=None,
 
     def one(gi, grp, st):
         b0, nb = grp
-        check(lib.asr_lstm_seq_bwd(T, B, nb, H, ndir, _off(gates, b0 * ndir * H4), ptr(w_hhT), _off(lens, b0),
+        if rows is not None:
+            check(lib.asr_lstm_seq_bwd(T, B, nb, H, ndir, ptr(gates), ptr(w_hhT), _off(lens, b0), _off(rows.base, b0),
+                                       _off(rows.ext, b0), ptr(dy), ptr(c), _off(dcarry, b0 * ndir * H), gh[gi], st),
+                  "asr_lstm_seq_bwd")
+            return
+        check(lib.asr_lstm_seq_bwd(T, B, nb, H, ndir, _off(gates, b0 * ndir * H4), ptr(w_hhT), _off(lens, b0), None, None,
                                    _off(dy, b0 * ndir * H), _off(c, b0 * ndir * H), _off(dcarry, b0 * ndir * H), gh[gi],
                                    st), "asr_lstm_seq_bwd")
 
@@ -709,3 +794,36 @@ def pyramid_bwd(dout, mask, din):
               "asr_pyramid_concat_bwd_seeded")
         return
     check(load().asr_pyramid_concat_bwd(T, B, C, ptr(dout), ptr(mask), ptr(din), stream()), "asr_pyramid_concat_bwd")
+
+
+def rows_pack(x, rows):
+    """x [B, T, C] (zero-padded batch, dataloader.py:6-12) -> [R, C] in the packed layout of `rows` (a LayerRows)."""
+    B, T, C = x.shape
+    out = torch.empty(rows.R, C, device=x.device, dtype=torch.float32)
+    check(load().asr_rows_pack_f32(B, T, C, ptr(x), ptr(rows.lens), ptr(rows.base), ptr(rows.ext), rows.T, ptr(out), stream()),
+          "asr_rows_pack_f32")
+    return out
+
+
+def rows_unpack_fwd(packed, rows, T, fill, mask):
+    """[R, C] -> [B, T, C]; frames behind an utterance = fill * mask (mask: None, a [B, T, C] tensor or a SeededMask)."""
+    C = packed.shape[1]
+    out = torch.empty(rows.B, T, C, device=packed.device, dtype=torch.float32)
+    seeded = isinstance(mask, SeededMask)
+    check(load().asr_rows_unpack_fwd_f32(rows.B, T, C, ptr(packed), ptr(rows.lens), ptr(rows.base), ptr(fill),
+                                         None if (mask is None or seeded) else ptr(mask), mask.seed if seeded else 0,
+                                         mask.p if seeded else 0.0, ptr(out), stream()), "asr_rows_unpack_fwd_f32")
+    return out
+
+
+def rows_unpack_bwd(dout, rows, C, mask, want_fill):
+    """-> (drows [R, C], dfill [C] or None)."""
+    B, T, _ = dout.shape
+    drows = torch.empty(rows.R, C, device=dout.device, dtype=torch.float32)
+    dfill = torch.zeros(C, device=dout.device, dtype=torch.float32) if want_fill else None
+    seeded = isinstance(mask, SeededMask)
+    check(load().asr_rows_unpack_bwd_f32(B, T, C, ptr(dout), ptr(rows.lens), ptr(rows.base), ptr(rows.ext), rows.T,
+                                         None if (mask is None or seeded) else ptr(mask), mask.seed if seeded else 0,
+                                         mask.p if seeded else 0.0, ptr(drows), ptr(dfill), stream()),
+          "asr_rows_unpack_bwd_f32")
+    return drows, dfill

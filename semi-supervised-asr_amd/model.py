@@ -97,7 +97,53 @@ class pBLSTM(torch.nn.Module):
     def forward(self, xpad, ilens, total_length=None):
         """xpad [B,T,idim] zero padded, ilens descending host ints -> ([B,T',H], list[int]).
         `total_length` (list from padded_lengths) keeps a data-parallel shard at the global padded
-        extent; default = max(ilens) like pad_packed_sequence (model.py:81)."""
+        extent; default = max(ilens) like pad_packed_sequence (model.py:81).
+
+        Default: PACKED ROWS (hb.RowLayout; include/asr_hip.h) - what pack_padded_sequence gives the reference's LSTM
+        (model.py:79-81), kept for the whole stack: every utterance is a block of consecutive rows (its frames + at least one
+        zero row), every product of the encoder a GEMM over sum(len) rows instead of B * T_max, the pair-concat a reshape.
+        The padded batch only exists at the two ends: the collated input is packed by one kernel, the output is unpacked into
+        the [B, T', H] tensor the decoder reads, its frames behind an utterance filled with what the reference computes
+        there, dropout(relu(bias)) of the last projection.  ASR_ENCODER_ROWS=padded: the time-major padded
+        path (measurement)."""
+        if hb.USE_PACKED_ROWS and xpad.is_cuda and xpad.shape[2] % 4 == 0:
+            return self._forward_packed(xpad, ilens, total_length)
+        return self._forward_padded(xpad, ilens, total_length)
+
+    def _forward_packed(self, xpad, ilens, total_length):
+        dev = xpad.device
+        layout = hb.RowLayout([int(l) for l in ilens], [self.subsample[i] for i in range(len(self.layers))], dev,
+                              t_pad=total_length)
+        drop = self.training and self.dropout_rate > 0
+        p = self.dropout_rate
+        x = hb.rows_pack(xpad if xpad.is_contiguous() else xpad.contiguous(), hb.LayerRows(layout, 0))      # [R_0, idim]
+        for i, (layer, proj) in enumerate(zip(self.layers, self.project_layers)):
+            rows = hb.LayerRows(layout, i)
+            y = ops.lstm_layer(x, None, layer.direction_params(0), 2, rows=rows)                 # [R_i, 2H]
+            mask = _drop_mask((rows.R, 1, y.shape[1]), p, dev) if drop else None
+            if self.subsample[i] > 1:
+                rep = layout.replicated_rows(i)
+                rep = hb.to_device_i64(rep, dev) if rep else None
+                y = ops.pyramid_concat(y.view(rows.R, 1, -1), mask, rep).view(rows.R // 2, -1)  # [R_{i+1}, 4H]
+            elif mask is not None:
+                y = y * _mask_tensor(mask).view_as(y)
+            if drop:
+                m2 = _drop_mask((y.shape[0], 1, proj.weight.shape[0]), p, dev)
+                if isinstance(m2, hb.SeededMask) and y.shape[0] * proj.weight.shape[0] % 4 == 0:
+                    x = ops.linear(y, proj.weight, proj.bias, relu=True, drop=m2)      # relu -> dropout in the op
+                else:
+                    x = ops.linear(y, proj.weight, proj.bias, relu=True) * _mask_tensor(m2).view(y.shape[0], -1)
+            else:
+                x = ops.linear(y, proj.weight, proj.bias, relu=True)
+        n = len(self.layers)
+        t_out = layout.t_pad[n]
+        pad_mask = _drop_mask((layout.B, t_out, x.shape[1]), p, dev) if drop else None
+        out = ops.rows_unpack(x, hb.LayerRows(layout, n), t_out, torch.relu(self.project_layers[-1].bias), pad_mask)
+        self.last_lens_dev = layout.lens_dev(n)                    # device copy of the output lengths
+        self.last_layout = layout                                  # (tests: where each utterance's rows were)
+        return out, [int(l) for l in layout.lens[n]]
+
+    def _forward_padded(self, xpad, ilens, total_length=None):
         dev = xpad.device
         lens = [int(l) for l in ilens]
         # lengths entering every layer are known on the host up front: one non-blocking upload for all layers

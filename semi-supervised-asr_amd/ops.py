@@ -118,47 +118,72 @@ def linear(x, weight, bias=None, relu=False, drop=None):
 
 
 # --------------------------------------------------------------------------------------
-def _lstm_workspace(T, B, H, ndir, dev, with_bwd):
+def _row_capacity(n):
+    """Rows a pooled workspace is allocated for: n rounded up to a quarter of its power of two (<= 25 % over), so that the
+    row counts of an epoch's batches (every batch has its own sum of lengths) share a handful of workspaces."""
+    n = max(int(n), 1)
+    q = max(256, 1 << max(n.bit_length() - 3, 0))
+    return (n + q - 1) // q * q
+
+
+def _lstm_workspace(rows, nbatch, H, ndir, dev, with_bwd):
+    """Buffers of one LSTM layer for up to `rows` (time, batch) rows and `nbatch` batch rows; _lstm_views cuts the views of a
+    call's actual shape out of them."""
     f32 = dict(device=dev, dtype=torch.float32)
-    ws = dict(gates=torch.empty(T, B, ndir, 4 * H, **f32), y=torch.empty(T, B, ndir * H, **f32),
-              c=torch.empty(T, B, ndir * H, **f32), w_hh=torch.empty(ndir, 4 * H, H, **f32),
-              lens=torch.empty(B, dtype=torch.int32, device=dev))
+    ws = dict(gates_buf=torch.empty(rows, ndir, 4 * H, **f32), y_buf=torch.empty(rows, ndir * H, **f32),
+              c_buf=torch.empty(rows, ndir * H, **f32), w_hh=torch.empty(ndir, 4 * H, H, **f32))
     if with_bwd:
         # the three accumulators the backward starts from zero share one buffer: one fill instead of three
-        n1, n2, n3 = B * ndir * H, ndir * 4 * H * H, ndir * 4 * H
+        n1, n2, n3 = nbatch * ndir * H, ndir * 4 * H * H, ndir * 4 * H
         zbuf = torch.empty(n1 + n2 + n3, **f32)
-        ws.update(w_hhT=torch.empty(ndir, H, 4 * H, **f32), dy=torch.empty(T, B, ndir * H, **f32), zbuf=zbuf,
-                  dcarry=zbuf[:n1].view(B, ndir * H), dw_hh=zbuf[n1:n1 + n2].view(ndir, 4 * H, H),
+        ws.update(w_hhT=torch.empty(ndir, H, 4 * H, **f32), dy_buf=torch.empty(rows, ndir * H, **f32), zbuf=zbuf,
+                  dcarry=zbuf[:n1].view(nbatch, ndir * H), dw_hh=zbuf[n1:n1 + n2].view(ndir, 4 * H, H),
                   db=zbuf[n1 + n2:].view(ndir * 4 * H))
+    return ws
+
+
+def _lstm_views(ws, T, B, H, ndir):
+    n = T * B
+    ws["gates"] = ws["gates_buf"][:n].view(T, B, ndir, 4 * H)
+    ws["y"] = ws["y_buf"][:n].view(T, B, ndir * H)
+    ws["c"] = ws["c_buf"][:n].view(T, B, ndir * H)
+    if "dy_buf" in ws:
+        ws["dy"] = ws["dy_buf"][:n].view(T, B, ndir * H)
     return ws
 
 
 class _LstmLayer(torch.autograd.Function):
     """One (bi)directional LSTM layer over a padded time-major batch (model.py:79-81).
-    params: for each direction w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H] (torch layout)."""
+    params: for each direction w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H] (torch layout).
+    rows (hb.LayerRows or None): the packed-row layout - x is then the row matrix [R, 1, I] (every product of this layer is
+    a GEMM over the R rows as if it were a time-major batch of one; only the recurrence kernels know about utterances)."""
 
     @staticmethod
-    def forward(ctx, x, lens, ndir, pooled, *params):
+    def forward(ctx, x, lens, ndir, pooled, rows, *params):
         ctx.arith = hb.current_arith()
         T, B, I = x.shape
         H = params[1].shape[1]
         dev = x.device
         x2 = x.reshape(T * B, I)
+        nbatch = rows.B if rows is not None else B
         if pooled:
-            lease = _POOL.acquire(("lstm", dev.index, T, B, H, ndir),
-                                  lambda: _lstm_workspace(T, B, H, ndir, dev, True))
+            cap = _row_capacity(T * B)
+            lease = _POOL.acquire(("lstm", dev.index, cap, nbatch, H, ndir),
+                                  lambda: _lstm_workspace(cap, nbatch, H, ndir, dev, True))
             ws = lease.ws
         else:
-            lease, ws = None, _lstm_workspace(T, B, H, ndir, dev, False)
+            lease, ws = None, _lstm_workspace(T * B, nbatch, H, ndir, dev, False)
+        _lstm_views(ws, T, B, H, ndir)
         # torch layout -> gate-interleaved kernel layout, one launch: w_ih [ndir*4H, I], w_hh [ndir, 4H, H], b_ih + b_hh
         w_ih = torch.empty(ndir * 4 * H, I, device=dev, dtype=torch.float32)
         bias = torch.empty(ndir * 4 * H, device=dev, dtype=torch.float32)
         hb.lstm_pack(params, ndir, w_ih, ws["w_hh"], bias)
         ws["lens"] = lens                      # int32 device tensor, kept for the backward (no copy)
         hb.gemm(x2, w_ih, trans_b=True, bias=bias, out=ws["gates"].view(T * B, ndir * 4 * H))
-        hb.lstm_seq_fwd(ws["gates"], ws["w_hh"], ws["lens"], ws["y"], ws["c"], use_graphs=pooled)
+        hb.lstm_seq_fwd(ws["gates"], ws["w_hh"], ws["lens"], ws["y"], ws["c"], use_graphs=pooled, rows=rows)
         ctx.save_for_backward(x2, w_ih)
         ctx.lease = lease
+        ctx.rows = rows
         ctx.dims = (T, B, I, H, ndir)
         return ws["y"].detach()      # fresh tensor object aliasing the workspace (no stale autograd metadata)
 
@@ -170,7 +195,7 @@ class _LstmLayer(torch.autograd.Function):
         lease = ctx.lease
         assert lease is not None and lease.ws is not None, "lstm_layer backward needs the leased workspace " \
             "(autograd was off in forward, or backward ran twice)"
-        ws = lease.ws
+        ws = _lstm_views(lease.ws, T, B, H, ndir)      # (the views of THIS call's shape: the buffers are shared by capacity)
         dev = dy.device
         dyc = dy if dy.is_contiguous() else ws["dy"].copy_(dy)
         ws["zbuf"].zero_()                     # dcarry, dw_hh, db
@@ -178,7 +203,7 @@ class _LstmLayer(torch.autograd.Function):
         # the transposed recurrent weights are only formed if the kernel that reads the forward layout does not apply
         fused_dw, fused_db = hb.lstm_seq_bwd(gates, lambda: ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2)), ws["lens"], dyc,
                                              ws["c"], ws["dcarry"], y=y, dw_hh=ws["dw_hh"], db=ws["db"],
-                                             w_hh=ws["w_hh"])                                   # gates <- dG in place
+                                             w_hh=ws["w_hh"], rows=ctx.rows)                    # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = hb.gemm(dG, x2, trans_a=True)                     # [ndir*4H, I]
@@ -197,36 +222,70 @@ class _LstmLayer(torch.autograd.Function):
         for d in range(ndir):
             grads += [g_ih[d], g_hh[d], g_b[d], g_b2[d]]
         lease.release()
-        return (dx, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None) + tuple(grads)
 
 
-def lstm_layer(x, lens, params, ndir):
-    """x [T,B,I] time-major contiguous, lens int32 device [B] -> y [T,B,ndir*H]."""
+def lstm_layer(x, lens, params, ndir, rows=None):
+    """x [T,B,I] time-major contiguous, lens int32 device [B] -> y [T,B,ndir*H].
+    rows (hb.LayerRows): packed rows - x [R, I] -> y [R, ndir*H], lens = rows.lens."""
     pooled = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-    return _LstmLayer.apply(x.contiguous(), lens, ndir, pooled, *params)
+    if rows is not None:
+        return _LstmLayer.apply(x.contiguous().view(rows.R, 1, -1), rows.lens, ndir, pooled, rows, *params).view(rows.R, -1)
+    return _LstmLayer.apply(x.contiguous(), lens, ndir, pooled, None, *params)
 
 
 # --------------------------------------------------------------------------------------
 class _Pyramid(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mask):
+    def forward(ctx, x, mask, rep):
         T, B, C = x.shape
         out = torch.empty((T + 1) // 2, B, 2 * C, device=x.device, dtype=torch.float32)
         hb.pyramid_fwd(x.contiguous(), mask, out)
+        if rep is not None:                        # packed rows: the replicate-padded frame of the longest utterances
+            out[rep, 0, C:] = out[rep, 0, :C]
         ctx.mask = mask                            # tensor, hb.SeededMask (regenerated in the backward) or None
+        ctx.rep = rep
         ctx.shape = (T, B, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        T, B, C = ctx.shape
         din = torch.empty(ctx.shape, device=dout.device, dtype=torch.float32)
-        hb.pyramid_bwd(dout.contiguous(), ctx.mask, din)
-        return din, None
+        dout = dout.contiguous()
+        if ctx.rep is not None:                    # the replica's gradient belongs to the frame it copies; the padding row
+            dout = dout.clone()                    # whose place it took gets none
+            dout[ctx.rep, 0, :C] += dout[ctx.rep, 0, C:]
+            dout[ctx.rep, 0, C:] = 0.0
+        hb.pyramid_bwd(dout, ctx.mask, din)
+        return din, None, None
 
 
-def pyramid_concat(x, mask=None):
-    """[T,B,C] -> [ceil(T/2),B,2C] (model.py:85-92); `mask` = pre-scaled dropout mask or None."""
-    return _Pyramid.apply(x, mask)
+def pyramid_concat(x, mask=None, rep_rows=None):
+    """[T,B,C] -> [ceil(T/2),B,2C] (model.py:85-92); `mask` = pre-scaled dropout mask or None.
+    Packed rows: x [R, 1, C] (R even) -> [R / 2, 1, 2C]; rep_rows = long tensor of the output rows whose second half is the
+    reference's replicate-padded frame (hb.RowLayout.replicated_rows), or None."""
+    return _Pyramid.apply(x, mask, rep_rows)
+
+
+class _RowsUnpack(torch.autograd.Function):
+    """Packed encoder output [R, C] -> the padded batch [B, T, C] the decoder reads (model.py:109-112).  The frames behind an
+    utterance are what the reference's last projection makes of a zero frame, dropout(relu(bias)): fill [C] * mask."""
+
+    @staticmethod
+    def forward(ctx, packed, fill, rows, T, mask):
+        ctx.rows, ctx.mask, ctx.C = rows, mask, packed.shape[1]
+        ctx.want_fill = fill is not None and fill.requires_grad
+        return hb.rows_unpack_fwd(packed.contiguous(), rows, T, fill.contiguous() if fill is not None else None, mask)
+
+    @staticmethod
+    def backward(ctx, dout):
+        drows, dfill = hb.rows_unpack_bwd(dout.contiguous(), ctx.rows, ctx.C, ctx.mask, ctx.want_fill)
+        return drows, dfill, None, None, None
+
+
+def rows_unpack(packed, rows, T, fill=None, mask=None):
+    return _RowsUnpack.apply(packed, fill, rows, T, mask)
 
 
 # --------------------------------------------------------------------------------------

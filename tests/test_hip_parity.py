@@ -613,13 +613,27 @@ def test_dropout_mask_injection(monkeypatch):
     logits, lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
     net.zero_grad()
     (-lp.mean()).backward()
-    # replay into the oracle: encoder masks are time-major here / batch-major there; the decoder mask is one
-    # [L,B,O+E] block laid out (ctx|emb) here and a per-step [B,E+O] (emb|ctx) mask there
+    # replay into the oracle: the encoder's masks cover the PACKED rows here (utterance b's frame t at row base[b] + t of its
+    # layer, model.pBLSTM._forward_packed) and the padded batch-major tensor there; the frames behind an utterance are dead
+    # in the encoder (ones) except in its output, whose mask is the one recorded after the last layer; the decoder mask is
+    # one [L,B,O+E] block laid out (ctx|emb) here and a per-step [B,E+O] (emb|ctx) mask there
     O_, E_ = cfg["att_odim"], cfg["embedding_dim"]
-    queue = [m.transpose(0, 1) for m in recorded[:-1]]
+    nl = cfg["enc_n_layers"]
+    assert len(recorded) == 2 * nl + 2
+    lay = net.encoder.enc2.last_layout
+
+    def padded(m, layer, fill=None):
+        out = torch.ones(len(ilens), int(lay.lens[layer].max()), m.shape[-1]) if fill is None else fill.clone()
+        for b_ in range(len(ilens)):
+            n_, r0 = int(lay.lens[layer][b_]), int(lay.base[layer][b_])
+            out[b_, :n_] = m[r0:r0 + n_, 0]
+        return out
+    queue = []
+    for li in range(nl):
+        queue.append(padded(recorded[2 * li], li))
+        queue.append(padded(recorded[2 * li + 1], li + 1, fill=recorded[2 * nl] if li == nl - 1 else None))
     xm = recorded[-1]
     queue += [torch.cat([xm[s][:, O_:], xm[s][:, :O_]], 1) for s in range(xm.shape[0])]
-    assert len(recorded) == 2 * cfg["enc_n_layers"] + 1
 
     def replay(x, p=0.5, training=True, inplace=False):
         if not training or p == 0:
@@ -790,6 +804,90 @@ def test_lstm_persistent_path(ndir, B, T, lens, H):
     _close(xg.grad, xc.grad, rtol=1e-3, atol=1e-5, what="dx")
     for i, (a, b) in enumerate(zip(gp, cp)):
         _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
+
+
+def _packed_lstm_case(ndir, B, T, H, sub, lens=None, persistent=False, I=24):
+    """ops.lstm_layer on PACKED rows (hb.RowLayout: utterance b = rows base[b] .. base[b] + ext[b] - 1, include/asr_hip.h)
+    against the oracle's packed-sequence LSTM: outputs and input gradients row by row, zeros on every block's padding rows
+    whatever the upstream gradient holds there, parameter gradients (dW_hh as ONE row-shifted product over all rows)."""
+    dev = _gpu()
+    import ops
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(B * 10 + T + H)
+    if lens is None:
+        lens = sorted([int(v) for v in torch.randint(1, T + 1, (B,), generator=g)], reverse=True)
+        lens[0] = T
+    x = torch.randn(B, T, I, generator=g)
+    for b_, n_ in enumerate(lens):
+        x[b_, n_:] = 0.0
+    k = 1.0 / np.sqrt(H)
+    prm = []
+    for d in range(ndir):
+        prm += [torch.empty(4 * H, I).uniform_(-k, k, generator=g), torch.empty(4 * H, H).uniform_(-k, k, generator=g),
+                torch.empty(4 * H).uniform_(-k, k, generator=g), torch.empty(4 * H).uniform_(-k, k, generator=g)]
+    cp = [p.clone().requires_grad_(True) for p in prm]
+    xc = x.clone().requires_grad_(True)
+    ref = torch.cat([O.lstm_direction(xc, lens, *cp[4 * d:4 * d + 4], reverse=(d == 1)) for d in range(ndir)], 2)
+    gp = [p.to(dev).requires_grad_(True) for p in prm]
+    layout = hb.RowLayout(lens, [sub], dev)
+    rows = hb.LayerRows(layout, 0)
+    assert all(int(e) > n_ for e, n_ in zip(layout.ext[0], lens)) and rows.R == int(layout.ext[0].sum())
+    xp = hb.rows_pack(x.to(dev), rows).requires_grad_(True)
+    hb.LAUNCHES.clear()
+    if persistent:
+        with hb.require_persistent():
+            got = ops.lstm_layer(xp, None, gp, ndir, rows=rows)
+    else:
+        got = ops.lstm_layer(xp, None, gp, ndir, rows=rows)
+    gy = got.detach().cpu()
+    dy = torch.randn(ref.shape, generator=g)
+    dyp = torch.randn(rows.R, ndir * H, generator=g)               # noise on the padding rows: must not reach any gradient
+    for b_, n_ in enumerate(lens):
+        r0, e_ = int(layout.base[0][b_]), int(layout.ext[0][b_])
+        _close(gy[r0:r0 + n_], ref[b_, :n_], rtol=1e-4, atol=1e-5, what="y of utterance %d" % b_)
+        assert float(gy[r0 + n_:r0 + e_].abs().max()) == 0.0, "padding rows of a block hold zeros"
+        dyp[r0:r0 + n_] = dy[b_, :n_]
+    ref.backward(dy)
+    if persistent:
+        with hb.require_persistent():
+            got.backward(dyp.to(dev))
+        assert not hb.persist_aborted(dev)
+        assert hb.LAUNCHES["lstm_fwd_persist"] == 1 and hb.LAUNCHES["lstm_bwd_persist"] == 1, dict(hb.LAUNCHES)
+    else:
+        got.backward(dyp.to(dev))
+    gx = xp.grad.cpu()
+    for b_, n_ in enumerate(lens):
+        r0, e_ = int(layout.base[0][b_]), int(layout.ext[0][b_])
+        _close(gx[r0:r0 + n_], xc.grad[b_, :n_], rtol=1e-3, atol=1e-5, what="dx of utterance %d" % b_)
+        assert float(gx[r0 + n_:r0 + e_].abs().max()) == 0.0
+    for i, (a, b) in enumerate(zip(gp, cp)):
+        _close(a.grad, b.grad, rtol=1e-3, atol=1e-5, what="param %d" % i)
+
+
+@pytest.mark.parametrize("ndir,B,T,H,sub,lens", [(2, 3, 9, 16, 1, [9, 7, 4]), (1, 5, 6, 32, 2, [6, 6, 3, 2, 1]), (2, 33, 5, 64, 2, None),
+                                                  (2, 20, 7, 48, 1, None), (2, 4, 1, 16, 2, [1, 1, 1, 1]), (2, 6, 13, 16, 2, [13, 13, 2, 1, 1, 1])])
+def test_lstm_layer_packed_rows_per_step_kernels(ndir, B, T, H, sub, lens):
+    _packed_lstm_case(ndir, B, T, H, sub, lens)
+
+
+@pytest.mark.parametrize("arith", ["bf16x6", "f32", "bf16x3"])
+@pytest.mark.parametrize("ndir,B,T,H,sub,lens", [(2, 32, 9, 512, 2, None), (2, 20, 6, 512, 1, None), (1, 40, 5, 512, 2, None),
+                                                  (2, 3, 4, 512, 2, [4, 2, 1]), (2, 48, 5, 320, 2, None), (2, 7, 6, 128, 1, None),
+                                                  (1, 70, 4, 256, 2, None), (2, 8, 40, 512, 2, None), (2, 32, 1, 512, 2, None),
+                                                  (2, 64, 9, 512, 2, None), (2, 96, 5, 512, 1, None), (2, 256, 3, 512, 2, None),
+                                                  (2, 32, 41, 512, 2, [41, 41, 40, 37, 33] + [9] * 20 + [1] * 7)])
+def test_lstm_layer_packed_rows_persistent_kernels(ndir, B, T, H, sub, lens, arith):
+    """The persistent XCD-local kernels on packed rows: every row-group shape (4 / 8 / 16 rows), row blocks whose later
+    blocks run fewer steps than the first (rowext_host), extreme raggedness (41 ... 1 frames in one group of eight)."""
+    _gpu()
+    import hip_backend as hb
+    with hb.arith(arith):
+        _packed_lstm_case(ndir, B, T, H, sub, lens, persistent=True)
+
+
+def test_lstm_judge_width_packed_rows():
+    """H = 640 (the judge LM's width) on packed rows: forward on the bf16 kernels, backward on its own exchanged-partials kernel."""
+    _packed_lstm_case(1, 32, 11, 640, 1, None, persistent=True)
 
 
 @pytest.mark.parametrize("arith", ["f32", "bf16x3", "bf16x3+gather", "bf16x6+gather"])
