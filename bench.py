@@ -265,7 +265,7 @@ def encoder_gate_gemms(dev, c, B, t_frames):
         cst = torch.empty(T, B, 2 * H, device=dev)
         torch.cuda.synchronize()
         e0.record(stream)
-        rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whh), hb.ptr(lens), hb.ptr(y), hb.ptr(cst),
+        rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whh), hb.ptr(lens), None, None, None, hb.ptr(y), hb.ptr(cst),
                                           hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
         e1.record(stream)
         torch.cuda.synchronize()
@@ -281,7 +281,7 @@ def encoder_gate_gemms(dev, c, B, t_frames):
             whT = whh.transpose(1, 2).contiguous()
             torch.cuda.synchronize()
             e0.record(stream)
-            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whT), hb.ptr(lens), hb.ptr(dy), hb.ptr(cst),
+            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whT), hb.ptr(lens), None, None, None, hb.ptr(dy), hb.ptr(cst),
                                               hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
                                               hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
             e1.record(stream)
@@ -373,7 +373,7 @@ def kernel_roofline(dev, c, B, t_frames, olength):
             gates.copy_(gates0)
             torch.cuda.synchronize()
             e0.record(stream)
-            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), hb.ptr(dy),
+            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), None, None, None, hb.ptr(dy),
                                               hb.ptr(cst), hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
                                               hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
             e1.record(stream)

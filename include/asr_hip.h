@@ -151,7 +151,8 @@ int asr_colsum_f32(int64_t M, int64_t N, const float* X, int64_t ldx, float* out
  * rows rowbase[b] .. rowbase[b] + rowext[b] - 1 of gates / y / c / dy (then [R][ndir][4H] and [R][ndir*H], R = the sum
  * of the extents), time t at row rowbase[b] + t.  lens[b] < rowext[b]: the rows lens[b] .. rowext[b] - 1 are padding
  * INSIDE the block - the kernels write y = c = 0 (forward) and dG = 0 (backward) there, as they do for the padded times
- * of the time-major layout - and times >= rowext[b] do not exist (nothing is read into a result or written).  With at
+ * of the time-major layout, also behind the T steps of the call (T >= max lens suffices) - and times >= rowext[b] do not
+ * exist (nothing is read into a result or written).  With at
  * least one padding row behind every utterance the products that pair a row with its time neighbour (dW_hh = sum_t
  * dG_t^T h_{t-1}) stay ONE row-shifted GEMM over all R rows: the neighbour across a block boundary is a zero row.
  * Blocks whose extents halve from layer to layer (rowext_l = 2 rowext_{l+1}) make the pyramid's pair-concat the
@@ -177,12 +178,14 @@ int asr_lstm_seq_fwd(int T, int B, int nb, int H, int ndir, float* gates, const 
  * never clears the latch words: a sequence operator is several launches, and the caller looks once, after the last
  * one, and clears the latch itself. */
 int asr_persist_scratch_bytes(int64_t* xch_bytes, int64_t* ctrl_bytes);   /* minimum sizes of the scratch pair; returns 0 */
-/* rowbase / rowext: packed rows (see asr_lstm_seq_fwd), NULL = time-major.  rowext_host: optional HOST copy of rowext
- * (packed rows only): every row block then runs max(rowext of its rows) steps instead of T - exact, since later times
- * do not exist for any of its rows (a batch of 256 length-sorted utterances on one GPU: the later blocks are shorter). */
+/* rowbase / rowext: packed rows (see asr_lstm_seq_fwd), NULL = time-major.  With packed rows T is the number of STEPS to
+ * run, at least the longest of the nb rows (it may be less than their extents: the kernels zero a block's padding rows
+ * behind the last step themselves).  lens_host: optional HOST copy of lens (packed rows only): every row block then runs
+ * max(lens of its rows) steps instead of T (a batch of 256 length-sorted utterances on one GPU: the later blocks are
+ * shorter). */
 int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
                              const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
-                             const int32_t* rowext_host, float* y, float* c, void* xch, void* ctrl, int arith,
+                             const int32_t* lens_host, float* y, float* c, void* xch, void* ctrl, int arith,
                              asr_stream_t stream);
 
 /* Backward through the same recurrence.
@@ -208,11 +211,11 @@ int asr_lstm_seq_bwd(int T, int B, int nb, int H, int ndir, float* gates, const 
  * are given, the recurrent weight gradient sum_t dG_t^T h_{t-1} is accumulated into dw_hh inside the kernel
  * (fp32 atomics across the row groups) and the caller skips that GEMM.  If db ([ndir][4H], gate-interleaved,
  * zero-filled) is given, the bias gradient sum_{t,b} dG is accumulated into it as well.
- * With packed rows (rowbase / rowext / rowext_host as in asr_lstm_seq_fwd_persist) y / dw_hh are ignored: dW_hh is the
+ * With packed rows (rowbase / rowext / lens_host as in asr_lstm_seq_fwd_persist) y / dw_hh are ignored: dW_hh is the
  * caller's row-shifted product over all R rows. */
 int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                              const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
-                             const int32_t* rowext_host, const float* dy, const float* c, const float* y,
+                             const int32_t* lens_host, const float* dy, const float* c, const float* y,
                              float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
 /* Does asr_lstm_seq_bwd_persist(_w) with this (H, arith) accumulate dW_hh itself when given y and dw_hh?  1 yes; 0 no -
  * the ASR_ARITH_BF16X6 exchanged-partials kernels (H in {128, 256, 320, 512, 640}) leave dW_hh = sum_t dG_t^T h_{t-1} to the caller
@@ -226,7 +229,7 @@ int asr_lstm_bwd_persist_fuses_dw(int H, int arith);
  * asr_lstm_seq_bwd_persist / asr_lstm_seq_bwd. */
 int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh_il,
                                const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
-                               const int32_t* rowext_host, const float* dy, const float* c, const float* y, float* dw_hh,
+                               const int32_t* lens_host, const float* dy, const float* c, const float* y, float* dw_hh,
                                float* db, void* xch, void* ctrl, int arith, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -2165,7 +2165,9 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   const bool sp_shape = base_shape && (K % WK == 0 || (K % 4 == 0 && K > WK)) &&       // a K tail is masked (K = 80: the features)
                         (akc ? M : K) * lda < ((int64_t)1 << 29) && (bkc ? N : K) * ldb < ((int64_t)1 << 29);
   static const int64_t sp_min_units = [] { const char* f = getenv("ASR_GEMM_SP_MIN"); return f ? (int64_t)atoll(f) : (int64_t)5000; }();   // measurement
-  const bool sp_pays = K % WK == 0 && wtiles * (K / WK) >= sp_min_units;      // (K = 80: 223 us against the 128 x 128 kernel's 195 - three K tiles are all prologue)
+  // (K = 80: 223 us against the 128 x 128 kernel's 195 - three K tiles are all prologue; a LONG K with a masked tail - the
+  // weight-gradient products over the packed rows of the encoder, K = sum of the utterances' extents - pays like any other)
+  const bool sp_pays = (K % WK == 0 || K >= 64 * WK) && wtiles * (K / WK) >= sp_min_units;
   const bool use_sp = ar != ASR_ARITH_F32 && sp_shape && (auto_split || split_k == 1) && (!small || (arith & ASR_GEMM_TILE_SP)) &&
                       ((arith & ASR_GEMM_TILE_SP) || (sp_pays && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_WIDE | ASR_GEMM_TILE_SMALL))));
   const bool wide = use_sp || (ar != ASR_ARITH_F32 && !(arith & (ASR_GEMM_TILE_NARROW | ASR_GEMM_TILE_SP | ASR_GEMM_TILE_SMALL)) && wide_shape &&

@@ -84,6 +84,13 @@ __global__ __launch_bounds__(256) void enc_step_fwd_kernel(int T, int B, int nb,
       c[so] = cn;
       y[so] = hn;
     }
+    if (rowbase && s == 0) {          // packed rows: the block's padding rows behind the T steps of the sequence
+      for (int tt = T; tt < rowext[b]; ++tt) {
+        const int64_t o = ((int64_t)rowbase[b] + tt) * ldy + d * H + unit;
+        c[o] = 0.f;
+        y[o] = 0.f;
+      }
+    }
   }
 }
 
@@ -174,6 +181,10 @@ __global__ __launch_bounds__(NW * 64) void enc_step_bwd_kernel(int T, int B, int
     if (t >= lenv[i]) { da = make_float4(0.f, 0.f, 0.f, 0.f); dcn = 0.f; }
     if (!rowbase || t < rowext[b])
       *reinterpret_cast<float4*>(gates + row_of(b, t) * ldg + (int64_t)d * 4 * H + unit * 4) = da;
+    if (rowbase && s == 0) {          // packed rows: dG of the block's padding rows behind the T steps of the sequence
+      for (int tt = T; tt < rowext[b]; ++tt)
+        *reinterpret_cast<float4*>(gates + ((int64_t)rowbase[b] + tt) * ldg + (int64_t)d * 4 * H + unit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     dcarry[b * ldy + d * H + unit] = dcn;
   }
 }

@@ -305,6 +305,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     a.c[st_so] = st_c;
     a.y[st_so] = st_y;
   }
+  // packed rows: the block's padding rows behind the T steps that were run (times T .. rowext - 1; PersistArgs)
+  if (prow_ok) {
+    for (int tt = T; tt < pext; ++tt) {
+      const int64_t so = row_at(tt) * ldy + d * PH + punit;
+      a.c[so] = 0.f;
+      a.y[so] = 0.f;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------- forward, split-bf16 products
@@ -705,6 +713,14 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
     a.c[st_so] = st_c;
     a.y[st_so] = st_y;
   }
+  // packed rows: the block's padding rows behind the T steps that were run (times T .. rowext - 1; PersistArgs)
+  if (prow_ok) {
+    for (int tt = T; tt < pext; ++tt) {
+      const int64_t so = row_at(tt) * ldy + d * PH + punit;
+      a.c[so] = 0.f;
+      a.y[so] = 0.f;
+    }
+  }
 }
 
 // --------------------------------------------------------------------------------------------------- backward
@@ -984,6 +1000,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
         }
       }
     }
+  }
+  // packed rows: dG of the block's padding rows behind the T steps that were run (PersistArgs)
+  if (prow_ok) {
+    for (int tt = T; tt < pext; ++tt)
+      *reinterpret_cast<float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (a.db != nullptr && pw_lane) {
     // rows of a unit sit in 8 consecutive lanes (pj = tid & 7); the 4 row groups (XCDs) of a direction add up
@@ -1284,6 +1305,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
         }
       }
     }
+  }
+  // packed rows: dG of the block's padding rows behind the T steps that were run (PersistArgs)
+  if (prow_ok) {
+    for (int tt = T; tt < pext; ++tt)
+      *reinterpret_cast<float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (a.db != nullptr && pw_lane) {
     // rows of a unit sit in 8 consecutive lanes (pj = tid & 7); the 4 row groups (XCDs) of a direction add up
@@ -1807,6 +1833,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     dwacc[0][0][0] = __builtin_nanf("");
   }
   if (st_gp) *st_gp = st_da;
+  // packed rows: dG of the block's padding rows behind the T steps that were run (PersistArgs)
+  if (prow_ok) {
+    for (int tt = T; tt < pext; ++tt)
+      *reinterpret_cast<float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (a.db != nullptr) {        // one atomic per (unit, gate) and CU; the rows are summed through LDS
     if (pw_lane) *reinterpret_cast<float4*>(&dbs[pj][4 * pu]) = dbacc;
     __syncthreads();
@@ -2073,6 +2104,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
     dbacc.x = __builtin_nanf("");
   }
   if (st_gp) *st_gp = st_da;
+  // packed rows: dG of the block's padding rows behind the T steps that were run (PersistArgs)
+  if (prow_ok) {
+    for (int tt = T; tt < pext; ++tt)
+      *reinterpret_cast<float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (a.db != nullptr) {        // one atomic per (unit, gate) and CU; the rows are summed through LDS
     if (pw_lane) *reinterpret_cast<float4*>(&dbs[pj][4 * pu]) = dbacc;
     __syncthreads();
@@ -2282,22 +2318,22 @@ extern "C" int asr_persist_scratch_bytes(int64_t* xch_bytes, int64_t* ctrl_bytes
   if (ctrl_bytes) *ctrl_bytes = 128;
   return 0;
 }
-// Steps a row block of PACKED rows has to run: the largest extent of its rows when the caller gave a host copy of rowext
-// (times >= rowext[b] do not exist, so this is exact), else T.
-static int block_steps(int T, const int32_t* rowext_host, int rb, int rows) {
-  if (!rowext_host) return T;
+// Steps a row block of PACKED rows has to run: the largest length of its rows when the caller gave a host copy of lens (the
+// kernels zero the padding rows of a block behind the steps they ran), else T.
+static int block_steps(int T, const int32_t* lens_host, int rb, int rows) {
+  if (!lens_host) return T;
   int m = 1;
-  for (int r = 0; r < rows; ++r) m = rowext_host[rb + r] > m ? rowext_host[rb + r] : m;
+  for (int r = 0; r < rows; ++r) m = lens_host[rb + r] > m ? lens_host[rb + r] : m;
   return m < T ? m : T;
 }
 
 extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh,
                                         const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
-                                        const int32_t* rowext_host, float* y, float* c, void* xch, void* ctrl, int arith,
+                                        const int32_t* lens_host, float* y, float* c, void* xch, void* ctrl, int arith,
                                         asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || !w_hh || !lens || !y || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B || !arith_ok(arith)) return ASR_E_ARG;
-  if ((rowbase == nullptr) != (rowext == nullptr) || (rowext_host && !rowbase)) return ASR_E_ARG;
+  if ((rowbase == nullptr) != (rowext == nullptr) || (lens_host && !rowbase)) return ASR_E_ARG;
   // H = 640 (the judge LM, config.yaml dis_hidden_dim): forward only - 20 units per CU = 5 M tiles of the bf16 MFMA
   if (!(persist_supported(H) || H == 640) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   if (H == 640 && (arith & ASR_ARITH_MASK) == ASR_ARITH_F32) return ASR_E_SHAPE;
@@ -2309,7 +2345,7 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
     if (e != hipSuccess) return (int)e;
     PersistArgs a = {};
     a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
-    a.T = block_steps(T, rowext_host, rb, a.nb);
+    a.T = block_steps(T, lens_host, rb, a.nb);
     // time-major: the row block starts rb rows into every time slab; packed rows: rowbase is absolute
     const int64_t ro = rowbase ? 0 : rb;
     a.gates = gates + ro * ndir * 4 * H; a.w = w_hh; a.lens = lens + rb;
@@ -2331,11 +2367,11 @@ extern "C" int asr_lstm_seq_fwd_persist(int T, int B, int nb, int H, int ndir, f
 // Persistent fast path of asr_lstm_seq_bwd (same arguments and results except that no dcarry scratch is needed).
 static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT, const float* w_hh_il,
                                      const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
-                                     const int32_t* rowext_host, const float* dy, const float* c, const float* y,
+                                     const int32_t* lens_host, const float* dy, const float* c, const float* y,
                                      float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!gates || (!w_hhT && !w_hh_il) || !lens || !dy || !c || !xch || !ctrl || T <= 0 || B <= 0 || nb <= 0 || nb > B || !arith_ok(arith)) return ASR_E_ARG;
-  if ((rowbase == nullptr) != (rowext == nullptr) || (rowext_host && !rowbase)) return ASR_E_ARG;
+  if ((rowbase == nullptr) != (rowext == nullptr) || (lens_host && !rowbase)) return ASR_E_ARG;
   if (rowbase) { y = nullptr; dw_hh = nullptr; }     // packed rows: dW_hh is the caller's (one product over all rows, see asr_hip.h)
   if (!bwd_persist_width(H) || (ndir != 1 && ndir != 2) || !asr_persist_device_ok()) return ASR_E_SHAPE;
   const int kind = bwd_kernel_kind(H, arith);
@@ -2352,7 +2388,7 @@ static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, floa
     if (e != hipSuccess) return (int)e;
     PersistArgs a = {};
     a.B = B; a.nb = nb - rb < rows_per_launch ? nb - rb : rows_per_launch; a.ndir = ndir;
-    a.T = block_steps(T, rowext_host, rb, a.nb);
+    a.T = block_steps(T, lens_host, rb, a.nb);
     const int64_t ro = rowbase ? 0 : rb;
     a.gates = gates + ro * ndir * 4 * H; a.w = w_hhT; a.w_il = w_hhT ? nullptr : w_hh_il; a.lens = lens + rb; a.y = nullptr;
     a.rowbase = rowbase ? rowbase + rb : nullptr; a.rowext = rowext ? rowext + rb : nullptr;
@@ -2369,10 +2405,10 @@ static int lstm_seq_bwd_persist_impl(int T, int B, int nb, int H, int ndir, floa
 
 extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hhT,
                                         const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
-                                        const int32_t* rowext_host, const float* dy, const float* c, const float* y,
+                                        const int32_t* lens_host, const float* dy, const float* c, const float* y,
                                         float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream) {
   if (!w_hhT) return ASR_E_ARG;
-  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, w_hhT, nullptr, lens, rowbase, rowext, rowext_host, dy, c, y,
+  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, w_hhT, nullptr, lens, rowbase, rowext, lens_host, dy, c, y,
                                    dw_hh, db, xch, ctrl, arith, stream);
 }
 
@@ -2382,9 +2418,9 @@ extern "C" int asr_lstm_seq_bwd_persist(int T, int B, int nb, int H, int ndir, f
 // asr_lstm_seq_bwd_persist.
 extern "C" int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gates, const float* w_hh_il,
                                           const int32_t* lens, const int32_t* rowbase, const int32_t* rowext,
-                                          const int32_t* rowext_host, const float* dy, const float* c, const float* y,
+                                          const int32_t* lens_host, const float* dy, const float* c, const float* y,
                                           float* dw_hh, float* db, void* xch, void* ctrl, int arith, asr_stream_t stream) {
   if (!w_hh_il) return ASR_E_ARG;
-  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, nullptr, w_hh_il, lens, rowbase, rowext, rowext_host, dy, c, y,
+  return lstm_seq_bwd_persist_impl(T, B, nb, H, ndir, gates, nullptr, w_hh_il, lens, rowbase, rowext, lens_host, dy, c, y,
                                    dw_hh, db, xch, ctrl, arith, stream);
 }

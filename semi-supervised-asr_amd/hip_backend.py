@@ -609,6 +609,13 @@ class RowLayout(object):
             pads.append(((pads[-1] + 1) // 2 if subsample[i] > 1 else pads[-1]) if t_pad is None else int(t_pad[i + 1]))
         ext = [None] * (n + 1)
         ext[n] = lens[n] + 1
+        # the row counts are the K of the weight-gradient GEMMs, whose kernels want K % 4 == 0: up to three of the shortest
+        # utterances get a second padding row (the extents below double it: every layer's row count is then a multiple of 4)
+        odd = (-int(ext[n].sum())) % 4
+        if odd:
+            ext[n][np.argsort(lens[n], kind="stable")[:odd]] += 1
+            odd -= min(odd, len(ilens))
+            ext[n][int(np.argmin(lens[n]))] += odd               # (fewer than three utterances)
         for i in range(n - 1, -1, -1):
             ext[i] = ext[i + 1] * 2 if subsample[i] > 1 else ext[i + 1].copy()
         self.B, self.n = len(ilens), n
@@ -616,7 +623,8 @@ class RowLayout(object):
         self.ext = [np.ascontiguousarray(e.astype(np.int32)) for e in ext]
         self.base = [np.concatenate([[0], np.cumsum(e)[:-1]]).astype(np.int32) for e in ext]
         self.rows = [int(e.sum()) for e in ext]                 # R per layer
-        self.steps = [int(e.max()) for e in ext]                # time steps the recurrence of layer l has to run
+        self.steps = [int(l.max()) for l in lens]               # time steps the recurrence of layer l has to run (the kernels
+                                                                # zero the padding rows of a block behind them themselves)
         self.t_pad = pads                                       # padded time extent per layer (the global one of a shard)
         table = np.stack([np.stack([self.lens[i], self.base[i], self.ext[i]]) for i in range(n + 1)])
         self.dev = to_device_i32(table, device)                 # [n + 1][3][B]
@@ -647,10 +655,10 @@ class LayerRows(object):
         self.layout, self.l = layout, l
         self.B, self.R, self.T = layout.B, layout.rows[l], layout.steps[l]
         self.lens, self.base, self.ext = layout.lens_dev(l), layout.base_dev(l), layout.ext_dev(l)
-        self.ext_host = layout.ext[l]
+        self.lens_host, self.ext_max = layout.lens[l], int(layout.ext[l].max())
 
     def host_ptr(self):
-        return c_p(self.ext_host.ctypes.data)
+        return c_p(self.lens_host.ctypes.data)
 
 
 def lstm_seq_fwd(gates, w_hh, lens, y, c, use_graphs=True, rows=None):
@@ -800,7 +808,7 @@ def rows_pack(x, rows):
     """x [B, T, C] (zero-padded batch, dataloader.py:6-12) -> [R, C] in the packed layout of `rows` (a LayerRows)."""
     B, T, C = x.shape
     out = torch.empty(rows.R, C, device=x.device, dtype=torch.float32)
-    check(load().asr_rows_pack_f32(B, T, C, ptr(x), ptr(rows.lens), ptr(rows.base), ptr(rows.ext), rows.T, ptr(out), stream()),
+    check(load().asr_rows_pack_f32(B, T, C, ptr(x), ptr(rows.lens), ptr(rows.base), ptr(rows.ext), rows.ext_max, ptr(out), stream()),
           "asr_rows_pack_f32")
     return out
 
@@ -822,7 +830,7 @@ def rows_unpack_bwd(dout, rows, C, mask, want_fill):
     drows = torch.empty(rows.R, C, device=dout.device, dtype=torch.float32)
     dfill = torch.zeros(C, device=dout.device, dtype=torch.float32) if want_fill else None
     seeded = isinstance(mask, SeededMask)
-    check(load().asr_rows_unpack_bwd_f32(B, T, C, ptr(dout), ptr(rows.lens), ptr(rows.base), ptr(rows.ext), rows.T,
+    check(load().asr_rows_unpack_bwd_f32(B, T, C, ptr(dout), ptr(rows.lens), ptr(rows.base), ptr(rows.ext), rows.ext_max,
                                          None if (mask is None or seeded) else ptr(mask), mask.seed if seeded else 0,
                                          mask.p if seeded else 0.0, ptr(drows), ptr(dfill), stream()),
           "asr_rows_unpack_bwd_f32")

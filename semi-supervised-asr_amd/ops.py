@@ -130,7 +130,10 @@ def _lstm_workspace(rows, nbatch, H, ndir, dev, with_bwd):
     """Buffers of one LSTM layer for up to `rows` (time, batch) rows and `nbatch` batch rows; _lstm_views cuts the views of a
     call's actual shape out of them."""
     f32 = dict(device=dev, dtype=torch.float32)
-    ws = dict(gates_buf=torch.empty(rows, ndir, 4 * H, **f32), y_buf=torch.empty(rows, ndir * H, **f32),
+    # (zeros, and one row more than asked for: the packed-row dW_hh product reads ONE row behind the matrix on each side -
+    # against a zero padding row of the other operand - and that row must hold finite numbers, stale or not)
+    alloc = torch.zeros if with_bwd else torch.empty
+    ws = dict(gates_buf=alloc(rows + 1, ndir, 4 * H, **f32), y_buf=alloc(rows + 1, ndir * H, **f32),
               c_buf=torch.empty(rows, ndir * H, **f32), w_hh=torch.empty(ndir, 4 * H, H, **f32))
     if with_bwd:
         # the three accumulators the backward starts from zero share one buffer: one fill instead of three
@@ -214,7 +217,11 @@ class _LstmLayer(torch.autograd.Function):
             #   d = 0: A = dG[B:, 0:4H],        B = y[:(T-1)B, 0:H]
             #   d = 1: A = dG[:(T-1)B, 4H:8H],  B = y[B:, H:2H]          -> batch strides relative to d = 0 (may be negative)
             ldg, ldy = ndir * 4 * H, ndir * H
-            hb.gemm_batched(dG, y, ws["dw_hh"], True, False, 4 * H, H, (T - 1) * B, ldg, ldy, H, ndir,
+            # packed rows: K = R instead of R - 1 (a multiple of 4: the GEMM's fast kernels want that).  The one extra pair
+            # is (row R of dG, the last row of y) resp. (the last row of dG, row R of y): the last row of the matrix is a
+            # padding row - zero in both - and row R exists in the workspace and holds finite numbers (_lstm_workspace)
+            kk = T * B if ctx.rows is not None else (T - 1) * B
+            hb.gemm_batched(dG, y, ws["dw_hh"], True, False, 4 * H, H, kk, ldg, ldy, H, ndir,
                             4 * H - B * ldg, B * ldy + H, 4 * H * H, accumulate=True, a_off=B * ldg, b_off=0)
         # gate-interleaved gradients -> torch layout, one launch
         g_ih, g_hh, g_b, g_b2 = hb.lstm_unpack(H, I, ndir, dw_ih, ws["dw_hh"], db, two_biases=True)

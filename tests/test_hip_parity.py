@@ -925,7 +925,7 @@ def test_lstm_bwd_persist_forward_layout_weights(H, B, T, ndir):
         gb = gact.clone()
         dw = torch.zeros(ndir, 4 * H, H, device=dev)
         db = torch.zeros(ndir * 4 * H, device=dev)
-        rc = fn(T, B, B, H, ndir, hb.ptr(gb), hb.ptr(wt), hb.ptr(lens), hb.ptr(dy), hb.ptr(c), hb.ptr(y), hb.ptr(dw), hb.ptr(db),
+        rc = fn(T, B, B, H, ndir, hb.ptr(gb), hb.ptr(wt), hb.ptr(lens), None, None, None, hb.ptr(dy), hb.ptr(c), hb.ptr(y), hb.ptr(dw), hb.ptr(db),
                 hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
         assert rc == 0, rc
         torch.cuda.synchronize()
@@ -937,7 +937,7 @@ def test_lstm_bwd_persist_forward_layout_weights(H, B, T, ndir):
     _close(outs[1][2], outs[0][2], rtol=1e-5, atol=1e-6, what="db")
     for declined in (hb.ARITH_F32, hb.ARITH_BF16X3 | hb.LSTM_BWD_GATHER):
         gb = gact.clone()
-        rc = lib.asr_lstm_seq_bwd_persist_w(T, B, B, H, ndir, hb.ptr(gb), hb.ptr(w), hb.ptr(lens), hb.ptr(dy), hb.ptr(c), None, None,
+        rc = lib.asr_lstm_seq_bwd_persist_w(T, B, B, H, ndir, hb.ptr(gb), hb.ptr(w), hb.ptr(lens), None, None, None, hb.ptr(dy), hb.ptr(c), None, None,
                                             None, hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), declined, hb.stream())
         assert rc == -2, rc
 

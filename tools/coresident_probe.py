@@ -26,10 +26,10 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 main = torch.cuda.current_stream(); side = torch.cuda.Stream()
 def fwd():
     ga = gates0.clone()
-    return lambda: lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), AR, ctypes.c_void_p(main.cuda_stream))
+    return lambda: lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), None, None, None, P(y), P(c), P(xch), P(ctrl), AR, ctypes.c_void_p(main.cuda_stream))
 def bwd():
     gb = gact.clone()
-    return lambda: lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), None, None, None, P(xch), P(ctrl), AR, ctypes.c_void_p(main.cuda_stream))
+    return lambda: lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), None, None, None, P(dy), P(cc), None, None, None, P(xch), P(ctrl), AR, ctypes.c_void_p(main.cuda_stream))
 def timed(run, spin=None):
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

@@ -30,11 +30,11 @@ def show(name):
     print(name, 'arrival at the top of a step relative to the earliest CU:', ' '.join('%d' % x for x in top))
 for _ in range(2):
     gb = gact.clone()
-    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), hb.current_arith(), st) == 0
+    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), None, None, None, P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), hb.current_arith(), st) == 0
     torch.cuda.synchronize()
 show('bwd')
 for _ in range(2):
     ga = gates0.clone()
-    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), hb.current_arith(), st) == 0
+    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), None, None, None, P(y), P(c), P(xch), P(ctrl), hb.current_arith(), st) == 0
     torch.cuda.synchronize()
 show('fwd')

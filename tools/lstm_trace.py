@@ -27,7 +27,7 @@ def report(name, n):
           ' tail->next top: %.0f' % (t[1:, 0] - t[:-1, n - 1]).mean())
 for _ in range(2):
     ga = gates0.clone(); ctrl.zero_()
-    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), hb.current_arith(), st) == 0
+    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), None, None, None, P(y), P(c), P(xch), P(ctrl), hb.current_arith(), st) == 0
     torch.cuda.synchronize(); report('fwd', 7)
     t = ctrl[32:32 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     print('   fwd poll split: top->sentinel ok %.0f | sentinel ok->tile gathered %.0f | failed polls %.1f' % ((t[:, 7] - t[:, 0]).mean(), (t[:, 1] - t[:, 7]).mean(), t[:, 8].mean()))
@@ -37,7 +37,7 @@ for _ in range(2):
         (t[:, 1] - t[:, 0]).mean(), (t[:, 2] - t[:, 0]).mean(), (t[:, 4] - t[:, 0]).mean(), (t[:, 6] - t[:, 0]).mean()))
 for _ in range(2):
     gb = gact.clone(); ctrl.zero_()
-    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), hb.current_arith(), st) == 0
+    assert l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), None, None, None, P(dy), P(cc), P(yy), P(dw), P(db), P(xch), P(ctrl), hb.current_arith(), st) == 0
     torch.cuda.synchronize(); report('bwd', 6)
     t = ctrl[32:32 + 8 * 16 * 2].cpu().numpy().view(np.int64).reshape(8, 16)
     print('   bwd pointwise split: partial sums %.0f | math+tags %.0f | publish %.0f | bulk store+db %.0f' % ((t[:, 9] - t[:, 4]).mean(), (t[:, 10] - t[:, 9]).mean(), (t[:, 11] - t[:, 10]).mean(), (t[:, 5] - t[:, 11]).mean()))

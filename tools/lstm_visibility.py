@@ -18,7 +18,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 l = ctypes.CDLL(ROOT + '/scratchlibs/lib_lptrace3.so')
 for rep in range(3):
     ga = gates0.clone(); ctrl.zero_()
-    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), hb.current_arith(), hb.stream()) == 0
+    assert l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), None, None, None, P(y), P(c), P(xch), P(ctrl), hb.current_arith(), hb.stream()) == 0
     torch.cuda.synchronize()
     t = ctrl[48:48 + 64 * 4].cpu().numpy().view(np.int64).reshape(64, 2)[8:60]
     ok = (t[:, 0] > 0) & (t[:, 1] > 0)

@@ -35,11 +35,11 @@ for rep in range(4):                 # interleaved repetitions: clocks / placeme
       for ar in ARITHS:
         l = libs[path]
         ga = gates0.clone()
-        tf = timeit(lambda: l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(y), P(c), P(xch), P(ctrl), ar, st))
+        tf = timeit(lambda: l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), None, None, None, P(y), P(c), P(xch), P(ctrl), ar, st))
         gb = gact.clone()
-        tb = timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), P(yy), P(dw), None, P(xch), P(ctrl), ar, st))
+        tb = timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), None, None, None, P(dy), P(cc), P(yy), P(dw), None, P(xch), P(ctrl), ar, st))
         gb = gact.clone()
-        tb0 = timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(dy), P(cc), None, None, None, P(xch), P(ctrl), ar, st))
+        tb0 = timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), None, None, None, P(dy), P(cc), None, None, None, P(xch), P(ctrl), ar, st))
         best[(path, ar)] = [min(a_, b_) for a_, b_ in zip(best[(path, ar)], (tf, tb, tb0))]
         if int(ctrl[0].item()) != 0: print('ABORT in', os.path.basename(path), 'code', int(ctrl[1].item()), 'rep', rep, flush=True); ctrl[:2].zero_()
 for path in paths:
