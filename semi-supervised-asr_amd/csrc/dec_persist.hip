@@ -156,6 +156,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
+  const bool dbg_stall = persist_debug_stall(a.ctrl) != 0u;        // test hook (persist.h): this launch exercises its abort path
+  const unsigned spin_limit = dbg_stall ? DEBUG_SPIN_LIMIT : SPIN_LIMIT;
   const int r0 = RG * g;
   if (r0 >= a.nb) return;                    // this group has no rows (nobody waits for it)
   const int Tp = a.Tp, C = a.C, K = a.K, B = a.B, L = a.L, nb = a.nb;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         const int row = (4 * id) / OO, o = 4 * id - row * OO;
         off[i] = cbase + (unsigned)((4 * id < RG * OO) ? row * 512 + o : 0) * 4u;      // rows >= RG are never published
       }
-      poll_quads<NQ, true>(xrs, off, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 11u);
+      poll_quads<NQ, true>(xrs, off, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 11u, spin_limit);
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const int id = tid_ + DP_NT * i;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
             const int row = (2 * id) / OO, o = 2 * id - row * OO;
             p[i] = reinterpret_cast<const u64*>(ux + ((2 * id < RG * OO) ? row * 512 + o : 0));
           }
-          poll_pairs<NC, ASR_DP_FULL>(p, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 16u);
+          poll_pairs<NC, ASR_DP_FULL>(p, tag_bit_of_step(s - 1), v, a.ctrl, aborted, 16u, spin_limit);
 #pragma unroll
           for (int i = 0; i < NC; ++i) {
             const int id = tid_ + DP_NT * i;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         const u64* p1[2] = {reinterpret_cast<const u64*>(xg + DX_S + ((s - 1) & 1) * 2),
                             reinterpret_cast<const u64*>(xg + DX_M + ((s - 1) & 1) * 512 + 2 * id)};
         u64 v1[2];
-        poll_pairs<2, true>(p1, tag_bit_of_step(s - 1), v1, a.ctrl, aborted, 17u);
+        poll_pairs<2, true>(p1, tag_bit_of_step(s - 1), v1, a.ctrl, aborted, 17u, spin_limit);
         if (tid_ < 256) {
           const int row = id >> 6, e2 = 2 * (id & 63);
           xs[row * XS + DD + OO + e2] = pair_lo(v1[1]);
@@ -511,7 +513,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         a.X[((int64_t)(s + 1) * B + pb_) * KX + punit_] = zn;
         if (drop) a.Xd[((int64_t)(s + 1) * B + pb_) * KX + punit_] = zn;
       }
-      word_store(xg + DX_Z + par * 4 * 512 + (tid_ & 3) * 512 + punit_, zn, bit);
+      if (!(dbg_stall && g == 0 && slice == 1 && s >= 1))          // (test hook: a producer that went silent)
+        word_store(xg + DX_Z + par * 4 * 512 + (tid_ & 3) * 512 + punit_, zn, bit);
     }
     DP_MARK(3);
     // ------------------------------------------------------------ (3b) location conv of w_{s-1} -> f_s (16 frames)
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         const int row = (4 * id) / DD, d = 4 * id - row * DD;
         off[NFQ + i] = zbase + (unsigned)((4 * id < 4 * DD) ? row * 512 + d : 0) * 4u;
       }
-      poll_quads<NZQ + NFQ, true>(xrs, off, bit, v, a.ctrl, aborted, 12u);
+      poll_quads<NZQ + NFQ, true>(xrs, off, bit, v, a.ctrl, aborted, 12u, spin_limit);
       DP_MARK(5);
 #pragma unroll
       for (int i = 0; i < NFQ; ++i)
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           p[i] = reinterpret_cast<const u64*>(ex + (4 * wave + i) * 4 * TPM + (ok ? 2 * t2 : 0));
-        poll_pairs<4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 14u);
+        poll_pairs<4, ASR_DP_FULL>(p, bit, v, a.ctrl, aborted, 14u, spin_limit);
         float e0 = 0.f, e1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { e0 += pair_lo(v[i]); e1 += pair_hi(v[i]); }

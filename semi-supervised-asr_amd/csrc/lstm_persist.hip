@@ -430,6 +430,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
+  const bool dbg_stall = persist_debug_stall(a.ctrl) != 0u;        // test hook (persist.h): this launch exercises its abort path
+  const unsigned spin_limit = dbg_stall ? DEBUG_SPIN_LIMIT : SPIN_LIMIT;
   const int T = a.T, B = a.B, ndir = a.ndir;
   const int d = ndir == 2 ? (g & 1) : 0;
   const int rowgroup = ndir == 2 ? (g >> 1) : g;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
             const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff[0], 0, 16);
             const bool ok1 = !gl[0] || (((q.x ^ tb) | (q.y ^ tb) | (q.z ^ tb) | (q.w ^ tb)) & 1u) == 0u;
             if (__all(ok1)) break;
-            if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) break;      // the loop below raises the abort
+            if (++spins > spin_limit || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) break;      // the loop below raises the abort
             __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
           }
         }
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
             ok = ok && (!gl[jc] || (bad & 1u) == 0u);
           }
           if (__all(ok)) break;
-          if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (++spins > spin_limit || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
             if (lane == 0) raise_abort(a.ctrl, 1u);
             aborted = true;
             break;
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   #pragma unroll
             for (int j = 0; j < NR / 4; ++j) ok = ok && (!gl[kc] || quad_ok(gw[kc][j], tb));
           if (__all(ok)) break;
-          if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+          if (++spins > spin_limit || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
             if (lane == 0) raise_abort(a.ctrl, 1u);
             aborted = true;
             break;
@@ -697,7 +699,8 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
       LP_MARK(5);
-      word_store(xw_g + (s & 1) * (PH * RG) + (int64_t)punit * RG + pj, hn, tag_bit_of_step(s));       // hand-off first
+      if (!(dbg_stall && g == 0 && slice == 1 && s >= 1))                                             // (test hook: a producer that went silent)
+        word_store(xw_g + (s & 1) * (PH * RG) + (int64_t)punit * RG + pj, hn, tag_bit_of_step(s));     // hand-off first
       LP_MARK(6);
       if (prow_ok && t < pext) {
         st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;

@@ -52,7 +52,13 @@ __device__ __forceinline__ void word_store(float* p, float v, unsigned bit) {
 //   latch words (ctrl - 16 inside a kernel; NEVER written by the host side of the library): [0] abort latch, [1] code of the
 //     abort that set it.  A sequence operator is several launches (one per LSTM layer, per row block, the decoder); the
 //     per-launch abort word of all but the last is gone when the host looks, the latch is not.  The caller clears it.
+//     [2] TEST HOOK, written by the caller only: non-zero arms a fault in the kernels that honour it (lstm_persist_fwd_bf3_kernel,
+//     dec_persist_fwd_kernel): slice 1 of group 0 stops publishing after its first step and every wait of the launch gives up
+//     after DEBUG_SPIN_LIMIT attempts instead of SPIN_LIMIT - the kernels' own abort path (bounded spin expires ->
+//     raise_abort -> NaN poison -> every other workgroup drains) runs in milliseconds (tests/test_hip_parity.py).
 static inline unsigned* persist_launch_words(void* ctrl) { return (unsigned*)ctrl + 16; }
+constexpr unsigned DEBUG_SPIN_LIMIT = 4096u;
+__device__ __forceinline__ unsigned persist_debug_stall(const unsigned* ctrl) { return flag_load(ctrl - 14); }
 __device__ __forceinline__ void raise_abort(unsigned* ctrl, unsigned code) {
   flag_store(ctrl + 9, code);
   flag_store(ctrl + 8, 1u);
@@ -93,7 +99,7 @@ __device__ __forceinline__ void take_role(unsigned* ctrl, int* lds_role, int& g,
 // already there; only for small N).  Returns with `aborted` set (values undefined) on a timeout or a raised abort word.
 template <int N, bool FULL = false>
 __device__ __forceinline__ void poll_pairs(const u64* const (&p)[N], unsigned want, u64 (&v)[N], unsigned* ctrl,
-                                           bool& aborted, unsigned code) {
+                                           bool& aborted, unsigned code, unsigned limit = SPIN_LIMIT) {
   const u64 m = 0x0000000100000001ull;
   const u64 expect = want ? m : 0ull;
   if (aborted) {
@@ -124,7 +130,7 @@ __device__ __forceinline__ void poll_pairs(const u64* const (&p)[N], unsigned wa
 #ifdef ASR_NO_POLL   /* measurement only: never wait (results are garbage) */
     return;
 #endif
-    if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(ctrl + 8) != 0u)) {
+    if (++spins > limit || ((spins & 63u) == 0u && flag_load(ctrl + 8) != 0u)) {
       if ((threadIdx.x & 63) == 0) raise_abort(ctrl, code);
       aborted = true;
       return;
@@ -145,7 +151,7 @@ __device__ __forceinline__ bool quad_ok(const u4v& q, unsigned tb) {
 }
 template <int N, bool FULL = false>
 __device__ __forceinline__ void poll_quads(__amdgpu_buffer_rsrc_t rs, const unsigned (&off)[N], unsigned want, u4v (&v)[N],
-                                           unsigned* ctrl, bool& aborted, unsigned code) {
+                                           unsigned* ctrl, bool& aborted, unsigned code, unsigned limit = SPIN_LIMIT) {
   const unsigned tb = want ? 1u : 0u;
   if (aborted) {
 #pragma unroll
@@ -174,7 +180,7 @@ __device__ __forceinline__ void poll_quads(__amdgpu_buffer_rsrc_t rs, const unsi
 #ifdef ASR_NO_POLL
     return;
 #endif
-    if (++spins > SPIN_LIMIT || ((spins & 63u) == 0u && flag_load(ctrl + 8) != 0u)) {
+    if (++spins > limit || ((spins & 63u) == 0u && flag_load(ctrl + 8) != 0u)) {
       if ((threadIdx.x & 63) == 0) raise_abort(ctrl, code);
       aborted = true;
       return;

@@ -532,6 +532,12 @@ class require_persistent(object):
         return False
 
 
+def _scratch_key(device):
+    """One scratch pair per physical device: "cuda" and "cuda:0" name the same one."""
+    d = torch.device(device)
+    return "%s:%d" % (d.type, torch.cuda.current_device() if d.index is None else d.index) if d.type == "cuda" else str(d)
+
+
 def persist_scratch(device, trace=False):
     """(xch, ctrl) scratch of the persistent kernels, one pair per device (calls are stream-ordered).  ctrl = 32 int32 words:
     [0] abort latch, [1] its code (set by any aborting launch, cleared only by persist_clear_abort), [16..31] the
@@ -543,7 +549,7 @@ def persist_scratch(device, trace=False):
             _persist_scratch[tkey] = (torch.zeros(XCH_BYTES // 8, dtype=torch.int64, device=device),
                                       torch.zeros(16384, dtype=torch.int32, device=device))     # 64 KB: tools/dec_trace2.py
         return _persist_scratch[tkey]
-    key = str(device)
+    key = _scratch_key(device)
     if key not in _persist_scratch:
         xb, cb = c_i64(0), c_i64(0)
         load().asr_persist_scratch_bytes(ctypes.byref(xb), ctypes.byref(cb))
@@ -558,13 +564,13 @@ def persist_scratch(device, trace=False):
 def persist_abort_code(device):
     """Which wait gave up first since the latch was cleared (ctrl[1]; 2 = unexpected workgroup placement, others = the
     poll site).  Synchronises."""
-    key = str(device)
+    key = _scratch_key(device)
     return int(_persist_scratch[key][1][1].item()) if key in _persist_scratch else 0
 
 
 def persist_clear_abort(device):
     """Clear the abort latch (start of a step / after the caller has dealt with an abort); stream-ordered, no sync."""
-    key = str(device)
+    key = _scratch_key(device)
     if key in _persist_scratch:
         _persist_scratch[key][1][:2].zero_()
 
@@ -582,7 +588,7 @@ def persist_aborted(device):
     """True if ANY persistent launch on `device` aborted since the latch was last cleared (synchronises; for tests /
     end-of-step checks).  The latch is sticky across launches: the per-launch abort word is zeroed before every launch,
     and a sequence operator is several launches."""
-    key = str(device)
+    key = _scratch_key(device)
     return key in _persist_scratch and int(_persist_scratch[key][1][0].item()) != 0
 
 

@@ -1713,3 +1713,108 @@ def test_rccl_allreduce_of_the_flat_gradient_buffer(tmp_path):
     for tag in ("collective", "overlapped"):
         for a, b in zip(res[tag], res["plain"]):
             assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (tag, a, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The kernels' OWN abort path (csrc/persist.h: a bounded spin expires -> raise_abort -> NaN poison -> every other workgroup
+# drains), run for real: latch word 2 of the caller-owned control block arms a fault in the launch - slice 1 of group 0 stops
+# publishing after its first step and every wait gives up after 4 096 attempts - instead of the host writing the latch.
+def _arm_stall(dev, on):
+    import hip_backend as hb
+    hb.persist_scratch(dev)[1][2] = 1 if on else 0
+
+
+def _timed_ms(fn):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return out, e0.elapsed_time(e1)
+
+
+def test_lstm_kernel_raises_its_own_abort_and_the_next_launch_is_clean():
+    dev = _gpu()
+    import hip_backend as hb
+    H, B, T, ndir = 512, 32, 24, 2
+    g = torch.Generator().manual_seed(5)
+    gates0 = (torch.randn(T, B, ndir, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.randn(ndir, 4 * H, H, generator=g) / np.sqrt(H)).to(dev)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+
+    def run():
+        gts, y, c = gates0.clone(), torch.empty(T, B, ndir * H, device=dev), torch.empty(T, B, ndir * H, device=dev)
+        with hb.require_persistent():
+            hb.lstm_seq_fwd(gts, whh, lens, y, c, use_graphs=False)
+        return y
+    hb.persist_clear_abort(dev)
+    want = run()
+    torch.cuda.synchronize()
+    assert not hb.persist_aborted(dev) and torch.isfinite(want).all()
+    try:
+        _arm_stall(dev, True)
+        got, ms = _timed_ms(run)
+    finally:
+        _arm_stall(dev, False)
+    ctrl = hb.persist_scratch(dev)[1].cpu().tolist()
+    assert ms < 100.0, "the bounded spins of the armed launch expire in milliseconds, got %.1f ms" % ms
+    assert ctrl[0] == 1 and ctrl[1] == 1, "latch + code of the forward hand-off's wait (code 1), got %s" % ctrl[:2]
+    assert ctrl[16 + 8] == 1 and ctrl[16 + 9] == 1, "per-launch abort word + code"
+    assert hb.persist_aborted(dev) and hb.persist_abort_code(dev) == 1
+    # group 0 = (direction 0, rows 0..7): the waves whose K range holds the silent producer's units give up at step 2 and
+    # poison what they produce from there on; the other waves of the group sample the abort word every 16th step and poison
+    # from then on.  The other groups do not depend on group 0: they may have finished - with valid numbers - before it gave up
+    assert torch.isnan(got[2, :8, :H]).any(), "the stalled group produces NaN from the step behind the silent producer"
+    assert torch.isnan(got[T - 1, :8, :H]).all()
+    hb.persist_clear_abort(dev)
+    again = run()
+    torch.cuda.synchronize()
+    assert not hb.persist_aborted(dev)
+    assert torch.equal(again, want), "the next clean launch on the same scratch is bit-identical to the one before the fault"
+
+
+def test_decoder_kernel_raises_its_own_abort_and_the_next_launch_is_clean():
+    dev = _gpu()
+    import ops
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(21)
+    D = A = O = 512
+    E, C, V, K, B, Tp, L = 128, 10, 34, 100, 8, 40, 10
+
+    def rnd(*sh, sc=1.0):
+        return (torch.randn(*sh, generator=g) * sc).to(dev)
+    sc0 = 1.0 / np.sqrt(D)
+    par = dict(P=rnd(B, Tp, A, sc=0.5), Q=rnd(B, Tp, O, sc=0.5), emb_w=rnd(V, E, sc=0.5), w_ih=rnd(4 * D, E + O, sc=sc0),
+               w_hh=rnd(4 * D, D, sc=sc0), b_ih=rnd(4 * D, sc=sc0), b_hh=rnd(4 * D, sc=sc0), wdec=rnd(A, D, sc=sc0),
+               convw=rnd(C, 1, 1, 2 * K + 1, sc=0.1), watt=rnd(A, C, sc=0.3), gvec=rnd(1, A, sc=sc0), bo=rnd(O, sc=sc0),
+               w_out=rnd(V, D + O, sc=sc0), b_out=rnd(V, sc=sc0))
+    w0 = torch.full((B, Tp), 1.0 / Tp, device=dev)
+    tokens = torch.randint(0, V, (B, L), generator=g).to(dev)
+
+    def run():
+        opts = dict(L=L, tokens=tokens, tf_flags=None, smooth=False, sample=False, scaling=2.0, xmask=None, bos=1)
+        with torch.no_grad(), hb.require_persistent():
+            logits, ws, _ = ops.decoder_sequence(par["P"], par["Q"], par["emb_w"], par["w_ih"], par["w_hh"], par["b_ih"],
+                                                 par["b_hh"], par["wdec"], par["convw"], par["watt"], par["gvec"], par["bo"],
+                                                 par["w_out"], par["b_out"], w0, opts)
+        return logits, ws
+    hb.persist_clear_abort(dev)
+    want_l, want_w = run()
+    torch.cuda.synchronize()
+    assert not hb.persist_aborted(dev) and torch.isfinite(want_l).all()
+    try:
+        _arm_stall(dev, True)
+        (got_l, got_w), ms = _timed_ms(run)
+    finally:
+        _arm_stall(dev, False)
+    ctrl = hb.persist_scratch(dev)[1].cpu().tolist()
+    assert ms < 100.0, "got %.1f ms" % ms
+    assert ctrl[0] == 1 and ctrl[1] in (11, 12, 14, 16, 17), "latch + the code of a decoder-forward wait, got %s" % ctrl[:2]
+    assert ctrl[16 + 8] == 1
+    assert torch.isnan(got_l[L - 1, :4]).all(), "the stalled group's utterances (rows 0..3) end in NaN"
+    hb.persist_clear_abort(dev)
+    again_l, again_w = run()
+    torch.cuda.synchronize()
+    assert not hb.persist_aborted(dev)
+    assert torch.equal(again_w, want_w), "the kernel's own outputs are bit-identical to those before the fault"
+    _close(again_l, want_l, rtol=1e-5, atol=1e-6, what="logits after the fault")     # (a split-K product: atomics, run-to-run order)
