@@ -420,6 +420,24 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     return first
 
 
+def row_geometry(n_rows, H, ndir=2):
+    """How the persistent LSTM kernels walk a batch of n_rows utterances on ONE GPU (csrc/lstm_persist.hip launchers): every
+    launch is one traversal of the layer's serial chain.  Explains the N = 1 base of a strong-scaling curve."""
+    per8, fwd, left = 8 * (8 // ndir), [], n_rows
+    while left > 0:
+        if H == 512 and left >= 16 * (8 // ndir):
+            fwd.append("%d rows (16 per XCD group)" % (16 * (8 // ndir)))
+            left -= 16 * (8 // ndir)
+        else:
+            rows = min(left, per8)
+            fwd.append("%d rows (%d per XCD group)" % (rows, 4 if n_rows <= 4 * (8 // ndir) else 8))
+            left -= rows
+    nb = (n_rows + per8 - 1) // per8
+    return dict(lstm_forward_passes=len(fwd), lstm_forward=fwd, lstm_backward_passes=nb,
+                lstm_backward="%d x %d-row passes" % (nb, min(n_rows, per8)),
+                note="packed rows: a pass runs max(len of ITS rows) steps, so the later passes of a length-sorted batch are shorter")
+
+
 VOCAB = ["<PAD>", "<BOS>", "<EOS>"] + ["c%02d" % i for i in range(29)] + ["<space>", "<NOISE>"]       # V = 34
 
 
@@ -559,10 +577,22 @@ def main():
 
     if rank == 0:
         note("%s, %d utterances per GPU x %d GPU(s), T=%d: warmup" % (args.config, b_local, world, t_frames))
+    seen_world = None
+    persist_at_start = bool(hb.USE_PERSIST)           # (False: several ranks share this card - parallel.init_distributed)
     if world > 1:
-        # communicator set-up (lazy in the first collective) and rank alignment before the first step
+        # communicator set-up (lazy in the first collective) and rank alignment before the first step; what every rank then
+        # believes the job to be goes into the record (config.per_rank)
         dist.all_reduce(torch.zeros(1, device=dev))
         fence()
+        mine = torch.tensor([float(dist.get_world_size()), float(dist.get_rank()), float(torch.cuda.current_device())], device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        seen_world = [[int(v) for v in t.tolist()] for t in allr]
+        note("rank %d of %d on cuda:%d (%s), backend %s, exchange: %s, step pipeline: %s"
+             % (rank, dist.get_world_size(), torch.cuda.current_device(), torch.cuda.get_device_name(dev), dist.get_backend(),
+                "one all-reduce of the flat buffer after the backward pass",
+                "host reads a step's record one step late (parallel.DpPipeline)" if int(solver.config.get("pipeline_steps", 1)) > 0
+                else "host read between all-reduce and update (parallel.dp_step)"))
     # Rehearsal of the product's abort handling (Solver._recover in one process, parallel.DpPipeline's coordinated
     # repeat under data parallelism): ASR_BENCH_INJECT_ABORT=warmup|timed sets the sticky latch from the host once, as an
     # aborting persistent kernel would (on the last rank only).
@@ -594,12 +624,23 @@ def main():
         retimed = True
     final_loss = float(last["loss"])
     paths = {k: v // max(1, args.steps) for k, v in sorted(hb.LAUNCHES.items())}
+    # which stage of the fallback ladder this rank is on after the timed steps
+    stage = ("persistent kernels" if hb.USE_PERSIST else
+             ("per-step kernels from the start (several ranks share this card)" if not persist_at_start else
+              "per-step kernels: left the persistent kernels after an abort in the %s steps" % ("timed" if persist_before else "warm-up")))
+    note("rank %d after the timed steps: %.2f ms/step (max over ranks), abort latch %s, %s, sequence-operator paths per step %s"
+         % (rank, el / args.steps * 1e3, bool(hb.persist_aborted(dev)), stage, paths))
     per_rank = None
     if world > 1:
-        mine = torch.tensor([float(hb.persist_aborted(dev)), float(bool(hb.USE_PERSIST))], device=dev)
+        mine = torch.tensor([float(hb.persist_aborted(dev)), float(bool(hb.USE_PERSIST)), float(persist_before), float(persist_at_start)], device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [dict(rank=i, abort_latch=bool(t[0].item()), persistent_kernels=bool(t[1].item())) for i, t in enumerate(allr)]
+        per_rank = [dict(rank=i, world_size_seen=seen_world[i][0], rank_seen=seen_world[i][1], device=seen_world[i][2],
+                         abort_latch=bool(t[0].item()), persistent_kernels=bool(t[1].item()),
+                         fallback_stage="none" if t[1].item() else (
+                             "per-step kernels from the start (several ranks share this card)" if not t[3].item() else
+                             "repeated a step on the per-step kernels during the %s steps" % ("timed" if t[2].item() else "warm-up")))
+                    for i, t in enumerate(allr)]
     # the gradient all-reduce alone (68.7 MB at cfg-2), outside the timed region
     allreduce_ms = None
     opt = solver.gen_opt
@@ -613,6 +654,12 @@ def main():
         e1.record()
         fence()
         allreduce_ms = e0.elapsed_time(e1) / 5
+        ar = torch.tensor([allreduce_ms], device=dev)
+        ar_all = [torch.zeros_like(ar) for _ in range(world)]
+        dist.all_gather(ar_all, ar)
+        for i, t in enumerate(ar_all):
+            per_rank[i]["allreduce_ms"] = float(t.item())
+        note("rank %d: all-reduce of the flat gradient buffer alone %.3f ms" % (rank, allreduce_ms))
     # the same steps under the other arithmetics (labelled sub-objects; never the headline)
     also = {}
     if not args.no_also:
@@ -667,6 +714,10 @@ def main():
                        "exchange": "one all-reduce of the flat gradient buffer after the backward pass (the Solver's default)"
                                    if world > 1 else "none (one process)",
                        "persistent_kernels": bool(hb.USE_PERSIST), "retimed_after_abort": retimed,
+                       "backend": (dist.get_backend() if world > 1 else None),
+                       "step_pipeline": "host reads a step's record one step late; the update is predicated on the device on the "
+                                        "abort latch%s" % (" summed over the ranks by the all-reduce (parallel.DpPipeline)" if world > 1 else ""),
+                       "row_geometry_per_gpu": row_geometry(b_local, cfg["enc_hidden_dim"]),
                        "per_rank": per_rank, "sequence_op_paths_per_step": paths},
             "loss": final_loss, "allreduce_ms": allreduce_ms,
             "allreduce": "one collective over the flat gradient buffer after the backward pass",

@@ -473,14 +473,16 @@ int asr_cell_unpack_f32(int D, int O, int E, const float* dwcat, const float* db
 /* ---------------------------------------------------------------------------------------
  * Label log-probabilities with label smoothing (Decoder.forward, model.py:354-366):
  *   out[r] = (1-ls) * log_softmax(logits[r])[index[r]] + ls * sum_v labeldist[v] * log_softmax(logits[r])[v]
- * (labeldist NULL: plain gather of the log-softmax).  rows = L*B; index is int64 (torch long).  The backward writes
- * d(logits) for an upstream gradient grad_out[rows].
+ * (labeldist NULL: plain gather of the log-softmax).  rows = L*B; index is int64 (torch long).  total (NULL, or one float
+ * the caller zeroed) += sum_r out[r]: the training loss -mean(log_probs) (solver.py:377) is that sum times a constant, so
+ * no reduction kernel follows.  The backward writes d(logits) for an upstream gradient grad_out[r * grad_stride]
+ * (grad_stride 0: ONE device scalar for every row - the gradient of that sum).
  * ------------------------------------------------------------------------------------- */
 int asr_label_logprob_fwd(int64_t rows, int V, const float* logits, int64_t ld, const int64_t* index,
-                          const float* labeldist, float ls_weight, float* out, asr_stream_t stream);
+                          const float* labeldist, float ls_weight, float* out, float* total, asr_stream_t stream);
 int asr_label_logprob_bwd(int64_t rows, int V, const float* logits, int64_t ld, const int64_t* index,
-                          const float* labeldist, float ls_weight, const float* grad_out, float* dlogits,
-                          int64_t lddz, asr_stream_t stream);
+                          const float* labeldist, float ls_weight, const float* grad_out, int64_t grad_stride,
+                          float* dlogits, int64_t lddz, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Free-running decoder feedback (Decoder.forward loop, model.py:329-351): one launch per decoder step each way for

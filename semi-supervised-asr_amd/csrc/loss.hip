@@ -9,26 +9,36 @@ namespace {
 __global__ __launch_bounds__(256) void label_logprob_fwd_kernel(int64_t rows, int V, const float* __restrict__ z,
                                                                 int64_t ld, const int64_t* __restrict__ idx,
                                                                 const float* __restrict__ dist, float ls,
-                                                                float* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* zr = z + row * ld;
-  float mx = -INFINITY;
-  for (int v = lane; v < V; v += 64) mx = fmaxf(mx, zr[v]);
-  mx = wave_max(mx);
-  float se = 0.f, sd = 0.f, sdz = 0.f;
-  for (int v = lane; v < V; v += 64) {
-    const float zv = zr[v];
-    se += expf(zv - mx);
-    if (dist) { sd += dist[v]; sdz += dist[v] * zv; }
+                                                                float* __restrict__ y, float* __restrict__ total) {
+  // a wave walks rows blockIdx.x * 4 + wave, + 4 gridDim.x, ...; `total` (optional) += the sum of all y: one atomic per block
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float* zr = z + row * ld;
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, zr[v]);
+    mx = wave_max(mx);
+    float se = 0.f, sd = 0.f, sdz = 0.f;
+    for (int v = lane; v < V; v += 64) {
+      const float zv = zr[v];
+      se += expf(zv - mx);
+      if (dist) { sd += dist[v]; sdz += dist[v] * zv; }
+    }
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    if (dist) { sd = wave_sum(sd); sdz = wave_sum(sdz); }
+    if (lane == 0) {
+      const float lp = zr[idx[row]] - lse;
+      const float out = dist ? (1.f - ls) * lp + ls * (sdz - sd * lse) : lp;
+      y[row] = out;
+      acc += out;
+    }
   }
-  se = wave_sum(se);
-  const float lse = mx + logf(se);
-  if (dist) { sd = wave_sum(sd); sdz = wave_sum(sdz); }
-  if (lane == 0) {
-    const float lp = zr[idx[row]] - lse;
-    y[row] = dist ? (1.f - ls) * lp + ls * (sdz - sd * lse) : lp;
+  if (total) {
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, (part[0] + part[1]) + (part[2] + part[3]));
   }
 }
 
@@ -36,8 +46,8 @@ __global__ __launch_bounds__(256) void label_logprob_fwd_kernel(int64_t rows, in
 __global__ __launch_bounds__(256) void label_logprob_bwd_kernel(int64_t rows, int V, const float* __restrict__ z,
                                                                 int64_t ld, const int64_t* __restrict__ idx,
                                                                 const float* __restrict__ dist, float ls,
-                                                                const float* __restrict__ g, float* __restrict__ dz,
-                                                                int64_t lddz) {
+                                                                const float* __restrict__ g, int64_t gstride,
+                                                                float* __restrict__ dz, int64_t lddz) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -52,7 +62,7 @@ __global__ __launch_bounds__(256) void label_logprob_bwd_kernel(int64_t rows, in
   }
   se = wave_sum(se);
   if (dist) sd = wave_sum(sd);
-  const float inv = 1.0f / se, gr = g[row];
+  const float inv = 1.0f / se, gr = g[row * gstride];
   const int64_t ix = idx[row];
   const float a = dist ? (1.f - ls) : 1.f, b = dist ? ls : 0.f;
   for (int v = lane; v < V; v += 64) {
@@ -66,20 +76,22 @@ __global__ __launch_bounds__(256) void label_logprob_bwd_kernel(int64_t rows, in
 }  // namespace
 
 extern "C" int asr_label_logprob_fwd(int64_t rows, int V, const float* logits, int64_t ld, const int64_t* index,
-                                     const float* labeldist, float ls_weight, float* out, asr_stream_t stream) {
+                                     const float* labeldist, float ls_weight, float* out, float* total,
+                                     asr_stream_t stream) {
   if (rows <= 0 || V <= 0 || !logits || !index || !out) return ASR_E_ARG;
-  hipLaunchKernelGGL(label_logprob_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, V,
-                     logits, ld, index, labeldist, ls_weight, out);
+  const int64_t blocks = (rows + 3) / 4;
+  hipLaunchKernelGGL(label_logprob_fwd_kernel, dim3((unsigned)(total && blocks > 512 ? 512 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, rows, V, logits, ld, index, labeldist, ls_weight, out, total);
   ASR_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int asr_label_logprob_bwd(int64_t rows, int V, const float* logits, int64_t ld, const int64_t* index,
-                                     const float* labeldist, float ls_weight, const float* grad_out, float* dlogits,
-                                     int64_t lddz, asr_stream_t stream) {
+                                     const float* labeldist, float ls_weight, const float* grad_out,
+                                     int64_t grad_stride, float* dlogits, int64_t lddz, asr_stream_t stream) {
   if (rows <= 0 || V <= 0 || !logits || !index || !grad_out || !dlogits) return ASR_E_ARG;
   hipLaunchKernelGGL(label_logprob_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, V,
-                     logits, ld, index, labeldist, ls_weight, grad_out, dlogits, lddz);
+                     logits, ld, index, labeldist, ls_weight, grad_out, grad_stride, dlogits, lddz);
   ASR_CHECK_LAUNCH();
   return 0;
 }

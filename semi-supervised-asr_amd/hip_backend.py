@@ -106,8 +106,8 @@ def load():
     lib.asr_dec_seq_bwd_persist_free.argtypes = [ctypes.POINTER(DecBwd), ctypes.POINTER(DecFeedbackBwd), c_p, c_p, c_p, c_p]
     lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]
-    lib.asr_label_logprob_fwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p]
-    lib.asr_label_logprob_bwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p, c_i64, c_p]
+    lib.asr_label_logprob_fwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p, c_p]
+    lib.asr_label_logprob_bwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_i64, c_p, c_i64, c_p]
     lib.asr_dec_feedback_fwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_i64,
                                          c_p, c_p, c_p, c_p, c_p, c_i64, c_p]
     lib.asr_dec_feedback_bwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_f, c_p, c_p]

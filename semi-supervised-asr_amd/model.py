@@ -366,8 +366,10 @@ class Decoder(torch.nn.Module):
             key = str(dev)
             if key not in self._dist_dev:
                 self._dist_dev[key] = self.vlabeldist.to(dev).float().contiguous()
-        ys_log_probs = ops.label_logprob(logits, index_lb, self._dist_dev[str(dev)] if smooth_on else None,
-                                         self.ls_weight if smooth_on else 0.0).transpose(0, 1)
+        ys_log_probs, total = ops.label_logprob(logits, index_lb, self._dist_dev[str(dev)] if smooth_on else None,
+                                                self.ls_weight if smooth_on else 0.0, with_sum=True)
+        ys_log_probs = ys_log_probs.transpose(0, 1)
+        ys_log_probs.fused_sum = total         # sum of all entries, from the same kernel (parallel.local_loss uses it)
         return logits.transpose(0, 1), ys_log_probs, prediction, ws
 
 
@@ -425,6 +427,7 @@ class LM(torch.nn.Module):
         self.dropout_rate, self.n_layers = dropout_rate, n_layers
         self.ls_weight = ls_weight
         self.labeldist = labeldist
+        self._dist_dev = {}
         if labeldist is not None:
             self.vlabeldist = cc(torch.from_numpy(np.array(labeldist, dtype=np.float32)))
 
@@ -457,13 +460,15 @@ class LM(torch.nn.Module):
         out = self._run_lstm(eys.transpose(0, 1).contiguous(), lens_dev).transpose(0, 1)
         out = self.dropout_layer(out)
         logits = ops.linear(out.contiguous(), self.output_layer.weight, self.output_layer.bias)
-        log_probs = F.log_softmax(logits, dim=2)
-        probs = F.softmax(logits, dim=2)
-        ys_log_probs = torch.gather(log_probs, dim=2, index=tok_out.unsqueeze(2)).squeeze(2)
-        ys_probs = torch.gather(probs, dim=2, index=tok_out.unsqueeze(2)).squeeze(2)
+        # log_softmax -> gather -> label smoothing (model.py:523-531) on the decoder's kernel (asr_label_logprob_*)
+        plain = ops.label_logprob(logits, tok_out)                    # log p(target)
+        ys_probs = plain.exp()
         if self.ls_weight > 0 and self.training:
-            reg = torch.sum(log_probs * self.vlabeldist.to(dev), dim=2)
-            ys_log_probs = (1 - self.ls_weight) * ys_log_probs + self.ls_weight * reg
+            if str(dev) not in self._dist_dev:
+                self._dist_dev[str(dev)] = self.vlabeldist.to(dev).float().contiguous()
+            ys_log_probs = ops.label_logprob(logits, tok_out, self._dist_dev[str(dev)], self.ls_weight)
+        else:
+            ys_log_probs = plain
         predictions = torch.argmax(logits, dim=-1)
         return ys_log_probs, ys_probs, predictions
 

@@ -62,6 +62,84 @@ class _Pool(object):
 _POOL = _Pool()
 
 
+# -------------------------------------------------------------------------------------- accumulator arena
+class _Arena(object):
+    """Every buffer of a train step that has to START FROM ZERO - split-K GEMM outputs (their partial products meet in
+    atomics), bias-gradient sums, the accumulators of the sequence operators' backward passes - cut from ONE buffer that
+    ONE fill zeroes at the start of the step (Solver._step opens the scope: `with ops.step_arena(device)`), instead of a
+    zero pass or a memset in front of each (39 fills per cfg-2 step, 0.2 ms).  A slice is valid until the next scope opens;
+    outside a scope, and for what does not fit yet (the buffer grows to the step's need at the next scope), take() returns
+    None and the caller falls back to its own zero fill."""
+
+    def __init__(self):
+        self.buf, self.cursor, self.want, self.active = None, 0, 0, False
+
+    def begin(self, device):
+        device = torch.device(device)
+        if self.buf is None or self.buf.device != device or self.buf.numel() < self.want:
+            # (first step, or the last step asked for more than there is: a new, larger buffer - zeros already)
+            self.buf = torch.zeros(int(self.want * 1.25) + 4096, device=device, dtype=torch.float32) if self.want > 0 else None
+        elif self.cursor > 0:
+            self.buf[:self.cursor].zero_()               # what the previous step used: ONE fill
+        self.cursor, self.want, self.active = 0, 0, True
+
+    def end(self):
+        self.active = False
+
+    def take(self, shape, device):
+        if not self.active:
+            return None
+        n = 1
+        for v in shape:
+            n *= int(v)
+        n4 = (n + 3) // 4 * 4                            # slices stay 16-byte aligned
+        self.want += n4
+        if self.buf is None or self.buf.device != torch.device(device) or self.cursor + n4 > self.buf.numel():
+            return None
+        out = self.buf[self.cursor:self.cursor + n].view(*shape)
+        self.cursor += n4
+        return out
+
+
+_ARENA = _Arena()
+
+
+class step_arena(object):
+    """Scope of one train step (forward + backward + optimiser): see _Arena."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        if torch.device(self.device).type == "cuda":
+            _ARENA.begin(self.device)
+        return _ARENA
+
+    def __exit__(self, *exc):
+        _ARENA.end()
+        return False
+
+
+def zeros_acc(shape, device):
+    """A zero-initialised accumulator: a slice of the step's arena when there is one, else a fresh zero tensor."""
+    t = _ARENA.take(shape, device)
+    return t if t is not None else torch.zeros(*shape, device=device, dtype=torch.float32)
+
+
+def _gemm_acc(A, B, trans_a=False, trans_b=False, shape=None):
+    """A product into a fresh output that no epilogue follows (the weight gradients): inside a step's arena the output is a
+    pre-zeroed slice and the library accumulates into it - no zero pass in front of a split-K product."""
+    out = _ARENA.take(shape, A.device) if shape is not None else None
+    if out is None:
+        return hb.gemm(A, B, trans_a=trans_a, trans_b=trans_b)
+    return hb.gemm(A, B, trans_a=trans_a, trans_b=trans_b, out=out, accumulate=True)
+
+
+def _colsum_acc(X):
+    out = _ARENA.take((X.shape[1],), X.device)
+    return hb.colsum(X) if out is None else hb.colsum(X, out=out, accumulate=True)
+
+
 # --------------------------------------------------------------------------------------
 def _with_saved_arith(bwd):
     """The backward of a sequence operator runs under the product arithmetic its FORWARD ran under (ctx.arith), not under
@@ -107,8 +185,8 @@ class _Linear(torch.autograd.Function):
         elif ctx.relu:
             dy2 = dy2 * (y > 0).to(dy2.dtype)
         dx = hb.gemm(dy2, weight).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
-        dw = hb.gemm(dy2, x2, trans_a=True)
-        db = hb.colsum(dy2) if ctx.has_bias else None
+        dw = _gemm_acc(dy2, x2, trans_a=True, shape=(dy2.shape[1], x2.shape[1]))
+        db = _colsum_acc(dy2) if ctx.has_bias else None
         return dx, dw, db, None, None
 
 
@@ -201,7 +279,13 @@ class _LstmLayer(torch.autograd.Function):
         ws = _lstm_views(lease.ws, T, B, H, ndir)      # (the views of THIS call's shape: the buffers are shared by capacity)
         dev = dy.device
         dyc = dy if dy.is_contiguous() else ws["dy"].copy_(dy)
-        ws["zbuf"].zero_()                     # dcarry, dw_hh, db
+        zb = _ARENA.take((ws["zbuf"].numel(),), dev)
+        if zb is None:
+            ws["zbuf"].zero_()                 # dcarry, dw_hh, db
+        else:                                  # ... or their places in the step's arena (zeroed with everything else)
+            nb_, n2 = ws["dcarry"].numel(), ws["dw_hh"].numel()
+            ws = dict(ws, dcarry=zb[:nb_].view_as(ws["dcarry"]), dw_hh=zb[nb_:nb_ + n2].view_as(ws["dw_hh"]),
+                      db=zb[nb_ + n2:].view_as(ws["db"]))
         gates, y = ws["gates"], ws["y"]
         # the transposed recurrent weights are only formed if the kernel that reads the forward layout does not apply
         fused_dw, fused_db = hb.lstm_seq_bwd(gates, lambda: ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2)), ws["lens"], dyc,
@@ -209,8 +293,8 @@ class _LstmLayer(torch.autograd.Function):
                                              w_hh=ws["w_hh"], rows=ctx.rows)                    # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
-        dw_ih = hb.gemm(dG, x2, trans_a=True)                     # [ndir*4H, I]
-        db = ws["db"] if fused_db else hb.colsum(dG)       # the persistent kernels sum the bias gradient themselves
+        dw_ih = _gemm_acc(dG, x2, trans_a=True, shape=(ndir * 4 * H, I))      # [ndir*4H, I]
+        db = ws["db"] if fused_db else _colsum_acc(dG)     # the persistent kernels sum the bias gradient themselves
         if not fused_dw and T > 1:
             # dW_hh[d] = sum_t dG_t[d]^T h_prev(t), h_prev = y[t-1] (d = 0) or y[t+1] (reverse direction): ONE batched GEMM
             # over the directions, K = (T-1)*B, accumulated into the zeroed dw_hh (no zero pass of its own).
@@ -579,20 +663,27 @@ class _DecoderSeq(torch.autograd.Function):
         if dlogits is None:
             dlogits = torch.zeros(L, B, V, device=dev, dtype=torch.float32)
         dlog2 = dlogits.contiguous().view(L * B, V)
+        zb = _ARENA.take((wk["zbuf"].numel(),), dev)
+        if zb is None:
+            wk["zbuf"].zero_()                 # G, dwext, dP, dcell, dgvec_part, dwatt_part, dconv_part
+        else:                                  # ... or their places in the step's arena (zeroed with everything else)
+            wk = dict(wk)
+            for k_ in ("G", "dwext", "dP", "dcell", "dgvec_part", "dwatt_part", "dconv_part"):
+                o_ = (wk[k_].data_ptr() - wk["zbuf"].data_ptr()) // 4
+                wk[k_] = zb[o_:o_ + wk[k_].numel()].view_as(wk[k_])
         G = wk["G"]
-        wk["zbuf"].zero_()                     # G, dwext, dP, dcell, dgvec_part, dwatt_part, dconv_part
         wk["wcatT"].copy_(wk["wcat"].t())
         wk["wdecT"].copy_(wdec.t())
         XO = X[1:].view(L * B, KX)[:, :D + O]
         hb.gemm(dlog2, w_out, out=G[1:].view(L * B, KX)[:, :D + O])
-        dw_out = hb.gemm(dlog2, XO, trans_a=True)
-        db_out = hb.colsum(dlog2)
+        dw_out = _gemm_acc(dlog2, XO, trans_a=True, shape=(V, D + O))
+        db_out = _colsum_acc(dlog2)
         w = dict(wk)
         if dws is not None:
             wk["dws"].copy_(dws)
         else:
             w["dws"] = None
-        demb_w = torch.zeros_like(emb_w)
+        demb_w = zeros_acc(tuple(emb_w.shape), dev)
         if not ctx.smooth:
             groups = hb.row_groups(B)
             done = False
@@ -674,9 +765,9 @@ class _DecoderSeq(torch.autograd.Function):
         # deferred weight gradients: one GEMM each over the whole sequence
         dg2 = wk["dgates"].view(L * B, 4 * D)
         Xin = X[:L] if Xd is None else Xd[:L]
-        dwcat = hb.gemm(dg2, Xin.reshape(L * B, KX), trans_a=True)               # [4D, KX] gate-interleaved rows
-        dw_ih, dw_hh, dbias = hb.cell_unpack(dwcat, hb.colsum(dg2), D, O, E)         # -> torch layout, one launch
-        dwdec = hb.gemm(wk["dD"].view(L * B, A), X[1:].view(L * B, KX)[:, :D], trans_a=True)
+        dwcat = _gemm_acc(dg2, Xin.reshape(L * B, KX), trans_a=True, shape=(4 * D, KX))     # [4D, KX] gate-interleaved rows
+        dw_ih, dw_hh, dbias = hb.cell_unpack(dwcat, _colsum_acc(dg2), D, O, E)       # -> torch layout, one launch
+        dwdec = _gemm_acc(wk["dD"].view(L * B, A), X[1:].view(L * B, KX)[:, :D], trans_a=True, shape=(A, D))
         dgvec = wk["dgvec_part"].sum(0).view(1, A)
         dwatt = wk["dwatt_part"].sum(0)
         dconvw = wk["dconv_part"].sum(0).view(C, 1, 1, 2 * K + 1)
@@ -685,7 +776,7 @@ class _DecoderSeq(torch.autograd.Function):
         dctx_base = G[1:]                               # [L, B, KX], ctx grad at columns D:D+O
         hb.gemm_batched(wk["ws"], dctx_base[:, :, D:], dQ, True, False, Tp, O, L, B * Tp, B * KX, O, B, Tp, KX,
                         Tp * O)
-        dbo = hb.colsum(dctx_base.view(L * B, KX)[:, D:D + O])
+        dbo = _colsum_acc(dctx_base.view(L * B, KX)[:, D:D + O])
         # embedding gradient for token-fed steps
         demb_all = G[:L, :, D + O:]
         if torch.is_tensor(probs_saved):   # smooth feedback: only step 0 was fed a token (<BOS>)
@@ -695,7 +786,7 @@ class _DecoderSeq(torch.autograd.Function):
         else:
             tokfed = fed >= 0
             demb_w.index_add_(0, fed[tokfed], demb_all[tokfed])
-        dP = wk["dP"].clone()
+        dP = wk["dP"] if zb is not None else wk["dP"].clone()      # (an arena slice outlives the lease)
         lease.release()
         return (dP, dQ, demb_w, dw_ih, dw_hh, dbias, dbias, dwdec, dconvw, dwatt, dgvec, dbo, dw_out, db_out,
                 None, None)
@@ -703,36 +794,48 @@ class _DecoderSeq(torch.autograd.Function):
 
 class _LabelLogProb(torch.autograd.Function):
     """(1-ls) log_softmax(logits)[target] + ls sum_v labeldist_v log_softmax(logits)_v  (model.py:354-366) in one
-    kernel each way.  logits [..., V] contiguous, index [...] long -> [...]"""
+    kernel each way.  logits [..., V] contiguous, index [...] long -> ([...], total): `total` (with_sum) is the sum of all
+    outputs, accumulated by the same kernel - the training loss is that sum times a constant (solver.py:377), so neither a
+    reduction kernel nor its backward follows; a gradient that arrives through `total` alone is one device scalar,
+    broadcast by the backward kernel."""
 
     @staticmethod
-    def forward(ctx, logits, index, labeldist, ls_weight):
+    def forward(ctx, logits, index, labeldist, ls_weight, with_sum):
         lg = logits.contiguous()
         V = lg.shape[-1]
         rows = lg.numel() // V
         idx = index.contiguous()
         out = torch.empty(lg.shape[:-1], device=lg.device, dtype=torch.float32)
+        total = torch.zeros((), device=lg.device, dtype=torch.float32) if with_sum else None
         dist = labeldist.contiguous() if labeldist is not None else None
         hb.check(hb.load().asr_label_logprob_fwd(rows, V, hb.ptr(lg), V, ctypes.c_void_p(idx.data_ptr()), hb.ptr(dist),
-                                                 float(ls_weight), hb.ptr(out), hb.stream()), "asr_label_logprob_fwd")
+                                                 float(ls_weight), hb.ptr(out), hb.ptr(total), hb.stream()),
+                 "asr_label_logprob_fwd")
         ctx.save_for_backward(lg, idx, dist)
         ctx.ls = float(ls_weight)
-        return out
+        ctx.set_materialize_grads(False)
+        return out, total
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gt):
         lg, idx, dist = ctx.saved_tensors
         V = lg.shape[-1]
         rows = lg.numel() // V
-        gc = g.contiguous()
+        if g is None and gt is None:
+            return None, None, None, None, None
+        if g is None:
+            gc, stride = gt.contiguous(), 0                  # d(total) alone: one scalar for every row
+        else:
+            gc, stride = (g if gt is None else g + gt).contiguous(), 1
         dz = torch.empty_like(lg)
         hb.check(hb.load().asr_label_logprob_bwd(rows, V, hb.ptr(lg), V, ctypes.c_void_p(idx.data_ptr()), hb.ptr(dist),
-                                                 ctx.ls, hb.ptr(gc), hb.ptr(dz), V, hb.stream()), "asr_label_logprob_bwd")
-        return dz, None, None, None
+                                                 ctx.ls, hb.ptr(gc), stride, hb.ptr(dz), V, hb.stream()), "asr_label_logprob_bwd")
+        return dz, None, None, None, None
 
 
-def label_logprob(logits, index, labeldist=None, ls_weight=0.0):
-    return _LabelLogProb.apply(logits, index, labeldist, ls_weight)
+def label_logprob(logits, index, labeldist=None, ls_weight=0.0, with_sum=False):
+    out, total = _LabelLogProb.apply(logits, index, labeldist, ls_weight, with_sum)
+    return (out, total) if with_sum else out
 
 
 def decoder_sequence(P, Q, emb_w, w_ih, w_hh, b_ih, b_hh, wdec, convw, watt, gvec, bo, w_out, b_out, w0, opts):

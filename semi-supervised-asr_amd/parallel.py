@@ -80,8 +80,12 @@ def shard_batch(xs, ilens, ys, rank, world):
 
 
 def local_loss(log_probs, info):
-    """-sum over this shard / (B_global * olength_global)  (solver.py:377 is the W=1 case)."""
-    return -log_probs.sum() / float(info["b_global"] * log_probs.shape[1])
+    """-sum over this shard / (B_global * olength_global)  (solver.py:377 is the W=1 case).  The product's decoder hands the
+    sum along with the log-probabilities (`fused_sum`, accumulated by the kernel that made them): one multiply is left."""
+    total = getattr(log_probs, "fused_sum", None)
+    if total is None:
+        total = log_probs.sum()
+    return total * (-1.0 / float(info["b_global"] * log_probs.shape[1]))
 
 
 def world():

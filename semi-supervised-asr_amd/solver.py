@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 import hip_backend as hb
+import ops
 import parallel
 from dataloader import get_data_loader, _raw_items, _raw_texts
 from dataset import PickleDataset
@@ -355,6 +356,11 @@ class Solver(object):
         buffer) as the device-side predicate - every rank skips or none does - and the coordinated repeat of _dp_step one
         step late (parallel.DpPipeline).  Every rank resolves its StepScalars at the same points of the program (the loops
         below run the same code on all ranks): a recovery is a sequence of collectives."""
+        dev0 = opt.buf.flat_g.device
+        with ops.step_arena(dev0):       # every zero-initialised accumulator of the step comes out of one buffer, one fill
+            return self._step_inner(make_local, opt, n_scalars)
+
+    def _step_inner(self, make_local, opt, n_scalars):
         depth = min(int(self.config.get("pipeline_steps", self.PIPELINE_STEPS)), self.PINNED_ROWS - 2)   # one landing row each
         if self.world > 1 or parallel.FORCE_DP:
             if depth <= 0 or opt.buf.flat_g.device.type != "cuda":

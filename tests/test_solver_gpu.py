@@ -208,6 +208,7 @@ def _tiny_solver(root, monkeypatch, t=None, l=None, seeds=(11, 31, 12, 32), **ov
         mod.labeldist = synth.labeldist(nv, seed)
         mod.vlabeldist = torch.from_numpy(np.asarray(mod.labeldist, dtype=np.float32)).to(dev)
     solver.model.decoder._dist_dev = {}
+    solver.judge._dist_dev = {}
     solver.proportion = 0.5
     return solver, dev
 
