@@ -1326,6 +1326,10 @@ typedef unsigned gu32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) gu32x2* lds_u2ptr;
 typedef __attribute__((address_space(3))) const gu32x4* lds_q4ptr;
 typedef __attribute__((address_space(3))) char* lds_cptr;
+// an LDS byte address held in a 32-bit register -> a typed LDS pointer.  Through uintptr_t: the host pass of the HIP
+// compile parses this code with 64-bit pointers and (rightly) objects to a cast from a narrower integer.
+template <typename P>
+__device__ __forceinline__ P lds_at(unsigned a) { return (P)(uintptr_t)a; }
 
 // split four consecutive k of one row and store them into the NT images at LDS byte address a, a + plane, a + 2 plane
 template <int NT>
@@ -1343,9 +1347,9 @@ __device__ __forceinline__ void bfs_write4(unsigned a, int plane, float x0, floa
   if constexpr (NT > 2) asm volatile("" ::"v"(p0[2]), "v"(p1[2]));
   return;
 #endif
-  *(lds_u2ptr)(a) = gu32x2{p0[0], p1[0]};
-  *(lds_u2ptr)(a + plane) = gu32x2{p0[1], p1[1]};
-  if constexpr (NT > 2) *(lds_u2ptr)(a + 2 * plane) = gu32x2{p0[2], p1[2]};
+  *lds_at<lds_u2ptr>(a) = gu32x2{p0[0], p1[0]};
+  *lds_at<lds_u2ptr>(a + plane) = gu32x2{p0[1], p1[1]};
+  if constexpr (NT > 2) *lds_at<lds_u2ptr>(a + 2 * plane) = gu32x2{p0[2], p1[2]};
 }
 
 template <bool AKC, bool BKC, int NT, bool KT>
@@ -1522,14 +1526,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bfs_kernel(GemmArgs g) {
     constexpr int KS = decltype(kstag)::value, Qs = decltype(qtag)::value, BUF = decltype(btag)::value;
     if constexpr (Qs < 4) {
       const unsigned a = rA[BUF][KS] + Qs * 2048;
-      FA[KS][Qs][0] = *(lds_q4ptr)(a);
-      FA[KS][Qs][1] = *(lds_q4ptr)(a + PLA);
-      if constexpr (NT > 2) FA[KS][Qs][2] = *(lds_q4ptr)(a + 2 * PLA);
+      FA[KS][Qs][0] = *lds_at<lds_q4ptr>(a);
+      FA[KS][Qs][1] = *lds_at<lds_q4ptr>(a + PLA);
+      if constexpr (NT > 2) FA[KS][Qs][2] = *lds_at<lds_q4ptr>(a + 2 * PLA);
     } else {
       const unsigned a = rB[BUF][KS] + (Qs - 4) * 2048;
-      FB[KS][Qs - 4][0] = *(lds_q4ptr)(a);
-      FB[KS][Qs - 4][1] = *(lds_q4ptr)(a + PLB);
-      if constexpr (NT > 2) FB[KS][Qs - 4][2] = *(lds_q4ptr)(a + 2 * PLB);
+      FB[KS][Qs - 4][0] = *lds_at<lds_q4ptr>(a);
+      FB[KS][Qs - 4][1] = *lds_at<lds_q4ptr>(a + PLB);
+      if constexpr (NT > 2) FB[KS][Qs - 4][2] = *lds_at<lds_q4ptr>(a + 2 * PLB);
     }
   };
 #define BFS(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a_), __builtin_bit_cast(gbf16x8, b_), c_, 0, 0, 0)
@@ -1790,9 +1794,9 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned a = rimg[BUF] + i * 32 * ROWB + 32 * KSI;
-      FA[SL][i][0] = *(lds_q4ptr)(a);
-      FA[SL][i][1] = *(lds_q4ptr)(a + PLANE);
-      if constexpr (NT > 2) FA[SL][i][2] = *(lds_q4ptr)(a + 2 * PLANE);
+      FA[SL][i][0] = *lds_at<lds_q4ptr>(a);
+      FA[SL][i][1] = *lds_at<lds_q4ptr>(a + PLANE);
+      if constexpr (NT > 2) FA[SL][i][2] = *lds_at<lds_q4ptr>(a + 2 * PLANE);
     }
   };
 #define BFK(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, a_), __builtin_bit_cast(gbf16x8, b_), c_, 0, 0, 0)
@@ -1868,9 +1872,9 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const unsigned a = bbase + 32 * ks;
-      FB[ks][0] = *(lds_q4ptr)(a);
-      FB[ks][1] = *(lds_q4ptr)(a + PLANE);
-      if constexpr (NT > 2) FB[ks][2] = *(lds_q4ptr)(a + 2 * PLANE);
+      FB[ks][0] = *lds_at<lds_q4ptr>(a);
+      FB[ks][1] = *lds_at<lds_q4ptr>(a + PLANE);
+      if constexpr (NT > 2) FB[ks][2] = *lds_at<lds_q4ptr>(a + 2 * PLANE);
     }
   }
 #define X_UNA0(u_) unit(I0(), std::integral_constant<int, u_>(), I0())
@@ -1916,13 +1920,17 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
       products(SL(), std::integral_constant<int, ks_>(), PT());                                                         \
       if ((ks_) + 1 < KS) read_fa(SN(), std::integral_constant<int, ((ks_) + 1 < KS ? (ks_) + 1 : 0)>(), PT());        \
       else if (has_next) read_fa(SN(), I0(), PN());                                                                     \
-      if (has_next && (ks_) < KS - 1 && !(ASR_GK_ABL & 2)) {                                                            \
-        constexpr int u0 = (ks_) * HP / (KS - 1), u1 = ((ks_) + 1) * HP / (KS - 1);                                     \
-        if constexpr (u0 < u1) BFK_UNIT(u0)                                                                             \
-        if constexpr (u0 + 1 < u1) BFK_UNIT(u0 + 1)                                                                     \
-        if constexpr (u0 + 2 < u1) BFK_UNIT(u0 + 2)                                                                     \
+      if constexpr ((ks_) < KS - 1) {          /* (constexpr: the discarded branch would index past RA / acc) */         \
+        if (has_next && !(ASR_GK_ABL & 2)) {                                                                            \
+          constexpr int u0 = (ks_) * HP / (KS - 1), u1 = ((ks_) + 1) * HP / (KS - 1);                                   \
+          if constexpr (u0 < u1) BFK_UNIT(u0)                                                                           \
+          if constexpr (u0 + 1 < u1) BFK_UNIT(u0 + 1)                                                                   \
+          if constexpr (u0 + 2 < u1) BFK_UNIT(u0 + 2)                                                                   \
+        }                                                                                                               \
       }                                                                                                                 \
-      if (has_prev && (ks_) < 4) store_half(PN(), std::integral_constant<int, ((ks_) / 2)>(), std::integral_constant<int, (ks_) & 1>(), mt - groups); \
+      if constexpr ((ks_) < 4) {                                                                                        \
+        if (has_prev) store_half(PN(), std::integral_constant<int, ((ks_) / 2)>(), std::integral_constant<int, (ks_) & 1>(), mt - groups); \
+      }                                                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                                \
     }
     BFK_STEP(0) BFK_STEP(1) BFK_STEP(2) BFK_STEP(3)

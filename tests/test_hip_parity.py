@@ -1818,3 +1818,71 @@ def test_decoder_kernel_raises_its_own_abort_and_the_next_launch_is_clean():
     assert not hb.persist_aborted(dev)
     assert torch.equal(again_w, want_w), "the kernel's own outputs are bit-identical to those before the fault"
     _close(again_l, want_l, rtol=1e-5, atol=1e-6, what="logits after the fault")     # (a split-K product: atomics, run-to-run order)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("with_labels", [False, True])
+def test_sampled_decoding_with_injected_draws(monkeypatch, with_labels):
+    """sample=True (model.py:347-351: Categorical(logits).sample() instead of argmax) cannot match across RNGs, so - like
+    the dropout masks - the DRAWS are injected: both sides turn the same pre-drawn uniforms into tokens through the inverse
+    CDF of their own probabilities.  Free-running sampling (ys=None) and scheduled sampling whose non-teacher steps feed the
+    SAMPLED token (ys given, tf_rate 0.5): predictions, log-probabilities, attention and every gradient against the oracle."""
+    dev = _gpu()
+    cfg = dict(synth.TINY)
+    ld = synth.labeldist(9, 12)
+    w = synth.e2e_weights(cfg, 11)
+    xs, ilens, ys = synth.batch(8, 9, synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    steps = 6
+    draws = torch.rand(64, len(ilens), generator=torch.Generator().manual_seed(77))
+    state = {"k": 0}
+
+    def inverse_cdf(self, sample_shape=torch.Size()):
+        u = draws[state["k"]].to(self.probs.device)
+        state["k"] += 1
+        cdf = torch.cumsum(self.probs.double(), dim=-1)
+        return (cdf < u.double().unsqueeze(-1)).sum(-1).clamp(max=self.probs.shape[-1] - 1)
+
+    monkeypatch.setattr(torch.distributions.Categorical, "sample", inverse_cdf)
+    net = _product(cfg, w, ld, dev)
+    kw = dict(sample=True, max_dec_timesteps=steps, tf_rate=0.5 if with_labels else 1.0)
+    state["k"] = 0
+    np.random.seed(4)
+    _, lp, pred, ws = net(torch.from_numpy(xs).to(dev), ilens,
+                          [torch.from_numpy(y).to(dev) for y in ys] if with_labels else None, **kw)
+    used = state["k"]
+    sd = O.make_leaf_state(w)
+    state["k"] = 0
+    np.random.seed(4)
+    _, rlp, rpred, rws = O.e2e_forward(sd, dict(cfg, labeldist=ld), torch.from_numpy(xs), ilens,
+                                       [torch.from_numpy(y) for y in ys] if with_labels else None, **kw)
+    assert used == state["k"] == pred.shape[1], "one draw per decoder step on both sides"
+    assert torch.equal(pred.cpu(), rpred), "the sampled hypotheses agree token for token"
+    _close(lp, rlp, what="log-probs of the sampled hypothesis"); _close(ws, rws, what="attention weights")
+    names = O.unique_param_names(sd)
+    rg = dict(zip(names, torch.autograd.grad(-rlp.mean(), [sd[n] for n in names])))
+    net.zero_grad()
+    (-lp.mean()).backward()
+    for n, gr in _grads(net).items():
+        _close(gr, rg[n], atol=1e-6, what="grad " + n)
+
+
+def test_greedy_decoding_with_a_large_vocabulary():
+    """V > 128 is outside the fused feedback kernels (their logits tile) and V > 64 outside the persistent free-running
+    kernel: greedy decoding then runs on the per-step kernels + torch glue (ops._DecoderSeq) - against the oracle."""
+    dev = _gpu()
+    cfg = dict(synth.TINY, output_dim=140)
+    ld = synth.labeldist(140, 12)
+    w = synth.e2e_weights(cfg, 17)
+    xs, ilens, _ = synth.batch(8, 140, synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    net = _product(cfg, w, ld, dev)
+    _, lp, pred, ws = net(torch.from_numpy(xs).to(dev), ilens, None, max_dec_timesteps=5)
+    sd = O.make_leaf_state(w)
+    _, rlp, rpred, rws = O.e2e_forward(sd, dict(cfg, labeldist=ld), torch.from_numpy(xs), ilens, None, max_dec_timesteps=5)
+    assert torch.equal(pred.cpu(), rpred)
+    _close(lp, rlp, what="lp"); _close(ws, rws, what="ws")
+    names = O.unique_param_names(sd)
+    rg = dict(zip(names, torch.autograd.grad(-rlp.mean(), [sd[n] for n in names])))
+    net.zero_grad()
+    (-lp.mean()).backward()
+    for n, gr in _grads(net).items():
+        _close(gr, rg[n], atol=1e-6, what="grad " + n)
