@@ -84,6 +84,10 @@ constexpr int PW = 8;            // waves per workgroup
 constexpr int PNT = PW * 64;     // 512 threads
 constexpr int PRG = 8;           // batch rows per XCD group
 
+// Row of (time tt, this thread's batch row) in gates / y / c / dy.  A macro over the kernel's locals (B, prow, pbase, pext) and
+// its template parameter PACKED; see PersistArgs and the note in lstm_persist_bwd_rs_kernel.
+#define ROW_AT(tt_) (PACKED ? (int64_t)(pbase + ((tt_) < pext ? (tt_) : pext - 1)) : ((int64_t)(tt_) * B + prow))
+
 struct PersistArgs {
   int T, B, nb, ndir;
   float* gates;         // [T][B][ndir][4H]
@@ -109,7 +113,7 @@ struct PersistArgs {
 // ---------------------------------------------------------------------------------------------------- forward
 // NR = batch rows per group actually used (8, or 4 for small batches: half the MFMA work and half the gather per step;
 // the exchange and LDS layouts keep their 8-row shape, rows NR..7 are simply never touched).
-template <int PH, int NR>
+template <int PH, int NR, bool PACKED = false>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   static_assert(NR == 4 || NR == PRG, "rows per group");
   constexpr int PKW = PH / PW;     // K columns per wave
@@ -149,9 +153,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
-  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
-  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
-  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
+  // row of (time, this thread's batch row): see PersistArgs and the note in lstm_persist_bwd_rs_kernel
+  const int pbase = (PACKED && prow_ok) ? a.rowbase[prow] : 0;
+  const int pext = PACKED ? (prow_ok ? a.rowext[prow] : 1) : a.T;
   float c_prev = 0.f;
   u64* xch_g = a.xch + (int64_t)g * PRG * PH;          // + parity * 8*PRG*PH
   float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * PRG;   // word protocol: [parity][unit][row]
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
   // left the pointwise waves waiting ~1 300 cycles there (tools/lstm_trace.py).
   auto gx_ptr = [&](int sn) {
     const int tt = d == 0 ? sn : T - 1 - sn;
-    return reinterpret_cast<const float4*>(a.gates + (row_at(tt) * ndir + d) * 4 * PH + punit * 4);
+    return reinterpret_cast<const float4*>(a.gates + (ROW_AT(tt) * ndir + d) * 4 * PH + punit * 4);
   };
   float4 gx_n1 = make_float4(0.f, 0.f, 0.f, 0.f), gx_n2 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (prow_ok) {
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     const float4 gx = gx_n1;
     gx_n1 = gx_n2;
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (row_at(t) * ndir + d) * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (ROW_AT(t) * ndir + d) * 4 * PH + punit * 4);
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       // Single-stage hand-off, 16-byte reads: h_{t-1} travels as LSB-tagged fp32 words laid out [unit][row], so the rows
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
 #ifdef ASR_LP_TRACE3   /* visibility probe: global 100 MHz clock at the publish of (slice 28, row 7, its first unit) ... */
       if (g == 0 && slice == 28 && tid == 7 && s < 64) ((unsigned long long*)a.ctrl)[16 + 2 * s] = wall_clock64();
 #endif
-      if (prow_ok && t < pext) {
+      if (prow_ok && (!PACKED || t < pext)) {
         st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
         st_gp = gp;
-        st_so = row_at(t) * ldy + d * PH + punit;
+        st_so = ROW_AT(t) * ldy + d * PH + punit;
       }
       LP_MARK(6);
     }
@@ -306,9 +310,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_kernel(PersistArgs a) {
     a.y[st_so] = st_y;
   }
   // packed rows: the block's padding rows behind the T steps that were run (times T .. rowext - 1; PersistArgs)
-  if (prow_ok) {
+  if constexpr (PACKED) if (prow_ok) {
     for (int tt = T; tt < pext; ++tt) {
-      const int64_t so = row_at(tt) * ldy + d * PH + punit;
+      const int64_t so = ROW_AT(tt) * ldy + d * PH + punit;
       a.c[so] = 0.f;
       a.y[so] = 0.f;
     }
@@ -408,7 +412,7 @@ __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, const 
 // RG = rows of a group in the exchange / LDS layouts: 8 (NR = 8 or 4 active rows), or 16 (NR = 16: batches of >= 64 rows run
 // 16 rows per XCD group - the MFMA's 16 batch columns all carry rows, six products per tile and k-step instead of the
 // folded four, twice the gather - so that two 32-row blocks share one traversal of the chain).
-template <int PH, int NR, int NT, int RG = PRG>
+template <int PH, int NR, int NT, int RG = PRG, bool PACKED = false>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a) {
   static_assert((RG == PRG && (NR == 4 || NR == PRG)) || (RG == 16 && NR == 16), "rows per group");
   constexpr bool FOLD = NT == 3 && RG == 8;        // the idle batch columns 8..15 carry a second term (fold_halves)
@@ -467,16 +471,23 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
-  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
-  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
-  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
+  // Row of (time, this thread's batch row); see PersistArgs.  PACKED is a template parameter, not a run-time branch: the
+  // time-major instantiation must compile from the expression it was tuned with.  These kernels live on the register
+  // allocator's goodwill - the forward data of a step is prefetched two steps ahead, and an allocation that cannot give a
+  // 16-byte load the four registers its value stays in copies it out of a temporary RIGHT BEHIND the load: a wait for an
+  // HBM first touch on the serial chain (bwd 1.80 -> 2.30 us per time step when the run-time form of this map moved it).
+  // tools/isa_waits.py lists the vmcnt waits of a kernel's loop; none may follow the prefetch loads.
+  const int pbase = (PACKED && prow_ok) ? a.rowbase[prow] : 0;
+  const int pext = PACKED ? (prow_ok ? a.rowext[prow] : 1) : a.T;
+  // (ROW_AT is a macro, not a lambda: with by-reference captures in the way hipcc allocated the backward kernel's
+  // registers differently - see above)
   float c_prev = 0.f;
   float* xw_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * 2 * PH * RG;   // [parity][unit][row]
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, 0x7ffffff0, 0x00020000);
   bool aborted = false;
   auto gx_ptr = [&](int sn) {
     const int tt = d == 0 ? sn : T - 1 - sn;
-    return reinterpret_cast<const float4*>(a.gates + (row_at(tt) * ndir + d) * 4 * PH + punit * 4);
+    return reinterpret_cast<const float4*>(a.gates + (ROW_AT(tt) * ndir + d) * 4 * PH + punit * 4);
   };
   float4 gx_n1 = make_float4(0.f, 0.f, 0.f, 0.f), gx_n2 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (prow_ok) {
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
     const float4 gx = gx_n1;
     gx_n1 = gx_n2;
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (row_at(t) * ndir + d) * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + (ROW_AT(t) * ndir + d) * 4 * PH + punit * 4);
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -702,10 +713,10 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       if (!(dbg_stall && g == 0 && slice == 1 && s >= 1))                                             // (test hook: a producer that went silent)
         word_store(xw_g + (s & 1) * (PH * RG) + (int64_t)punit * RG + pj, hn, tag_bit_of_step(s));     // hand-off first
       LP_MARK(6);
-      if (prow_ok && t < pext) {
+      if (prow_ok && (!PACKED || t < pext)) {
         st_g = make_float4(gi, gf, gg, go); st_c = cn; st_y = hn;
         st_gp = gp;
-        st_so = row_at(t) * ldy + d * PH + punit;
+        st_so = ROW_AT(t) * ldy + d * PH + punit;
       }
     }
   }
@@ -717,9 +728,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
     a.y[st_so] = st_y;
   }
   // packed rows: the block's padding rows behind the T steps that were run (times T .. rowext - 1; PersistArgs)
-  if (prow_ok) {
+  if constexpr (PACKED) if (prow_ok) {
     for (int tt = T; tt < pext; ++tt) {
-      const int64_t so = row_at(tt) * ldy + d * PH + punit;
+      const int64_t so = ROW_AT(tt) * ldy + d * PH + punit;
       a.c[so] = 0.f;
       a.y[so] = 0.f;
     }
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
 // (the in-place dG used by the weight-gradient GEMMs is untouched).  Float4 traffic both ways.
 // MFMA blocks: 16 = 4 unit-groups x 4 k-subs; A[blk][i] = W_hhT[unit 4ug+i][k], B[blk][j] = dG[row j][k],
 // k = 256*wave + 64*ks + q.  The 4 k-sub partials and the 8 waves' partials are summed by the pointwise thread.
-template <int PH, int NR>
+template <int PH, int NR, bool PACKED = false>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   static_assert(NR == 4 || NR == PRG, "rows per group (see the forward kernel)");
   constexpr int PUC = PH / 32;       // hidden units per CU
@@ -786,9 +797,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
   const bool touch_ok = ASR_LSTM_TOUCH && tid >= 384 && mt < PUC * PRG && pj < NR && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
-  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
-  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
-  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
+  // row of (time, this thread's batch row): see PersistArgs and the note in lstm_persist_bwd_rs_kernel
+  const int pbase = (PACKED && prow_ok) ? a.rowbase[prow] : 0;
+  const int pext = PACKED ? (prow_ok ? a.rowext[prow] : 1) : a.T;
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of this thread's (unit, row): sum of dG over time
   float* xch_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * PRG * 4 * PH;   // + parity * 8*PRG*4H
@@ -812,11 +823,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     const int tt = (ASR_LP_ABL & 8) ? 1 : (d == 0 ? T - 1 - sn : sn);      // bit 8 (measurement): always the same, cached row
     const int ttp = d == 0 ? tt - 1 : tt + 1;
     const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
-    const int64_t so = row_at(tt) * ldy + d * PH + punit;
+    const int64_t so = ROW_AT(tt) * ldy + d * PH + punit;
     n_dy = a.dy[so];
-    n_av = *reinterpret_cast<const float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    n_av = *reinterpret_cast<const float4*>(a.gates + ROW_AT(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
     n_ct = a.c[so];
-    n_cp = hp ? a.c[row_at(ttp) * ldy + d * PH + punit] : 0.f;
+    n_cp = hp ? a.c[ROW_AT(ttp) * ldy + d * PH + punit] : 0.f;
     if (fuse_dw) n_y = a.yfwd[so];
   };
   if (prow_ok) fetch_step(0);
@@ -827,7 +838,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     const float dyv = n_dy, ct = n_ct, cp = n_cp;
     const float4 av = n_av;
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + row_at(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ROW_AT(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
     if (fuse_dw && pw_thread) ysl[s & 1][pj][pu] = prow_ok ? n_y : 0.f;     // h_t of this CU's units (read after the barrier)
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
@@ -976,7 +987,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
                          __HIP_MEMORY_SCOPE_WORKGROUP);
       LP_MARK(11);
       if (prow_ok) {     // after the hand-off: the bulk store and the bias-gradient sum are off the serial chain
-        if (!(ASR_LP_ABL & 16) && t < pext) *gp = da;
+        if (!(ASR_LP_ABL & 16) && (!PACKED || t < pext)) *gp = da;
         dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
       }
     }
@@ -1005,9 +1016,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
     }
   }
   // packed rows: dG of the block's padding rows behind the T steps that were run (PersistArgs)
-  if (prow_ok) {
+  if constexpr (PACKED) if (prow_ok) {
     for (int tt = T; tt < pext; ++tt)
-      *reinterpret_cast<float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(a.gates + ROW_AT(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (a.db != nullptr && pw_lane) {
     // rows of a unit sit in 8 consecutive lanes (pj = tid & 7); the 4 row groups (XCDs) of a direction add up
@@ -1046,7 +1057,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_kernel(PersistArgs a) {
 // registers, B = the gathered dG tile, which the gathering lanes write to LDS twice - as fp32 for the fused dW_hh
 // product (unchanged, exact fp32, off the serial chain) and split in bf16 for this one.  D puts the 4 units 4 (l >> 4)
 // .. + 3 of batch row l & 15 in one lane: the 4 k-sub partials and their DPP reduction of the 4x4x1 mapping are gone.
-template <int PH, int NR, int NT>
+template <int PH, int NR, int NT, bool PACKED = false>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a) {
   static_assert(NR == 4 || NR == PRG, "rows per group (see the forward kernel)");
   constexpr int PUC = PH / 32;       // hidden units per CU
@@ -1106,9 +1117,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
   const bool touch_ok = ASR_LSTM_TOUCH && tid >= 384 && mt < PUC * PRG && pj < NR && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
-  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
-  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
-  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
+  // row of (time, this thread's batch row): see PersistArgs and the note in lstm_persist_bwd_rs_kernel
+  const int pbase = (PACKED && prow_ok) ? a.rowbase[prow] : 0;
+  const int pext = PACKED ? (prow_ok ? a.rowext[prow] : 1) : a.T;
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient of this thread's (unit, row): sum of dG over time
   float* xch_g = reinterpret_cast<float*>(a.xch) + (int64_t)g * PRG * 4 * PH;   // + parity * 8*PRG*4H
@@ -1132,11 +1143,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
     const int tt = (ASR_LP_ABL & 8) ? 1 : (d == 0 ? T - 1 - sn : sn);      // bit 8 (measurement): always the same, cached row
     const int ttp = d == 0 ? tt - 1 : tt + 1;
     const bool hp = d == 0 ? (tt > 0) : (tt < T - 1);
-    const int64_t so = row_at(tt) * ldy + d * PH + punit;
+    const int64_t so = ROW_AT(tt) * ldy + d * PH + punit;
     n_dy = a.dy[so];
-    n_av = *reinterpret_cast<const float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    n_av = *reinterpret_cast<const float4*>(a.gates + ROW_AT(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
     n_ct = a.c[so];
-    n_cp = hp ? a.c[row_at(ttp) * ldy + d * PH + punit] : 0.f;
+    n_cp = hp ? a.c[ROW_AT(ttp) * ldy + d * PH + punit] : 0.f;
     if (fuse_dw) n_y = a.yfwd[so];
   };
   if (prow_ok) fetch_step(0);
@@ -1147,7 +1158,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
     const float dyv = n_dy, ct = n_ct, cp = n_cp;
     const float4 av = n_av;
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + row_at(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ROW_AT(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
     if (fuse_dw && pw_thread) ysl[s & 1][pj][pu] = prow_ok ? n_y : 0.f;     // h_t of this CU's units (read after the barrier)
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
@@ -1281,7 +1292,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
                          __HIP_MEMORY_SCOPE_WORKGROUP);
       LP_MARK(11);
       if (prow_ok) {     // after the hand-off: the bulk store and the bias-gradient sum are off the serial chain
-        if (!(ASR_LP_ABL & 16) && t < pext) *gp = da;
+        if (!(ASR_LP_ABL & 16) && (!PACKED || t < pext)) *gp = da;
         dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
       }
     }
@@ -1310,9 +1321,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_bf3_kernel(PersistArgs a
     }
   }
   // packed rows: dG of the block's padding rows behind the T steps that were run (PersistArgs)
-  if (prow_ok) {
+  if constexpr (PACKED) if (prow_ok) {
     for (int tt = T; tt < pext; ++tt)
-      *reinterpret_cast<float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(a.gates + ROW_AT(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (a.db != nullptr && pw_lane) {
     // rows of a unit sit in 8 consecutive lanes (pj = tid & 7); the 4 row groups (XCDs) of a direction add up
@@ -1391,7 +1402,7 @@ struct RsDims {
   static_assert(PH % 32 == 0 && PHP % 128 == 0 && PUC <= 16, "H in {128, 256, 320, 512}");
 };
 
-template <int PH, int NR, int NT>
+template <int PH, int NR, int NT, bool PACKED = false>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a) {
   using RD = RsDims<PH>;
   constexpr int PUC = RD::PUC, PUR = RD::PUR, NC = RD::NC, NCR = RD::NCR, KS = RD::KS, MTW = RD::MTW, CT = RD::CT, UPW = RD::UPW, CPW = RD::CPW;
@@ -1483,9 +1494,16 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUR * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
-  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
-  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
-  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
+  // Row of (time, this thread's batch row); see PersistArgs.  PACKED is a template parameter, not a run-time branch: the
+  // time-major instantiation must compile from the expression it was tuned with.  These kernels live on the register
+  // allocator's goodwill - the forward data of a step is prefetched two steps ahead, and an allocation that cannot give a
+  // 16-byte load the four registers its value stays in copies it out of a temporary RIGHT BEHIND the load: a wait for an
+  // HBM first touch on the serial chain (bwd 1.80 -> 2.30 us per time step when the run-time form of this map moved it).
+  // tools/isa_waits.py lists the vmcnt waits of a kernel's loop; none may follow the prefetch loads.
+  const int pbase = (PACKED && prow_ok) ? a.rowbase[prow] : 0;
+  const int pext = PACKED ? (prow_ok ? a.rowext[prow] : 1) : a.T;
+  // (ROW_AT is a macro, not a lambda: with by-reference captures in the way hipcc allocated the backward kernel's
+  // registers differently - see above)
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
   float* xg = reinterpret_cast<float*>(a.xch) + (int64_t)g * RD::group_floats;
@@ -1511,9 +1529,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   auto time_of = [&](int sn) { return d == 0 ? T - 1 - sn : sn; };
   auto fetch_step = [&](int sn, float& o_dy, float& o_ct, float4& o_av) {
     const int tt = time_of(sn);
-    const int64_t so = row_at(tt) * ldy + d * PH + punit;
+    const int64_t so = ROW_AT(tt) * ldy + d * PH + punit;
     o_dy = a.dy[so];
-    o_av = *reinterpret_cast<const float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    o_av = *reinterpret_cast<const float4*>(a.gates + ROW_AT(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
     o_ct = a.c[so];
   };
   // forward hidden state at the time that fed step sn's time.  Bare loads from clamped addresses: nothing may touch a
@@ -1634,7 +1652,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
     if (h_lane && s + 1 < T && !(ASR_RA & 256)) stage_h((s + 1) & 3, s + 1);
 #endif
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + row_at(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ROW_AT(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
     // ---------------------------------------------------------------- (1) gather the partials addressed to this CU
     float dh_rec = 0.f;
     if (s > 0) {
@@ -1710,7 +1728,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
         }
         if (prow_ok) {
           st_da = da;
-          st_gp = t < pext ? gp : nullptr;
+          st_gp = (!PACKED || t < pext) ? gp : nullptr;
           dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
         }
       }
@@ -1837,9 +1855,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
   }
   if (st_gp) *st_gp = st_da;
   // packed rows: dG of the block's padding rows behind the T steps that were run (PersistArgs)
-  if (prow_ok) {
+  if constexpr (PACKED) if (prow_ok) {
     for (int tt = T; tt < pext; ++tt)
-      *reinterpret_cast<float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(a.gates + ROW_AT(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (a.db != nullptr) {        // one atomic per (unit, gate) and CU; the rows are summed through LDS
     if (pw_lane) *reinterpret_cast<float4*>(&dbs[pj][4 * pu]) = dbacc;
@@ -1873,7 +1891,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs_kernel(PersistArgs a)
 //   * pointwise lanes: lanes 0..3 of DPP row rr -> unit 4 rr + lane, lanes 4..7 of row 0 -> units 16..19.
 // Everything else (exchange layout [dest][src][row][unit], tags, abort handling, stores / prefetches behind the poll, two
 // dG slots, forward-data factors formed in front of the gather) is that kernel's.  dW_hh is left to the caller, db is summed.
-template <int NR>
+template <int NR, bool PACKED = false>
 __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs a) {
   constexpr int PH = 640, NT = 3, PUC = 20, NC = 80, MTW = 5, GST = 96 + 8, NE = 2;
   constexpr int PARSZ = 32 * 32 * PRG * PUC;      // floats per parity
@@ -1927,9 +1945,16 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
   const bool prow_ok = pw_thread && prow < a.nb;
   const int punit = PUC * slice + pu;
   const int plen = prow_ok ? a.lens[prow] : 0;
-  const int64_t pbase = a.rowbase ? (prow_ok ? a.rowbase[prow] : 0) : prow, tstr = a.rowbase ? 1 : a.B;
-  const int pext = a.rowbase ? (prow_ok ? a.rowext[prow] : 1) : a.T;       // row of (time, this thread's batch row); see PersistArgs
-  auto row_at = [&](int tt) -> int64_t { return (int64_t)(tt < pext ? tt : pext - 1) * tstr + pbase; };
+  // Row of (time, this thread's batch row); see PersistArgs.  PACKED is a template parameter, not a run-time branch: the
+  // time-major instantiation must compile from the expression it was tuned with.  These kernels live on the register
+  // allocator's goodwill - the forward data of a step is prefetched two steps ahead, and an allocation that cannot give a
+  // 16-byte load the four registers its value stays in copies it out of a temporary RIGHT BEHIND the load: a wait for an
+  // HBM first touch on the serial chain (bwd 1.80 -> 2.30 us per time step when the run-time form of this map moved it).
+  // tools/isa_waits.py lists the vmcnt waits of a kernel's loop; none may follow the prefetch loads.
+  const int pbase = (PACKED && prow_ok) ? a.rowbase[prow] : 0;
+  const int pext = PACKED ? (prow_ok ? a.rowext[prow] : 1) : a.T;
+  // (ROW_AT is a macro, not a lambda: with by-reference captures in the way hipcc allocated the backward kernel's
+  // registers differently - see above)
   float dcarry = 0.f;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
   float* xg = reinterpret_cast<float*>(a.xch) + (int64_t)g * (2 * PARSZ);
@@ -1940,9 +1965,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
   auto time_of = [&](int sn) { return d == 0 ? T - 1 - sn : sn; };
   auto fetch_step = [&](int sn, float& o_dy, float& o_ct, float4& o_av) {
     const int tt = time_of(sn);
-    const int64_t so = row_at(tt) * ldy + d * PH + punit;
+    const int64_t so = ROW_AT(tt) * ldy + d * PH + punit;
     o_dy = a.dy[so];
-    o_av = *reinterpret_cast<const float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    o_av = *reinterpret_cast<const float4*>(a.gates + ROW_AT(tt) * ldg + (int64_t)d * 4 * PH + punit * 4);
     o_ct = a.c[so];
   };
   // gather descriptors: DPP row rr sums the 32 sources of (row = wave, unit quad rr), two sources per lane; row 0 also quad 4
@@ -1993,7 +2018,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
       asm volatile("" : "+v"(k_dc), "+v"(k_i), "+v"(k_f), "+v"(k_g), "+v"(k_o), "+v"(k_cn));
     }
     float4* gp = nullptr;
-    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + row_at(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
+    if (prow_ok) gp = reinterpret_cast<float4*>(a.gates + ROW_AT(t) * ldg + (int64_t)d * 4 * PH + punit * 4);
     // ---------------------------------------------------------------- (1) gather the partials addressed to this CU
     float dh_rec = 0.f;
     if (s > 0) {
@@ -2047,7 +2072,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
       for (int k = 0; k < NT; ++k) *reinterpret_cast<uint2*>(&dgs[k][s & 1][pj][4 * pu]) = make_uint2(p0[k], p1[k]);
       if (prow_ok) {
         st_da = da;
-        st_gp = t < pext ? gp : nullptr;
+        st_gp = (!PACKED || t < pext) ? gp : nullptr;
         dbacc.x += da.x; dbacc.y += da.y; dbacc.z += da.z; dbacc.w += da.w;
       }
     }
@@ -2108,9 +2133,9 @@ __global__ __launch_bounds__(PNT) void lstm_persist_bwd_rs640_kernel(PersistArgs
   }
   if (st_gp) *st_gp = st_da;
   // packed rows: dG of the block's padding rows behind the T steps that were run (PersistArgs)
-  if (prow_ok) {
+  if constexpr (PACKED) if (prow_ok) {
     for (int tt = T; tt < pext; ++tt)
-      *reinterpret_cast<float4*>(a.gates + row_at(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(a.gates + ROW_AT(tt) * ldg + (int64_t)d * 4 * PH + punit * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (a.db != nullptr) {        // one atomic per (unit, gate) and CU; the rows are summed through LDS
     if (pw_lane) *reinterpret_cast<float4*>(&dbs[pj][4 * pu]) = dbacc;
@@ -2132,10 +2157,11 @@ template <int PH, int NR>
 int launch_fwd(const PersistArgs& a, hipStream_t stream) {
   const size_t stat = sizeof(float) * ((size_t)PW * PRG * (PH / PW + 4) + 2 * PW * 64 * 8) + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_kernel<PH, NR>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  const void* fn = a.rowbase ? (const void*)lstm_persist_fwd_kernel<PH, NR, true> : (const void*)lstm_persist_fwd_kernel<PH, NR, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_fwd_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
+  if (a.rowbase) hipLaunchKernelGGL((lstm_persist_fwd_kernel<PH, NR, true>), dim3(256), dim3(PNT), pad, stream, a);
+  else hipLaunchKernelGGL((lstm_persist_fwd_kernel<PH, NR, false>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
@@ -2144,10 +2170,13 @@ int launch_fwd_bf3(const PersistArgs& a, hipStream_t stream) {
   constexpr int KP = ((PH / PW + 31) / 32) * 32, MT = (PH / 32 + 3) / 4;
   const size_t stat = (size_t)((NT == 3 && RG == 8) ? 4 : NT) * PW * RG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * RG * 4 + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  // (packed rows / time-major rows: two instantiations, see the row map in the kernel)
+  const void* fn = a.rowbase ? (const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, true>
+                             : (const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG>), dim3(256), dim3(PNT), pad, stream, a);
+  if (a.rowbase) hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, true>), dim3(256), dim3(PNT), pad, stream, a);
+  else hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, false>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
@@ -2155,10 +2184,11 @@ template <int PH, int NR>
 int launch_bwd(const PersistArgs& a, hipStream_t stream) {
   const size_t stat = sizeof(float) * ((size_t)PW * PRG * 4 * (PH / 2 / 4 + 4) + 2 * PW * 64 * 9) + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel<PH, NR>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  const void* fn = a.rowbase ? (const void*)lstm_persist_bwd_kernel<PH, NR, true> : (const void*)lstm_persist_bwd_kernel<PH, NR, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_bwd_kernel<PH, NR>), dim3(256), dim3(PNT), pad, stream, a);
+  if (a.rowbase) hipLaunchKernelGGL((lstm_persist_bwd_kernel<PH, NR, true>), dim3(256), dim3(PNT), pad, stream, a);
+  else hipLaunchKernelGGL((lstm_persist_bwd_kernel<PH, NR, false>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
@@ -2167,10 +2197,11 @@ int launch_bwd_bf3(const PersistArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * ((size_t)PW * PRG * 4 * (PH / 2 / 4 + 4) + 2 * PW * PRG * 16 + 2 * PRG * 16) +
                      (size_t)NT * PW * PRG * (PH / 2 + 8) * 2 + 64;
   const size_t pad = lds > 82 * 1024 ? 0 : 82 * 1024 - lds;
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_bf3_kernel<PH, NR, NT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  const void* fn = a.rowbase ? (const void*)lstm_persist_bwd_bf3_kernel<PH, NR, NT, true> : (const void*)lstm_persist_bwd_bf3_kernel<PH, NR, NT, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_bwd_bf3_kernel<PH, NR, NT>), dim3(256), dim3(PNT), pad, stream, a);
+  if (a.rowbase) hipLaunchKernelGGL((lstm_persist_bwd_bf3_kernel<PH, NR, NT, true>), dim3(256), dim3(PNT), pad, stream, a);
+  else hipLaunchKernelGGL((lstm_persist_bwd_bf3_kernel<PH, NR, NT, false>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
@@ -2180,10 +2211,12 @@ int launch_bwd_rs(const PersistArgs& a, hipStream_t stream) {
   const size_t stat = (size_t)(NT == 3 ? 4 : NT) * (NT == 2 ? 4 : 1) * PRG * RD::GST * 2 + PRG * 16 * sizeof(float) + 64 +
                       (NT == 2 ? (size_t)2 * PH * 4 * PRG * 2 : (size_t)64);
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_rs_kernel<PH, NR, NT>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  const void* fn = a.rowbase ? (const void*)lstm_persist_bwd_rs_kernel<PH, NR, NT, true>
+                             : (const void*)lstm_persist_bwd_rs_kernel<PH, NR, NT, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_bwd_rs_kernel<PH, NR, NT>), dim3(256), dim3(PNT), pad, stream, a);
+  if (a.rowbase) hipLaunchKernelGGL((lstm_persist_bwd_rs_kernel<PH, NR, NT, true>), dim3(256), dim3(PNT), pad, stream, a);
+  else hipLaunchKernelGGL((lstm_persist_bwd_rs_kernel<PH, NR, NT, false>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 
@@ -2247,9 +2280,11 @@ int bwd_kernel_kind(int H, int arith) {
 template <int NR>
 int launch_bwd_rs640(const PersistArgs& a, hipStream_t stream) {
   const size_t pad = 70 * 1024;                      // static (15 KB) + pad > 80 KB: one workgroup per CU
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_persist_bwd_rs640_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+  const void* fn = a.rowbase ? (const void*)lstm_persist_bwd_rs640_kernel<NR, true> : (const void*)lstm_persist_bwd_rs640_kernel<NR, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((lstm_persist_bwd_rs640_kernel<NR>), dim3(256), dim3(PNT), pad, stream, a);
+  if (a.rowbase) hipLaunchKernelGGL((lstm_persist_bwd_rs640_kernel<NR, true>), dim3(256), dim3(PNT), pad, stream, a);
+  else hipLaunchKernelGGL((lstm_persist_bwd_rs640_kernel<NR, false>), dim3(256), dim3(PNT), pad, stream, a);
   return 0;
 }
 

@@ -605,6 +605,8 @@ class RowLayout(object):
     and every block ends with at least one padding row (ext > len).  Built on the host from the utterance lengths and
     uploaded once per batch (one non-blocking copy): `dev` [n + 1][3][B] int32 = (lens, base, ext) per layer."""
 
+    ROW_QUANTUM = 16
+
     def __init__(self, ilens, subsample, device, t_pad=None):
         import numpy as np
         n = len(subsample)
@@ -615,13 +617,17 @@ class RowLayout(object):
             pads.append(((pads[-1] + 1) // 2 if subsample[i] > 1 else pads[-1]) if t_pad is None else int(t_pad[i + 1]))
         ext = [None] * (n + 1)
         ext[n] = lens[n] + 1
-        # the row counts are the K of the weight-gradient GEMMs, whose kernels want K % 4 == 0: up to three of the shortest
-        # utterances get a second padding row (the extents below double it: every layer's row count is then a multiple of 4)
-        odd = (-int(ext[n].sum())) % 4
-        if odd:
-            ext[n][np.argsort(lens[n], kind="stable")[:odd]] += 1
-            odd -= min(odd, len(ilens))
-            ext[n][int(np.argmin(lens[n]))] += odd               # (fewer than three utterances)
+        # The row counts are the M of the forward products and the K of the weight-gradient products.  The output's count is
+        # rounded up to a multiple of ROW_QUANTUM = 16 (the extents double from there: 32 / 64 / 128 rows for a three-layer
+        # pyramid), so that K % 32 == 0 where the GEMM's fast kernels want it and the layer-0 input projection has whole
+        # 128-row tiles (its plain epilogue: 97 against 137 us at cfg-2).  The extra padding rows go to the shortest utterances
+        # first (round robin); the recurrences run max(lens) steps whatever the extents are.
+        odd = (-int(ext[n].sum())) % self.ROW_QUANTUM
+        order = np.argsort(lens[n], kind="stable")
+        while odd > 0:
+            take = min(odd, len(ilens))
+            ext[n][order[:take]] += 1
+            odd -= take
         for i in range(n - 1, -1, -1):
             ext[i] = ext[i + 1] * 2 if subsample[i] > 1 else ext[i + 1].copy()
         self.B, self.n = len(ilens), n

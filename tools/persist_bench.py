@@ -46,3 +46,21 @@ for path in paths:
     for ar in ARITHS:
         tf, tb, tb0 = best[(path, ar)]
         print('%-26s %-7s fwd %.2f us/step | bwd %.2f us/step (no dW: %.2f)' % (os.path.basename(path), hb.arith_name(ar), tf, tb, tb0), flush=True)
+
+# the same recurrences on PACKED rows (every utterance T frames + 8 padding rows: rowbase / rowext of include/asr_hip.h)
+l = libs[hb.LIB_PATH]
+ext = T + 8
+R = B * ext
+base_h = (np.arange(B) * ext).astype(np.int32); ext_h = np.full(B, ext, dtype=np.int32)
+rbase, rext = torch.from_numpy(base_h).to(dev), torch.from_numpy(ext_h).to(dev)
+pg0 = (torch.randn(R, 2, 4 * H, generator=g) * 0.5).to(dev); pga = (torch.rand(R, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
+py = torch.empty(R, 2 * H, device=dev); pc = torch.empty(R, 2 * H, device=dev)
+pdy = (torch.randn(R, 2 * H, generator=g) * 0.01).to(dev); pcc = torch.randn(R, 2 * H, generator=g).to(dev)
+for ar in ARITHS:
+    bf = bb = 1e9
+    for rep in range(4):
+        ga = pg0.clone()
+        bf = min(bf, timeit(lambda: l.asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), P(rbase), P(rext), None, P(py), P(pc), P(xch), P(ctrl), ar, st)))
+        gb = pga.clone()
+        bb = min(bb, timeit(lambda: l.asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), P(rbase), P(rext), None, P(pdy), P(pcc), None, None, None, P(xch), P(ctrl), ar, st)))
+    print('%-26s %-7s fwd %.2f us/step | bwd %.2f us/step   (packed rows)' % (os.path.basename(hb.LIB_PATH), hb.arith_name(ar), bf, bb), flush=True)
