@@ -185,11 +185,11 @@ def _time_events(fn, reps):
 
 def mfma_busy_table():
     """MFMA-pipe busy fractions per kernel family from the committed counter pass (tools/pmc_mfma.py ->
-    profiles/r04_pmc_mfma.json (r03 when absent): SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES-derived kernel cycles), keyed for the rows
+    profiles/r05_pmc_mfma.json (r04 / r03 when absent): SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES-derived kernel cycles), keyed for the rows
     of this bench; {} when the file is absent or was collected under another arithmetic."""
     import hip_backend as hb
     try:
-        for name in ("r04_pmc_mfma.json", "r03_pmc_mfma.json"):
+        for name in ("r05_pmc_mfma.json", "r04_pmc_mfma.json", "r03_pmc_mfma.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:
@@ -209,7 +209,7 @@ def encoder_gate_gemms(dev, c, B, t_frames):
     arithmetic it runs on (bf16 peak / products per product: 416.7 TF for bf16x6); `x_f32_mfma_peak` = the same throughput
     as a MULTIPLE of the 157.3 TF fp32-input MFMA peak (a speed ratio against the pipe the reference's arithmetic would
     otherwise need, not a utilisation); `mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE-
-    equivalent cycles) of the same kernel from the committed PMC pass (profiles/r04_pmc_mfma.json) when it exists."""
+    equivalent cycles) of the same kernel from the committed PMC pass (profiles/r05_pmc_mfma.json) when it exists."""
     import hip_backend as hb
     an = hb.arith_name()
     peak = arith_peak_tf(an)
@@ -404,7 +404,7 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     # HBM-side traffic of that kernel from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
     # tools/pmc_probe.py, FETCH doubled as the gfx950 guide prescribes); measured at H=512, 8-row groups
     if H == 512 and B >= 32:
-        for name in ("r04_pmc_lstm_persist.json", "r03_pmc_lstm_persist.json", "r02_pmc_lstm_persist.json", "r01_pmc_lstm_persist.json"):
+        for name in ("r05_pmc_lstm_persist.json", "r04_pmc_lstm_persist.json", "r03_pmc_lstm_persist.json", "r02_pmc_lstm_persist.json", "r01_pmc_lstm_persist.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)["lstm_persist_bwd_kernel<512>"]

@@ -12,7 +12,7 @@ lens=torch.full((B,),T,dtype=torch.int32,device=dev)
 y=torch.empty(T,B,2*H,device=dev); c=torch.empty(T,B,2*H,device=dev)
 A=torch.randn(4096,12800,device=dev); Bm=torch.randn(12800,512,device=dev); out=torch.empty(4096,512,device=dev)
 side=torch.cuda.Stream()
-def chain(st): hb.check(lib.asr_lstm_seq_fwd(T,B,B,H,2,hb.ptr(gates),hb.ptr(wf),hb.ptr(lens),hb.ptr(y),hb.ptr(c),None,ctypes.c_void_p(st.cuda_stream)),'x')
+def chain(st): hb.check(lib.asr_lstm_seq_fwd(T,B,B,H,2,hb.ptr(gates),hb.ptr(wf),hb.ptr(lens),None,None,hb.ptr(y),hb.ptr(c),None,ctypes.c_void_p(st.cuda_stream)),'x')
 def gemms(n):
     for _ in range(n): hb.gemm(A,Bm,out=out,split_k=4)
 def t(fn):

@@ -24,7 +24,7 @@ if mode == 'persist':
     hb.check(lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, hb.ptr(g2), hb.ptr(wf), hb.ptr(lens), None, None, None, hb.ptr(y), hb.ptr(c2), x_, c_, hb.current_arith(), hb.stream()), 'fwd')
     hb.check(lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), None, None, None, hb.ptr(dy), hb.ptr(c), hb.ptr(y), hb.ptr(dw), None, x_, c_, hb.current_arith(), hb.stream()), 'bwd')
 else:
-    hb.check(lib.asr_lstm_seq_fwd(T, B, B, H, 2, hb.ptr(g2), hb.ptr(wf), hb.ptr(lens), None, None, None, hb.ptr(y), hb.ptr(c2), None, hb.stream()), 'fwd')
-    hb.check(lib.asr_lstm_seq_bwd(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), None, None, None, hb.ptr(dy), hb.ptr(c), hb.ptr(dcarry), None, hb.stream()), 'bwd')
+    hb.check(lib.asr_lstm_seq_fwd(T, B, B, H, 2, hb.ptr(g2), hb.ptr(wf), hb.ptr(lens), None, None, hb.ptr(y), hb.ptr(c2), None, hb.stream()), 'fwd')
+    hb.check(lib.asr_lstm_seq_bwd(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), None, None, hb.ptr(dy), hb.ptr(c), hb.ptr(dcarry), None, hb.stream()), 'bwd')
 torch.cuda.synchronize()
 print('done', 'aborted' if mode == 'persist' and hb.persist_aborted(dev) else '')
