@@ -149,20 +149,23 @@ def encoder_layer_frames(c, t_frames):
     return out, t
 
 
-def tn_gemm_shapes(c, B, t_frames, olength, fused_dw_hh=True):
+def tn_gemm_shapes(c, B, t_frames, olength, fused_dw_hh=True, rows=None):
     """The weight-gradient (transA) GEMM launches of ONE train step: (M, N, K, batch).  dW_hh is among them only when the
-    persistent LSTM backward kernel does not accumulate it itself (bf16x6: one GEMM per layer, batched over the directions)."""
+    persistent LSTM backward kernel does not accumulate it itself (bf16x6: one GEMM per layer, batched over the directions).
+    rows: the packed row counts of the encoder layers (+ the output), hb.RowLayout.rows - K of the encoder's products; None:
+    the padded counts T_l * B."""
     H, I = c["enc_hidden_dim"], c["input_dim"]
     D, O, E, A, V = c["dec_hidden_dim"], c["att_odim"], c["embedding_dim"], c["att_dim"], c["output_dim"]
     shapes = []
     frames, tp = encoder_layer_frames(c, t_frames)
     for layer, t in enumerate(frames):
         idim = I if layer == 0 else H
-        shapes.append((8 * H, idim, t * B, 1))                       # dW_ih (both directions)
+        k_in = rows[layer] if rows is not None else t * B
+        shapes.append((8 * H, idim, k_in, 1))                        # dW_ih (both directions)
         if not fused_dw_hh and t > 1:
-            shapes.append((4 * H, H, (t - 1) * B, 2))                # dW_hh = dG^T h_prev, batched over the directions
+            shapes.append((4 * H, H, k_in if rows is not None else (t - 1) * B, 2))     # dW_hh = dG^T h_prev, batched over the directions
         sub = c["subsample"][layer] > 1
-        shapes.append((H, 4 * H if sub else 2 * H, ((t + 1) // 2 if sub else t) * B, 1))   # dW of the projection
+        shapes.append((H, 4 * H if sub else 2 * H, rows[layer + 1] if rows is not None else ((t + 1) // 2 if sub else t) * B, 1))   # dW of the projection
     L = olength
     shapes += [(A, H, tp * B, 1), (O, H, tp * B, 1)]                 # mlp_enc, mlp_o (hoisted)
     shapes += [(V, D + O, L * B, 1), (4 * D, D + O + E, L * B, 1), (A, D, L * B, 1)]   # output layer, cell, mlp_dec
@@ -200,7 +203,7 @@ def mfma_busy_table():
         return {}
 
 
-def encoder_gate_gemms(dev, c, B, t_frames):
+def encoder_gate_gemms(dev, c, B, t_frames, lens=None):
     """north_star: ">= 40 % MFMA utilisation on the encoder gate GEMM".  Per encoder layer, on operands of the step's
     shapes that were evicted from the caches before each launch (a 512 MB fill in between: the train step finds them in
     HBM too): the input-gate projection [T*B, in] x [in, 8H] (forward), its two backward GEMMs (dX = dG W_ih,
@@ -217,6 +220,9 @@ def encoder_gate_gemms(dev, c, B, t_frames):
     lib = hb.load()
     H, I = c["enc_hidden_dim"], c["input_dim"]
     frames, _ = encoder_layer_frames(c, t_frames)
+    # the encoder runs on PACKED rows (hb.RowLayout): M of layer l = the sum of the utterances' extents, not T_l * B
+    layout = hb.RowLayout([int(v) for v in lens], [c["subsample"][i] for i in range(c["enc_n_layers"])], dev) \
+        if (lens is not None and hb.USE_PACKED_ROWS) else None
     flush = torch.empty(128 * 1024 * 1024, device=dev)
     stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -238,7 +244,7 @@ def encoder_gate_gemms(dev, c, B, t_frames):
     xch, ctrl = hb.persist_scratch(dev)
     for layer, T in enumerate(frames):
         idim = I if layer == 0 else H
-        M = T * B
+        M = layout.rows[layer] if layout is not None else T * B
         x = torch.randn(M, idim, device=dev)
         w = torch.randn(8 * H, idim, device=dev) / np.sqrt(idim)
         dG = torch.randn(M, 8 * H, device=dev)
@@ -246,10 +252,10 @@ def encoder_gate_gemms(dev, c, B, t_frames):
         bias = torch.zeros(8 * H, device=dev)
         rows = []
         for op, fn, flops in (
-                ("in-proj fwd  [T*B,%d]x[%d,8H]" % (idim, idim), lambda: hb.gemm(x, w, trans_b=True, bias=bias, out=gates),
+                ("in-proj fwd  [R=%d,%d]x[%d,8H]" % (M, idim, idim), lambda: hb.gemm(x, w, trans_b=True, bias=bias, out=gates),
                  2.0 * M * idim * 8 * H),
-                ("dX = dG W_ih [T*B,8H]x[8H,%d]" % idim, lambda: hb.gemm(dG, w), 2.0 * M * idim * 8 * H),
-                ("dW_ih = dG^T X [8H,T*B]x[T*B,%d]" % idim, lambda: hb.gemm(dG, x, trans_a=True), 2.0 * M * idim * 8 * H)):
+                ("dX = dG W_ih [R,8H]x[8H,%d]" % idim, lambda: hb.gemm(dG, w), 2.0 * M * idim * 8 * H),
+                ("dW_ih = dG^T X [8H,R]x[R,%d]" % idim, lambda: hb.gemm(dG, x, trans_a=True), 2.0 * M * idim * 8 * H)):
             if layer == 0 and op.startswith("dX"):
                 continue                                  # the features need no gradient
             dt = cold(fn)
@@ -258,14 +264,14 @@ def encoder_gate_gemms(dev, c, B, t_frames):
                              mfma_busy_frac=busy.get("gemm/%d/%s" % (layer, op.split(" ")[0]))))
         del x, w, dG, gates
         # recurrent products: the persistent kernels of this layer (both directions)
-        lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        lens_t = torch.full((B,), T, dtype=torch.int32, device=dev)     # (time-major, every row full length: us per time step)
         gts = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).to(dev)
         whh = (torch.randn(2, 4 * H, H, generator=g) / np.sqrt(H)).to(dev)
         y = torch.empty(T, B, 2 * H, device=dev)
         cst = torch.empty(T, B, 2 * H, device=dev)
         torch.cuda.synchronize()
         e0.record(stream)
-        rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whh), hb.ptr(lens), None, None, None, hb.ptr(y), hb.ptr(cst),
+        rc = lib.asr_lstm_seq_fwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whh), hb.ptr(lens_t), None, None, None, hb.ptr(y), hb.ptr(cst),
                                           hb.c_p(xch.data_ptr()), hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
         e1.record(stream)
         torch.cuda.synchronize()
@@ -281,7 +287,7 @@ def encoder_gate_gemms(dev, c, B, t_frames):
             whT = whh.transpose(1, 2).contiguous()
             torch.cuda.synchronize()
             e0.record(stream)
-            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whT), hb.ptr(lens), None, None, None, hb.ptr(dy), hb.ptr(cst),
+            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gts), hb.ptr(whT), hb.ptr(lens_t), None, None, None, hb.ptr(dy), hb.ptr(cst),
                                               hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
                                               hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
             e1.record(stream)
@@ -298,7 +304,7 @@ def encoder_gate_gemms(dev, c, B, t_frames):
     return out
 
 
-def kernel_roofline(dev, c, B, t_frames, olength):
+def kernel_roofline(dev, c, B, t_frames, olength, lens_batch=None):
     """Roofline of the dominant kernel of the train step, timed live with HIP events on the launch stream.
 
     Two kernels compete for "dominant by total time per step" (profiles/*_bench_kernel_stats*.csv), so both are
@@ -318,8 +324,11 @@ def kernel_roofline(dev, c, B, t_frames, olength):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     # ---- transA GEMMs
+    packed = lens_batch is not None and hb.USE_PACKED_ROWS
+    layout = hb.RowLayout([int(v) for v in lens_batch], [c["subsample"][i] for i in range(c["enc_n_layers"])], dev) if packed else None
     shapes = tn_gemm_shapes(c, B, t_frames, olength,
-                            fused_dw_hh=lib.asr_lstm_bwd_persist_fuses_dw(c["enc_hidden_dim"], hb.current_arith()) != 0)
+                            fused_dw_hh=(not packed) and lib.asr_lstm_bwd_persist_fuses_dw(c["enc_hidden_dim"], hb.current_arith()) != 0,
+                            rows=layout.rows if packed else None)
     bufs = []
     for (M, N, K, batch) in shapes:
         bufs.append((torch.randn(batch * K, M, device=dev) if batch == 1 else torch.randn(K, batch, M, device=dev),
@@ -348,32 +357,41 @@ def kernel_roofline(dev, c, B, t_frames, olength):
                 mfma_busy_frac=busy.get("gemm_tn"), traffic=None, launches_per_step=len(shapes),
                 us_per_launch=gemm_s / len(shapes) * 1e6, ms_per_step=gemm_s * 1e3)
 
-    # ---- persistent LSTM backward (with the fused recurrent weight gradient), the encoder layers
+    # ---- persistent LSTM backward, the encoder layers, AS THE STEP RUNS IT: packed rows (hb.RowLayout) with the lengths of the
+    # bench's batch - the `..., true>` instantiation rocprofv3 lists.  Algorithmic flops: the valid (utterance, frame) pairs
+    # only, 2 * 4H * H per pair and direction (the kernel's MFMAs also run over the dead rows of a group whose other rows are
+    # still alive; those are not counted).  Without lengths (or ASR_ENCODER_ROWS=padded): time-major, every row T frames.
     H = c["enc_hidden_dim"]
     g = torch.Generator().manual_seed(3)
     layers, _ = encoder_layer_frames(c, t_frames)
     w = (torch.randn(2, H, 4 * H, generator=g) / np.sqrt(H)).to(dev)
-    lens = torch.full((B,), t_frames, dtype=torch.int32, device=dev)
-    T0 = layers[0]
-    gates0 = (torch.rand(T0, B, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
+    R0 = layout.rows[0] if packed else layers[0] * B
+    gates0 = (torch.rand(R0, 2, 4 * H, generator=g) * 0.8 + 0.1).to(dev)
     gates = torch.empty_like(gates0)
-    dy = (torch.randn(T0, B, 2 * H, generator=g) * 0.01).to(dev)
-    cst = torch.randn(T0, B, 2 * H, generator=g).to(dev)
-    y = torch.tanh(torch.randn(T0, B, 2 * H, generator=g)).to(dev)
+    dy = (torch.randn(R0, 2 * H, generator=g) * 0.01).to(dev)
+    cst = torch.randn(R0, 2 * H, generator=g).to(dev)
+    y = torch.tanh(torch.randn(R0, 2 * H, generator=g)).to(dev)
     dw = torch.zeros(2, 4 * H, H, device=dev)
     xch, ctrl = hb.persist_scratch(dev)
-    lstm_s, lstm_flops, launches = 0.0, 0.0, 0
-    fused = lib.asr_lstm_bwd_persist_fuses_dw(H, hb.current_arith()) == 1
+    lstm_s, lstm_flops, launches, steps_total = 0.0, 0.0, 0, 0
+    fused = (not packed) and lib.asr_lstm_bwd_persist_fuses_dw(H, hb.current_arith()) == 1
     db = torch.zeros(2 * 4 * H, device=dev)
     rows_per_launch = 16 if B <= 16 else 32
-    for T in layers:
-        lens.fill_(T)
+    lens_full = torch.empty(B, dtype=torch.int32, device=dev)
+    for li, T in enumerate(layers):
+        if packed:
+            rows = hb.LayerRows(layout, li)
+            T, lens_d, rb, re_, rh = rows.T, rows.lens, hb.ptr(rows.base), hb.ptr(rows.ext), rows.host_ptr()
+            valid = float(layout.lens[li].sum())
+        else:
+            lens_full.fill_(T)
+            lens_d, rb, re_, rh, valid = lens_full, None, None, None, float(T * B)
         best = None
         for _rep in range(3):                      # first pass warms clocks / code; report the best of the next two
             gates.copy_(gates0)
             torch.cuda.synchronize()
             e0.record(stream)
-            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens), None, None, None, hb.ptr(dy),
+            rc = lib.asr_lstm_seq_bwd_persist(T, B, B, H, 2, hb.ptr(gates), hb.ptr(w), hb.ptr(lens_d), rb, re_, rh, hb.ptr(dy),
                                               hb.ptr(cst), hb.ptr(y), hb.ptr(dw), hb.ptr(db), hb.c_p(xch.data_ptr()),
                                               hb.c_p(ctrl.data_ptr()), hb.current_arith(), hb.stream())
             e1.record(stream)
@@ -385,21 +403,25 @@ def kernel_roofline(dev, c, B, t_frames, olength):
                 dt = e0.elapsed_time(e1) * 1e-3
                 best = dt if best is None else min(best, dt)
         lstm_s += best
-        lstm_flops += T * (2.0 if fused else 1.0) * (2.0 * B * 4 * H * H * 2)
+        lstm_flops += valid * (2.0 if fused else 1.0) * (2.0 * 4 * H * H * 2)
         launches += (B + rows_per_launch - 1) // rows_per_launch
+        steps_total += T * ((B + rows_per_launch - 1) // rows_per_launch)
     rs = an != "f32" and H in (128, 256, 512)
     lpeak = gpeak
-    lstm = dict(bound="mfma", kernel="%s<%d> (dG recurrence%s, %d encoder layers)"
+    lstm = dict(bound="mfma", kernel="%s<%d> (dG recurrence%s, %d encoder layers%s)"
                                      % ("lstm_persist_bwd_rs_kernel" if rs else "lstm_persist_bwd_kernel", H,
-                                        " + fused dW_hh" if fused else "; dW_hh is a batched GEMM after it", len(layers)),
+                                        " + fused dW_hh" if fused else "; dW_hh is a batched GEMM after it", len(layers),
+                                        "; packed rows, the batch's own lengths: the `true` instantiation" if packed else ""),
                 algorithmic_flops_per_time_step=(2.0 if fused else 1.0) * (2.0 * B * 4 * H * H * 2),
+                algorithmic_flops_counted="valid (utterance, frame) pairs of the batch: %.0f of the %d x T the kernel's row groups walk"
+                                          % (lstm_flops / ((2.0 if fused else 1.0) * (2.0 * 4 * H * H * 2)), B) if packed else "B x T",
                 limiter="dependent chain: per time step two barriers and one L2 hand-off of partial sums between the 32 CUs "
                         "of an XCD; the MFMA floor of the step is ~0.3-0.6 us",
                 achieved=lstm_flops / lstm_s / 1e12, peak=lpeak, unit="TFLOP/s", peak_is=gemm["peak_is"],
                 frac=lstm_flops / lstm_s / 1e12 / lpeak, x_f32_mfma_peak=lstm_flops / lstm_s / 1e12 / MFMA_F32_PEAK_TF,
                 mfma_busy_frac=busy.get("lstm_bwd"), traffic=None, launches_per_step=launches,
                 us_per_launch=lstm_s / launches * 1e6, ms_per_step=lstm_s * 1e3,
-                us_per_time_step=lstm_s / (sum(layers) * (launches // len(layers))) * 1e6,
+                us_per_time_step=lstm_s / max(1, steps_total) * 1e6,
                 aborted=bool(hb.persist_aborted(dev)))
     # HBM-side traffic of that kernel from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
     # tools/pmc_probe.py, FETCH doubled as the gfx950 guide prescribes); measured at H=512, 8-row groups
@@ -408,7 +430,7 @@ def kernel_roofline(dev, c, B, t_frames, olength):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)["lstm_persist_bwd_kernel<512>"]
-                scale = (B / 32.0) * sum(layers) / launches          # PMC bytes are per time step of a 32-row launch
+                scale = (B / 32.0) * steps_total / launches          # PMC bytes are per time step of a 32-row launch
                 lstm["traffic"] = pmc["hbm_side_bytes_per_time_step"] * scale
                 lstm["traffic_unit"] = "bytes/launch (PMC bytes per time step x mean T of the launches), " + name
                 lstm["algorithmic_bytes_per_launch"] = pmc["algorithmic_bytes_per_time_step"] * scale
@@ -743,9 +765,10 @@ def main():
             out["workloads"]["epoch"] = ep
     if rank == 0:
         note("measuring dominant kernel")
-        out["roofline"] = kernel_roofline(dev, cfg, b_local, t_frames, info["olength"])
+        lens_local = [lens[i] for i in parallel.shard_indices(n_global, rank, world)]
+        out["roofline"] = kernel_roofline(dev, cfg, b_local, t_frames, info["olength"], lens_local)
         if not args.no_layer_gemms:
-            out["encoder_gate_gemm"] = encoder_gate_gemms(dev, cfg, b_local, t_frames)
+            out["encoder_gate_gemm"] = encoder_gate_gemms(dev, cfg, b_local, t_frames, lens_local)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, xs, lens, ys, args.config + " T=%d" % t_frames,
                                                3 if args.config == "cfg1" else 1)

@@ -349,6 +349,7 @@ class FlatBuffers(object):
         self._pending = [i1 - i0 for (i0, i1, _, _) in self.buckets]
         self._ready = [False] * len(self.buckets)
         self._issued = 0
+        self._started = False          # a gradient hook of this step has fired (its backward pass began)
         self._works = []
 
     def enable_overlap(self, group=None, force=False):
@@ -363,7 +364,7 @@ class FlatBuffers(object):
     def disable_overlap(self):
         """Back to ONE collective after the backward pass (removes the hooks; outstanding collectives are awaited, and a
         step abandoned between two buckets issues the rest of the fixed sequence first, as zero_grad does)."""
-        if self.overlap and 0 < self._issued < len(self.buckets):
+        if self.overlap and self._started and self._issued < len(self.buckets):
             self._issue_ready(force=True)
         for w in self._works:
             w.wait()
@@ -374,6 +375,7 @@ class FlatBuffers(object):
 
     def _on_grad(self, i):
         b = self.bucket_of[i]
+        self._started = True
         self._pending[b] -= 1
         if self._pending[b] < 0:
             raise RuntimeError("FlatBuffers overlap: a second backward pass reached a gradient of this step (one backward "
@@ -409,9 +411,10 @@ class FlatBuffers(object):
         """Detach every .grad: autograd then stores each gradient by reference instead of launching one add kernel per
         parameter into the flat buffer; collect() gathers them with a single multi-tensor copy before the step."""
         if self.overlap:
-            # a step that was abandoned after (part of) its backward: ranks may have stopped at different buckets, so
-            # every rank issues the rest of the fixed sequence before waiting - the collectives stay matched
-            if 0 < self._issued < len(self.buckets):
+            # a step that was abandoned after (part of) its backward: ranks may have stopped at different buckets - one
+            # of them possibly before its first bucket was complete - so every rank whose backward had BEGUN issues the
+            # rest of the fixed sequence before waiting: the collectives stay matched
+            if self._started and self._issued < len(self.buckets):
                 self._issue_ready(force=True)
             for w in self._works:
                 w.wait()

@@ -28,7 +28,10 @@ from utils import Logger, adjust_learning_rate, calculate_cer, cc, infinite_iter
 class StepScalar(object):
     """A scalar of a train step (loss, ...) whose host copy may still be on its way: the step's kernels, its optimiser
     update included, are enqueued without waiting for it (Solver._step).  float() / format() / arithmetic resolve it -
-    which waits for that step and deals with an abort latch it may carry."""
+    which waits for that step and deals with an abort latch it may carry.  Under data parallelism resolving a record may
+    turn into a sequence of collectives (the coordinated repeat, parallel.DpPipeline._recover), so every rank has to
+    resolve at the same points of its program: the Solver's loops do (they run the same code on all ranks); code of its own
+    that reads a scalar on ONE rank only (a rank-0 log, a rank-0 save) calls Solver.flush() on EVERY rank first."""
     __slots__ = ("_rec", "_i")
 
     def __init__(self, rec, i):
