@@ -66,7 +66,12 @@ int asr_abi_version(void);
  *                     each is used for the shapes it pays on (csrc/gemm.hip: asr_gemm_f32);
  *   ASR_GEMM_TILE_SMALL   asr_gemm_f32: 64 x 64 tiles on the 128 x 128 kernel's code (by default for products whose large tiles,
  *                     K split included, would be at most one workgroup per CU: decoder-side projections, output layer);
- *   ASR_LSTM_BWD_GATHER   asr_lstm_seq_bwd_persist: the gathered-dG kernel instead of the one with exchanged partials. */
+ *   ASR_LSTM_BWD_GATHER   asr_lstm_seq_bwd_persist: the gathered-dG kernel instead of the one with exchanged partials.
+ *   ASR_DEBUG_FAULT       asr_lstm_seq_fwd_persist (ASR_ARITH_BF16X6, H = 512 only; ASR_E_SHAPE otherwise): TESTS ONLY - the
+ *                         FAULT instantiation of the kernel: slice 1 of group 0 stops publishing after its first step and
+ *                         every wait gives up after 4 096 attempts, so the launch runs the kernels' own abort path (bounded
+ *                         spin expires -> abort word + latch + code -> NaN poison -> every workgroup drains) in a
+ *                         millisecond.  asr_dec_seq_fwd_persist_fault is the decoder's. */
 #define ASR_ARITH_F32        0
 #define ASR_ARITH_BF16X6     1
 #define ASR_ARITH_BF16X3     2
@@ -76,6 +81,7 @@ int asr_abi_version(void);
 #define ASR_GEMM_TILE_SP     0x800
 #define ASR_GEMM_TILE_SMALL  0x1000
 #define ASR_LSTM_BWD_GATHER  0x400
+#define ASR_DEBUG_FAULT      0x10000
 
 /* ---------------------------------------------------------------------------------------
  * Graph memo for the per-time-step launch chains (asr_lstm_seq_*, asr_dec_seq_*).  The `graphs`
@@ -344,6 +350,9 @@ int asr_dec_seq_fwd(const asr_dec_fwd_t* p, int s_begin, int s_end, void* graphs
  * xch and ctrl: the scratch pair of asr_lstm_seq_fwd_persist (sizes: asr_persist_scratch_bytes(); the decoder kernels
  * zero up to 3.6 MB of xch and use all 128 bytes of ctrl); abort convention as asr_lstm_seq_fwd_persist. */
 int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream);
+/* TESTS ONLY: asr_dec_seq_fwd_persist on the FAULT instantiation of its kernel (see ASR_DEBUG_FAULT): the launch aborts by
+ * itself within a millisecond.  cfg-2 widths (512, 512, 512, 128), T' <= 102; ASR_E_SHAPE otherwise. */
+int asr_dec_seq_fwd_persist_fault(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream);
 /* Free-running variant (greedy / smooth-embedding decode, model.py:334-341; solver.py:230-231,466-470): the embedding
  * input of step s >= 1 is made inside the kernel from the logits of step s-1: mode 1 = emb[argmax], mode 2 =
  * softmax(scaling * logits) @ emb.  The caller fills X[0] / Xd[0] (embedding columns of <BOS>) and fed[0].  Written:

@@ -125,7 +125,7 @@ struct DecDims {
 // W_out [z, ctx] + b (W_out streamed from L2, one wave per output), argmax / softmax(scale * logits), embedding row or
 // p @ E, dropout mask, -> X/Xd, logits, pred, fed, probs in global memory and one more exchange (DX_M) from which all
 // 32 CUs take the 4 x 128 embedding values.  The logits of the last step are left to the caller.
-template <int DD, int AA, int OO, int EE, bool FB, int RG = 4, int TPM = DP_TPM>
+template <int DD, int AA, int OO, int EE, bool FB, int RG = 4, int TPM = DP_TPM, bool FAULT = false>
 __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a) {
   using DM = DecDims<DD, AA, OO, EE, RG, TPM>;
   using GEO = DecGeo<RG, TPM>;
@@ -156,8 +156,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
-  const bool dbg_stall = persist_debug_stall(a.ctrl) != 0u;        // test hook (persist.h): this launch exercises its abort path
-  const unsigned spin_limit = dbg_stall ? DEBUG_SPIN_LIMIT : SPIN_LIMIT;
+  constexpr unsigned spin_limit = FAULT ? DEBUG_SPIN_LIMIT : SPIN_LIMIT;     // (FAULT: persist.h - tests of the abort path)
   const int r0 = RG * g;
   if (r0 >= a.nb) return;                    // this group has no rows (nobody waits for it)
   const int Tp = a.Tp, C = a.C, K = a.K, B = a.B, L = a.L, nb = a.nb;
@@ -513,7 +512,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
         a.X[((int64_t)(s + 1) * B + pb_) * KX + punit_] = zn;
         if (drop) a.Xd[((int64_t)(s + 1) * B + pb_) * KX + punit_] = zn;
       }
-      if (!(dbg_stall && g == 0 && slice == 1 && s >= 1))          // (test hook: a producer that went silent)
+      if (!(FAULT && g == 0 && slice == 1 && s >= 1))              // (FAULT: a producer that went silent)
         word_store(xg + DX_Z + par * 4 * 512 + (tid_ & 3) * 512 + punit_, zn, bit);
     }
     DP_MARK(3);
@@ -752,16 +751,16 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_fwd_kernel(DecPersistArgs a
   }
 }
 
-template <int DD, int AA, int OO, int EE, bool FB, int RG = 4, int TPM = DP_TPM>
+template <int DD, int AA, int OO, int EE, bool FB, int RG = 4, int TPM = DP_TPM, bool FAULT = false>
 int launch_dec_fwd(const DecPersistArgs& a, hipStream_t stream) {
   using DM = DecDims<DD, AA, OO, EE, RG, TPM>;
   const size_t lds = DM::lds_floats * sizeof(float);     // > 80 KB: one workgroup per CU
   static_assert(DM::lds_floats * sizeof(float) > 82 * 1024 && DM::lds_floats * sizeof(float) <= 160 * 1024, "LDS budget");
   static_assert(!FB || (EE == 128 && DD % 64 == 0 && OO % 64 == 0), "free-running feedback mapping");
-  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_fwd_kernel<DD, AA, OO, EE, FB, RG, TPM>,
+  hipError_t e = hipFuncSetAttribute((const void*)dec_persist_fwd_kernel<DD, AA, OO, EE, FB, RG, TPM, FAULT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((dec_persist_fwd_kernel<DD, AA, OO, EE, FB, RG, TPM>), dim3(256), dim3(DP_NT), lds, stream, a);
+  hipLaunchKernelGGL((dec_persist_fwd_kernel<DD, AA, OO, EE, FB, RG, TPM, FAULT>), dim3(256), dim3(DP_NT), lds, stream, a);
   return 0;
 }
 
@@ -1685,7 +1684,8 @@ bool asr_persist_device_ok();
 
 namespace {
 
-int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, void* xch, void* ctrl, hipStream_t stream) {
+int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, void* xch, void* ctrl, hipStream_t stream,
+                         bool fault = false) {
   if (!p || !xch || !ctrl || !p->P || !p->Q || !p->bo || !p->wcat || !p->bcat || !p->wdec || !p->convw || !p->watt ||
       !p->gvec || !p->w0 || !p->X || !p->gates || !p->cstate || !p->fconv || !p->S || !p->energy || !p->ws)
     return ASR_E_ARG;
@@ -1739,6 +1739,9 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
       if (geo4) rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true>(a, stream) : launch_dec_fwd<320, 320, 320, 128, true>(a, stream);
       else rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, true, 2, 256>(a, stream)
                      : launch_dec_fwd<320, 320, 320, 128, true, 2, 256>(a, stream);
+    } else if (fault) {          // the FAULT instantiation (persist.h) exists for the cfg-2 widths in the 4-row geometry only
+      if (!geo4 || !cfg2) return ASR_E_SHAPE;
+      rc = launch_dec_fwd<512, 512, 512, 128, false, 4, DP_TPM, true>(a, stream);
     } else if (geo4) {
       rc = cfg2 ? launch_dec_fwd<512, 512, 512, 128, false>(a, stream) : launch_dec_fwd<320, 320, 320, 128, false>(a, stream);
     } else {
@@ -1758,6 +1761,11 @@ int dec_fwd_persist_impl(const asr_dec_fwd_t* p, const asr_dec_feedback_t* f, vo
 // does not apply (the caller then uses asr_dec_seq_fwd).  xch / ctrl: asr_persist_scratch_bytes() (zeroed here on the stream: up to 3.6 MB and the 64 bytes of per-launch words).
 extern "C" int asr_dec_seq_fwd_persist(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream_) {
   return dec_fwd_persist_impl(p, nullptr, xch, ctrl, (hipStream_t)stream_);
+}
+// Test entry: the same launch on the FAULT instantiation of the kernel (csrc/persist.h) - a producer goes silent, the
+// bounded spins expire in a millisecond, the launch aborts by itself.  cfg-2 widths, T' <= 102; ASR_E_SHAPE otherwise.
+extern "C" int asr_dec_seq_fwd_persist_fault(const asr_dec_fwd_t* p, void* xch, void* ctrl, asr_stream_t stream_) {
+  return dec_fwd_persist_impl(p, nullptr, xch, ctrl, (hipStream_t)stream_, true);
 }
 
 // Free-running variant: steps 1..L-1 take their embedding input from the previous step's logits (f->mode 1: row of the

@@ -412,7 +412,7 @@ __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& a, const u32x4& b, const 
 // RG = rows of a group in the exchange / LDS layouts: 8 (NR = 8 or 4 active rows), or 16 (NR = 16: batches of >= 64 rows run
 // 16 rows per XCD group - the MFMA's 16 batch columns all carry rows, six products per tile and k-step instead of the
 // folded four, twice the gather - so that two 32-row blocks share one traversal of the chain).
-template <int PH, int NR, int NT, int RG = PRG, bool PACKED = false>
+template <int PH, int NR, int NT, int RG = PRG, bool PACKED = false, bool FAULT = false>
 __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a) {
   static_assert((RG == PRG && (NR == 4 || NR == PRG)) || (RG == 16 && NR == 16), "rows per group");
   constexpr bool FOLD = NT == 3 && RG == 8;        // the idle batch columns 8..15 carry a second term (fold_halves)
@@ -434,8 +434,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
   int g, slice;
   take_role(a.ctrl, role, g, slice);
   if (slice < 0) return;
-  const bool dbg_stall = persist_debug_stall(a.ctrl) != 0u;        // test hook (persist.h): this launch exercises its abort path
-  const unsigned spin_limit = dbg_stall ? DEBUG_SPIN_LIMIT : SPIN_LIMIT;
+  constexpr unsigned spin_limit = FAULT ? DEBUG_SPIN_LIMIT : SPIN_LIMIT;     // (FAULT: persist.h - tests of the abort path)
   const int T = a.T, B = a.B, ndir = a.ndir;
   const int d = ndir == 2 ? (g & 1) : 0;
   const int rowgroup = ndir == 2 ? (g >> 1) : g;
@@ -710,7 +709,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       if (aborted || abort_seen != 0u) hn = __builtin_nanf("");
       c_prev = cn;
       LP_MARK(5);
-      if (!(dbg_stall && g == 0 && slice == 1 && s >= 1))                                             // (test hook: a producer that went silent)
+      if (!(FAULT && g == 0 && slice == 1 && s >= 1))                                                 // (FAULT: a producer that went silent)
         word_store(xw_g + (s & 1) * (PH * RG) + (int64_t)punit * RG + pj, hn, tag_bit_of_step(s));     // hand-off first
       LP_MARK(6);
       if (prow_ok && (!PACKED || t < pext)) {
@@ -2166,11 +2165,24 @@ int launch_fwd(const PersistArgs& a, hipStream_t stream) {
 }
 
 template <int PH, int NR, int NT, int RG = PRG>
-int launch_fwd_bf3(const PersistArgs& a, hipStream_t stream) {
+int launch_fwd_bf3(const PersistArgs& a, hipStream_t stream, bool fault = false) {
   constexpr int KP = ((PH / PW + 31) / 32) * 32, MT = (PH / 32 + 3) / 4;
   const size_t stat = (size_t)((NT == 3 && RG == 8) ? 4 : NT) * PW * RG * (KP + 8) * 2 + sizeof(float) * 2 * PW * 4 * MT * RG * 4 + 64;
   const size_t pad = stat > 82 * 1024 ? 0 : 82 * 1024 - stat;       // static + pad > 80 KB: one workgroup per CU
   // (packed rows / time-major rows: two instantiations, see the row map in the kernel)
+  if constexpr (PH == 512 && NT == 3 && RG == PRG) {      // the FAULT instantiations exist for the default arithmetic at H = 512 only
+    if (fault) {
+      const void* ff = a.rowbase ? (const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, true, true>
+                                 : (const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, false, true>;
+      hipError_t ef = hipFuncSetAttribute(ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+      if (ef != hipSuccess) return (int)ef;
+      if (a.rowbase) hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, true, true>), dim3(256), dim3(PNT), pad, stream, a);
+      else hipLaunchKernelGGL((lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, false, true>), dim3(256), dim3(PNT), pad, stream, a);
+      return 0;
+    }
+  } else if (fault) {
+    return ASR_E_SHAPE;
+  }
   const void* fn = a.rowbase ? (const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, true>
                              : (const void*)lstm_persist_fwd_bf3_kernel<PH, NR, NT, RG, false>;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
@@ -2253,16 +2265,19 @@ bool fwd_rows16(int left, int ndir, int H, int arith) {
 // arith (include/asr_hip.h): ASR_ARITH_F32 -> the 4x4x1 fp32-MFMA kernels; ASR_ARITH_BF16X6 / _BF16X3 -> the bf16-MFMA
 // kernels with three / two split terms.  H = 640 (the judge's width) exists on the bf16 kernels only.
 template <int NR, int NT>
-int dispatch_fwd_split(int H, const PersistArgs& a, hipStream_t stream) {
-  return H == 640 ? launch_fwd_bf3<640, NR, NT>(a, stream) : H == 512 ? launch_fwd_bf3<512, NR, NT>(a, stream)
+int dispatch_fwd_split(int H, const PersistArgs& a, hipStream_t stream, bool fault) {
+  if (fault && H != 512) return ASR_E_SHAPE;
+  return H == 640 ? launch_fwd_bf3<640, NR, NT>(a, stream) : H == 512 ? launch_fwd_bf3<512, NR, NT>(a, stream, fault)
        : H == 320 ? launch_fwd_bf3<320, NR, NT>(a, stream) : H == 256 ? launch_fwd_bf3<256, NR, NT>(a, stream)
                                                            : launch_fwd_bf3<128, NR, NT>(a, stream);
 }
 template <int NR>
 int dispatch_fwd(int H, int arith, const PersistArgs& a, hipStream_t stream) {
   const int ar = arith & ASR_ARITH_MASK;
-  if (ar == ASR_ARITH_BF16X6) return dispatch_fwd_split<NR, 3>(H, a, stream);
-  if (ar == ASR_ARITH_BF16X3) return dispatch_fwd_split<NR, 2>(H, a, stream);
+  const bool fault = (arith & ASR_DEBUG_FAULT) != 0;
+  if (ar == ASR_ARITH_BF16X6) return dispatch_fwd_split<NR, 3>(H, a, stream, fault);
+  if (fault) return ASR_E_SHAPE;
+  if (ar == ASR_ARITH_BF16X3) return dispatch_fwd_split<NR, 2>(H, a, stream, false);
   if (H == 640) return ASR_E_SHAPE;
   return H == 512 ? launch_fwd<512, NR>(a, stream) : H == 320 ? launch_fwd<320, NR>(a, stream)
        : H == 256 ? launch_fwd<256, NR>(a, stream) : launch_fwd<128, NR>(a, stream);

@@ -52,13 +52,14 @@ __device__ __forceinline__ void word_store(float* p, float v, unsigned bit) {
 //   latch words (ctrl - 16 inside a kernel; NEVER written by the host side of the library): [0] abort latch, [1] code of the
 //     abort that set it.  A sequence operator is several launches (one per LSTM layer, per row block, the decoder); the
 //     per-launch abort word of all but the last is gone when the host looks, the latch is not.  The caller clears it.
-//     [2] TEST HOOK, written by the caller only: non-zero arms a fault in the kernels that honour it (lstm_persist_fwd_bf3_kernel,
-//     dec_persist_fwd_kernel): slice 1 of group 0 stops publishing after its first step and every wait of the launch gives up
-//     after DEBUG_SPIN_LIMIT attempts instead of SPIN_LIMIT - the kernels' own abort path (bounded spin expires ->
-//     raise_abort -> NaN poison -> every other workgroup drains) runs in milliseconds (tests/test_hip_parity.py).
 static inline unsigned* persist_launch_words(void* ctrl) { return (unsigned*)ctrl + 16; }
+// FAULT instantiations (template parameter of lstm_persist_fwd_bf3_kernel and dec_persist_fwd_kernel; the launch argument
+// ASR_DEBUG_FAULT / the entry asr_dec_seq_fwd_persist_fault select them; tests only): slice 1 of group 0 stops publishing
+// after its first step and every wait gives up after DEBUG_SPIN_LIMIT attempts instead of SPIN_LIMIT - the kernels' own abort
+// path (bounded spin expires -> raise_abort -> NaN poison -> every other workgroup drains) runs in a millisecond.  A template
+// parameter, not a run-time flag: with the flag in the shipped instantiation the decoder forward ran 5 % slower (10.2 ->
+// 10.7 us per step; same lesson as the row map of lstm_persist.hip).
 constexpr unsigned DEBUG_SPIN_LIMIT = 4096u;
-__device__ __forceinline__ unsigned persist_debug_stall(const unsigned* ctrl) { return flag_load(ctrl - 14); }
 __device__ __forceinline__ void raise_abort(unsigned* ctrl, unsigned code) {
   flag_store(ctrl + 9, code);
   flag_store(ctrl + 8, 1u);

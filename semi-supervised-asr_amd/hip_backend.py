@@ -18,7 +18,7 @@ EXPORTS = (
     "asr_lstm_seq_fwd", "asr_lstm_seq_fwd_persist", "asr_lstm_seq_bwd", "asr_lstm_seq_bwd_persist", "asr_lstm_seq_bwd_persist_w", "asr_lstm_bwd_persist_fuses_dw", "asr_pyramid_concat_fwd", "asr_pyramid_concat_bwd",
     "asr_pyramid_concat_fwd_seeded", "asr_pyramid_concat_bwd_seeded", "asr_rows_pack_f32", "asr_rows_unpack_fwd_f32", "asr_rows_unpack_bwd_f32", "asr_dropout_seeded_f32", "asr_relu_dropout_bwd_f32",
     "asr_dropout_mask_f32",
-    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
+    "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_fault", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
@@ -99,6 +99,7 @@ def load():
     lib.asr_att_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_dec_seq_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_i, c_p, c_p]
     lib.asr_dec_seq_fwd_persist.argtypes = [ctypes.POINTER(DecFwd), c_p, c_p, c_p]
+    lib.asr_dec_seq_fwd_persist_fault.argtypes = lib.asr_dec_seq_fwd_persist.argtypes
     lib.asr_dec_seq_fwd_persist_free.argtypes = [ctypes.POINTER(DecFwd), ctypes.POINTER(DecFeedback), c_p, c_p, c_p]
     lib.asr_dec_step_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_p]
     lib.asr_dec_seq_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_i, c_p, c_p]
@@ -129,6 +130,9 @@ def load():
 # fp32-equivalent), overridable with ASR_ARITH=f32|bf16x6|bf16x3 or `with hb.arith("f32"):`.
 ARITH_F32, ARITH_BF16X6, ARITH_BF16X3 = 0, 1, 2
 GEMM_TILE_NARROW, GEMM_TILE_WIDE, LSTM_BWD_GATHER, GEMM_TILE_SP, GEMM_TILE_SMALL = 0x100, 0x200, 0x400, 0x800, 0x1000
+DEBUG_FAULT = 0x10000        # ASR_DEBUG_FAULT: the persistent LSTM forward launch aborts by itself (tests of the abort path)
+# tests of the abort path: True routes the next teacher-forced persistent decoder launch to asr_dec_seq_fwd_persist_fault
+DEC_FAULT = [False]
 ARITH_NAMES = {"f32": ARITH_F32, "bf16x6": ARITH_BF16X6, "bf16x3": ARITH_BF16X3}
 ARITH_LABEL = {ARITH_F32: "f32", ARITH_BF16X6: "bf16x6", ARITH_BF16X3: "bf16x3"}
 
@@ -138,7 +142,7 @@ def _arith_code(a):
         code = 0
         for part in a.lower().split("+"):
             code |= {"narrow": GEMM_TILE_NARROW, "wide": GEMM_TILE_WIDE, "gather": LSTM_BWD_GATHER, "sp": GEMM_TILE_SP,
-                     "small": GEMM_TILE_SMALL}.get(part, 0) or \
+                     "small": GEMM_TILE_SMALL, "fault": DEBUG_FAULT}.get(part, 0) or \
                     ARITH_NAMES[part]
         return code
     return int(a)

@@ -517,8 +517,8 @@ class _DecoderSeq(torch.autograd.Function):
             if hb.USE_PERSIST_DEC and len(groups) == 1:          # one launch for the whole sequence
                 fg = _dec_fwd_struct(d, 0, B)
                 xch, ctrl = hb.persist_scratch(dev)
-                rc = lib.asr_dec_seq_fwd_persist(ctypes.byref(fg), ctypes.c_void_p(xch.data_ptr()),
-                                                 ctypes.c_void_p(ctrl.data_ptr()), hb.stream())
+                entry = lib.asr_dec_seq_fwd_persist_fault if hb.DEC_FAULT[0] else lib.asr_dec_seq_fwd_persist
+                rc = entry(ctypes.byref(fg), ctypes.c_void_p(xch.data_ptr()), ctypes.c_void_p(ctrl.data_ptr()), hb.stream())
                 if rc == 0:
                     done = True
                 elif rc != -2:                                  # -2: shape/device not covered by the fast path

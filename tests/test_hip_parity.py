@@ -1717,11 +1717,9 @@ def test_rccl_allreduce_of_the_flat_gradient_buffer(tmp_path):
 
 # ----------------------------------------------------------------------------------------------------------------------
 # The kernels' OWN abort path (csrc/persist.h: a bounded spin expires -> raise_abort -> NaN poison -> every other workgroup
-# drains), run for real: latch word 2 of the caller-owned control block arms a fault in the launch - slice 1 of group 0 stops
-# publishing after its first step and every wait gives up after 4 096 attempts - instead of the host writing the latch.
-def _arm_stall(dev, on):
-    import hip_backend as hb
-    hb.persist_scratch(dev)[1][2] = 1 if on else 0
+# drains), run for real instead of the host writing the latch: the FAULT instantiations of the persistent LSTM / decoder
+# forward kernels (ASR_DEBUG_FAULT in `arith`; asr_dec_seq_fwd_persist_fault) - slice 1 of group 0 stops publishing after its
+# first step and every wait gives up after 4 096 attempts.
 
 
 def _timed_ms(fn):
@@ -1751,11 +1749,8 @@ def test_lstm_kernel_raises_its_own_abort_and_the_next_launch_is_clean():
     want = run()
     torch.cuda.synchronize()
     assert not hb.persist_aborted(dev) and torch.isfinite(want).all()
-    try:
-        _arm_stall(dev, True)
+    with hb.arith("bf16x6+fault"):
         got, ms = _timed_ms(run)
-    finally:
-        _arm_stall(dev, False)
     ctrl = hb.persist_scratch(dev)[1].cpu().tolist()
     assert ms < 100.0, "the bounded spins of the armed launch expire in milliseconds, got %.1f ms" % ms
     assert ctrl[0] == 1 and ctrl[1] == 1, "latch + code of the forward hand-off's wait (code 1), got %s" % ctrl[:2]
@@ -1803,10 +1798,10 @@ def test_decoder_kernel_raises_its_own_abort_and_the_next_launch_is_clean():
     torch.cuda.synchronize()
     assert not hb.persist_aborted(dev) and torch.isfinite(want_l).all()
     try:
-        _arm_stall(dev, True)
+        hb.DEC_FAULT[0] = True
         (got_l, got_w), ms = _timed_ms(run)
     finally:
-        _arm_stall(dev, False)
+        hb.DEC_FAULT[0] = False
     ctrl = hb.persist_scratch(dev)[1].cpu().tolist()
     assert ms < 100.0, "got %.1f ms" % ms
     assert ctrl[0] == 1 and ctrl[1] in (11, 12, 14, 16, 17), "latch + the code of a decoder-forward wait, got %s" % ctrl[:2]
