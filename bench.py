@@ -775,6 +775,7 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+    if dist.is_available() and dist.is_initialized():      # (also the one-rank group of ASR_FORCE_DP=1)
         dist.destroy_process_group()
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
