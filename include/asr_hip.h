@@ -114,6 +114,12 @@ int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                  float* C, int64_t ldc, const float* bias, int relu, int accumulate,
                  int batch, int64_t sA, int64_t sB, int64_t sC, int split_k, int arith,
                  asr_stream_t stream);
+/* C = dropout(act(op(A) op(B) + bias)): asr_gemm_f32 (batch 1, no accumulate) followed by the seeded mask of
+ * asr_dropout_seeded_f32 over the element index m N + n of C (project_layer -> relu -> dropout, model.py:93-95): in the
+ * bias / ReLU pass where the product was split over K, in a pass of its own otherwise. */
+int asr_gemm_drop_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                      const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu, int split_k,
+                      int arith, uint64_t seed, float p, asr_stream_t stream);
 
 /* Skinny GEMM for the sequential chains (M = batch rows, tens not thousands):
  *   C[M,N] (ldc) (+)= A[M,K] (lda) * Bt[N,K]^T (ldb)  (+ bias[N]) (* mask[M,N] from col mask_from)
@@ -247,17 +253,20 @@ int asr_lstm_seq_bwd_persist_w(int T, int B, int nb, int H, int ndir, float* gat
  *                            out[b][t] = rows[rowbase[b] + t] for t < lens[b]; the frames behind an utterance hold what the
  *                            reference's last projection makes of an all-zero frame, dropout(relu(bias)) (model.py:93-95,
  *                            SURVEY F2): fill [C] (NULL = zeros) times the dropout mask - `mask` [B][T][C] given, or
- *                            regenerated from (seed, p) over the element index of out (asr_dropout_seeded_f32; p = 0: none)
+ *                            regenerated from (seed, p) over the element index of out (asr_dropout_seeded_f32; p = 0: none).
+ *                            fill_relu != 0: `fill` is the projection's bias itself and the kernel takes relu(fill)
  *   asr_rows_unpack_bwd_f32  drows[rowbase[b] + t] = dout[b][t] for t < lens[b], zeros on the block's padding rows;
  *                            dfill [C] (NULL, or zero-filled by the caller) += sum of dout * mask over the padded frames
+ *                            (relu_of != NULL: only where relu_of[c] > 0 - the gradient of the bias behind that relu)
  * ------------------------------------------------------------------------------------- */
 int asr_rows_pack_f32(int B, int T, int C, const float* x, const int32_t* lens, const int32_t* rowbase,
                       const int32_t* rowext, int ext_max, float* rows, asr_stream_t stream);
 int asr_rows_unpack_fwd_f32(int B, int T, int C, const float* rows, const int32_t* lens, const int32_t* rowbase,
-                            const float* fill, const float* mask, uint64_t seed, float p, float* out, asr_stream_t stream);
+                            const float* fill, int fill_relu, const float* mask, uint64_t seed, float p, float* out,
+                            asr_stream_t stream);
 int asr_rows_unpack_bwd_f32(int B, int T, int C, const float* dout, const int32_t* lens, const int32_t* rowbase,
                             const int32_t* rowext, int ext_max, const float* mask, uint64_t seed, float p, float* drows,
-                            float* dfill, asr_stream_t stream);
+                            float* dfill, const float* relu_of, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pyramidal pair-concat (model.py:85-92), time-major:
@@ -455,8 +464,43 @@ int asr_dec_seq_bwd_persist_free(const asr_dec_bwd_t* p, const asr_dec_feedback_
  *   asr_lstm_unpack_f32  gradients in the interleaved layout -> per-direction torch-layout dw_ih [4H][I],
  *                        dw_hh [4H][H], db [4H] (the gradient of b_ih and of b_hh)
  *   asr_cell_pack_f32    decoder cell: wcat [4D][D+O+E] = [w_hh | w_ih[:, E:E+O] | w_ih[:, :E]] interleaved, bcat
- *   asr_cell_unpack_f32  dwcat, db (interleaved) -> dw_ih [4D][E+O], dw_hh [4D][D], db [4D]
+ *   asr_cell_unpack_f32  dwcat, db (interleaved) -> dw_ih [4D][E+O], dw_hh [4D][D], db [4D] (+ db2: a second copy, or NULL)
+ *   asr_dec_pack_f32     asr_cell_pack_f32 + the transposed images the decoder kernels read, one launch: wcatT [D+O+E][4D]
+ *                        (the backward's dX product), wdecT [D][A] of mlp_dec.weight [A][D], wattT [C][A] of mlp_att.weight
+ *                        [A][C] (each output NULL = not wanted)
+ *   asr_lstm_pack_multi_f32 / asr_lstm_unpack_multi_f32   asr_lstm_pack_f32 / asr_lstm_unpack2_f32 for up to
+ *                        ASR_PACK_MAX_LAYERS layers in one launch (the encoder's three, the judge's two)
+ *   asr_colsum_parts_f32 dst[i][j] = sum_r src[i][r * n[i] + j], r < rows, for up to four matrices: the decoder backward's
+ *                        per-utterance partial gradients (gvec, mlp_att.weight, loc_conv.weight) in one launch
  * ------------------------------------------------------------------------------------- */
+#define ASR_PACK_MAX_LAYERS 4
+typedef struct {
+  int H, I, ndir;
+  const float* w_ih[2];
+  const float* w_hh[2];
+  const float* b_ih[2];
+  const float* b_hh[2];
+  float* w_ih_cat;
+  float* w_hh_il;
+  float* bias;
+} asr_lstm_pack_job_t;
+typedef struct {
+  int H, I, ndir;
+  const float* dw_ih_cat;
+  const float* dw_hh_il;
+  const float* db_il;
+  float* dw_ih[2];
+  float* dw_hh[2];
+  float* db[2];
+  float* db2[2];   /* second copy of the bias gradient (b_hh), or NULL */
+} asr_lstm_unpack_job_t;
+int asr_lstm_pack_multi_f32(int nlayers, const asr_lstm_pack_job_t* jobs, asr_stream_t stream);
+int asr_lstm_unpack_multi_f32(int nlayers, const asr_lstm_unpack_job_t* jobs, asr_stream_t stream);
+int asr_dec_pack_f32(int D, int O, int E, int A, int C, const float* w_ih, const float* w_hh, const float* b_ih,
+                     const float* b_hh, const float* wdec, const float* watt, float* wcat, float* bcat, float* wcatT,
+                     float* wdecT, float* wattT, asr_stream_t stream);
+int asr_colsum_parts_f32(int nparts, int rows, const float* const* src, const int32_t* n, float* const* dst,
+                         asr_stream_t stream);
 int asr_lstm_pack_f32(int H, int I, int ndir, const float* const* w_ih, const float* const* w_hh,
                       const float* const* b_ih, const float* const* b_hh, float* w_ih_cat, float* w_hh_il,
                       float* bias, asr_stream_t stream);
@@ -477,21 +521,24 @@ int asr_dec_prepare_f32(int L, int B, int D, int O, int E, const long long* toke
 int asr_cell_pack_f32(int D, int O, int E, const float* w_ih, const float* w_hh, const float* b_ih,
                       const float* b_hh, float* wcat, float* bcat, asr_stream_t stream);
 int asr_cell_unpack_f32(int D, int O, int E, const float* dwcat, const float* db_il, float* dw_ih, float* dw_hh,
-                        float* db, asr_stream_t stream);
+                        float* db, float* db2, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Label log-probabilities with label smoothing (Decoder.forward, model.py:354-366):
  *   out[r] = (1-ls) * log_softmax(logits[r])[index[r]] + ls * sum_v labeldist[v] * log_softmax(logits[r])[v]
  * (labeldist NULL: plain gather of the log-softmax).  rows = L*B; index is int64 (torch long).  total (NULL, or one float
- * the caller zeroed) += sum_r out[r]: the training loss -mean(log_probs) (solver.py:377) is that sum times a constant, so
- * no reduction kernel follows.  The backward writes d(logits) for an upstream gradient grad_out[r * grad_stride]
- * (grad_stride 0: ONE device scalar for every row - the gradient of that sum).
+ * the caller zeroed) += total_scale * sum_r out[r]: the training loss -mean(log_probs) (solver.py:377) is that sum times a
+ * constant, so with total_scale = -1 / (B L) `total` IS the loss and neither a reduction nor a multiply follows.  argmax
+ * (NULL, or int64 [rows]) receives argmax_v logits[r][v] (lowest index on ties: the `prediction` output of model.py:346).
+ * The backward writes d(logits) for an upstream gradient grad_scale * grad_out[r * grad_stride] (grad_stride 0: ONE device
+ * scalar for every row - the gradient of `total`, grad_scale = the forward's total_scale).
  * ------------------------------------------------------------------------------------- */
 int asr_label_logprob_fwd(int64_t rows, int V, const float* logits, int64_t ld, const int64_t* index,
-                          const float* labeldist, float ls_weight, float* out, float* total, asr_stream_t stream);
+                          const float* labeldist, float ls_weight, float* out, float* total, float total_scale,
+                          int64_t* argmax, asr_stream_t stream);
 int asr_label_logprob_bwd(int64_t rows, int V, const float* logits, int64_t ld, const int64_t* index,
                           const float* labeldist, float ls_weight, const float* grad_out, int64_t grad_stride,
-                          float* dlogits, int64_t lddz, asr_stream_t stream);
+                          float grad_scale, float* dlogits, int64_t lddz, asr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Free-running decoder feedback (Decoder.forward loop, model.py:329-351): one launch per decoder step each way for
@@ -525,11 +572,13 @@ int asr_dec_feedback_bwd(int B, int V, int E, int DO, const float* demb, float* 
  * is NULL) and p.  bias_c1 = 1-beta1^t, bias_c2 = 1-beta2^t are passed by the host.  skip_if_nonzero (may be
  * NULL): a 4-byte device word; when it is not zero at the time the kernel runs, nothing is updated - the abort latch
  * of the persistent kernels (or its all-reduced sum), so that the step can be enqueued before the host has read it.
+ * zero_word (may be NULL): one float the kernel sets to zero whether or not the update is skipped - the accumulator the
+ * NEXT step's asr_sumsq_f32 adds into (a caller that alternates between two words needs no fill launch per step).
  * ------------------------------------------------------------------------------------- */
 int asr_sumsq_f32(int64_t n, const float* g, float* out, asr_stream_t stream);
 int asr_adam_clip_f32(int64_t n, float* p, const float* g, float* m, float* v, float* vmax,
                       const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, float bias_c1, float bias_c2, const void* skip_if_nonzero,
+                      float weight_decay, float bias_c1, float bias_c2, const void* skip_if_nonzero, float* zero_word,
                       asr_stream_t stream);
 
 #ifdef __cplusplus

@@ -1957,14 +1957,21 @@ __global__ __launch_bounds__(512) void gemm_bfk_kernel(GemmArgs g, int groups) {
 #undef BFK_FOR_PIECES
 }
 
-// bias (+ReLU) pass after a split-K product (the atomics cannot carry an epilogue)
+// bias (+ReLU) pass after a split-K product (the atomics cannot carry an epilogue); with drop.thresh != 0 the seeded
+// dropout mask over the element index m N + n (asr_dropout_seeded_f32's) goes into the same pass (asr_gemm_drop_f32)
+struct DropEpi {
+  unsigned long long seed;
+  unsigned thresh;
+  float scale;
+};
 __global__ void bias_act_kernel(float* C, int64_t ldc, int64_t M, int64_t N, int64_t sC, const float* __restrict__ bias,
-                                int relu) {
+                                int relu, DropEpi drop) {
   float* p = C + blockIdx.z * sC;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M * N; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / N, n = i % N;
     float v = p[m * ldc + n] + (bias ? bias[n] : 0.f);
     if (relu) v = fmaxf(v, 0.f);
+    if (drop.thresh) v = asr_drop_keep(drop.seed, i, drop.thresh) ? v * drop.scale : 0.f;
     p[m * ldc + n] = v;
   }
 }
@@ -2100,12 +2107,20 @@ static void launch_narrow_split(bool akc, bool bkc, dim3 grid, hipStream_t strea
   else hipLaunchKernelGGL((gemm_bf3_kernel<false, false, NT, TS>), grid, block, 0, stream, g);
 }
 
-extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                            const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
-                            int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC, int split_k, int arith,
-                            asr_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                     const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
+                     int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC, int split_k, int arith,
+                     DropEpi drop, hipStream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return ASR_E_ARG;
+  if (drop.thresh && (batch != 1 || accumulate)) return ASR_E_ARG;
+  const DropEpi no_drop = {0ull, 0u, 1.f};
+  // the pass behind the product: the late epilogue of a split product and / or the dropout mask
+  auto pass_behind = [&](bool late) {
+    if (!late && !drop.thresh) return;
+    dim3 eg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
+    hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, late ? bias : nullptr, late ? relu : 0,
+                       drop.thresh ? drop : no_drop);
+  };
   const int ar = arith & ASR_ARITH_MASK;
   if (ar != ASR_ARITH_F32 && ar != ASR_ARITH_BF16X6 && ar != ASR_ARITH_BF16X3) return ASR_E_ARG;
   const bool auto_split = split_k <= 0;           // the kernel chooses; split_k == 1 is honoured as "unsplit" (run-to-run
@@ -2152,6 +2167,7 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
         if (plain) hipLaunchKernelGGL((gemm_bfk_kernel<2, 5, true>), grid, b4, 0, stream, g, groups);
         else hipLaunchKernelGGL((gemm_bfk_kernel<2, 5, false>), grid, b4, 0, stream, g, groups);
       }
+      pass_behind(false);
       ASR_CHECK_LAUNCH();
       return 0;
     }
@@ -2234,10 +2250,7 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
       else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3w_kernel<false, true>), grid, block, 0, stream, g);
       else hipLaunchKernelGGL((gemm_bf3w_kernel<false, false>), grid, block, 0, stream, g);
     }
-    if (late_epi) {
-      dim3 eg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
-      hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, bias, relu);
-    }
+    pass_behind(late_epi);
     ASR_CHECK_LAUNCH();
     return 0;
   }
@@ -2266,12 +2279,29 @@ extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
   else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
   else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
-  if (late_epilogue) {
-    dim3 eg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
-    hipLaunchKernelGGL(bias_act_kernel, eg, dim3(256), 0, stream, C, ldc, M, N, sC, bias, relu);
-  }
+  pass_behind(late_epilogue);
   ASR_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
+                            int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC, int split_k, int arith,
+                            asr_stream_t stream) {
+  const DropEpi none = {0ull, 0u, 1.f};
+  return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, batch, sA, sB, sC, split_k, arith,
+                   none, (hipStream_t)stream);
+}
+
+// C = dropout(act(A B + bias)): asr_gemm_f32 (batch 1, no accumulate) with the seeded mask of asr_dropout_seeded_f32 over the
+// element index m N + n of C - in the bias / ReLU pass where the product was split over K, else in a pass of its own.
+extern "C" int asr_gemm_drop_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                 const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
+                                 int split_k, int arith, uint64_t seed, float p, asr_stream_t stream) {
+  if (p < 0.f || p >= 1.f) return ASR_E_ARG;
+  const DropEpi d = {(unsigned long long)seed, asr_drop_thresh(p), 1.0f / (1.0f - p)};
+  return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, 0, 1, 0, 0, 0, split_k, arith, d,
+                   (hipStream_t)stream);
 }
 
 int asr_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bt, int64_t ldb,

@@ -36,7 +36,10 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float* __restrict__ vmax, const float* __restrict__ gnorm_sq,
                             float max_norm, float lr_c1, float b1, float b2, float eps, float wd, float rs_c2,
-                            const unsigned* __restrict__ skip) {
+                            const unsigned* __restrict__ skip, float* __restrict__ zero_word) {
+  // (the accumulator the NEXT step's asr_sumsq_f32 adds into: zeroed here, also by a skipped update, so that no fill launch
+  // precedes the norm - the caller alternates between two words)
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0.f;
   // device-side predicate: a non-zero word (the abort latch of the persistent kernels, or the all-reduced latch sum of a
   // data-parallel step) turns the whole update into a no-op, so the host can launch it without reading the latch first
   if (skip && *skip != 0u) return;
@@ -66,12 +69,12 @@ extern "C" int asr_sumsq_f32(int64_t n, const float* g, float* out, asr_stream_t
 extern "C" int asr_adam_clip_f32(int64_t n, float* p, const float* g, float* m, float* v, float* vmax,
                                  const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
                                  float weight_decay, float bias_c1, float bias_c2, const void* skip_if_nonzero,
-                                 asr_stream_t stream) {
+                                 float* zero_word, asr_stream_t stream) {
   if (!p || !g || !m || !v || n <= 0) return ASR_E_ARG;
   const int64_t nb = (n + 255) / 256;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, n, p, g,
                      m, v, vmax, gnorm_sq, max_norm, lr / bias_c1, beta1, beta2, eps, weight_decay,
-                     1.0f / sqrtf(bias_c2), (const unsigned*)skip_if_nonzero);
+                     1.0f / sqrtf(bias_c2), (const unsigned*)skip_if_nonzero, zero_word);
   ASR_CHECK_LAUNCH();
   return 0;
 }

@@ -32,7 +32,7 @@ __device__ __forceinline__ float4 pad_mask(const float4* mask, int64_t i4, unsig
 }
 
 __global__ void rows_unpack_fwd_kernel(int T, int C4, const float4* __restrict__ rows, const int32_t* __restrict__ lens,
-                                       const int32_t* __restrict__ rowbase, const float4* __restrict__ fill,
+                                       const int32_t* __restrict__ rowbase, const float4* __restrict__ fill, int fill_relu,
                                        const float4* __restrict__ mask, unsigned long long seed, unsigned thresh, float scale,
                                        float4* __restrict__ out) {
   const int b = blockIdx.y;
@@ -47,6 +47,7 @@ __global__ void rows_unpack_fwd_kernel(int T, int C4, const float4* __restrict__
       if (t < len) v = rows[(base + t) * C4 + c];
       else {
         v = fill ? fill[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fill_relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         const float4 m = pad_mask(mask, o, seed, thresh, scale);
         v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
       }
@@ -73,7 +74,7 @@ __global__ void rows_unpack_bwd_kernel(int T, int C4, const float4* __restrict__
 // dfill[c] += sum over the padded frames of utterance b of dout * mask: one block per utterance, one atomic per element
 __global__ void rows_fill_grad_kernel(int T, int C4, const float4* __restrict__ dout, const int32_t* __restrict__ lens,
                                       const float4* __restrict__ mask, unsigned long long seed, unsigned thresh, float scale,
-                                      float* __restrict__ dfill) {
+                                      float* __restrict__ dfill, const float4* __restrict__ relu_of) {
   const int b = blockIdx.x;
   const int len = lens[b];
   for (int c = threadIdx.x; c < C4; c += blockDim.x) {
@@ -84,8 +85,11 @@ __global__ void rows_fill_grad_kernel(int T, int C4, const float4* __restrict__ 
       acc.x += g.x * m.x; acc.y += g.y * m.y; acc.z += g.z * m.z; acc.w += g.w * m.w;
     }
     if (len < T) {
-      atomicAdd(dfill + 4 * c, acc.x); atomicAdd(dfill + 4 * c + 1, acc.y);
-      atomicAdd(dfill + 4 * c + 2, acc.z); atomicAdd(dfill + 4 * c + 3, acc.w);
+      const float4 r = relu_of ? relu_of[c] : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (r.x > 0.f) atomicAdd(dfill + 4 * c, acc.x);
+      if (r.y > 0.f) atomicAdd(dfill + 4 * c + 1, acc.y);
+      if (r.z > 0.f) atomicAdd(dfill + 4 * c + 2, acc.z);
+      if (r.w > 0.f) atomicAdd(dfill + 4 * c + 3, acc.w);
     }
   }
 }
@@ -106,13 +110,13 @@ extern "C" int asr_rows_pack_f32(int B, int T, int C, const float* x, const int3
 }
 
 extern "C" int asr_rows_unpack_fwd_f32(int B, int T, int C, const float* rows, const int32_t* lens, const int32_t* rowbase,
-                                       const float* fill, const float* mask, uint64_t seed, float p, float* out,
-                                       asr_stream_t stream) {
+                                       const float* fill, int fill_relu, const float* mask, uint64_t seed, float p,
+                                       float* out, asr_stream_t stream) {
   if (!rows || !lens || !rowbase || !out || B <= 0 || T <= 0 || C <= 0 || p < 0.f || p >= 1.f) return ASR_E_ARG;
   if (C % 4) return ASR_E_SHAPE;
   if (!asr_aligned16(rows) || !asr_aligned16(out) || (fill && !asr_aligned16(fill)) || (mask && !asr_aligned16(mask))) return ASR_E_ALIGN;
   hipLaunchKernelGGL(rows_unpack_fwd_kernel, dim3((T + 3) / 4, B), dim3(threads_for(C / 4)), 0, (hipStream_t)stream, T, C / 4,
-                     (const float4*)rows, lens, rowbase, (const float4*)fill, (const float4*)mask, seed,
+                     (const float4*)rows, lens, rowbase, (const float4*)fill, fill_relu, (const float4*)mask, seed,
                      mask ? 0u : asr_drop_thresh(p), 1.0f / (1.0f - p), (float4*)out);
   ASR_CHECK_LAUNCH();
   return 0;
@@ -120,15 +124,17 @@ extern "C" int asr_rows_unpack_fwd_f32(int B, int T, int C, const float* rows, c
 
 extern "C" int asr_rows_unpack_bwd_f32(int B, int T, int C, const float* dout, const int32_t* lens, const int32_t* rowbase,
                                        const int32_t* rowext, int ext_max, const float* mask, uint64_t seed, float p,
-                                       float* drows, float* dfill, asr_stream_t stream) {
+                                       float* drows, float* dfill, const float* relu_of, asr_stream_t stream) {
   if (!dout || !lens || !rowbase || !rowext || !drows || B <= 0 || T <= 0 || C <= 0 || ext_max <= 0 || p < 0.f || p >= 1.f) return ASR_E_ARG;
   if (C % 4) return ASR_E_SHAPE;
-  if (!asr_aligned16(dout) || !asr_aligned16(drows) || (mask && !asr_aligned16(mask))) return ASR_E_ALIGN;
+  if (!asr_aligned16(dout) || !asr_aligned16(drows) || (mask && !asr_aligned16(mask)) || (relu_of && !asr_aligned16(relu_of)))
+    return ASR_E_ALIGN;
   hipLaunchKernelGGL(rows_unpack_bwd_kernel, dim3((ext_max + 3) / 4, B), dim3(threads_for(C / 4)), 0, (hipStream_t)stream, T, C / 4,
                      (const float4*)dout, lens, rowbase, rowext, (float4*)drows);
   if (dfill)
     hipLaunchKernelGGL(rows_fill_grad_kernel, dim3(B), dim3(threads_for(C / 4)), 0, (hipStream_t)stream, T, C / 4,
-                       (const float4*)dout, lens, (const float4*)mask, seed, mask ? 0u : asr_drop_thresh(p), 1.0f / (1.0f - p), dfill);
+                       (const float4*)dout, lens, (const float4*)mask, seed, mask ? 0u : asr_drop_thresh(p), 1.0f / (1.0f - p), dfill,
+                       (const float4*)relu_of);
   ASR_CHECK_LAUNCH();
   return 0;
 }

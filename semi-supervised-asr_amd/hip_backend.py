@@ -20,6 +20,7 @@ EXPORTS = (
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_fault", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
+    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
@@ -27,6 +28,21 @@ EXPORTS = (
 _lib = None
 
 c_i, c_i64, c_f, c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+PACK_MAX_LAYERS = 4      # ASR_PACK_MAX_LAYERS
+
+
+class LstmPackJob(ctypes.Structure):
+    """asr_lstm_pack_job_t"""
+    _fields_ = [("H", c_i), ("I", c_i), ("ndir", c_i), ("w_ih", c_p * 2), ("w_hh", c_p * 2), ("b_ih", c_p * 2),
+                ("b_hh", c_p * 2), ("w_ih_cat", c_p), ("w_hh_il", c_p), ("bias", c_p)]
+
+
+class LstmUnpackJob(ctypes.Structure):
+    """asr_lstm_unpack_job_t"""
+    _fields_ = [("H", c_i), ("I", c_i), ("ndir", c_i), ("dw_ih_cat", c_p), ("dw_hh_il", c_p), ("db_il", c_p),
+                ("dw_ih", c_p * 2), ("dw_hh", c_p * 2), ("db", c_p * 2), ("db2", c_p * 2)]
 
 
 class DecFeedback(ctypes.Structure):
@@ -85,8 +101,8 @@ def load():
     lib.asr_lstm_bwd_persist_fuses_dw.argtypes = [c_i, c_i]
     lib.asr_lstm_seq_bwd.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_rows_pack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]
-    lib.asr_rows_unpack_fwd_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, ctypes.c_uint64, c_f, c_p, c_p]
-    lib.asr_rows_unpack_bwd_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, ctypes.c_uint64, c_f, c_p, c_p, c_p]
+    lib.asr_rows_unpack_fwd_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, ctypes.c_uint64, c_f, c_p, c_p]
+    lib.asr_rows_unpack_bwd_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, ctypes.c_uint64, c_f, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_fwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     lib.asr_pyramid_concat_bwd.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p]
     c_u64 = ctypes.c_uint64
@@ -105,10 +121,10 @@ def load():
     lib.asr_dec_seq_bwd.argtypes = [ctypes.POINTER(DecBwd), c_i, c_i, c_p, c_p]
     lib.asr_dec_seq_bwd_persist.argtypes = [ctypes.POINTER(DecBwd), c_p, c_p, c_p, c_p]
     lib.asr_dec_seq_bwd_persist_free.argtypes = [ctypes.POINTER(DecBwd), ctypes.POINTER(DecFeedbackBwd), c_p, c_p, c_p, c_p]
-    lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]
+    lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]
-    lib.asr_label_logprob_fwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p, c_p]
-    lib.asr_label_logprob_bwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_i64, c_p, c_i64, c_p]
+    lib.asr_label_logprob_fwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_p]
+    lib.asr_label_logprob_bwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_i64, c_f, c_p, c_i64, c_p]
     lib.asr_dec_feedback_fwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_i64,
                                          c_p, c_p, c_p, c_p, c_p, c_i64, c_p]
     lib.asr_dec_feedback_bwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p, c_p, c_f, c_p, c_p]
@@ -118,7 +134,13 @@ def load():
     lib.asr_lstm_unpack2_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, pp, pp, pp, pp, c_p]
     lib.asr_dec_prepare_f32.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]
     lib.asr_cell_pack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
-    lib.asr_cell_unpack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_cell_unpack_f32.argtypes = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
+    lib.asr_lstm_pack_multi_f32.argtypes = [c_i, ctypes.POINTER(LstmPackJob), c_p]
+    lib.asr_lstm_unpack_multi_f32.argtypes = [c_i, ctypes.POINTER(LstmUnpackJob), c_p]
+    lib.asr_dec_pack_f32.argtypes = [c_i, c_i, c_i, c_i, c_i] + [c_p] * 12
+    lib.asr_colsum_parts_f32.argtypes = [c_i, c_i, pp, ctypes.POINTER(ctypes.c_int32), pp, c_p]
+    lib.asr_gemm_drop_f32.argtypes = [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_i, c_i,
+                                      ctypes.c_uint64, c_f, c_p]
     if lib.asr_abi_version() != ABI_VERSION:
         raise RuntimeError("libasr_hip.so ABI %d != expected %d" % (lib.asr_abi_version(), ABI_VERSION))
     _lib = lib
@@ -202,9 +224,11 @@ def _rowmajor(t):
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1))
 
 
-def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, split_k=None, arith=None):
+def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, split_k=None, arith=None,
+         drop=None):
     """out[M,N] = op(A) op(B) (+bias)(relu)(+out).  A, B, out are 2-D row-major views (row stride free).
-    split_k None: the library chooses (asr_gemm_f32 with split_k = 0); 1: unsplit, run-to-run deterministic."""
+    split_k None: the library chooses (asr_gemm_f32 with split_k = 0); 1: unsplit, run-to-run deterministic.
+    drop (SeededMask): the seeded dropout mask over out's element index behind the epilogue (asr_gemm_drop_f32)."""
     A, lda = _rowmajor(_dev(A, "A"))
     B, ldb = _rowmajor(_dev(B, "B"))
     M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
@@ -214,6 +238,13 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, ac
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     out, ldc = _rowmajor(out)
     assert out.shape == (M, N)
+    if drop is not None:
+        assert not accumulate and ldc == N
+        check(load().asr_gemm_drop_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
+                                       ptr(bias), int(relu), 0 if split_k is None else int(split_k),
+                                       ARITH[0] if arith is None else _arith_code(arith), drop.seed, float(drop.p), stream()),
+              "asr_gemm_drop_f32")
+        return out
     check(load().asr_gemm_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
                               ptr(bias), int(relu), int(accumulate), 1, 0, 0, 0, 0 if split_k is None else int(split_k),
                               ARITH[0] if arith is None else _arith_code(arith), stream()), "asr_gemm_f32")
@@ -464,6 +495,61 @@ def lstm_unpack(H, I, ndir, dw_ih_cat, dw_hh_il, db_il, two_biases=False):
     return (dw_ih, dw_hh, db, db2) if two_biases else (dw_ih, dw_hh, db)
 
 
+def lstm_pack_multi(layers, ndir):
+    """layers: per layer the list of per-direction (w_ih, w_hh, b_ih, b_hh) in torch layout -> per layer (w_ih_cat
+    [ndir*4H, I], w_hh_il [ndir, 4H, H], bias [ndir*4H]) in the kernels' gate-interleaved layout; one launch for up to
+    PACK_MAX_LAYERS layers."""
+    outs, keep = [], []
+    jobs = (LstmPackJob * len(layers))()
+    for j, params in enumerate(layers):
+        H, I = params[1].shape[1], params[0].shape[1]
+        ps = [p if p.is_contiguous() else p.contiguous() for p in params]
+        keep.append(ps)
+        f32 = dict(device=ps[0].device, dtype=torch.float32)
+        out = (torch.empty(ndir * 4 * H, I, **f32), torch.empty(ndir, 4 * H, H, **f32), torch.empty(ndir * 4 * H, **f32))
+        outs.append(out)
+        job = jobs[j]
+        job.H, job.I, job.ndir = H, I, ndir
+        for d in range(ndir):
+            job.w_ih[d], job.w_hh[d] = _dev(ps[4 * d]).data_ptr(), _dev(ps[4 * d + 1]).data_ptr()
+            job.b_ih[d], job.b_hh[d] = _dev(ps[4 * d + 2]).data_ptr(), _dev(ps[4 * d + 3]).data_ptr()
+        job.w_ih_cat, job.w_hh_il, job.bias = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()
+    lib = load()
+    for j0 in range(0, len(layers), PACK_MAX_LAYERS):
+        n = min(PACK_MAX_LAYERS, len(layers) - j0)
+        check(lib.asr_lstm_pack_multi_f32(n, ctypes.cast(ctypes.byref(jobs, j0 * ctypes.sizeof(LstmPackJob)),
+                                                         ctypes.POINTER(LstmPackJob)), stream()), "asr_lstm_pack_multi_f32")
+    return outs
+
+
+def lstm_unpack_multi(grads, dims, ndir):
+    """grads: per layer (dw_ih_cat, dw_hh_il, db_il) in the interleaved layout (a layer whose three are all None gets no
+    gradients), dims: per layer (H, I) -> per layer [per direction dw_ih, dw_hh, db_ih, db_hh] flattened in torch layout
+    (b_ih and b_hh get their own tensors); one launch."""
+    live = [j for j, g in enumerate(grads) if g[0] is not None]
+    outs = [None] * len(grads)
+    jobs = (LstmUnpackJob * max(len(live), 1))()
+    for k, j in enumerate(live):
+        H, I = dims[j]
+        dw_ih, dw_hh, db = grads[j]
+        f32 = dict(device=dw_ih.device, dtype=torch.float32)
+        o = []
+        job = jobs[k]
+        job.H, job.I, job.ndir = H, I, ndir
+        job.dw_ih_cat, job.dw_hh_il, job.db_il = _dev(dw_ih).data_ptr(), _dev(dw_hh).data_ptr(), _dev(db).data_ptr()
+        for d in range(ndir):
+            t = [torch.empty(4 * H, I, **f32), torch.empty(4 * H, H, **f32), torch.empty(4 * H, **f32), torch.empty(4 * H, **f32)]
+            job.dw_ih[d], job.dw_hh[d], job.db[d], job.db2[d] = [x.data_ptr() for x in t]
+            o += t
+        outs[j] = o
+    lib = load()
+    for k0 in range(0, len(live), PACK_MAX_LAYERS):
+        n = min(PACK_MAX_LAYERS, len(live) - k0)
+        check(lib.asr_lstm_unpack_multi_f32(n, ctypes.cast(ctypes.byref(jobs, k0 * ctypes.sizeof(LstmUnpackJob)),
+                                                           ctypes.POINTER(LstmUnpackJob)), stream()), "asr_lstm_unpack_multi_f32")
+    return outs
+
+
 def dec_prepare(tokens, emb_w, xmask, X, Xd, fed, L, B, D, O, E):
     """Teacher-forced decoder input (embedding gather into X / Xd, zero recurrent slots, fed = tokens^T) in one launch.
     tokens [B, >= L] int64 on the device (row stride free)."""
@@ -479,12 +565,31 @@ def cell_pack(w_ih, w_hh, b_ih, b_hh, D, O, E, wcat, bcat):
                                    ptr(b_hh.contiguous()), ptr(wcat), ptr(bcat), stream()), "asr_cell_pack_f32")
 
 
+def dec_pack(w_ih, w_hh, b_ih, b_hh, wdec, watt, D, O, E, A, C, wcat, bcat, wcatT=None, wdecT=None, wattT=None):
+    """cell_pack + the transposed images wcatT [KX, 4D], wdecT [D, A], wattT [C, A] (each optional) in one launch."""
+    check(load().asr_dec_pack_f32(D, O, E, A, C, ptr(w_ih.contiguous()), ptr(w_hh.contiguous()), ptr(b_ih.contiguous()),
+                                  ptr(b_hh.contiguous()), ptr(wdec.contiguous()), ptr(watt.contiguous()), ptr(wcat), ptr(bcat),
+                                  ptr(wcatT), ptr(wdecT), ptr(wattT), stream()), "asr_dec_pack_f32")
+
+
 def cell_unpack(dwcat, db_il, D, O, E):
+    """-> dw_ih, dw_hh, db_ih, db_hh (the two bias gradients are equal, in tensors of their own)."""
     f32 = dict(device=dwcat.device, dtype=torch.float32)
-    dw_ih, dw_hh, db = torch.empty(4 * D, E + O, **f32), torch.empty(4 * D, D, **f32), torch.empty(4 * D, **f32)
-    check(load().asr_cell_unpack_f32(D, O, E, ptr(dwcat), ptr(db_il), ptr(dw_ih), ptr(dw_hh), ptr(db), stream()),
+    dw_ih, dw_hh, db, db2 = (torch.empty(4 * D, E + O, **f32), torch.empty(4 * D, D, **f32), torch.empty(4 * D, **f32),
+                             torch.empty(4 * D, **f32))
+    check(load().asr_cell_unpack_f32(D, O, E, ptr(dwcat), ptr(db_il), ptr(dw_ih), ptr(dw_hh), ptr(db), ptr(db2), stream()),
           "asr_cell_unpack_f32")
-    return dw_ih, dw_hh, db
+    return dw_ih, dw_hh, db, db2
+
+
+def colsum_parts(parts):
+    """parts: up to four [rows, ...] contiguous tensors with the same `rows` -> their sums over dim 0, one launch."""
+    rows = parts[0].shape[0]
+    outs = [torch.empty(p.shape[1:], device=p.device, dtype=torch.float32) for p in parts]
+    n = (ctypes.c_int32 * len(parts))(*[int(p.numel() // rows) for p in parts])
+    assert all(p.is_contiguous() and p.shape[0] == rows for p in parts) and len(parts) <= 4
+    check(load().asr_colsum_parts_f32(len(parts), rows, _ptr_array(parts), n, _ptr_array(outs), stream()), "asr_colsum_parts_f32")
+    return outs
 
 
 def _off(t, elems):
@@ -829,25 +934,31 @@ def rows_pack(x, rows):
     return out
 
 
-def rows_unpack_fwd(packed, rows, T, fill, mask):
-    """[R, C] -> [B, T, C]; frames behind an utterance = fill * mask (mask: None, a [B, T, C] tensor or a SeededMask)."""
+def rows_unpack_fwd(packed, rows, T, fill, mask, fill_relu=False):
+    """[R, C] -> [B, T, C]; frames behind an utterance = fill * mask (mask: None, a [B, T, C] tensor or a SeededMask);
+    fill_relu: relu(fill) * mask (fill = the last projection's bias as it is)."""
     C = packed.shape[1]
     out = torch.empty(rows.B, T, C, device=packed.device, dtype=torch.float32)
     seeded = isinstance(mask, SeededMask)
     check(load().asr_rows_unpack_fwd_f32(rows.B, T, C, ptr(packed), ptr(rows.lens), ptr(rows.base), ptr(fill),
+                                         1 if fill_relu else 0,
                                          None if (mask is None or seeded) else ptr(mask), mask.seed if seeded else 0,
                                          mask.p if seeded else 0.0, ptr(out), stream()), "asr_rows_unpack_fwd_f32")
     return out
 
 
-def rows_unpack_bwd(dout, rows, C, mask, want_fill):
-    """-> (drows [R, C], dfill [C] or None)."""
+def rows_unpack_bwd(dout, rows, C, mask, want_fill, relu_of=None, dfill=None):
+    """-> (drows [R, C], dfill [C] or None).  relu_of: the fill vector in front of its relu (fill_relu of the forward): its
+    gradient is masked by relu_of > 0.  dfill: a zeroed accumulator to use instead of a fresh one."""
     B, T, _ = dout.shape
     drows = torch.empty(rows.R, C, device=dout.device, dtype=torch.float32)
-    dfill = torch.zeros(C, device=dout.device, dtype=torch.float32) if want_fill else None
+    if not want_fill:
+        dfill = None
+    elif dfill is None:
+        dfill = torch.zeros(C, device=dout.device, dtype=torch.float32)
     seeded = isinstance(mask, SeededMask)
     check(load().asr_rows_unpack_bwd_f32(B, T, C, ptr(dout), ptr(rows.lens), ptr(rows.base), ptr(rows.ext), rows.ext_max,
                                          None if (mask is None or seeded) else ptr(mask), mask.seed if seeded else 0,
-                                         mask.p if seeded else 0.0, ptr(drows), ptr(dfill), stream()),
+                                         mask.p if seeded else 0.0, ptr(drows), ptr(dfill), ptr(relu_of), stream()),
           "asr_rows_unpack_bwd_f32")
     return drows, dfill

@@ -117,9 +117,10 @@ class pBLSTM(torch.nn.Module):
         drop = self.training and self.dropout_rate > 0
         p = self.dropout_rate
         x = hb.rows_pack(xpad if xpad.is_contiguous() else xpad.contiguous(), hb.LayerRows(layout, 0))      # [R_0, idim]
+        packs = ops.lstm_pack([layer.direction_params(0) for layer in self.layers], 2)   # kernel layout, all layers: one launch
         for i, (layer, proj) in enumerate(zip(self.layers, self.project_layers)):
             rows = hb.LayerRows(layout, i)
-            y = ops.lstm_layer(x, None, layer.direction_params(0), 2, rows=rows)                 # [R_i, 2H]
+            y = ops.lstm_layer(x, None, None, 2, rows=rows, packed=packs[i])                     # [R_i, 2H]
             mask = _drop_mask((rows.R, 1, y.shape[1]), p, dev) if drop else None
             if self.subsample[i] > 1:
                 rep = layout.replicated_rows(i)
@@ -138,7 +139,8 @@ class pBLSTM(torch.nn.Module):
         n = len(self.layers)
         t_out = layout.t_pad[n]
         pad_mask = _drop_mask((layout.B, t_out, x.shape[1]), p, dev) if drop else None
-        out = ops.rows_unpack(x, hb.LayerRows(layout, n), t_out, torch.relu(self.project_layers[-1].bias), pad_mask)
+        # (frames behind an utterance: dropout(relu(bias)) of the last projection, SURVEY F2 - the relu is the kernel's)
+        out = ops.rows_unpack(x, hb.LayerRows(layout, n), t_out, self.project_layers[-1].bias, pad_mask, fill_relu=True)
         self.last_lens_dev = layout.lens_dev(n)                    # device copy of the output lengths
         self.last_layout = layout                                  # (tests: where each utterance's rows were)
         return out, [int(l) for l in layout.lens[n]]
@@ -154,6 +156,7 @@ class pBLSTM(torch.nn.Module):
         lens_all = hb_to_device(per_layer, dev)                    # [n_layers+1, B] int32
         x = xpad.transpose(0, 1)                                   # time-major
         drop = self.training and self.dropout_rate > 0
+        packs = ops.lstm_pack([layer.direction_params(0) for layer in self.layers], 2)
         for i, (layer, proj) in enumerate(zip(self.layers, self.project_layers)):
             steps = max(lens) if total_length is None else int(total_length[i])
             if steps != x.shape[0]:                                 # (a no-op slice still records a SliceBackward:
@@ -161,7 +164,7 @@ class pBLSTM(torch.nn.Module):
             if not x.is_contiguous():
                 x = x.contiguous()
             lens_dev = lens_all[i]
-            y = ops.lstm_layer(x, lens_dev, layer.direction_params(0), 2)      # [T,B,2H]
+            y = ops.lstm_layer(x, lens_dev, None, 2, packed=packs[i])          # [T,B,2H]
             mask = _drop_mask(y.shape, self.dropout_rate, dev) if drop else None
             sub = self.subsample[i]
             if sub > 1:
@@ -295,7 +298,8 @@ class Decoder(torch.nn.Module):
         return logit, dec_z, dec_c, c, w
 
     def _label_matrices(self, ys, olength=None):
-        """ys_in = [BOS, y], ys_out = [y, EOS], both padded with EOS (model.py:301-306), as [B, L] matrices.
+        """ys_in = [BOS, y], ys_out = [y, EOS], both padded with EOS (model.py:301-306): ys_in as a [B, L] matrix, ys_out
+        as [B, L] (a view) AND in the time-major [L, B] order the loss kernel indexes the logits with (third result).
         One concatenation + one gather on the device with indices built on the host from the (host-known) label
         lengths, instead of 2B concatenations and 2B row copies that leave the GPU idle behind the launch queue."""
         lens = [int(y.size(0)) for y in ys]
@@ -310,25 +314,30 @@ class Decoder(torch.nn.Module):
             const = torch.tensor([self.bos, self.eos], dtype=ys[0].dtype, device=dev)
             self._tok_const[key] = const
         flat = torch.cat([y.reshape(-1) for y in ys] + [const])          # [n + 2]; n = BOS slot, n + 1 = EOS slot
-        idx = np.full((2, bsz, steps), n + 1, dtype=np.int32)
+        idx = np.full((2, bsz * steps), n + 1, dtype=np.int32)
+        t_in, t_out = idx[0].reshape(bsz, steps), idx[1].reshape(steps, bsz)       # [B, L] and [L, B]
         off = 0
         for b, ln in enumerate(lens):
-            idx[0, b, 0] = n
-            idx[0, b, 1:1 + ln] = np.arange(off, off + ln)
-            idx[1, b, :ln] = np.arange(off, off + ln)
+            t_in[b, 0] = n
+            t_in[b, 1:1 + ln] = np.arange(off, off + ln)
+            t_out[:ln, b] = np.arange(off, off + ln)
             off += ln
         if dev.type == "cuda":
             didx = hb.to_device_i64(idx, dev)
         else:
             didx = torch.from_numpy(idx).to(torch.long)
         both = flat[didx]
-        return both[0], both[1]
+        out_lb = both[1].view(steps, bsz)
+        return both[0].view(bsz, steps), out_lb.t(), out_lb
 
     def forward(self, enc_pad, enc_len, ys=None, tf_rate=1.0, max_dec_timesteps=500, sample=False, smooth=False,
-                scaling=1.0, label_smoothing=True, olength=None):
+                scaling=1.0, label_smoothing=True, olength=None, loss_norm=None):
         """-> (logits [B,L,V], ys_log_probs [B,L], prediction [B,L], ws [B,L,T']).
         `olength` (not in the reference) forces the number of teacher-forced steps so every
-        data-parallel shard decodes the global olength."""
+        data-parallel shard decodes the global olength.
+        `loss_norm` (not in the reference): the number of utterances B the caller's loss -sum(ys_log_probs) / (B L)
+        (solver.py:377) divides by - the kernel that forms ys_log_probs then leaves that loss in `ys_log_probs.fused_loss`
+        (a device scalar with the graph behind it; parallel.local_loss returns it)."""
         dev = enc_pad.device
         bsz, frames, _ = enc_pad.shape
         att = self.attention
@@ -337,12 +346,13 @@ class Decoder(torch.nn.Module):
         opts = dict(scaling=2.0, smooth=bool(smooth), smooth_scaling=float(scaling), sample=bool(sample),
                     bos=self.bos, eos=self.eos)      # attention temperature is the AttLoc default
         if ys is not None:
-            tok_in, tok_out = self._label_matrices(ys, olength)
+            tok_in, tok_out, tok_out_lb = self._label_matrices(ys, olength)
             steps = tok_out.size(1)
             # one numpy draw per step, also at tf_rate=1 and for step 0 (model.py:328)
             draws = [np.random.random_sample() <= tf_rate for _ in range(steps)]
             draws[0] = True
-            opts.update(tokens=tok_in.to(dev), tf_flags=draws)
+            # every step teacher-forced: the argmax of the logits is only an output, and the loss kernel below reads them anyway
+            opts.update(tokens=tok_in.to(dev), tf_flags=draws, skip_pred=have_ys and all(draws) and not sample)
         if not have_ys:
             steps = max_dec_timesteps
         opts["L"] = steps
@@ -357,19 +367,27 @@ class Decoder(torch.nn.Module):
             P, Q, self.embedding.weight, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh,
             att.mlp_dec.weight, att.loc_conv.weight, att.mlp_att.weight, att.gvec.weight, att.mlp_o.bias,
             self.output_layer.weight, self.output_layer.bias, w0, opts)
-        prediction = pred.transpose(0, 1)
         ws = ws.transpose(0, 1)
         # log_softmax -> gather target (or own prediction) -> label smoothing (model.py:354-366), one kernel each way
-        index_lb = (tok_out.to(dev) if have_ys else prediction).t()              # [L, B] like the time-major logits
+        index_lb = tok_out_lb.to(dev) if have_ys else pred                       # [L, B] like the time-major logits
         smooth_on = label_smoothing and self.ls_weight > 0 and self.training
         if smooth_on:
             key = str(dev)
             if key not in self._dist_dev:
                 self._dist_dev[key] = self.vlabeldist.to(dev).float().contiguous()
-        ys_log_probs, total = ops.label_logprob(logits, index_lb, self._dist_dev[str(dev)] if smooth_on else None,
-                                                self.ls_weight if smooth_on else 0.0, with_sum=True)
+        scale = -1.0 / float(loss_norm * steps) if loss_norm else 1.0
+        res = ops.label_logprob(logits, index_lb, self._dist_dev[str(dev)] if smooth_on else None,
+                                self.ls_weight if smooth_on else 0.0, with_sum=True, sum_scale=scale, with_argmax=pred is None)
+        ys_log_probs, total = res[0], res[1]
+        if pred is None:
+            pred = res[2]
+        prediction = pred.transpose(0, 1)
         ys_log_probs = ys_log_probs.transpose(0, 1)
-        ys_log_probs.fused_sum = total         # sum of all entries, from the same kernel (parallel.local_loss uses it)
+        # sum of all entries (times the loss's constant), from the same kernel (parallel.local_loss uses it)
+        if loss_norm:
+            ys_log_probs.fused_loss, ys_log_probs.fused_loss_scale = total, scale
+        else:
+            ys_log_probs.fused_sum = total
         return logits.transpose(0, 1), ys_log_probs, prediction, ws
 
 
@@ -389,13 +407,16 @@ class E2E(torch.nn.Module):
                                attention=self.attention, dropout_rate=dropout_rate, att_odim=att_odim,
                                ls_weight=ls_weight, labeldist=labeldist, bos=bos, eos=eos, pad=pad)
 
+    accepts_loss_norm = True           # (parallel.sup_local_loss: this forward takes the loss's normaliser along)
+
     def forward(self, data, ilens, ys=None, tf_rate=1.0, max_dec_timesteps=200, sample=False, smooth=False,
-                scaling=1.0, label_smoothing=True, total_length=None, olength=None):
+                scaling=1.0, label_smoothing=True, total_length=None, olength=None, loss_norm=None):
         if data.is_cuda:
             hb.upload_side_stream_for(data.shape[0] * data.shape[1])       # small uploads leave the compute stream when the GPU is the bottleneck
         enc_h, enc_lens = self.encoder(data, ilens, total_length)
         return self.decoder(enc_h, enc_lens, ys, tf_rate=tf_rate, max_dec_timesteps=max_dec_timesteps, sample=sample,
-                            smooth=smooth, scaling=scaling, label_smoothing=label_smoothing, olength=olength)
+                            smooth=smooth, scaling=scaling, label_smoothing=label_smoothing, olength=olength,
+                            loss_norm=loss_norm)
 
     def mask_and_cal_loss(self, log_probs, ys, mask=None):
         if mask is None:
@@ -433,8 +454,9 @@ class LM(torch.nn.Module):
 
     def _run_lstm(self, x_tm, lens_dev):
         """x_tm [T,B,E] -> [T,B,H] through all layers; inter-layer dropout like nn.LSTM(dropout=p)."""
+        packs = ops.lstm_pack([self.LSTM.direction_params(l) for l in range(self.n_layers)], 1)    # all layers: one launch
         for l in range(self.n_layers):
-            x_tm = ops.lstm_layer(x_tm, lens_dev, self.LSTM.direction_params(l), 1)
+            x_tm = ops.lstm_layer(x_tm, lens_dev, None, 1, packed=packs[l])
             if l + 1 < self.n_layers and self.training and self.dropout_rate > 0:
                 x_tm = F.dropout(x_tm, self.dropout_rate, True)
         return x_tm
@@ -461,7 +483,7 @@ class LM(torch.nn.Module):
         out = self.dropout_layer(out)
         logits = ops.linear(out.contiguous(), self.output_layer.weight, self.output_layer.bias)
         # log_softmax -> gather -> label smoothing (model.py:523-531) on the decoder's kernel (asr_label_logprob_*)
-        plain = ops.label_logprob(logits, tok_out)                    # log p(target)
+        plain, predictions = ops.label_logprob(logits, tok_out, with_argmax=True)      # log p(target); argmax of the logits
         ys_probs = plain.exp()
         if self.ls_weight > 0 and self.training:
             if str(dev) not in self._dist_dev:
@@ -469,7 +491,6 @@ class LM(torch.nn.Module):
             ys_log_probs = ops.label_logprob(logits, tok_out, self._dist_dev[str(dev)], self.ls_weight)
         else:
             ys_log_probs = plain
-        predictions = torch.argmax(logits, dim=-1)
         return ys_log_probs, ys_probs, predictions
 
     def zero_state(self, ref, dim=None):

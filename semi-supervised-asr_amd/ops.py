@@ -159,11 +159,10 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias, relu, drop):
         ctx.arith = hb.current_arith()
         x2 = x.reshape(-1, x.shape[-1])
-        y = hb.gemm(x2, weight, trans_b=True, bias=bias, relu=relu)
         seeded = isinstance(drop, hb.SeededMask)
-        if seeded:                                   # relu -> dropout fused: mask regenerated in the backward
-            assert relu and y.numel() % 4 == 0
-            hb.dropout_seeded_(y, drop)
+        if seeded:                                   # relu -> dropout in the product's own epilogue pass; the mask is
+            assert relu and (x2.shape[0] * weight.shape[0]) % 4 == 0      # regenerated in the backward
+        y = hb.gemm(x2, weight, trans_b=True, bias=bias, relu=relu, drop=drop if seeded else None)
         ctx.save_for_backward(x2, weight, y if relu else None)
         ctx.relu = relu
         ctx.drop = (drop.seed, drop.p) if seeded else None
@@ -212,7 +211,7 @@ def _lstm_workspace(rows, nbatch, H, ndir, dev, with_bwd):
     # against a zero padding row of the other operand - and that row must hold finite numbers, stale or not)
     alloc = torch.zeros if with_bwd else torch.empty
     ws = dict(gates_buf=alloc(rows + 1, ndir, 4 * H, **f32), y_buf=alloc(rows + 1, ndir * H, **f32),
-              c_buf=torch.empty(rows, ndir * H, **f32), w_hh=torch.empty(ndir, 4 * H, H, **f32))
+              c_buf=torch.empty(rows, ndir * H, **f32))
     if with_bwd:
         # the three accumulators the backward starts from zero share one buffer: one fill instead of three
         n1, n2, n3 = nbatch * ndir * H, ndir * 4 * H * H, ndir * 4 * H
@@ -233,17 +232,58 @@ def _lstm_views(ws, T, B, H, ndir):
     return ws
 
 
+class _LstmPack(torch.autograd.Function):
+    """torch layout of nn.LSTM's parameters (per direction w_ih [4H,I], w_hh [4H,H], b_ih, b_hh; gate-major rows, model.py:
+    67-68) -> the kernels' gate-interleaved layout, for ALL layers of a stack in one launch; the backward takes the layers'
+    gradients in that layout back in one launch.  Outputs per layer: w_ih_cat [ndir*4H, I], w_hh_il [ndir, 4H, H], bias
+    [ndir*4H] (= b_ih + b_hh)."""
+
+    @staticmethod
+    def forward(ctx, ndir, nlayers, *params):
+        per = 4 * ndir
+        layers = [params[per * j:per * (j + 1)] for j in range(nlayers)]
+        ctx.ndir, ctx.dims = ndir, [(lp[1].shape[1], lp[0].shape[1]) for lp in layers]
+        ctx.set_materialize_grads(False)
+        outs = hb.lstm_pack_multi(layers, ndir)
+        return tuple(t for out in outs for t in out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = len(ctx.dims)
+        per_layer = [grads[3 * j:3 * j + 3] for j in range(n)]
+        for j, g in enumerate(per_layer):
+            if any(t is None for t in g) and not all(t is None for t in g):     # (never on the product's paths)
+                H, I = ctx.dims[j]
+                ref = next(t for t in g if t is not None)
+                shp = ((ctx.ndir * 4 * H, I), (ctx.ndir, 4 * H, H), (ctx.ndir * 4 * H,))
+                per_layer[j] = [t if t is not None else torch.zeros(shp[k], device=ref.device) for k, t in enumerate(g)]
+        outs = hb.lstm_unpack_multi(per_layer, ctx.dims, ctx.ndir)
+        flat = []
+        for j in range(n):
+            flat += outs[j] if outs[j] is not None else [None] * (4 * ctx.ndir)
+        return (None, None) + tuple(flat)
+
+
+def lstm_pack(layers, ndir):
+    """layers: per layer the flat parameter list of its directions (model._LstmWeights.direction_params) -> per layer
+    (w_ih_cat, w_hh_il, bias) for lstm_layer(packed=...)."""
+    flat = [p for lp in layers for p in lp]
+    out = _LstmPack.apply(ndir, len(layers), *flat)
+    return [out[3 * j:3 * j + 3] for j in range(len(layers))]
+
+
 class _LstmLayer(torch.autograd.Function):
     """One (bi)directional LSTM layer over a padded time-major batch (model.py:79-81).
-    params: for each direction w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H] (torch layout).
+    w_ih [ndir*4H, I], w_hh [ndir, 4H, H], bias [ndir*4H]: the gate-interleaved parameters (_LstmPack); their gradients
+    leave in the same layout.
     rows (hb.LayerRows or None): the packed-row layout - x is then the row matrix [R, 1, I] (every product of this layer is
     a GEMM over the R rows as if it were a time-major batch of one; only the recurrence kernels know about utterances)."""
 
     @staticmethod
-    def forward(ctx, x, lens, ndir, pooled, rows, *params):
+    def forward(ctx, x, lens, ndir, pooled, rows, w_ih, w_hh, bias):
         ctx.arith = hb.current_arith()
         T, B, I = x.shape
-        H = params[1].shape[1]
+        H = w_hh.shape[2]
         dev = x.device
         x2 = x.reshape(T * B, I)
         nbatch = rows.B if rows is not None else B
@@ -255,14 +295,10 @@ class _LstmLayer(torch.autograd.Function):
         else:
             lease, ws = None, _lstm_workspace(T * B, nbatch, H, ndir, dev, False)
         _lstm_views(ws, T, B, H, ndir)
-        # torch layout -> gate-interleaved kernel layout, one launch: w_ih [ndir*4H, I], w_hh [ndir, 4H, H], b_ih + b_hh
-        w_ih = torch.empty(ndir * 4 * H, I, device=dev, dtype=torch.float32)
-        bias = torch.empty(ndir * 4 * H, device=dev, dtype=torch.float32)
-        hb.lstm_pack(params, ndir, w_ih, ws["w_hh"], bias)
         ws["lens"] = lens                      # int32 device tensor, kept for the backward (no copy)
         hb.gemm(x2, w_ih, trans_b=True, bias=bias, out=ws["gates"].view(T * B, ndir * 4 * H))
-        hb.lstm_seq_fwd(ws["gates"], ws["w_hh"], ws["lens"], ws["y"], ws["c"], use_graphs=pooled, rows=rows)
-        ctx.save_for_backward(x2, w_ih)
+        hb.lstm_seq_fwd(ws["gates"], w_hh, ws["lens"], ws["y"], ws["c"], use_graphs=pooled, rows=rows)
+        ctx.save_for_backward(x2, w_ih, w_hh)
         ctx.lease = lease
         ctx.rows = rows
         ctx.dims = (T, B, I, H, ndir)
@@ -271,7 +307,7 @@ class _LstmLayer(torch.autograd.Function):
     @staticmethod
     @_with_saved_arith
     def backward(ctx, dy):
-        x2, w_ih = ctx.saved_tensors
+        x2, w_ih, w_hh = ctx.saved_tensors
         T, B, I, H, ndir = ctx.dims
         lease = ctx.lease
         assert lease is not None and lease.ws is not None, "lstm_layer backward needs the leased workspace " \
@@ -288,9 +324,9 @@ class _LstmLayer(torch.autograd.Function):
                       db=zb[nb_ + n2:].view_as(ws["db"]))
         gates, y = ws["gates"], ws["y"]
         # the transposed recurrent weights are only formed if the kernel that reads the forward layout does not apply
-        fused_dw, fused_db = hb.lstm_seq_bwd(gates, lambda: ws["w_hhT"].copy_(ws["w_hh"].transpose(1, 2)), ws["lens"], dyc,
+        fused_dw, fused_db = hb.lstm_seq_bwd(gates, lambda: ws["w_hhT"].copy_(w_hh.transpose(1, 2)), ws["lens"], dyc,
                                              ws["c"], ws["dcarry"], y=y, dw_hh=ws["dw_hh"], db=ws["db"],
-                                             w_hh=ws["w_hh"], rows=ctx.rows)                    # gates <- dG in place
+                                             w_hh=w_hh, rows=ctx.rows)                    # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         dw_ih = _gemm_acc(dG, x2, trans_a=True, shape=(ndir * 4 * H, I))      # [ndir*4H, I]
@@ -307,22 +343,25 @@ class _LstmLayer(torch.autograd.Function):
             kk = T * B if ctx.rows is not None else (T - 1) * B
             hb.gemm_batched(dG, y, ws["dw_hh"], True, False, 4 * H, H, kk, ldg, ldy, H, ndir,
                             4 * H - B * ldg, B * ldy + H, 4 * H * H, accumulate=True, a_off=B * ldg, b_off=0)
-        # gate-interleaved gradients -> torch layout, one launch
-        g_ih, g_hh, g_b, g_b2 = hb.lstm_unpack(H, I, ndir, dw_ih, ws["dw_hh"], db, two_biases=True)
-        grads = []
-        for d in range(ndir):
-            grads += [g_ih[d], g_hh[d], g_b[d], g_b2[d]]
+        # the gradients stay gate-interleaved (_LstmPack.backward converts every layer's in one launch); what lives in the
+        # leased workspace is copied out of it, slices of the step's arena outlive the lease
+        dw_hh, db = (ws["dw_hh"], db) if zb is not None else (ws["dw_hh"].clone(), db.clone() if fused_db else db)
         lease.release()
-        return (dx, None, None, None, None) + tuple(grads)
+        return dx, None, None, None, None, dw_ih, dw_hh, db
 
 
-def lstm_layer(x, lens, params, ndir, rows=None):
+def lstm_layer(x, lens, params, ndir, rows=None, packed=None):
     """x [T,B,I] time-major contiguous, lens int32 device [B] -> y [T,B,ndir*H].
-    rows (hb.LayerRows): packed rows - x [R, I] -> y [R, ndir*H], lens = rows.lens."""
-    pooled = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    rows (hb.LayerRows): packed rows - x [R, I] -> y [R, ndir*H], lens = rows.lens.
+    packed: this layer's (w_ih_cat, w_hh_il, bias) from lstm_pack (a stack converts all its layers in one launch); None:
+    converted here from the torch-layout `params`."""
+    if packed is None:
+        packed = lstm_pack([params], ndir)[0]
+    w_ih, w_hh, bias = packed
+    pooled = torch.is_grad_enabled() and (x.requires_grad or w_hh.requires_grad)
     if rows is not None:
-        return _LstmLayer.apply(x.contiguous().view(rows.R, 1, -1), rows.lens, ndir, pooled, rows, *params).view(rows.R, -1)
-    return _LstmLayer.apply(x.contiguous(), lens, ndir, pooled, None, *params)
+        return _LstmLayer.apply(x.contiguous().view(rows.R, 1, -1), rows.lens, ndir, pooled, rows, w_ih, w_hh, bias).view(rows.R, -1)
+    return _LstmLayer.apply(x.contiguous(), lens, ndir, pooled, None, w_ih, w_hh, bias)
 
 
 # --------------------------------------------------------------------------------------
@@ -364,19 +403,25 @@ class _RowsUnpack(torch.autograd.Function):
     utterance are what the reference's last projection makes of a zero frame, dropout(relu(bias)): fill [C] * mask."""
 
     @staticmethod
-    def forward(ctx, packed, fill, rows, T, mask):
+    def forward(ctx, packed, fill, rows, T, mask, fill_relu):
         ctx.rows, ctx.mask, ctx.C = rows, mask, packed.shape[1]
         ctx.want_fill = fill is not None and fill.requires_grad
-        return hb.rows_unpack_fwd(packed.contiguous(), rows, T, fill.contiguous() if fill is not None else None, mask)
+        fc = fill.contiguous() if fill is not None else None
+        ctx.relu_of = fc if (fill_relu and ctx.want_fill) else None
+        return hb.rows_unpack_fwd(packed.contiguous(), rows, T, fc, mask, fill_relu=fill_relu)
 
     @staticmethod
     def backward(ctx, dout):
-        drows, dfill = hb.rows_unpack_bwd(dout.contiguous(), ctx.rows, ctx.C, ctx.mask, ctx.want_fill)
-        return drows, dfill, None, None, None
+        acc = _ARENA.take((ctx.C,), dout.device) if ctx.want_fill else None
+        drows, dfill = hb.rows_unpack_bwd(dout.contiguous(), ctx.rows, ctx.C, ctx.mask, ctx.want_fill, relu_of=ctx.relu_of,
+                                          dfill=acc)
+        return drows, dfill, None, None, None, None
 
 
-def rows_unpack(packed, rows, T, fill=None, mask=None):
-    return _RowsUnpack.apply(packed, fill, rows, T, mask)
+def rows_unpack(packed, rows, T, fill=None, mask=None, fill_relu=False):
+    """fill_relu: the padded frames hold relu(fill) * mask - `fill` is the last projection's bias as it is (no relu launch in
+    front, none of its backward behind)."""
+    return _RowsUnpack.apply(packed, fill, rows, T, mask, fill_relu)
 
 
 # --------------------------------------------------------------------------------------
@@ -475,8 +520,10 @@ class _DecoderSeq(torch.autograd.Function):
             ws = lease.ws
         else:
             lease, ws = None, _dec_workspace(B, Tp, A, D, O, E, C, K, L, drop, dev, False)
-        hb.cell_pack(w_ih, w_hh, b_ih, b_hh, D, O, E, ws["wcat"], ws["bcat"])       # [4D, KX] gate-interleaved rows
-        ws["wattT"].copy_(watt.t())
+        # [4D, KX] gate-interleaved rows + the transposed images the per-step forward (wattT) and the backward (wcatT, wdecT)
+        # read, one launch
+        hb.dec_pack(w_ih, w_hh, b_ih, b_hh, wdec, watt, D, O, E, A, C, ws["wcat"], ws["bcat"], ws.get("wcatT"),
+                    ws.get("wdecT"), ws["wattT"])
         # inputs used as they are (no staging copies); the dict keeps them alive until the backward has run
         ws["convw"] = convw.reshape(C, 2 * K + 1).contiguous()
         ws["gvec"] = gvec.reshape(A).contiguous()
@@ -533,7 +580,8 @@ class _DecoderSeq(torch.autograd.Function):
 
                 hb.run_grouped(groups, run)
             logits = hb.gemm(X[1:].view(L * B, KX)[:, :D + O], w_out_c, trans_b=True, bias=b_out).view(L, B, V)
-            pred = logits.argmax(-1)
+            # (skip_pred: the caller takes the argmax from the loss kernel that reads the logits anyway - label_logprob)
+            pred = None if opts.get("skip_pred") else logits.argmax(-1)
         else:
             fs = _dec_fwd_struct(d, 0, B)
             logits = torch.empty(L, B, V, **f32)
@@ -645,9 +693,12 @@ class _DecoderSeq(torch.autograd.Function):
         # flows through an argmax, the backward only needs what the forward saved (X, fed)
         ctx.free_persist = (not all_teacher) and bool(done) and not (smooth and tokens is None)
         ctx.smooth_scaling = float(opts.get("smooth_scaling", 1.0))
-        ctx.mark_non_differentiable(pred)
+        if pred is not None:
+            ctx.mark_non_differentiable(pred)
         ctx.set_materialize_grads(False)       # an unused `ws` output arrives as None instead of a zero tensor + copy
-        return logits, ws["ws"].clone(), pred
+        # the attention weights: in a training step a view of the leased workspace (valid until the next forward of the same
+        # shape; nothing on the training path keeps them), a copy otherwise
+        return logits, (ws["ws"].detach() if pooled else ws["ws"].clone()), pred
 
     @staticmethod
     @_with_saved_arith
@@ -671,9 +722,7 @@ class _DecoderSeq(torch.autograd.Function):
             for k_ in ("G", "dwext", "dP", "dcell", "dgvec_part", "dwatt_part", "dconv_part"):
                 o_ = (wk[k_].data_ptr() - wk["zbuf"].data_ptr()) // 4
                 wk[k_] = zb[o_:o_ + wk[k_].numel()].view_as(wk[k_])
-        G = wk["G"]
-        wk["wcatT"].copy_(wk["wcat"].t())
-        wk["wdecT"].copy_(wdec.t())
+        G = wk["G"]                            # (wcatT, wdecT: written by the forward's dec_pack)
         XO = X[1:].view(L * B, KX)[:, :D + O]
         hb.gemm(dlog2, w_out, out=G[1:].view(L * B, KX)[:, :D + O])
         dw_out = _gemm_acc(dlog2, XO, trans_a=True, shape=(V, D + O))
@@ -766,11 +815,10 @@ class _DecoderSeq(torch.autograd.Function):
         dg2 = wk["dgates"].view(L * B, 4 * D)
         Xin = X[:L] if Xd is None else Xd[:L]
         dwcat = _gemm_acc(dg2, Xin.reshape(L * B, KX), trans_a=True, shape=(4 * D, KX))     # [4D, KX] gate-interleaved rows
-        dw_ih, dw_hh, dbias = hb.cell_unpack(dwcat, _colsum_acc(dg2), D, O, E)       # -> torch layout, one launch
+        dw_ih, dw_hh, dbias, dbias2 = hb.cell_unpack(dwcat, _colsum_acc(dg2), D, O, E)       # -> torch layout, one launch
         dwdec = _gemm_acc(wk["dD"].view(L * B, A), X[1:].view(L * B, KX)[:, :D], trans_a=True, shape=(A, D))
-        dgvec = wk["dgvec_part"].sum(0).view(1, A)
-        dwatt = wk["dwatt_part"].sum(0)
-        dconvw = wk["dconv_part"].sum(0).view(C, 1, 1, 2 * K + 1)
+        dgvec, dwatt, dconvw = hb.colsum_parts([wk["dgvec_part"], wk["dwatt_part"], wk["dconv_part"]])   # sums over utterances
+        dgvec, dconvw = dgvec.view(1, A), dconvw.view(C, 1, 1, 2 * K + 1)
         # dQ[b] = ws[:, b, :]^T dctx[:, b, :]   (batched over utterances)
         dQ = torch.empty(B, Tp, O, device=dev, dtype=torch.float32)
         dctx_base = G[1:]                               # [L, B, KX], ctx grad at columns D:D+O
@@ -788,54 +836,63 @@ class _DecoderSeq(torch.autograd.Function):
             demb_w.index_add_(0, fed[tokfed], demb_all[tokfed])
         dP = wk["dP"] if zb is not None else wk["dP"].clone()      # (an arena slice outlives the lease)
         lease.release()
-        return (dP, dQ, demb_w, dw_ih, dw_hh, dbias, dbias, dwdec, dconvw, dwatt, dgvec, dbo, dw_out, db_out,
+        return (dP, dQ, demb_w, dw_ih, dw_hh, dbias, dbias2, dwdec, dconvw, dwatt, dgvec, dbo, dw_out, db_out,
                 None, None)
 
 
 class _LabelLogProb(torch.autograd.Function):
     """(1-ls) log_softmax(logits)[target] + ls sum_v labeldist_v log_softmax(logits)_v  (model.py:354-366) in one
-    kernel each way.  logits [..., V] contiguous, index [...] long -> ([...], total): `total` (with_sum) is the sum of all
-    outputs, accumulated by the same kernel - the training loss is that sum times a constant (solver.py:377), so neither a
-    reduction kernel nor its backward follows; a gradient that arrives through `total` alone is one device scalar,
-    broadcast by the backward kernel."""
+    kernel each way.  logits [..., V] contiguous, index [...] long -> ([...], total, argmax): `total` (with_sum) is
+    sum_scale times the sum of all outputs, accumulated by the same kernel - the training loss is that sum times a constant
+    (solver.py:377; sum_scale = that constant makes `total` the loss itself), so neither a reduction kernel nor a multiply nor
+    their backward follow; a gradient that arrives through `total` alone is one device scalar, broadcast by the backward
+    kernel.  argmax (with_argmax): the row's argmax over V, long - the `prediction` output of model.py:346, read off the
+    logits the kernel has in its registers anyway."""
 
     @staticmethod
-    def forward(ctx, logits, index, labeldist, ls_weight, with_sum):
+    def forward(ctx, logits, index, labeldist, ls_weight, with_sum, sum_scale, with_argmax):
         lg = logits.contiguous()
         V = lg.shape[-1]
         rows = lg.numel() // V
         idx = index.contiguous()
         out = torch.empty(lg.shape[:-1], device=lg.device, dtype=torch.float32)
-        total = torch.zeros((), device=lg.device, dtype=torch.float32) if with_sum else None
+        total = zeros_acc((1,), lg.device).view(()) if with_sum else None
+        amax = torch.empty(lg.shape[:-1], device=lg.device, dtype=torch.long) if with_argmax else None
         dist = labeldist.contiguous() if labeldist is not None else None
         hb.check(hb.load().asr_label_logprob_fwd(rows, V, hb.ptr(lg), V, ctypes.c_void_p(idx.data_ptr()), hb.ptr(dist),
-                                                 float(ls_weight), hb.ptr(out), hb.ptr(total), hb.stream()),
+                                                 float(ls_weight), hb.ptr(out), hb.ptr(total), float(sum_scale),
+                                                 None if amax is None else ctypes.c_void_p(amax.data_ptr()), hb.stream()),
                  "asr_label_logprob_fwd")
         ctx.save_for_backward(lg, idx, dist)
-        ctx.ls = float(ls_weight)
+        ctx.ls, ctx.sum_scale = float(ls_weight), float(sum_scale)
         ctx.set_materialize_grads(False)
-        return out, total
+        if amax is not None:
+            ctx.mark_non_differentiable(amax)
+        return out, total, amax
 
     @staticmethod
-    def backward(ctx, g, gt):
+    def backward(ctx, g, gt, _gamax):
         lg, idx, dist = ctx.saved_tensors
         V = lg.shape[-1]
         rows = lg.numel() // V
         if g is None and gt is None:
-            return None, None, None, None, None
+            return (None,) * 7
         if g is None:
-            gc, stride = gt.contiguous(), 0                  # d(total) alone: one scalar for every row
+            gc, stride, scale = gt.contiguous(), 0, ctx.sum_scale       # d(total) alone: one scalar for every row
         else:
-            gc, stride = (g if gt is None else g + gt).contiguous(), 1
+            gc, stride, scale = (g if gt is None else g + gt * ctx.sum_scale).contiguous(), 1, 1.0
         dz = torch.empty_like(lg)
         hb.check(hb.load().asr_label_logprob_bwd(rows, V, hb.ptr(lg), V, ctypes.c_void_p(idx.data_ptr()), hb.ptr(dist),
-                                                 ctx.ls, hb.ptr(gc), stride, hb.ptr(dz), V, hb.stream()), "asr_label_logprob_bwd")
-        return dz, None, None, None, None
+                                                 ctx.ls, hb.ptr(gc), stride, scale, hb.ptr(dz), V, hb.stream()),
+                 "asr_label_logprob_bwd")
+        return (dz,) + (None,) * 6
 
 
-def label_logprob(logits, index, labeldist=None, ls_weight=0.0, with_sum=False):
-    out, total = _LabelLogProb.apply(logits, index, labeldist, ls_weight, with_sum)
-    return (out, total) if with_sum else out
+def label_logprob(logits, index, labeldist=None, ls_weight=0.0, with_sum=False, sum_scale=1.0, with_argmax=False):
+    """-> out, + total (with_sum), + argmax (with_argmax)."""
+    out, total, amax = _LabelLogProb.apply(logits, index, labeldist, ls_weight, with_sum, sum_scale, with_argmax)
+    res = (out,) + ((total,) if with_sum else ()) + ((amax,) if with_argmax else ())
+    return res if len(res) > 1 else out
 
 
 def decoder_sequence(P, Q, emb_w, w_ih, w_hh, b_ih, b_hh, wdec, convw, watt, gvec, bo, w_out, b_out, w0, opts):

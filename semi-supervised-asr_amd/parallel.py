@@ -82,10 +82,29 @@ def shard_batch(xs, ilens, ys, rank, world):
 def local_loss(log_probs, info):
     """-sum over this shard / (B_global * olength_global)  (solver.py:377 is the W=1 case).  The product's decoder hands the
     sum along with the log-probabilities (`fused_sum`, accumulated by the kernel that made them): one multiply is left."""
+    want = -1.0 / float(info["b_global"] * log_probs.shape[1])
+    loss = getattr(log_probs, "fused_loss", None)
+    if loss is not None:                     # the kernel scaled its sum already (Decoder.forward, loss_norm)
+        have = log_probs.fused_loss_scale
+        return loss if abs(have - want) <= 1e-12 * abs(want) else loss * (want / have)
     total = getattr(log_probs, "fused_sum", None)
     if total is None:
         total = log_probs.sum()
-    return total * (-1.0 / float(info["b_global"] * log_probs.shape[1]))
+    return total * want
+
+
+_ONE = {}
+
+
+def backward(loss):
+    """loss.backward() without the fill launch of its seed: a device scalar's d(loss)/d(loss) = 1 is a cached tensor."""
+    if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
+        one = _ONE.get(loss.device)
+        if one is None:
+            one = _ONE[loss.device] = torch.ones((), device=loss.device, dtype=torch.float32)
+        loss.backward(gradient=one)
+    else:
+        loss.backward()
 
 
 def world():
@@ -121,9 +140,10 @@ def sup_local_loss(model_fwd, xs, ilens, ys, tf_rate, rank, world_size, n_layers
     if not il_r:
         skip_decoder_draws(info["olength"])
         return None
+    extra = dict(loss_norm=info["b_global"]) if getattr(model_fwd, "accepts_loss_norm", False) else {}
     _, log_probs, _, _ = model_fwd(xs_r, il_r, ys_r, tf_rate=tf_rate, sample=False,
                                    total_length=padded_lengths(info["t_max"], n_layers, subsample),
-                                   olength=info["olength"])
+                                   olength=info["olength"], **extra)
     return local_loss(log_probs, info)
 
 
@@ -194,7 +214,7 @@ def dp_step(make_loss, opt, n_aux, latch, leave_fast_path):
         loss, scalars = make_loss()
         opt.zero_grad()
         if loss is not None:
-            loss.backward()
+            backward(loss)
         aux = [v if v is not None else 0.0 for v in scalars[:n_aux]] + [0.0] * (flag_slot - n_aux)
         aux.append(latch())
         opt.buf.set_aux(aux)
@@ -241,7 +261,7 @@ class DpPipeline(object):
         loss, scalars = make_loss()
         opt.zero_grad()
         if loss is not None:
-            loss.backward()
+            backward(loss)
         aux = [v if v is not None else 0.0 for v in scalars[:n_aux]] + [0.0] * (flag_slot - n_aux)
         aux.append(self.latch())
         opt.buf.set_aux(aux)
@@ -505,7 +525,11 @@ class FlatAdam(object):
         self.m = torch.zeros_like(self.buf.flat_p)
         self.v = torch.zeros_like(self.buf.flat_p)
         self.vmax = torch.zeros_like(self.buf.flat_p) if amsgrad else None
-        self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float32)
+        # ||g||^2 of a step: two words used in turn - the update kernel of one step zeroes the word the next step's norm
+        # accumulates into (no fill launch per step)
+        self.gnorm_pair = torch.zeros(2, device=dev, dtype=torch.float32)
+        self.gnorm_sq = self.gnorm_pair[0:1]
+        self._applies = 0
         self.t = 0
 
     def zero_grad(self):
@@ -519,7 +543,7 @@ class FlatAdam(object):
 
     def apply(self, max_grad_norm=None, skip_if=None):
         """Second half: global grad norm -> clip + Adam on the (reduced) flat buffer.  Returns the device scalar holding
-        ||g||^2 (read it with .item() only if you need the number).  skip_if: a 1-element device tensor (4 bytes); if it is
+        ||g||^2 (read it with .item() only if you need the number, and before the NEXT apply() has run on the device).  skip_if: a 1-element device tensor (4 bytes); if it is
         not zero when the kernel runs the update is a no-op on the device - the caller that finds it set later takes the
         step count back with unapply()."""
         import hip_backend as hb
@@ -529,9 +553,12 @@ class FlatAdam(object):
         b1, b2 = g["betas"]
         lib = hb.load()
         n = self.buf.total
-        gptr = None
+        gptr = nxt = None
         if clip is not None:
-            self.gnorm_sq.zero_()
+            k = self._applies & 1
+            self._applies += 1
+            self.gnorm_sq = self.gnorm_pair[k:k + 1]
+            nxt = hb.ptr(self.gnorm_pair[1 - k:2 - k])
             hb.check(lib.asr_sumsq_f32(n, hb.ptr(self.buf.flat_g), hb.ptr(self.gnorm_sq), hb.stream()),
                      "asr_sumsq_f32")
             gptr = hb.ptr(self.gnorm_sq)
@@ -540,7 +567,8 @@ class FlatAdam(object):
                                        float(clip if clip is not None else 0.0), float(g["lr"]), float(b1),
                                        float(b2), float(g["eps"]), float(g["weight_decay"]),
                                        1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
-                                       None if skip_if is None else hb.c_p(skip_if.data_ptr()), hb.stream()), "asr_adam_clip_f32")
+                                       None if skip_if is None else hb.c_p(skip_if.data_ptr()), nxt, hb.stream()),
+                 "asr_adam_clip_f32")
         return self.gnorm_sq
 
     def unapply(self, n=1):

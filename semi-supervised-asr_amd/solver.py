@@ -377,7 +377,7 @@ class Solver(object):
                    values=None, event=None, slot=None)
         loss, scalars = make_local()
         opt.zero_grad()
-        loss.backward()
+        parallel.backward(loss)                          # (the seed of the backward pass is a cached tensor)
         opt.reduce()                                     # gradients -> flat buffer (no collective in one process)
         if not loss.is_cuda:                             # CPU tensors (tests of the host logic): nothing to pipeline
             opt.apply()

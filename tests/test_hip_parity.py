@@ -1106,6 +1106,26 @@ def test_label_logprob_kernels(V, ls):
     ref.backward(up)
     _close(got, ref, rtol=1e-5, atol=1e-6, what="label log-probs")
     _close(g_got, ref_in.grad, rtol=1e-5, atol=1e-6, what="d(logits)")
+    # the sum of all outputs times a constant (the training loss, solver.py:377) and the argmax from the same launch; the
+    # gradient through that scalar alone is the gradient of the loss
+    scale = -1.0 / (L * B)
+    lg2 = logits.detach().clone().requires_grad_(True)
+    out, total, amax = ops.label_logprob(lg2, idx, dist if ls > 0 else None, ls, with_sum=True, sum_scale=scale, with_argmax=True)
+    _close(total, ref.detach().sum() * scale, rtol=1e-5, atol=1e-6, what="scaled sum")
+    assert torch.equal(amax, logits.detach().argmax(-1))
+    total.backward()
+    ref_in.grad = None
+    lp2 = torch.log_softmax(ref_in, dim=2)
+    ref2 = torch.gather(lp2, 2, idx.unsqueeze(2)).squeeze(2)
+    if ls > 0:
+        ref2 = (1 - ls) * ref2 + ls * torch.sum(lp2 * dist, dim=2)
+    (ref2.sum() * scale).backward()
+    _close(lg2.grad, ref_in.grad, rtol=1e-5, atol=1e-7, what="d(logits) through the scaled sum")
+    # both gradients at once
+    lg3 = logits.detach().clone().requires_grad_(True)
+    out3, total3 = ops.label_logprob(lg3, idx, dist if ls > 0 else None, ls, with_sum=True, sum_scale=scale)
+    ((out3 * up).sum() + 2.0 * total3).backward()
+    _close(lg3.grad, g_got + 2.0 * lg2.grad, rtol=1e-5, atol=1e-6, what="d(logits), both paths")
 
 
 @pytest.mark.parametrize("drop", [False, True])
@@ -1159,6 +1179,51 @@ def test_lstm_pack_unpack_roundtrip(H, I, ndir):
         assert torch.equal(g_b[d], prm[4 * d + 2] + prm[4 * d + 3])
 
 
+@pytest.mark.parametrize("ndir,dims", [(2, [(16, 12), (16, 64), (16, 64)]), (1, [(20, 8), (20, 20)]),
+                                       (2, [(8, 4), (8, 32), (8, 32), (8, 32), (8, 32)])])
+def test_lstm_pack_multi_equals_per_layer(ndir, dims):
+    """asr_lstm_pack_multi_f32 / asr_lstm_unpack_multi_f32: the layers of a stack (the encoder's three, the judge's two, and
+    more than ASR_PACK_MAX_LAYERS) in one launch = asr_lstm_pack_f32 / asr_lstm_unpack2_f32 layer by layer; and through
+    autograd (ops.lstm_pack) the gradients of interleaved-layout consumers come back in torch layout."""
+    dev = _gpu()
+    import hip_backend as hb
+    import ops
+    g = torch.Generator().manual_seed(len(dims) + ndir)
+    layers = []
+    for H, I in dims:
+        prm = []
+        for _ in range(ndir):
+            prm += [torch.randn(4 * H, I, generator=g).to(dev), torch.randn(4 * H, H, generator=g).to(dev),
+                    torch.randn(4 * H, generator=g).to(dev), torch.randn(4 * H, generator=g).to(dev)]
+        layers.append(prm)
+    outs = hb.lstm_pack_multi(layers, ndir)
+    for (H, I), prm, (w_ih, w_hh, bias) in zip(dims, layers, outs):
+        r_ih, r_hh, r_b = torch.empty_like(w_ih), torch.empty_like(w_hh), torch.empty_like(bias)
+        hb.lstm_pack(prm, ndir, r_ih, r_hh, r_b)
+        assert torch.equal(w_ih, r_ih) and torch.equal(w_hh, r_hh) and torch.equal(bias, r_b)
+    grads = [tuple(torch.randn(t.shape, generator=g).to(dev) for t in out) for out in outs]
+    grads[1] = (None, None, None)                       # a layer without gradients gets none
+    back = hb.lstm_unpack_multi(grads, dims, ndir)
+    assert back[1] is None
+    for j, ((H, I), gr) in enumerate(zip(dims, grads)):
+        if gr[0] is None:
+            continue
+        r_ih, r_hh, r_b, r_b2 = hb.lstm_unpack(H, I, ndir, gr[0], gr[1], gr[2], two_biases=True)
+        for d in range(ndir):
+            got = back[j][4 * d:4 * d + 4]
+            assert torch.equal(got[0], r_ih[d]) and torch.equal(got[1], r_hh[d]) and torch.equal(got[2], r_b[d])
+            assert torch.equal(got[3], r_b2[d]) and got[2].data_ptr() != got[3].data_ptr()
+    # autograd: sum_j <c_j, pack(params)_j> differentiates to unpack(c)
+    leaves = [[p.clone().requires_grad_(True) for p in prm] for prm in layers]
+    packed = ops.lstm_pack(leaves, ndir)
+    coef = [tuple(torch.randn(t.shape, generator=g).to(dev) for t in out) for out in packed]
+    sum((c * t).sum() for cs, ts in zip(coef, packed) for c, t in zip(cs, ts)).backward()
+    want = hb.lstm_unpack_multi(coef, dims, ndir)
+    for prm, w in zip(leaves, want):
+        for p, t in zip(prm, w):
+            _close(p.grad, t, rtol=1e-6, atol=1e-6, what="d(param) through the pack node")
+
+
 def test_cell_pack_unpack_roundtrip():
     dev = _gpu()
     import hip_backend as hb
@@ -1172,8 +1237,37 @@ def test_cell_pack_unpack_roundtrip():
     perm = ops.gate_perm(D, dev)
     assert torch.equal(wcat, torch.cat([w_hh, w_ih[:, E:E + O], w_ih[:, :E]], 1)[perm])
     assert torch.equal(bcat, (b_ih + b_hh)[perm])
-    dw_ih, dw_hh, db = hb.cell_unpack(wcat, bcat, D, O, E)
+    dw_ih, dw_hh, db, db2 = hb.cell_unpack(wcat, bcat, D, O, E)
     assert torch.equal(dw_ih, w_ih) and torch.equal(dw_hh, w_hh) and torch.equal(db, b_ih + b_hh)
+    assert torch.equal(db2, db) and db2.data_ptr() != db.data_ptr()
+
+
+@pytest.mark.parametrize("D,O,E,A,C", [(32, 16, 8, 24, 3), (512, 512, 128, 512, 10), (20, 12, 4, 36, 5)])
+def test_dec_pack_and_colsum_parts(D, O, E, A, C):
+    """asr_dec_pack_f32 = asr_cell_pack_f32 + the transposed images wcatT / wdecT / wattT (tile transposes, ragged edges
+    included); asr_colsum_parts_f32 = the sums over utterances of the decoder backward's three partial gradients."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(D + A)
+    KX = D + O + E
+    w_ih, w_hh = torch.randn(4 * D, E + O, generator=g).to(dev), torch.randn(4 * D, D, generator=g).to(dev)
+    b_ih, b_hh = torch.randn(4 * D, generator=g).to(dev), torch.randn(4 * D, generator=g).to(dev)
+    wdec, watt = torch.randn(A, D, generator=g).to(dev), torch.randn(A, C, generator=g).to(dev)
+    ref_cat, ref_b = torch.empty(4 * D, KX, device=dev), torch.empty(4 * D, device=dev)
+    hb.cell_pack(w_ih, w_hh, b_ih, b_hh, D, O, E, ref_cat, ref_b)
+    wcat, bcat = torch.full((4 * D, KX), 9.0, device=dev), torch.full((4 * D,), 9.0, device=dev)
+    wcatT, wdecT, wattT = torch.full((KX, 4 * D), 9.0, device=dev), torch.full((D, A), 9.0, device=dev), torch.full((C, A), 9.0, device=dev)
+    hb.dec_pack(w_ih, w_hh, b_ih, b_hh, wdec, watt, D, O, E, A, C, wcat, bcat, wcatT, wdecT, wattT)
+    assert torch.equal(wcat, ref_cat) and torch.equal(bcat, ref_b)
+    assert torch.equal(wcatT, ref_cat.t()) and torch.equal(wdecT, wdec.t()) and torch.equal(wattT, watt.t())
+    only = torch.full((C, A), 9.0, device=dev)                  # the forward-only form: no backward images
+    hb.dec_pack(w_ih, w_hh, b_ih, b_hh, wdec, watt, D, O, E, A, C, wcat, bcat, None, None, only)
+    assert torch.equal(only, watt.t())
+    B = 7
+    parts = [torch.randn(B, A, generator=g).to(dev), torch.randn(B, A, C, generator=g).to(dev),
+             torch.randn(B, C, 2 * 3 + 1, generator=g).to(dev)]
+    for got, p in zip(hb.colsum_parts(parts), parts):
+        _close(got, p.sum(0), rtol=1e-6, atol=1e-6, what="column sums of a part")
 
 
 @pytest.mark.parametrize("B,V,E,DO", [(32, 34, 128, 1024), (5, 7, 12, 40), (3, 100, 64, 640)])
@@ -1361,6 +1455,36 @@ def test_seeded_dropout_kernels(p):
         go = torch.randn(ya.shape, generator=g).to(dev)
         ya.backward(go); yb.backward(go)
         assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("M,N,K", [(1368, 512, 2048), (5472, 512, 2048), (96, 64, 64), (2736, 512, 512)])
+def test_gemm_with_dropout_epilogue(M, N, K):
+    """asr_gemm_drop_f32: relu(x W^T + b) -> seeded dropout (model.py:93-95) as ONE call - the mask goes into the bias / ReLU
+    pass of a product that was split over K, or into a pass of its own - equals the product followed by
+    asr_dropout_seeded_f32 (same mask: a pure function of seed and element index), and ops.linear's backward regenerates it."""
+    dev = _gpu()
+    import hip_backend as hb
+    import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    m = hb.SeededMask((M, 1, N), 0.3, dev, seed=4242 + M)
+    for split in (None, 1):
+        got = hb.gemm(x, w, trans_b=True, bias=b, relu=True, drop=m, split_k=split)
+        ref = hb.dropout_seeded_(hb.gemm(x, w, trans_b=True, bias=b, relu=True, split_k=split), m)
+        _close(got, ref, rtol=1e-5, atol=1e-5, what="product with the dropout epilogue (split_k=%s)" % split)
+        if split == 1:                                   # (no atomics: the same product bit for bit)
+            assert torch.equal(got, ref)
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ya = ops.linear(xa, wa, ba, relu=True, drop=m)
+    xb, wb, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yb = torch.relu(xb @ wb.t() + bb) * m.tensor().view(M, N)
+    go = torch.randn(M, N, generator=g).to(dev)
+    ya.backward(go); yb.backward(go)
+    _close(ya, yb, rtol=1e-4, atol=1e-4, what="linear + relu + dropout")
+    for a_, b_, nm in ((xa, xb, "dx"), (wa, wb, "dw"), (ba, bb, "db")):
+        _close(a_.grad, b_.grad, rtol=2e-3, atol=2e-3 * float(b_.grad.abs().max()), what=nm)
 
 
 def test_seeded_dropout_end_to_end_equals_explicit_masks(monkeypatch):
@@ -1613,7 +1737,7 @@ def test_decoder_and_lm_forward_step_methods():
         enc_h, enc_lens = net.encoder(xs_d, ilens)
         logits, _, _, ws = net.decoder(enc_h, enc_lens, ys_d, tf_rate=1.0)
         dec = net.decoder
-        tok_in, _ = dec._label_matrices(ys_d)
+        tok_in = dec._label_matrices(ys_d)[0]
         z, cst = dec.zero_state(enc_h), dec.zero_state(enc_h)
         c, w = dec.zero_state(enc_h, dim=dec.att_odim), None
         assert z.shape == (len(ys), cfg["dec_hidden_dim"]) and c.shape == (len(ys), cfg["att_odim"])

@@ -432,6 +432,56 @@ def test_epoch_through_the_input_pipeline_equals_the_to_gpu_loop(tmp_path, monke
         assert float((w1[n] - w2[n]).abs().max()) <= 1e-5 * float(w2[n].abs().max()) + 1e-6, n
 
 
+def test_bucketed_pickle_epoch_on_the_gpu(tmp_path, monkeypatch):
+    """SURVEY 8f-2 on the GPU: PickleDataset (dataset.py:8-80 of the reference) -> BucketBatchSampler (`bucket_batches`)
+    -> feed.DeviceFeed -> Solver.sup_train_one_epoch.  The bucketed epoch sees every utterance exactly once, pads less than
+    the reference's shuffled batches of the same pickle, and trains to the same numbers as the to_gpu loop over the same
+    loader."""
+    import __graft_entry__ as entry
+    entry.build()
+    from utils import to_gpu
+    from dataloader import BucketBatchSampler, padded_fraction
+    results = []
+    for mode in ("feed", "to_gpu"):
+        root = str(tmp_path / mode)
+        os.makedirs(root)
+        torch.manual_seed(0)
+        solver, dev = _tiny_solver(root, monkeypatch, batch_size=4, shuffle=True, numpy_seed=5, bucket_batches=True)
+        assert isinstance(solver.train_lab_loader.batch_sampler, BucketBatchSampler)
+        if mode == "feed":
+            seen = []
+            keep = solver.sup_train_one_iteration
+
+            def spy(xs, ilens, ys, *a, **k):
+                seen.append([int(v) for v in ilens])
+                return keep(xs, ilens, ys, *a, **k)
+            monkeypatch.setattr(solver, "sup_train_one_iteration", spy)
+            mean = solver.sup_train_one_epoch(0, 0.7)
+            monkeypatch.setattr(solver, "sup_train_one_iteration", keep)
+            lens = sorted(v for b in seen for v in b)
+            want = sorted(int(solver.train_lab_dataset[i][0].shape[0]) for i in range(len(solver.train_lab_dataset)))
+            assert lens == want, (lens, want)                                     # every utterance once
+            assert all(b == sorted(b, reverse=True) for b in seen)                # collate order (dataloader.py:8-9)
+            frames = sum(sum(b) for b in seen)
+            bucketed = 1.0 - frames / float(sum(max(b) * len(b) for b in seen))
+            n, every = len(want), [int(solver.train_lab_dataset[i][0].shape[0]) for i in range(len(want))]
+            floor = padded_fraction(every, [list(range(i, min(i + 4, n))) for i in range(0, n, 4)])   # neighbours of the sorted keys
+            strided = padded_fraction(every, [list(range(i, n, (n + 3) // 4)) for i in range((n + 3) // 4)])
+            assert abs(bucketed - floor) <= 1e-9 and bucketed < strided, (bucketed, floor, strided)
+        else:
+            losses = []
+            for data in solver.train_lab_loader:
+                xs, ilens, ys = to_gpu(data)
+                losses.append(float(solver.sup_train_one_iteration(xs, ilens, ys, 0.7)))
+            mean = sum(losses) / len(losses)
+        solver.flush()
+        results.append((mean, {n: p.detach().cpu().clone() for n, p in solver.model.named_parameters()}))
+    (m1, w1), (m2, w2) = results
+    assert np.isfinite(m1) and abs(m1 - m2) <= 1e-5 * abs(m2), (m1, m2)
+    for n in w2:
+        assert float((w1[n] - w2[n]).abs().max()) <= 1e-5 * float(w2[n].abs().max()) + 1e-6, n
+
+
 def test_solver_recovers_from_a_kernel_raised_abort(tmp_path, monkeypatch):
     """the abort of test_solver_recovers_from_aborted_persistent_kernel raised by the KERNEL - the armed
     fault of csrc/persist.h (ASR_DEBUG_FAULT in the launch's `arith`: a producer of the encoder's persistent LSTM forward goes
