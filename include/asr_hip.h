@@ -66,6 +66,9 @@ int asr_abi_version(void);
  *                     each is used for the shapes it pays on (csrc/gemm.hip: asr_gemm_f32);
  *   ASR_GEMM_TILE_SMALL   asr_gemm_f32: 64 x 64 tiles on the 128 x 128 kernel's code (by default for products whose large tiles,
  *                     K split included, would be at most one workgroup per CU: decoder-side projections, output layer);
+ *   ASR_GEMM_C_ZEROED     asr_gemm_f32 / asr_gemm_drop_f32: a promise, not a selector - C holds zeros already (a slice of a
+ *                     buffer the caller zeroes once per step), so a product the library splits over K needs no zero pass
+ *                     of its own in front of the atomics.  Ignored with accumulate != 0.
  *   ASR_LSTM_BWD_GATHER   asr_lstm_seq_bwd_persist: the gathered-dG kernel instead of the one with exchanged partials.
  *   ASR_DEBUG_FAULT       asr_lstm_seq_fwd_persist (ASR_ARITH_BF16X6, H = 512 only; ASR_E_SHAPE otherwise): TESTS ONLY - the
  *                         FAULT instantiation of the kernel: slice 1 of group 0 stops publishing after its first step and
@@ -80,6 +83,7 @@ int asr_abi_version(void);
 #define ASR_GEMM_TILE_WIDE   0x200
 #define ASR_GEMM_TILE_SP     0x800
 #define ASR_GEMM_TILE_SMALL  0x1000
+#define ASR_GEMM_C_ZEROED    0x2000
 #define ASR_LSTM_BWD_GATHER  0x400
 #define ASR_DEBUG_FAULT      0x10000
 
@@ -291,6 +295,10 @@ int asr_pyramid_concat_bwd(int T, int B, int C, const float* dout, const float* 
  *   asr_pyramid_concat_*_seeded the pair-concat kernels with mask(i) over the [T][B][C] input regenerated in flight
  * ------------------------------------------------------------------------------------- */
 int asr_dropout_seeded_f32(int64_t n, float* x, uint64_t seed, float p, asr_stream_t stream);
+/* asr_relu_dropout_bwd_f32 over a contiguous [M][N] matrix (N % 4 == 0) that also leaves the column sums of its result in
+ * colsum [N] (+=; the caller zeroed it): the bias gradient of the projection behind it (model.py:93-95), no second pass. */
+int asr_relu_dropout_bwd_colsum_f32(int64_t M, int64_t N, const float* grad, const float* y, uint64_t seed, float p,
+                                    float* out, float* colsum, asr_stream_t stream);
 int asr_relu_dropout_bwd_f32(int64_t n, const float* grad, const float* y, uint64_t seed, float p, float* out,
                              asr_stream_t stream);
 int asr_dropout_mask_f32(int64_t n, float* mask, uint64_t seed, float p, asr_stream_t stream);

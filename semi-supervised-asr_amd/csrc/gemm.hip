@@ -2222,7 +2222,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     g.split_k = best;
     g.tiles_m = (int)((M + WM - 1) / WM);
     g.tiles_n = (int)((N + WN - 1) / WN);
-    if (best > 1 && !accumulate) {
+    if (best > 1 && !accumulate && !(arith & ASR_GEMM_C_ZEROED)) {
       dim3 zg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
       hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
     }
@@ -2266,7 +2266,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
   const int64_t ktiles = (K + BK - 1) / BK;
   if (split_k > ktiles) split_k = (int)ktiles;
   g.split_k = split_k;
-  if (split_k > 1 && !accumulate) {
+  if (split_k > 1 && !accumulate && !(arith & ASR_GEMM_C_ZEROED)) {
     dim3 zg((unsigned)((M * N + 255) / 256 > 2048 ? 2048 : (M * N + 255) / 256), 1, batch);
     hipLaunchKernelGGL(zero_rows_kernel, zg, dim3(256), 0, stream, C, ldc, M, N, sC);
   }

@@ -20,7 +20,7 @@ EXPORTS = (
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_fault", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
-    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32",
+    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32", "asr_relu_dropout_bwd_colsum_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
@@ -111,6 +111,7 @@ def load():
     lib.asr_dropout_seeded_f32.argtypes = [c_i64, c_p, c_u64, c_f, c_p]
     lib.asr_relu_dropout_bwd_f32.argtypes = [c_i64, c_p, c_p, c_u64, c_f, c_p, c_p]
     lib.asr_dropout_mask_f32.argtypes = [c_i64, c_p, c_u64, c_f, c_p]
+    lib.asr_relu_dropout_bwd_colsum_f32.argtypes = [c_i64, c_i64, c_p, c_p, c_u64, c_f, c_p, c_p, c_p]
     lib.asr_dec_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_att_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_dec_seq_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_i, c_p, c_p]
@@ -224,11 +225,15 @@ def _rowmajor(t):
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1))
 
 
+C_ZEROED = 0x2000          # ASR_GEMM_C_ZEROED
+
+
 def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, split_k=None, arith=None,
-         drop=None):
+         drop=None, out_zeroed=False):
     """out[M,N] = op(A) op(B) (+bias)(relu)(+out).  A, B, out are 2-D row-major views (row stride free).
     split_k None: the library chooses (asr_gemm_f32 with split_k = 0); 1: unsplit, run-to-run deterministic.
-    drop (SeededMask): the seeded dropout mask over out's element index behind the epilogue (asr_gemm_drop_f32)."""
+    drop (SeededMask): the seeded dropout mask over out's element index behind the epilogue (asr_gemm_drop_f32).
+    out_zeroed: `out` holds zeros (a slice of the step's arena): a product split over K needs no zero pass of its own."""
     A, lda = _rowmajor(_dev(A, "A"))
     B, ldb = _rowmajor(_dev(B, "B"))
     M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
@@ -238,16 +243,16 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, out=None, ac
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     out, ldc = _rowmajor(out)
     assert out.shape == (M, N)
+    code = (ARITH[0] if arith is None else _arith_code(arith)) | (C_ZEROED if out_zeroed else 0)
     if drop is not None:
         assert not accumulate and ldc == N
         check(load().asr_gemm_drop_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
-                                       ptr(bias), int(relu), 0 if split_k is None else int(split_k),
-                                       ARITH[0] if arith is None else _arith_code(arith), drop.seed, float(drop.p), stream()),
-              "asr_gemm_drop_f32")
+                                       ptr(bias), int(relu), 0 if split_k is None else int(split_k), code, drop.seed,
+                                       float(drop.p), stream()), "asr_gemm_drop_f32")
         return out
     check(load().asr_gemm_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
                               ptr(bias), int(relu), int(accumulate), 1, 0, 0, 0, 0 if split_k is None else int(split_k),
-                              ARITH[0] if arith is None else _arith_code(arith), stream()), "asr_gemm_f32")
+                              code, stream()), "asr_gemm_f32")
     return out
 
 
@@ -899,9 +904,15 @@ def dropout_seeded_(x, m):
     return x
 
 
-def relu_dropout_bwd(grad, y, seed, p):
-    """grad * mask * (y > 0) in one pass (p == 0: the plain relu gradient)."""
+def relu_dropout_bwd(grad, y, seed, p, colsum=None):
+    """grad * mask * (y > 0) in one pass (p == 0: the plain relu gradient).  colsum [N] (zeroed): y is [M, N] and the column
+    sums of the result are added into it by the same launch."""
     out = torch.empty_like(y)
+    if colsum is not None:
+        M, N = y.shape
+        check(load().asr_relu_dropout_bwd_colsum_f32(M, N, ptr(grad), ptr(y), int(seed), float(p), ptr(out), ptr(colsum),
+                                                     stream()), "asr_relu_dropout_bwd_colsum_f32")
+        return out
     check(load().asr_relu_dropout_bwd_f32(y.numel(), ptr(grad), ptr(y), int(seed), float(p), ptr(out), stream()),
           "asr_relu_dropout_bwd_f32")
     return out

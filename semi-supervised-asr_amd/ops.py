@@ -96,7 +96,16 @@ class _Arena(object):
         self.want += n4
         if self.buf is None or self.buf.device != torch.device(device) or self.cursor + n4 > self.buf.numel():
             return None
-        out = self.buf[self.cursor:self.cursor + n].view(*shape)
+        # a tensor of its own over the buffer's storage, not a view of the buffer: views share ONE version counter, and an
+        # in-place torch op on any slice (index_add_ into an accumulator) would then invalidate every slice that an
+        # autograd node saved for its backward (the outputs of ops.linear live here)
+        shape = tuple(int(v) for v in shape)
+        strides, acc = [], 1
+        for v in reversed(shape):
+            strides.append(acc)
+            acc *= v
+        out = torch.empty(0, device=self.buf.device, dtype=torch.float32).set_(
+            self.buf.untyped_storage(), self.buf.storage_offset() + self.cursor, shape, tuple(reversed(strides)))
         self.cursor += n4
         return out
 
@@ -162,7 +171,11 @@ class _Linear(torch.autograd.Function):
         seeded = isinstance(drop, hb.SeededMask)
         if seeded:                                   # relu -> dropout in the product's own epilogue pass; the mask is
             assert relu and (x2.shape[0] * weight.shape[0]) % 4 == 0      # regenerated in the backward
-        y = hb.gemm(x2, weight, trans_b=True, bias=bias, relu=relu, drop=drop if seeded else None)
+        # (inside a train step the output is a pre-zeroed slice of the step's arena: a product the library splits over K
+        # then needs no zero pass of its own)
+        out = _ARENA.take((x2.shape[0], weight.shape[0]), x2.device)
+        y = hb.gemm(x2, weight, trans_b=True, bias=bias, relu=relu, drop=drop if seeded else None, out=out,
+                    out_zeroed=out is not None)
         ctx.save_for_backward(x2, weight, y if relu else None)
         ctx.relu = relu
         ctx.drop = (drop.seed, drop.p) if seeded else None
@@ -177,15 +190,20 @@ class _Linear(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        db = None
         if ctx.relu and y.numel() % 4 == 0:
-            # one pass: relu gradient (and the dropout mask: y is the dropped-out output, y > 0 <=> kept and active)
+            # one pass: relu gradient (and the dropout mask: y is the dropped-out output, y > 0 <=> kept and active) - and,
+            # into a zeroed slice of the step's arena, its column sums = the bias gradient
             seed, p = ctx.drop if ctx.drop is not None else (0, 0.0)
-            dy2 = hb.relu_dropout_bwd(dy2, y, seed, p)
+            acc = _ARENA.take((y.shape[1],), dy2.device) if (ctx.has_bias and y.shape[1] % 4 == 0) else None
+            dy2 = hb.relu_dropout_bwd(dy2, y, seed, p, colsum=acc)
+            db = acc
         elif ctx.relu:
             dy2 = dy2 * (y > 0).to(dy2.dtype)
         dx = hb.gemm(dy2, weight).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
         dw = _gemm_acc(dy2, x2, trans_a=True, shape=(dy2.shape[1], x2.shape[1]))
-        db = _colsum_acc(dy2) if ctx.has_bias else None
+        if db is None and ctx.has_bias:
+            db = _colsum_acc(dy2)
         return dx, dw, db, None, None
 
 
