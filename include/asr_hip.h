@@ -295,10 +295,6 @@ int asr_pyramid_concat_bwd(int T, int B, int C, const float* dout, const float* 
  *   asr_pyramid_concat_*_seeded the pair-concat kernels with mask(i) over the [T][B][C] input regenerated in flight
  * ------------------------------------------------------------------------------------- */
 int asr_dropout_seeded_f32(int64_t n, float* x, uint64_t seed, float p, asr_stream_t stream);
-/* asr_relu_dropout_bwd_f32 over a contiguous [M][N] matrix (N % 4 == 0) that also leaves the column sums of its result in
- * colsum [N] (+=; the caller zeroed it): the bias gradient of the projection behind it (model.py:93-95), no second pass. */
-int asr_relu_dropout_bwd_colsum_f32(int64_t M, int64_t N, const float* grad, const float* y, uint64_t seed, float p,
-                                    float* out, float* colsum, asr_stream_t stream);
 int asr_relu_dropout_bwd_f32(int64_t n, const float* grad, const float* y, uint64_t seed, float p, float* out,
                              asr_stream_t stream);
 int asr_dropout_mask_f32(int64_t n, float* mask, uint64_t seed, float p, asr_stream_t stream);

@@ -30,30 +30,6 @@ __global__ void dropout_kernel(int64_t n4, float4* __restrict__ x, const float4*
   }
 }
 
-// op 2 over a [M][N4 float4] matrix with the column sums of the result: block (bx, by) walks rows by, by + gridDim.y, ... of
-// the 256 float4 columns 256 bx ..; one atomic per column and block at the end
-__global__ __launch_bounds__(256) void relu_dropout_bwd_colsum_kernel(int64_t M, int64_t N4, float4* __restrict__ out,
-                                                                      const float4* __restrict__ g, const float4* __restrict__ y,
-                                                                      unsigned long long seed, unsigned thresh, float scale,
-                                                                      float* __restrict__ colsum) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= N4) return;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t r = blockIdx.y; r < M; r += gridDim.y) {
-    const int64_t i = r * N4 + c;
-    const float4 gv = g[i], yv = y[i];
-    float4 v;
-    v.x = yv.x > 0.f ? gv.x * ((!thresh || asr_drop_keep(seed, 4 * i, thresh)) ? scale : 0.f) : 0.f;
-    v.y = yv.y > 0.f ? gv.y * ((!thresh || asr_drop_keep(seed, 4 * i + 1, thresh)) ? scale : 0.f) : 0.f;
-    v.z = yv.z > 0.f ? gv.z * ((!thresh || asr_drop_keep(seed, 4 * i + 2, thresh)) ? scale : 0.f) : 0.f;
-    v.w = yv.w > 0.f ? gv.w * ((!thresh || asr_drop_keep(seed, 4 * i + 3, thresh)) ? scale : 0.f) : 0.f;
-    out[i] = v;
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-  }
-  atomicAdd(colsum + 4 * c, acc.x); atomicAdd(colsum + 4 * c + 1, acc.y);
-  atomicAdd(colsum + 4 * c + 2, acc.z); atomicAdd(colsum + 4 * c + 3, acc.w);
-}
-
 template <int OP>
 int launch(int64_t n, float* x, const float* g, const float* y, uint64_t seed, float p, hipStream_t stream) {
   if (!x || n <= 0 || p < 0.f || p >= 1.f) return ASR_E_ARG;
@@ -78,20 +54,4 @@ extern "C" int asr_relu_dropout_bwd_f32(int64_t n, const float* grad, const floa
                                         asr_stream_t stream) {
   if (!grad || !y) return ASR_E_ARG;
   return launch<2>(n, out, grad, y, seed, p, (hipStream_t)stream);
-}
-extern "C" int asr_relu_dropout_bwd_colsum_f32(int64_t M, int64_t N, const float* grad, const float* y, uint64_t seed, float p,
-                                               float* out, float* colsum, asr_stream_t stream) {
-  if (!grad || !y || !out || !colsum || M <= 0 || N <= 0 || p < 0.f || p >= 1.f) return ASR_E_ARG;
-  if (N % 4) return ASR_E_SHAPE;
-  if (!asr_aligned16(grad) || !asr_aligned16(y) || !asr_aligned16(out)) return ASR_E_ALIGN;
-  const int64_t N4 = N / 4;
-  const unsigned bx = (unsigned)((N4 + 255) / 256);
-  int64_t by = 2048 / bx;                                  // ~2048 blocks, at least 8 rows each
-  if (by > (M + 7) / 8) by = (M + 7) / 8;
-  if (by < 1) by = 1;
-  hipLaunchKernelGGL(relu_dropout_bwd_colsum_kernel, dim3(bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream, M, N4,
-                     (float4*)out, (const float4*)grad, (const float4*)y, (unsigned long long)seed, asr_drop_thresh(p),
-                     1.0f / (1.0f - p), colsum);
-  ASR_CHECK_LAUNCH();
-  return 0;
 }

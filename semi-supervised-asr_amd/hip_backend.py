@@ -20,7 +20,7 @@ EXPORTS = (
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_fault", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
-    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32", "asr_relu_dropout_bwd_colsum_f32",
+    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
@@ -111,7 +111,6 @@ def load():
     lib.asr_dropout_seeded_f32.argtypes = [c_i64, c_p, c_u64, c_f, c_p]
     lib.asr_relu_dropout_bwd_f32.argtypes = [c_i64, c_p, c_p, c_u64, c_f, c_p, c_p]
     lib.asr_dropout_mask_f32.argtypes = [c_i64, c_p, c_u64, c_f, c_p]
-    lib.asr_relu_dropout_bwd_colsum_f32.argtypes = [c_i64, c_i64, c_p, c_p, c_u64, c_f, c_p, c_p, c_p]
     lib.asr_dec_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_att_step_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_p]
     lib.asr_dec_seq_fwd.argtypes = [ctypes.POINTER(DecFwd), c_i, c_i, c_p, c_p]
@@ -904,15 +903,9 @@ def dropout_seeded_(x, m):
     return x
 
 
-def relu_dropout_bwd(grad, y, seed, p, colsum=None):
-    """grad * mask * (y > 0) in one pass (p == 0: the plain relu gradient).  colsum [N] (zeroed): y is [M, N] and the column
-    sums of the result are added into it by the same launch."""
+def relu_dropout_bwd(grad, y, seed, p):
+    """grad * mask * (y > 0) in one pass (p == 0: the plain relu gradient)."""
     out = torch.empty_like(y)
-    if colsum is not None:
-        M, N = y.shape
-        check(load().asr_relu_dropout_bwd_colsum_f32(M, N, ptr(grad), ptr(y), int(seed), float(p), ptr(out), ptr(colsum),
-                                                     stream()), "asr_relu_dropout_bwd_colsum_f32")
-        return out
     check(load().asr_relu_dropout_bwd_f32(y.numel(), ptr(grad), ptr(y), int(seed), float(p), ptr(out), stream()),
           "asr_relu_dropout_bwd_f32")
     return out

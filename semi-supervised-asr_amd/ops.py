@@ -19,6 +19,7 @@ them immediately; double backward / retain_graph through these ops is not suppor
 GPU only; see hip_backend for the no-fallback rule.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -92,7 +93,7 @@ class _Arena(object):
         n = 1
         for v in shape:
             n *= int(v)
-        n4 = (n + 3) // 4 * 4                            # slices stay 16-byte aligned
+        n4 = (n + 63) // 64 * 64                         # slices stay 256-byte aligned (GEMM operands live here)
         self.want += n4
         if self.buf is None or self.buf.device != torch.device(device) or self.cursor + n4 > self.buf.numel():
             return None
@@ -111,6 +112,7 @@ class _Arena(object):
 
 
 _ARENA = _Arena()
+_LINEAR_ARENA = os.environ.get("ASR_LINEAR_ARENA", "1") != "0"      # measurement: the outputs of ops.linear from the arena
 
 
 class step_arena(object):
@@ -173,7 +175,7 @@ class _Linear(torch.autograd.Function):
             assert relu and (x2.shape[0] * weight.shape[0]) % 4 == 0      # regenerated in the backward
         # (inside a train step the output is a pre-zeroed slice of the step's arena: a product the library splits over K
         # then needs no zero pass of its own)
-        out = _ARENA.take((x2.shape[0], weight.shape[0]), x2.device)
+        out = _ARENA.take((x2.shape[0], weight.shape[0]), x2.device) if _LINEAR_ARENA else None
         y = hb.gemm(x2, weight, trans_b=True, bias=bias, relu=relu, drop=drop if seeded else None, out=out,
                     out_zeroed=out is not None)
         ctx.save_for_backward(x2, weight, y if relu else None)
@@ -190,20 +192,17 @@ class _Linear(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        db = None
         if ctx.relu and y.numel() % 4 == 0:
-            # one pass: relu gradient (and the dropout mask: y is the dropped-out output, y > 0 <=> kept and active) - and,
-            # into a zeroed slice of the step's arena, its column sums = the bias gradient
+            # one pass: relu gradient (and the dropout mask: y is the dropped-out output, y > 0 <=> kept and active)
+            # (its column sums - the bias gradient - from the same pass were tried: the atomics of a column meet in one L2
+            # line, 32 us against 8 + 5 for the two launches at the layer-0 projection)
             seed, p = ctx.drop if ctx.drop is not None else (0, 0.0)
-            acc = _ARENA.take((y.shape[1],), dy2.device) if (ctx.has_bias and y.shape[1] % 4 == 0) else None
-            dy2 = hb.relu_dropout_bwd(dy2, y, seed, p, colsum=acc)
-            db = acc
+            dy2 = hb.relu_dropout_bwd(dy2, y, seed, p)
         elif ctx.relu:
             dy2 = dy2 * (y > 0).to(dy2.dtype)
         dx = hb.gemm(dy2, weight).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
         dw = _gemm_acc(dy2, x2, trans_a=True, shape=(dy2.shape[1], x2.shape[1]))
-        if db is None and ctx.has_bias:
-            db = _colsum_acc(dy2)
+        db = _colsum_acc(dy2) if ctx.has_bias else None
         return dx, dw, db, None, None
 
 
