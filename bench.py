@@ -601,6 +601,8 @@ def main():
         note("%s, %d utterances per GPU x %d GPU(s), T=%d: warmup" % (args.config, b_local, world, t_frames))
     seen_world = None
     persist_at_start = bool(hb.USE_PERSIST)           # (False: several ranks share this card - parallel.init_distributed)
+    hb.PERSIST_RETRY_STEPS = 0                        # a timed region is ONE path: no return to the persistent kernels after an
+                                                      # abort inside this process (the product's default is a 200-step probation)
     if world > 1:
         # communicator set-up (lazy in the first collective) and rank alignment before the first step; what every rank then
         # believes the job to be goes into the record (config.per_rank)

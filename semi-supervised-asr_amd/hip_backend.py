@@ -531,11 +531,12 @@ def lstm_unpack_multi(grads, dims, ndir):
     gradients), dims: per layer (H, I) -> per layer [per direction dw_ih, dw_hh, db_ih, db_hh] flattened in torch layout
     (b_ih and b_hh get their own tensors); one launch."""
     live = [j for j, g in enumerate(grads) if g[0] is not None]
-    outs = [None] * len(grads)
+    outs, keep = [None] * len(grads), []
     jobs = (LstmUnpackJob * max(len(live), 1))()
     for k, j in enumerate(live):
         H, I = dims[j]
-        dw_ih, dw_hh, db = grads[j]
+        dw_ih, dw_hh, db = [g if g.is_contiguous() else g.contiguous() for g in grads[j]]
+        keep.append((dw_ih, dw_hh, db))
         f32 = dict(device=dw_ih.device, dtype=torch.float32)
         o = []
         job = jobs[k]
@@ -688,13 +689,52 @@ def persist_clear_abort(device):
         _persist_scratch[key][1][:2].zero_()
 
 
-def disable_persistent(device=None):
-    """Route every sequence operator of this process to the per-step HIP kernels (after an abort, or when several
-    processes share one GPU) and clear the abort latch."""
+# An abort of the persistent kernels is a PLACEMENT problem - a workgroup that did not get its CU because another process's
+# kernels held it, a bounded spin that expired behind one - and those pass.  So leaving the persistent kernels is a probation,
+# not a verdict: after PERSIST_RETRY_STEPS train steps on the per-step kernels (3x slower at cfg-2) they are tried again,
+# twice as late after every further abort (200, 400, ... capped at 64x).  0: never again (the behaviour up to round 4).
+# Env ASR_PERSIST_RETRY_STEPS, config key `persist_retry_steps` (not a reference key).
+PERSIST_RETRY_STEPS = int(os.environ.get("ASR_PERSIST_RETRY_STEPS", "200"))
+_PROBATION = dict(wanted=None, aborts=0, steps=0, retry_at=None)
+
+
+def disable_persistent(device=None, permanent=False):
+    """Route every sequence operator of this process to the per-step HIP kernels (after an abort, or - permanent - when
+    several processes share one GPU) and clear the abort latch.  Unless permanent, persistent_step_tick() brings the
+    persistent kernels back after a probation (see PERSIST_RETRY_STEPS)."""
     global USE_PERSIST, USE_PERSIST_DEC, USE_PERSIST_DEC_BWD
+    st = _PROBATION
+    if st["wanted"] is None:
+        st["wanted"] = (USE_PERSIST, USE_PERSIST_DEC, USE_PERSIST_DEC_BWD)       # what this process started with
+    if permanent:
+        st["wanted"] = (False, False, False)
     USE_PERSIST = USE_PERSIST_DEC = USE_PERSIST_DEC_BWD = False
+    st["aborts"] += 1
+    if permanent or PERSIST_RETRY_STEPS <= 0 or not any(st["wanted"]):
+        st["retry_at"] = None
+    else:
+        st["retry_at"] = st["steps"] + PERSIST_RETRY_STEPS * (1 << min(st["aborts"] - 1, 6))
     if device is not None:
         persist_clear_abort(device)
+
+
+def persistent_step_tick():
+    """Called once per train step (Solver._step).  True when this call ended a probation: the sequence operators of the
+    step that follows run on the persistent kernels again (an abort there is found and repeated like any other)."""
+    global USE_PERSIST, USE_PERSIST_DEC, USE_PERSIST_DEC_BWD
+    st = _PROBATION
+    st["steps"] += 1
+    if st["retry_at"] is None or st["steps"] < st["retry_at"]:
+        return False
+    USE_PERSIST, USE_PERSIST_DEC, USE_PERSIST_DEC_BWD = st["wanted"]
+    st["retry_at"] = None
+    return True
+
+
+def persistent_probation():
+    """(aborts so far, train steps until the persistent kernels are tried again or None)."""
+    st = _PROBATION
+    return st["aborts"], (None if st["retry_at"] is None else max(0, st["retry_at"] - st["steps"]))
 
 
 def persist_aborted(device):

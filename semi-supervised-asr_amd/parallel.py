@@ -637,7 +637,7 @@ def init_distributed():
             # sharing a card could each get part of it and starve each other until the bounded spins abort, so a
             # shared-card rehearsal takes the per-step kernels.
             import hip_backend as hb
-            hb.USE_PERSIST = hb.USE_PERSIST_DEC = hb.USE_PERSIST_DEC_BWD = False
+            hb.disable_persistent(permanent=True)
         backend = os.environ.get("ASR_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
     else:
         backend = "gloo"

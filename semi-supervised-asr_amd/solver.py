@@ -197,6 +197,10 @@ class Solver(object):
         # (_dp_step raises).  bench.py turns it on and falls back by itself; turn it on here once a multi-GPU run has
         # shown the latch stays clear.
         overlap = bool(cfg.get("dp_overlap", False))
+        # `persist_retry_steps` (not a reference key): train steps on the per-step kernels after an abort of the persistent
+        # ones before they are tried again (hip_backend.PERSIST_RETRY_STEPS: 200, doubling per abort; 0: never)
+        if "persist_retry_steps" in cfg:
+            hb.PERSIST_RETRY_STEPS = int(cfg["persist_retry_steps"])
         self.gen_opt = FlatAdam(self.model, lr=cfg["learning_rate"], weight_decay=cfg["weight_decay"], amsgrad=True,
                                 max_grad_norm=cfg["max_grad_norm"], overlap=overlap)
         if load_model:
@@ -360,6 +364,8 @@ class Solver(object):
         step late (parallel.DpPipeline).  Every rank resolves its StepScalars at the same points of the program (the loops
         below run the same code on all ranks): a recovery is a sequence of collectives."""
         dev0 = opt.buf.flat_g.device
+        if hb.persistent_step_tick() and self.rank == 0:     # the end of a probation after an abort (hb.PERSIST_RETRY_STEPS)
+            print("persistent kernels: trying them again after %d abort(s)" % hb.persistent_probation()[0])
         with ops.step_arena(dev0):       # every zero-initialised accumulator of the step comes out of one buffer, one fill
             return self._step_inner(make_local, opt, n_scalars)
 

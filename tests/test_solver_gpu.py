@@ -527,6 +527,17 @@ def test_solver_recovers_from_a_kernel_raised_abort(tmp_path, monkeypatch):
         assert not hb.persist_aborted(dev)
         for name, prm in solver.model.named_parameters():
             assert torch.isfinite(prm).all(), name
+        # the per-step kernels are a probation, not a verdict (hb.PERSIST_RETRY_STEPS): when it ends the next step runs on the
+        # persistent kernels again - here the fault is no longer armed, so it completes there
+        aborts, left = hb.persistent_probation()
+        assert aborts == 1 and left is not None and 0 < left <= hb.PERSIST_RETRY_STEPS
+        hb._PROBATION["retry_at"] = hb._PROBATION["steps"] + 2
+        before = hb.LAUNCHES.get("lstm_fwd_persist", 0)
+        mean2 = solver.sup_train_one_epoch(1, 1.0)
+        solver.flush()
+        assert hb.USE_PERSIST and hb.persistent_probation() == (1, None)
+        assert hb.LAUNCHES.get("lstm_fwd_persist", 0) >= before + steps - 1, "the encoder is back on the persistent kernel"
+        assert np.isfinite(mean2) and not hb.persist_aborted(dev)
     finally:
         hb.USE_PERSIST, hb.USE_PERSIST_DEC, hb.USE_PERSIST_DEC_BWD = flags
         hb.persist_clear_abort(dev)
