@@ -272,6 +272,49 @@ __global__ void dec_prepare_kernel(int L, int B, int DO4, int E4, const long lon
   }
 }
 
+// Gradient of the embedding rows behind dec_prepare_kernel (autograd of nn.Embedding, model.py:337): demb[tok[r]][:] +=
+// g[r][:] for r < rows, g row-strided (the embedding columns of the decoder's dX buffer).  A block folds its rows into an
+// LDS table [V][E] (ds_add_f32) and adds the table to global memory once: V E atomics per block instead of one per row and
+// element on V hot rows (torch's index_add_ on a contiguous copy of g: 16 + 5 us at cfg-2).
+__global__ __launch_bounds__(256) void embedding_grad_kernel(int64_t rows, int E4, int V, const long long* __restrict__ tok,
+                                                             const float* __restrict__ g, int64_t ldg, float* __restrict__ demb) {
+  extern __shared__ float table[];                       // [V][4 E4]
+  const int E = 4 * E4;
+  for (int i = threadIdx.x; i < V * E; i += blockDim.x) table[i] = 0.f;
+  __syncthreads();
+  const int lanes = blockDim.x / E4;                     // rows in flight per block
+  const int c = threadIdx.x % E4, rl = threadIdx.x / E4;
+  if (rl < lanes) {
+    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < rows; r += (int64_t)gridDim.x * lanes) {
+      const long long t = tok[r];
+      if (t < 0 || t >= V) continue;                     // (a step that was not fed a token: -1)
+      const float4 v = *reinterpret_cast<const float4*>(g + r * ldg + 4 * c);
+      float* d = table + t * E + 4 * c;
+      atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V * E; i += blockDim.x) {
+    const float v = table[i];
+    if (v != 0.f) atomicAdd(demb + i, v);
+  }
+}
+
+extern "C" int asr_embedding_grad_f32(int64_t rows, int E, int V, const long long* tokens, const float* grad, int64_t ldg,
+                                      float* demb, asr_stream_t stream) {
+  if (rows <= 0 || E <= 0 || V <= 0 || !tokens || !grad || !demb) return ASR_E_ARG;
+  if (E % 4 || ldg % 4 || E / 4 > 256 || (size_t)V * E * sizeof(float) > 64 * 1024) return ASR_E_SHAPE;
+  if (!asr_aligned16(grad)) return ASR_E_ALIGN;
+  const int lanes = 256 / (E / 4);
+  int64_t blocks = (rows + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16);      // >= 16 rows per row lane
+  if (blocks > 64) blocks = 64;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(embedding_grad_kernel, dim3((unsigned)blocks), dim3(256), (size_t)V * E * sizeof(float), (hipStream_t)stream,
+                     rows, E / 4, V, tokens, grad, ldg, demb);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int asr_dec_prepare_f32(int L, int B, int D, int O, int E, const long long* tokens, int64_t tok_row_stride,
                                    const float* emb_w, const float* xmask, float* X, float* Xd, long long* fed,
                                    asr_stream_t stream) {

@@ -71,20 +71,22 @@ __global__ void rows_unpack_bwd_kernel(int T, int C4, const float4* __restrict__
   }
 }
 
-// dfill[c] += sum over the padded frames of utterance b of dout * mask: one block per utterance, one atomic per element
+// dfill[c] += sum over the padded frames of utterance b of dout * mask: block (b, chunk) sums the padded frames len + chunk,
+// + gridDim.y, ... of utterance b, one atomic per element and block (one block per utterance took 17 us at cfg-2: 32 blocks)
 __global__ void rows_fill_grad_kernel(int T, int C4, const float4* __restrict__ dout, const int32_t* __restrict__ lens,
                                       const float4* __restrict__ mask, unsigned long long seed, unsigned thresh, float scale,
                                       float* __restrict__ dfill, const float4* __restrict__ relu_of) {
   const int b = blockIdx.x;
-  const int len = lens[b];
+  const int t0 = lens[b] + (int)blockIdx.y;                // this block's first padded frame
+  const int tstep = (int)gridDim.y;
   for (int c = threadIdx.x; c < C4; c += blockDim.x) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = len; t < T; ++t) {
+    for (int t = t0; t < T; t += tstep) {
       const int64_t o = ((int64_t)b * T + t) * C4 + c;
       const float4 g = dout[o], m = pad_mask(mask, o, seed, thresh, scale);
       acc.x += g.x * m.x; acc.y += g.y * m.y; acc.z += g.z * m.z; acc.w += g.w * m.w;
     }
-    if (len < T) {
+    if (t0 < T) {
       const float4 r = relu_of ? relu_of[c] : make_float4(1.f, 1.f, 1.f, 1.f);
       if (r.x > 0.f) atomicAdd(dfill + 4 * c, acc.x);
       if (r.y > 0.f) atomicAdd(dfill + 4 * c + 1, acc.y);
@@ -132,7 +134,7 @@ extern "C" int asr_rows_unpack_bwd_f32(int B, int T, int C, const float* dout, c
   hipLaunchKernelGGL(rows_unpack_bwd_kernel, dim3((ext_max + 3) / 4, B), dim3(threads_for(C / 4)), 0, (hipStream_t)stream, T, C / 4,
                      (const float4*)dout, lens, rowbase, rowext, (float4*)drows);
   if (dfill)
-    hipLaunchKernelGGL(rows_fill_grad_kernel, dim3(B), dim3(threads_for(C / 4)), 0, (hipStream_t)stream, T, C / 4,
+    hipLaunchKernelGGL(rows_fill_grad_kernel, dim3(B, T < 8 ? T : 8), dim3(threads_for(C / 4)), 0, (hipStream_t)stream, T, C / 4,
                        (const float4*)dout, lens, (const float4*)mask, seed, mask ? 0u : asr_drop_thresh(p), 1.0f / (1.0f - p), dfill,
                        (const float4*)relu_of);
   ASR_CHECK_LAUNCH();

@@ -20,7 +20,7 @@ EXPORTS = (
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_fault", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
-    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32",
+    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32", "asr_embedding_grad_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
@@ -139,6 +139,7 @@ def load():
     lib.asr_lstm_unpack_multi_f32.argtypes = [c_i, ctypes.POINTER(LstmUnpackJob), c_p]
     lib.asr_dec_pack_f32.argtypes = [c_i, c_i, c_i, c_i, c_i] + [c_p] * 12
     lib.asr_colsum_parts_f32.argtypes = [c_i, c_i, pp, ctypes.POINTER(ctypes.c_int32), pp, c_p]
+    lib.asr_embedding_grad_f32.argtypes = [c_i64, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]
     lib.asr_gemm_drop_f32.argtypes = [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_i, c_i,
                                       ctypes.c_uint64, c_f, c_p]
     if lib.asr_abi_version() != ABI_VERSION:
@@ -585,6 +586,19 @@ def cell_unpack(dwcat, db_il, D, O, E):
     check(load().asr_cell_unpack_f32(D, O, E, ptr(dwcat), ptr(db_il), ptr(dw_ih), ptr(dw_hh), ptr(db), ptr(db2), stream()),
           "asr_cell_unpack_f32")
     return dw_ih, dw_hh, db, db2
+
+
+def embedding_grad(tokens, grad, demb):
+    """demb [V, E] += grad[r] for the token of row r (tokens [rows] int64, -1 = none; grad [rows, E] row-strided view).
+    False when the shape is outside the kernel's table (the caller then uses index_add_)."""
+    V, E = demb.shape
+    rows = tokens.numel()
+    if (grad.stride(1) != 1 or grad.shape != (rows, E) or not tokens.is_contiguous() or not demb.is_contiguous()
+            or E % 4 or grad.stride(0) % 4 or V * E * 4 > 65536 or E // 4 > 256 or grad.data_ptr() % 16):
+        return False
+    check(load().asr_embedding_grad_f32(rows, E, V, c_p(tokens.data_ptr()), ptr(grad), grad.stride(0), ptr(demb), stream()),
+          "asr_embedding_grad_f32")
+    return True
 
 
 def colsum_parts(parts):

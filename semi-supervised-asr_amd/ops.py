@@ -842,15 +842,18 @@ class _DecoderSeq(torch.autograd.Function):
         hb.gemm_batched(wk["ws"], dctx_base[:, :, D:], dQ, True, False, Tp, O, L, B * Tp, B * KX, O, B, Tp, KX,
                         Tp * O)
         dbo = _colsum_acc(dctx_base.view(L * B, KX)[:, D:D + O])
-        # embedding gradient for token-fed steps
+        # embedding gradient for token-fed steps: one launch over the embedding columns of G as they lie (fed = -1: a step
+        # whose input was not a token)
         demb_all = G[:L, :, D + O:]
-        if torch.is_tensor(probs_saved):   # smooth feedback: only step 0 was fed a token (<BOS>)
-            demb_w.index_add_(0, fed[0], demb_all[0])
-        elif not probs_saved:        # every step was fed a token (decided on the host: no device sync here)
-            demb_w.index_add_(0, fed.view(-1), demb_all.reshape(L * B, E))
-        else:
-            tokfed = fed >= 0
-            demb_w.index_add_(0, fed[tokfed], demb_all[tokfed])
+        nsteps = 1 if torch.is_tensor(probs_saved) else L     # smooth feedback: only step 0 was fed a token (<BOS>)
+        if not hb.embedding_grad(fed[:nsteps].reshape(-1), G[:nsteps].view(nsteps * B, KX)[:, D + O:], demb_w):
+            if torch.is_tensor(probs_saved):
+                demb_w.index_add_(0, fed[0], demb_all[0])
+            elif not probs_saved:    # every step was fed a token (decided on the host: no device sync here)
+                demb_w.index_add_(0, fed.view(-1), demb_all.reshape(L * B, E))
+            else:
+                tokfed = fed >= 0
+                demb_w.index_add_(0, fed[tokfed], demb_all[tokfed])
         dP = wk["dP"] if zb is not None else wk["dP"].clone()      # (an arena slice outlives the lease)
         lease.release()
         return (dP, dQ, demb_w, dw_ih, dw_hh, dbias, dbias2, dwdec, dconvw, dwatt, dgvec, dbo, dw_out, db_out,

@@ -1153,6 +1153,27 @@ def test_dec_prepare_matches_torch(drop):
         assert torch.equal(Xd, wd)
 
 
+@pytest.mark.parametrize("rows,E,V,KX", [(3232, 128, 34, 1152), (37, 16, 12, 48), (5, 8, 140, 8), (640, 256, 64, 256)])
+def test_embedding_grad_kernel(rows, E, V, KX):
+    """asr_embedding_grad_f32 (autograd of nn.Embedding over the decoder's token-fed steps, model.py:337) against
+    index_add_: row-strided gradient (the embedding columns of the dX buffer), -1 = a step that was not fed a token."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(rows + V)
+    buf = torch.randn(rows, KX, generator=g).to(dev)
+    grad = buf[:, KX - E:]
+    tok = torch.randint(0, V, (rows,), generator=g)
+    tok[torch.rand(rows, generator=g) < 0.2] = -1
+    tok = tok.to(dev)
+    acc = torch.randn(V, E, generator=g).to(dev)
+    want = acc.clone()
+    fedmask = tok >= 0
+    want.index_add_(0, tok[fedmask], grad[fedmask])
+    assert hb.embedding_grad(tok, grad, acc)
+    _close(acc, want, rtol=1e-5, atol=1e-5, what="embedding gradient")
+    assert not hb.embedding_grad(tok, buf[:, 1:1 + E], acc.clone())          # unaligned rows: the caller's own path
+
+
 @pytest.mark.parametrize("H,I,ndir", [(16, 12, 2), (128, 80, 2), (32, 32, 1)])
 def test_lstm_pack_unpack_roundtrip(H, I, ndir):
     """asr_lstm_pack_f32 produces the gate-interleaved layout (row = unit*4 + gate) and asr_lstm_unpack_f32 inverts it."""
