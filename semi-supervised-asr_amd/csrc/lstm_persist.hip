@@ -56,6 +56,11 @@
 #ifndef ASR_POLL_FIRST_SLEEP
 #define ASR_POLL_FIRST_SLEEP 0
 #endif
+#ifndef ASR_LA_HALVES   /* forward, H = 512, 8-row groups, three terms: the wave's h tile as TWO load instructions - k 0-31 and k 32-63 of
+                           its range - and the split + products of the first half while the second is still arriving: 1.75 -> 1.68 us
+                           per time step, same box, bit-identical results (tools/persist_bench.py against -DASR_LA_HALVES=0) */
+#define ASR_LA_HALVES 1
+#endif
 #ifndef ASR_POLL_SENTINEL_ROWS /* forward (split-bf16) kernel: groups of at least this many rows spin on one quad per lane before requesting the tile (99 = never) */
 #define ASR_POLL_SENTINEL_ROWS 16
 #endif
@@ -512,8 +517,75 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr bool HALVES = ASR_LA_HALVES != 0 && FOLD && PKW == 64 && NR == 8;
+    // the products of k-step ks_ on the staged tile (FOLD form)
+#define LP_KSTEP(ks_)                                                                                                  \
+    do {                                                                                                               \
+      const u32x4 b1 = *reinterpret_cast<const u32x4*>(&hh[ml >> 3][wave][ml & 7][32 * (ks_) + 8 * kq]);                \
+      const u32x4 b2 = *reinterpret_cast<const u32x4*>(&hh[2 + (ml >> 3)][wave][ml & 7][32 * (ks_) + 8 * kq]);          \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks_][0], b1, acc[mt]);                \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks_][1], b1, acc[mt]);                \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks_][0], b2, acc[mt]);                \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt] = bf3_mfma(wt[mt][ks_][2], b1, acc[mt]);                \
+    } while (0)
     if (s > 0) {
-      if constexpr (NR >= 8) {
+      if constexpr (HALVES) {
+        // lane l: k = l & 31 of the k-step, rows 4 (l >> 5) .. + 3: ONE quad per lane and k-step, two load instructions in
+        // flight; lanes l and l ^ 1 hold adjacent k of the same rows and trade halves (one DPP swap per value), so that
+        // every lane splits two (k, k + 1) pairs - rows 0, 1 of its quad on even lanes, rows 2, 3 on odd lanes - and the
+        // staging stays 4-byte stores
+        const int kk = lane & 31, rh = lane >> 5;
+        const unsigned offa = (unsigned)((xw_g - reinterpret_cast<float*>(a.xch)) + ((s - 1) & 1) * (PH * RG) +
+                                         (wave * PKW + kk) * RG + 4 * rh) * 4u;
+        const unsigned tb = tag_bit_of_step(s - 1);
+        u32x4 qa = __builtin_amdgcn_raw_buffer_load_b128(xrs, offa, 0, 16);
+        u32x4 qb = __builtin_amdgcn_raw_buffer_load_b128(xrs, offa + 32u * RG * 4u, 0, 16);
+        const bool odd = kk & 1;
+        const int srow = 4 * rh + (odd ? 2 : 0), scol = kk & ~1;
+#define LP_STAGE(q_, ks_)                                                                                              \
+        do {                                                                                                           \
+          const unsigned t0 = odd ? (q_).x : (q_).z, t1 = odd ? (q_).y : (q_).w;                                       \
+          const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)t0, 0xB1, 0xF, 0xF, true);   /* quad_perm [1,0,3,2] */ \
+          const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)t1, 0xB1, 0xF, 0xF, true);                        \
+          unsigned tk0[NT], tk1[NT];                                                                                   \
+          if (odd) {                                                                                                   \
+            bfn_split2<NT>(__uint_as_float(r0), __uint_as_float((q_).z), tk0);                                         \
+            bfn_split2<NT>(__uint_as_float(r1), __uint_as_float((q_).w), tk1);                                         \
+          } else {                                                                                                     \
+            bfn_split2<NT>(__uint_as_float((q_).x), __uint_as_float(r0), tk0);                                         \
+            bfn_split2<NT>(__uint_as_float((q_).y), __uint_as_float(r1), tk1);                                         \
+          }                                                                                                            \
+          _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                                             \
+            *reinterpret_cast<unsigned*>(&hh[k][wave][srow][32 * (ks_) + scol]) = tk0[k];                              \
+            *reinterpret_cast<unsigned*>(&hh[k][wave][srow + 1][32 * (ks_) + scol]) = tk1[k];                          \
+          }                                                                                                            \
+        } while (0)
+        unsigned spins = 0;
+        while (!__all(quad_ok(qa, tb))) {
+          if (++spins > spin_limit || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+            if (lane == 0) raise_abort(a.ctrl, 1u);
+            aborted = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+          qa = __builtin_amdgcn_raw_buffer_load_b128(xrs, offa, 0, 16);
+          qb = __builtin_amdgcn_raw_buffer_load_b128(xrs, offa + 32u * RG * 4u, 0, 16);
+        }
+        if (!(ASR_LA & 2)) LP_STAGE(qa, 0);
+        if (!(ASR_LA & 1)) LP_KSTEP(0);
+        while (!aborted && !__all(quad_ok(qb, tb))) {
+          if (++spins > spin_limit || ((spins & 63u) == 0u && flag_load(a.ctrl + 8) != 0u)) {
+            if (lane == 0) raise_abort(a.ctrl, 1u);
+            aborted = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(ASR_POLL_SLEEP);
+          qb = __builtin_amdgcn_raw_buffer_load_b128(xrs, offa + 32u * RG * 4u, 0, 16);
+        }
+        LP_MARK(7);
+        if (!(ASR_LA & 2)) LP_STAGE(qb, 1);
+#undef LP_STAGE
+      } else if constexpr (NR >= 8) {
         // single-stage hand-off: a lane owns two adjacent k of the wave's range for half of the rows (job = (k pair, row
         // half): 64 jobs at H = 512; H = 640 needs a second job on 16 lanes) and reads them as two 16-byte quads.  The pair is what makes the staging cheap: one packed split (v_cvt_pk_bf16_f32 works on two values
         // anyway) and one 4-byte LDS store per row and term - with one k and all NR rows per lane the same tile took 24
@@ -650,8 +722,11 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
       }
       if (prow_ok && s + 2 < T && !(ASR_LA & 4)) gx_n2 = *gx_ptr(s + 2);     // in flight for two steps
       // (wave-private LDS tile: program order within the wave is enough)
+      if constexpr (HALVES) {
+        if (!(ASR_LA & 1)) LP_KSTEP(1);
+      }
 #pragma unroll
-      for (int ks = 0; ks < ((ASR_LA & 1) ? 0 : KS); ++ks) {
+      for (int ks = 0; ks < ((ASR_LA & 1) || HALVES ? 0 : KS); ++ks) {
         if constexpr (FOLD) {
           // columns 8..15 of the batch side carry a second term (fold_halves): four MFMAs per tile and k-step
           const u32x4 b1 = *reinterpret_cast<const u32x4*>(&hh[ml >> 3][wave][ml & 7][32 * ks + 8 * kq]);
@@ -678,6 +753,7 @@ __global__ __launch_bounds__(PNT) void lstm_persist_fwd_bf3_kernel(PersistArgs a
         }
       }
     }
+#undef LP_KSTEP
     LP_MARK(2);
     if (s == 0 && prow_ok && T > 2) gx_n2 = *gx_ptr(2);
     if constexpr (FOLD) {

@@ -47,6 +47,21 @@ for path in paths:
         tf, tb, tb0 = best[(path, ar)]
         print('%-26s %-7s fwd %.2f us/step | bwd %.2f us/step (no dW: %.2f)' % (os.path.basename(path), hb.arith_name(ar), tf, tb, tb0), flush=True)
 
+# a variant must compute what the shipped library computes (forward outputs; the hand-off's tag bit costs <= 1 ulp)
+if len(paths) > 1:
+    ref = {}
+    for path in paths:
+        ga = gates0.clone(); y.zero_(); c.zero_()
+        assert libs[path].asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), None, None, None, P(y), P(c), P(xch), P(ctrl), ARITHS[0], st) == 0
+        torch.cuda.synchronize()
+        out = (y.clone(), c.clone(), ga)
+        if path == hb.LIB_PATH:
+            ref = out
+        else:
+            print('%-26s forward vs shipped: max |dy| %.2e  |dc| %.2e  |dgates| %.2e' % (
+                os.path.basename(path), float((out[0] - ref[0]).abs().max()), float((out[1] - ref[1]).abs().max()),
+                float((out[2] - ref[2]).abs().max())), flush=True)
+
 # the same recurrences on PACKED rows (every utterance T frames + 8 padding rows: rowbase / rowext of include/asr_hip.h)
 l = libs[hb.LIB_PATH]
 ext = T + 8
