@@ -54,13 +54,16 @@ if len(paths) > 1:
         ga = gates0.clone(); y.zero_(); c.zero_()
         assert libs[path].asr_lstm_seq_fwd_persist(T, B, B, H, 2, P(ga), P(wf), P(lens), None, None, None, P(y), P(c), P(xch), P(ctrl), ARITHS[0], st) == 0
         torch.cuda.synchronize()
-        out = (y.clone(), c.clone(), ga)
+        gb = gact.clone()
+        assert libs[path].asr_lstm_seq_bwd_persist(T, B, B, H, 2, P(gb), P(w), P(lens), None, None, None, P(dy), P(cc), None, None, None, P(xch), P(ctrl), ARITHS[0], st) == 0
+        torch.cuda.synchronize()
+        out = (y.clone(), c.clone(), ga, gb)
         if path == hb.LIB_PATH:
             ref = out
         else:
-            print('%-26s forward vs shipped: max |dy| %.2e  |dc| %.2e  |dgates| %.2e' % (
+            print('%-26s vs shipped: forward max |dy| %.2e  |dc| %.2e  |dgates| %.2e; backward max |d(dG)| %.2e of %.2e' % (
                 os.path.basename(path), float((out[0] - ref[0]).abs().max()), float((out[1] - ref[1]).abs().max()),
-                float((out[2] - ref[2]).abs().max())), flush=True)
+                float((out[2] - ref[2]).abs().max()), float((out[3] - ref[3]).abs().max()), float(ref[3].abs().max())), flush=True)
 
 # the same recurrences on PACKED rows (every utterance T frames + 8 padding rows: rowbase / rowext of include/asr_hip.h)
 l = libs[hb.LIB_PATH]
