@@ -66,7 +66,8 @@ _POOL = _Pool()
 # -------------------------------------------------------------------------------------- accumulator arena
 class _Arena(object):
     """Every buffer of a train step that has to START FROM ZERO - split-K GEMM outputs (their partial products meet in
-    atomics), bias-gradient sums, the accumulators of the sequence operators' backward passes - cut from ONE buffer that
+    atomics; the outputs of ops.linear among them), bias-gradient sums, the accumulators of the sequence operators' backward
+    passes, the loss scalar - cut from ONE buffer that
     ONE fill zeroes at the start of the step (Solver._step opens the scope: `with ops.step_arena(device)`), instead of a
     zero pass or a memset in front of each (39 fills per cfg-2 step, 0.2 ms).  A slice is valid until the next scope opens;
     outside a scope, and for what does not fit yet (the buffer grows to the step's need at the next scope), take() returns
