@@ -586,6 +586,13 @@ int asr_dec_feedback_bwd(int B, int V, int E, int DO, const float* demb, float* 
  * NEXT step's asr_sumsq_f32 adds into (a caller that alternates between two words needs no fill launch per step).
  * ------------------------------------------------------------------------------------- */
 int asr_sumsq_f32(int64_t n, const float* g, float* out, asr_stream_t stream);
+/* The gradient gather in front of them in a one-process step: flat[dst_offset[j] .. + count[j]) = src[j][0 .. count[j]) for
+ * njobs contiguous tensors (what autograd left in the parameters' .grad) and, if sumsq != NULL, sumsq[0] += the sum of their
+ * squares - torch._foreach_copy_ and asr_sumsq_f32 in one pass over the gradients (the norm of clip_grad_norm_,
+ * solver.py:384, is taken where they are read anyway).  Jobs beyond ASR_GATHER_MAX_JOBS take further launches. */
+#define ASR_GATHER_MAX_JOBS 64
+int asr_gather_sumsq_f32(int njobs, const float* const* src, const int64_t* dst_offset, const int64_t* count, float* flat,
+                         float* sumsq, asr_stream_t stream);
 int asr_adam_clip_f32(int64_t n, float* p, const float* g, float* m, float* v, float* vmax,
                       const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
                       float weight_decay, float bias_c1, float bias_c2, const void* skip_if_nonzero, float* zero_word,

@@ -23,6 +23,51 @@ __global__ void sumsq_kernel(int64_t n4, int64_t n, const float* __restrict__ g,
   if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// Gradient gather: the tensors autograd produced -> their slices of the flat buffer, and (optionally) the sum of their
+// squares on the way - the two passes in front of the update of a one-process step (torch._foreach_copy_ + asr_sumsq_f32)
+// as one.  Jobs travel by value; a block owns GATHER_CHUNK consecutive elements of one job.
+constexpr int GATHER_JOBS = ASR_GATHER_MAX_JOBS, GATHER_CHUNK = 256 * 4 * 4;
+struct GatherJobs {
+  int n;
+  int first[GATHER_JOBS + 1];          // first block of job j
+  const float* src[GATHER_JOBS];
+  int64_t dst[GATHER_JOBS];            // element offset in the flat buffer
+  int64_t count[GATHER_JOBS];
+};
+__global__ __launch_bounds__(256) void gather_sumsq_kernel(GatherJobs t, float* __restrict__ flat, float* __restrict__ sumsq) {
+  int lo = 0, hi = t.n - 1;            // the job of this block: last j with first[j] <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int j = lo;
+  const int64_t e0 = (int64_t)(blockIdx.x - t.first[j]) * GATHER_CHUNK;
+  const int64_t e1 = e0 + GATHER_CHUNK < t.count[j] ? e0 + GATHER_CHUNK : t.count[j];
+  const float* __restrict__ s = t.src[j];
+  float* __restrict__ d = flat + t.dst[j];
+  float acc = 0.f;
+  if ((((uintptr_t)s) & 15) == 0 && (t.dst[j] & 3) == 0) {
+    const int64_t n4 = (e1 - e0) >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(s + e0);
+    float4* d4 = reinterpret_cast<float4*>(d + e0);
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      const float4 v = s4[i];
+      d4[i] = v;
+      acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int64_t i = e0 + 4 * n4 + threadIdx.x; i < e1; i += 256) { const float v = s[i]; d[i] = v; acc += v * v; }
+  } else {
+    for (int64_t i = e0 + threadIdx.x; i < e1; i += 256) { const float v = s[i]; d[i] = v; acc += v * v; }
+  }
+  if (sumsq) {
+    acc = wave_sum(acc);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sumsq, (part[0] + part[1]) + (part[2] + part[3]));
+  }
+}
+
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float* vmax, float coef, float lr_c1,
                                          float b1, float b2, float eps, float wd, float rs_c2) {
   g = g * coef + wd * p;
@@ -75,6 +120,31 @@ extern "C" int asr_adam_clip_f32(int64_t n, float* p, const float* g, float* m, 
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, (hipStream_t)stream, n, p, g,
                      m, v, vmax, gnorm_sq, max_norm, lr / bias_c1, beta1, beta2, eps, weight_decay,
                      1.0f / sqrtf(bias_c2), (const unsigned*)skip_if_nonzero, zero_word);
+  ASR_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int asr_gather_sumsq_f32(int njobs, const float* const* src, const int64_t* dst_offset, const int64_t* count,
+                                    float* flat, float* sumsq, asr_stream_t stream) {
+  if (njobs <= 0 || !src || !dst_offset || !count || !flat) return ASR_E_ARG;
+  for (int j0 = 0; j0 < njobs; j0 += GATHER_JOBS) {
+    GatherJobs t;
+    t.n = njobs - j0 < GATHER_JOBS ? njobs - j0 : GATHER_JOBS;
+    int64_t at = 0;
+    for (int j = 0; j < GATHER_JOBS; ++j) {
+      t.first[j] = (int)at;
+      if (j < t.n) {
+        if (!src[j0 + j] || count[j0 + j] <= 0 || dst_offset[j0 + j] < 0) return ASR_E_ARG;
+        t.src[j] = src[j0 + j]; t.dst[j] = dst_offset[j0 + j]; t.count[j] = count[j0 + j];
+        at += (count[j0 + j] + GATHER_CHUNK - 1) / GATHER_CHUNK;
+        if (at > 0x7fffffff) return ASR_E_SHAPE;
+      } else {
+        t.src[j] = nullptr; t.dst[j] = 0; t.count[j] = 0;
+      }
+    }
+    t.first[GATHER_JOBS] = (int)at;
+    hipLaunchKernelGGL(gather_sumsq_kernel, dim3((unsigned)at), dim3(256), 0, (hipStream_t)stream, t, flat, sumsq);
+  }
   ASR_CHECK_LAUNCH();
   return 0;
 }

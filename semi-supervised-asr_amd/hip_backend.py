@@ -22,7 +22,7 @@ EXPORTS = (
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
     "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32", "asr_embedding_grad_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
-    "asr_adam_clip_f32", "asr_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
+    "asr_adam_clip_f32", "asr_sumsq_f32", "asr_gather_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
 
 _lib = None
@@ -123,6 +123,7 @@ def load():
     lib.asr_dec_seq_bwd_persist_free.argtypes = [ctypes.POINTER(DecBwd), ctypes.POINTER(DecFeedbackBwd), c_p, c_p, c_p, c_p]
     lib.asr_adam_clip_f32.argtypes = [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]
     lib.asr_sumsq_f32.argtypes = [c_i64, c_p, c_p, c_p]
+    lib.asr_gather_sumsq_f32.argtypes = [c_i, ctypes.POINTER(c_p), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_p, c_p, c_p]
     lib.asr_label_logprob_fwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_p]
     lib.asr_label_logprob_bwd.argtypes = [c_i64, c_i, c_p, c_i64, c_p, c_p, c_f, c_p, c_i64, c_f, c_p, c_i64, c_p]
     lib.asr_dec_feedback_fwd.argtypes = [c_i, c_i, c_i, c_i, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_i64,
@@ -599,6 +600,15 @@ def embedding_grad(tokens, grad, demb):
     check(load().asr_embedding_grad_f32(rows, E, V, c_p(tokens.data_ptr()), ptr(grad), grad.stride(0), ptr(demb), stream()),
           "asr_embedding_grad_f32")
     return True
+
+
+def gather_sumsq(srcs, offsets, flat, sumsq=None):
+    """flat[offsets[j] : + srcs[j].numel()] = srcs[j] (contiguous fp32 device tensors) in one launch; sumsq (1-element
+    tensor or None) += the sum of their squares."""
+    n = len(srcs)
+    check(load().asr_gather_sumsq_f32(n, _ptr_array(srcs), (c_i64 * n)(*[int(o) for o in offsets]),
+                                      (c_i64 * n)(*[int(t.numel()) for t in srcs]), ptr(flat), ptr(sumsq), stream()),
+          "asr_gather_sumsq_f32")
 
 
 def colsum_parts(parts):

@@ -446,9 +446,13 @@ class FlatBuffers(object):
         p, o = self.params[i], self.offsets[i]
         return self.flat_g[o:o + p.numel()].view_as(p.data)
 
-    def collect(self):
-        """Move the gradients autograd produced into the flat buffer and re-attach .grad to its views."""
-        dst, src, missing = [], [], False
+    def collect(self, sumsq=None):
+        """Move the gradients autograd produced into the flat buffer and re-attach .grad to its views.
+        sumsq (a zeroed 1-element device tensor, one-process steps): the sum of squares of ALL gradients is added to it on the
+        way (asr_gather_sumsq_f32: the gather and the norm of clip_grad_norm_ in one pass); returns True if it was - False
+        (the caller takes the norm over the flat buffer) when a gradient is missing, already in place, not contiguous, or
+        the buffers are not on a GPU."""
+        dst, src, offs, missing, in_place = [], [], [], False, False
         for i, p in enumerate(self.params):
             v = self._view(i)
             if p.grad is None:
@@ -456,12 +460,22 @@ class FlatBuffers(object):
             elif p.grad.data_ptr() != v.data_ptr():
                 dst.append(v)
                 src.append(p.grad)
+                offs.append(self.offsets[i])
+            else:
+                in_place = True
         if missing:
             self.flat_g[:self.total].zero_()
+        fused = False
         if dst:
-            torch._foreach_copy_(dst, src)
+            if (self.flat_g.is_cuda and all(g.is_cuda and g.is_contiguous() and g.dtype == torch.float32 for g in src)):
+                import hip_backend as hb
+                fused = sumsq is not None and not in_place
+                hb.gather_sumsq(src, offs, self.flat_g, sumsq if fused else None)
+            else:
+                torch._foreach_copy_(dst, src)
         for i, p in enumerate(self.params):
             p.grad = self._view(i)
+        return fused
 
     def set_aux(self, values):
         """Scalars (tensors or floats, at most NAUX) that should come out of the step's all-reduce summed over ranks.
@@ -483,7 +497,7 @@ class FlatBuffers(object):
                 for i, v in zip(where, on_dev):
                     self.aux[i].copy_(v)
 
-    def allreduce_grads(self, group=None):
+    def allreduce_grads(self, group=None, sumsq=None):
         """The gradient exchange of the step.  Default: ONE SUM all-reduce over the flat gradient buffer (+ aux scalars).
         With enable_overlap(): the buckets not yet issued from the backward pass are issued now (same fixed order on every
         rank), all are awaited, and the aux scalars travel in a 16-byte collective of their own."""
@@ -493,10 +507,13 @@ class FlatBuffers(object):
                 w.wait()
             self._works = []
             dist.all_reduce(self.aux, op=dist.ReduceOp.SUM, group=self._group)
-            return
-        self.collect()
-        if world() > 1 or (FORCE_DP and dist.is_initialized()):
+            return False
+        exchange = world() > 1 or (FORCE_DP and dist.is_initialized())
+        # (one process: the norm the clip needs is the norm of what is being gathered - taken in the same pass)
+        fused = self.collect(None if exchange else sumsq)
+        if exchange:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+        return fused
 
 
 # ------------------------------------------------------------------------------ optimiser
@@ -530,6 +547,7 @@ class FlatAdam(object):
         self.gnorm_pair = torch.zeros(2, device=dev, dtype=torch.float32)
         self.gnorm_sq = self.gnorm_pair[0:1]
         self._applies = 0
+        self._norm_taken = False
         self.t = 0
 
     def zero_grad(self):
@@ -539,7 +557,24 @@ class FlatAdam(object):
         """First half of a step: gather the gradients into the flat buffer and (if distributed) all-reduce it together
         with the aux scalars behind it.  A caller that has to look at the reduced aux values before committing to the
         update (Solver._dp_step: the abort flag of the persistent kernels) calls reduce(), reads, then apply()."""
-        self.buf.allreduce_grads(group)
+        if self._norm_taken:                         # a reduce() whose apply() never came: its word holds a stale norm and
+            self.gnorm_pair.zero_()                  # the other one was not cleared for this step
+            self._norm_taken = False
+        word = None
+        if self.max_grad_norm is not None and self.buf.flat_g.is_cuda:
+            word = self._norm_word()
+        # one process: ||g||^2 is taken in the pass that gathers the gradients (FlatBuffers.collect)
+        self._norm_taken = bool(self.buf.allreduce_grads(group, sumsq=word))
+        if word is not None and not self._norm_taken:
+            self._applies -= 1                       # (the word was not used: apply() takes it again)
+
+    def _norm_word(self):
+        """The accumulator of this step's ||g||^2: the two words of gnorm_pair in turn (apply() has the update kernel clear
+        the other one for the next step)."""
+        k = self._applies & 1
+        self._applies += 1
+        self.gnorm_sq = self.gnorm_pair[k:k + 1]
+        return self.gnorm_sq
 
     def apply(self, max_grad_norm=None, skip_if=None):
         """Second half: global grad norm -> clip + Adam on the (reduced) flat buffer.  Returns the device scalar holding
@@ -555,12 +590,13 @@ class FlatAdam(object):
         n = self.buf.total
         gptr = nxt = None
         if clip is not None:
-            k = self._applies & 1
-            self._applies += 1
-            self.gnorm_sq = self.gnorm_pair[k:k + 1]
+            if not self._norm_taken:                 # (else reduce() took the norm with the gather)
+                self._norm_word()
+                hb.check(lib.asr_sumsq_f32(n, hb.ptr(self.buf.flat_g), hb.ptr(self.gnorm_sq), hb.stream()),
+                         "asr_sumsq_f32")
+            self._norm_taken = False
+            k = (self._applies - 1) & 1
             nxt = hb.ptr(self.gnorm_pair[1 - k:2 - k])
-            hb.check(lib.asr_sumsq_f32(n, hb.ptr(self.buf.flat_g), hb.ptr(self.gnorm_sq), hb.stream()),
-                     "asr_sumsq_f32")
             gptr = hb.ptr(self.gnorm_sq)
         hb.check(lib.asr_adam_clip_f32(n, hb.ptr(self.buf.flat_p), hb.ptr(self.buf.flat_g), hb.ptr(self.m),
                                        hb.ptr(self.v), hb.ptr(self.vmax), gptr,

@@ -1156,6 +1156,33 @@ def test_dec_prepare_matches_torch(drop):
         assert torch.equal(Xd, wd)
 
 
+def test_gather_sumsq_kernel():
+    """asr_gather_sumsq_f32: the gradient gather of a one-process step (torch._foreach_copy_ into the flat buffer) with the
+    sum of squares of clip_grad_norm_ (solver.py:384) taken on the way; more jobs than one launch carries, odd sizes, an
+    unaligned source."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(17)
+    sizes = [1, 3, 4, 5, 4096, 4097, 12345, 2048 * 512, 7] + [33] * 70
+    srcs, offs, off = [], [], 0
+    for i, n in enumerate(sizes):
+        t = torch.randn(n + 1, generator=g).to(dev)
+        srcs.append(t[1:] if i == 6 else t[:n])                       # one source that is not 16-byte aligned
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    flat = torch.full((off,), 7.0, device=dev)
+    acc = torch.zeros(1, device=dev)
+    hb.gather_sumsq([s_.contiguous() if False else s_ for s_ in srcs], offs, flat, acc)
+    want = 0.0
+    for s_, o in zip(srcs, offs):
+        assert torch.equal(flat[o:o + s_.numel()], s_)
+        want += float((s_.double() ** 2).sum())
+    assert abs(float(acc) - want) <= 1e-5 * want
+    keep = flat.clone()
+    hb.gather_sumsq(srcs[:3], offs[:3], flat, None)                    # without the norm
+    assert torch.equal(flat, keep)
+
+
 @pytest.mark.parametrize("rows,E,V,KX", [(3232, 128, 34, 1152), (37, 16, 12, 48), (5, 8, 140, 8), (640, 256, 64, 256)])
 def test_embedding_grad_kernel(rows, E, V, KX):
     """asr_embedding_grad_f32 (autograd of nn.Embedding over the decoder's token-fed steps, model.py:337) against
