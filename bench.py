@@ -810,6 +810,8 @@ def epoch_workload(dev, tmp, steps=60, config="cfg2"):
     def loop(n_batches, epoch):
         sv.train_lab_dataset = corpus(n_batches)
         sv.train_lab_loader = sv._loader(sv.train_lab_dataset, B, False, False)
+        if os.environ.get("ASR_BENCH_GC_FREEZE", "1") != "0":
+            sv.settle_host_memory()                # what Solver.__init__ does after loading its corpora
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(sys.stderr):
