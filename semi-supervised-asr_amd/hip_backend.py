@@ -211,7 +211,16 @@ def ptr(t):
     return None if t is None else c_p(_dev(t).data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """The current HIP stream of the current device as the C ABI takes it.  Asked ~85 times per train step (once per launch):
+    the raw handle straight from torch's C layer (0.3 us) instead of a torch.cuda.Stream object per call (2.3 us each - 0.2
+    ms of a cfg-1 step whose 2.4 ms ARE its host time)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return c_p(_raw_stream(_raw_device()))
     return c_p(torch.cuda.current_stream().cuda_stream)
 
 
