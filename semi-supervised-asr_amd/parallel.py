@@ -443,8 +443,11 @@ class FlatBuffers(object):
             p.grad = None
 
     def _view(self, i):
-        p, o = self.params[i], self.offsets[i]
-        return self.flat_g[o:o + p.numel()].view_as(p.data)
+        """Parameter i's slice of the flat gradient buffer, shaped like the parameter (built once: 100 lookups per step)."""
+        views = self.__dict__.get("_views")
+        if views is None:
+            views = self._views = [self.flat_g[o:o + p.numel()].view_as(p.data) for p, o in zip(self.params, self.offsets)]
+        return views[i]
 
     def collect(self, sumsq=None):
         """Move the gradients autograd produced into the flat buffer and re-attach .grad to its views.
