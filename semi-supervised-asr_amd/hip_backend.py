@@ -446,7 +446,9 @@ def _to_device(arr, torch_dtype, device):
     host runs ahead of the GPU, so the copy has long finished when the stream gets there; as an in-stream copy each of
     these small uploads cost ~10 us of the step)."""
     key = (str(device), str(torch_dtype), arr.size)
-    ring = _pinned_ring.setdefault(key, dict(bufs=[torch.empty(arr.size, dtype=torch_dtype).pin_memory() for _ in range(8)], i=0))
+    ring = _pinned_ring.get(key)
+    if ring is None:            # (not setdefault(key, dict(...)): its default is built - eight pinned allocations - on EVERY call)
+        ring = _pinned_ring[key] = dict(bufs=[torch.empty(arr.size, dtype=torch_dtype).pin_memory() for _ in range(8)], i=0)
     buf = ring["bufs"][ring["i"] % 8]
     ring["i"] += 1
     buf.copy_(torch.from_numpy(arr.reshape(-1)))

@@ -35,4 +35,4 @@ if os.environ.get("PROFILE"):
     for _ in range(5):
         sv.sup_train_one_iteration(xs_d, lens, ys_d, 1.0)
     pr.disable(); sv.flush()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("TOP", "45")))
