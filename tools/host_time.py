@@ -32,7 +32,7 @@ if os.environ.get("PROFILE"):
     import cProfile, pstats
     torch.cuda.synchronize()
     pr = cProfile.Profile(); pr.enable()
-    for _ in range(5):
+    for _ in range(int(os.environ.get("PROFILE_STEPS", "5"))):
         sv.sup_train_one_iteration(xs_d, lens, ys_d, 1.0)
     pr.disable(); sv.flush()
     pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("TOP", "45")))
