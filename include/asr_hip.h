@@ -524,8 +524,9 @@ int asr_dec_prepare_f32(int L, int B, int D, int O, int E, const long long* toke
                         const float* emb_w, const float* xmask, float* X, float* Xd, long long* fed, asr_stream_t stream);
 /* The gradient of those embedding rows (autograd of nn.Embedding, model.py:337): demb [V][E] (caller-zeroed or accumulating)
  * += grad[r][0..E) for every r < rows with 0 <= tokens[r] < V (a step that was not fed a token carries -1); grad row-strided
- * (ldg floats: the embedding columns of the decoder's dX buffer).  E % 4 == 0, ldg % 4 == 0, V * E * 4 <= 64 KB (the
- * table a workgroup folds its rows into); ASR_E_SHAPE otherwise - the caller then takes its own index_add. */
+ * (ldg floats: the embedding columns of the decoder's dX buffer, read where they lie).  E % 4 == 0, ldg % 4 == 0, V * E * 4 <=
+ * 64 KB (the table a workgroup folds its rows into: label matrices are skewed towards <EOS>); ASR_E_SHAPE otherwise - the
+ * caller then takes its own index_add. */
 int asr_embedding_grad_f32(int64_t rows, int E, int V, const long long* tokens, const float* grad, int64_t ldg,
                            float* demb, asr_stream_t stream);
 int asr_cell_pack_f32(int D, int O, int E, const float* w_ih, const float* w_hh, const float* b_ih,

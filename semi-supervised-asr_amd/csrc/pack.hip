@@ -277,24 +277,43 @@ __global__ void dec_prepare_kernel(int L, int B, int DO4, int E4, const long lon
 }
 
 // Gradient of the embedding rows behind dec_prepare_kernel (autograd of nn.Embedding, model.py:337): demb[tok[r]][:] +=
-// g[r][:] for r < rows, g row-strided (the embedding columns of the decoder's dX buffer).  A block folds its rows into an
-// LDS table [V][E] (ds_add_f32) and adds the table to global memory once: V E atomics per block instead of one per row and
-// element on V hot rows (torch's index_add_ on a contiguous copy of g: 16 + 5 us at cfg-2).
+// g[r][:] for r < rows, g row-strided (the embedding columns of the decoder's dX buffer, read where they lie).  Real label
+// matrices are SKEWED - the <EOS> padding makes one of the V rows the target of a third of all adds - so one global atomic
+// per (row, element) serialises on that row's addresses (52 us inside a cfg-2 step, 13 with uniform random tokens).  A
+// workgroup therefore folds its rows into an LDS table [V][E] (ds_add_f32) and adds the table's non-zero entries to global
+// memory once.  Per row lane the loop is a chain of dependent loads (token -> gradient row): four rows per trip, all eight
+// loads in flight before the first add (one row per trip: 24 us).
 __global__ __launch_bounds__(256) void embedding_grad_kernel(int64_t rows, int E4, int V, const long long* __restrict__ tok,
                                                              const float* __restrict__ g, int64_t ldg, float* __restrict__ demb) {
   extern __shared__ float table[];                       // [V][4 E4]
   const int E = 4 * E4;
   for (int i = threadIdx.x; i < V * E; i += blockDim.x) table[i] = 0.f;
   __syncthreads();
-  const int lanes = blockDim.x / E4;                     // rows in flight per block
+  const int lanes = blockDim.x / E4;                     // rows in flight per trip and block (x 4)
   const int c = threadIdx.x % E4, rl = threadIdx.x / E4;
   if (rl < lanes) {
-    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < rows; r += (int64_t)gridDim.x * lanes) {
-      const long long t = tok[r];
-      if (t < 0 || t >= V) continue;                     // (a step that was not fed a token: -1)
-      const float4 v = *reinterpret_cast<const float4*>(g + r * ldg + 4 * c);
-      float* d = table + t * E + 4 * c;
-      atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+    const int64_t stride = (int64_t)gridDim.x * lanes;
+    for (int64_t r0 = (int64_t)blockIdx.x * lanes + rl; r0 < rows; r0 += 4 * stride) {
+      long long t[4];
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + u * stride;
+        t[u] = r < rows ? tok[r] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + u * stride;
+        const bool ok = t[u] >= 0 && t[u] < V;            // (-1: a step that was not fed a token)
+        v[u] = *reinterpret_cast<const float4*>(g + (ok ? r : 0) * ldg + 4 * c);
+        if (!ok) t[u] = -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (t[u] < 0) continue;
+        float* d = table + t[u] * E + 4 * c;
+        atomicAdd(d, v[u].x); atomicAdd(d + 1, v[u].y); atomicAdd(d + 2, v[u].z); atomicAdd(d + 3, v[u].w);
+      }
     }
   }
   __syncthreads();
@@ -310,7 +329,7 @@ extern "C" int asr_embedding_grad_f32(int64_t rows, int E, int V, const long lon
   if (E % 4 || ldg % 4 || E / 4 > 256 || (size_t)V * E * sizeof(float) > 64 * 1024) return ASR_E_SHAPE;
   if (!asr_aligned16(grad)) return ASR_E_ALIGN;
   const int lanes = 256 / (E / 4);
-  int64_t blocks = (rows + (int64_t)lanes * 16 - 1) / ((int64_t)lanes * 16);      // >= 16 rows per row lane
+  int64_t blocks = (rows + (int64_t)lanes * 8 - 1) / ((int64_t)lanes * 8);       // >= 8 rows (two trips) per row lane
   if (blocks > 64) blocks = 64;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(embedding_grad_kernel, dim3((unsigned)blocks), dim3(256), (size_t)V * E * sizeof(float), (hipStream_t)stream,

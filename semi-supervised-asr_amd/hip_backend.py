@@ -602,7 +602,7 @@ def cell_unpack(dwcat, db_il, D, O, E):
 
 def embedding_grad(tokens, grad, demb):
     """demb [V, E] += grad[r] for the token of row r (tokens [rows] int64, -1 = none; grad [rows, E] row-strided view).
-    False when the shape is outside the kernel's table (the caller then uses index_add_)."""
+    False when the layout is outside the kernel's (the caller then uses index_add_)."""
     V, E = demb.shape
     rows = tokens.numel()
     if (grad.stride(1) != 1 or grad.shape != (rows, E) or not tokens.is_contiguous() or not demb.is_contiguous()
