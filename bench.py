@@ -724,10 +724,12 @@ def main():
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"bf16x6": "f32 (fp32-equivalent bf16x6 products)", "f32": "f32", "bf16x3": "f32 (bf16x3 products: 16-bit significands)"}[args.arith],
             "data": "synthetic", "arithmetic": ARITH_TEXT[args.arith],
-            "config": {"workload": "%s, batch %d per GPU, 80x%d synthetic fbank (ragged 0.6T..T), V=%d, L+1=%d, "
-                                   "dropout %.2f, Adam(amsgrad)+clip 5" % (spec["name"], b_local, t_frames,
-                                                                           cfg["output_dim"], info["olength"],
-                                                                           cfg["dropout_rate"]),
+            "config": {"workload": "%s: batch %d per GPU, 80x%d synthetic fbank, RAGGED lengths U[0.6T, T] (mean %.0f frames per "
+                                   "utterance, longest %d; the fixed-length reading is workloads.cfg2_fixed_T), V=%d, L+1=%d, "
+                                   "dropout %.2f, Adam(amsgrad)+clip 5; %s"
+                                   % (args.config, b_local, t_frames, float(np.mean(lens)), int(max(lens)), cfg["output_dim"],
+                                      info["olength"], cfg["dropout_rate"], spec["name"]),
+                       "mean_frames_per_utterance": float(np.mean(lens)),
                        "config": args.config, "global_batch": n_global, "frames": t_frames,
                        "parallelism": "dp%d" % world, "pad_mode": "global-exact", "launch_mode": "eager",
                        "timed_call": "Solver.sup_train_one_iteration (semi-supervised-asr_amd/solver.py): forward, loss, zero_grad, "
@@ -869,6 +871,34 @@ def other_workloads(dev, tmp, main_config, main_frames):
                          ms_per_step=ms, value=B / ms * 1e3, unit="utterances/sec", loss=float(loss), sequence_op_paths=paths)
         del sv, xs_d, ys_d
         torch.cuda.empty_cache()
+    # BASELINE.json quotes cfg-2 on "80x800" batches and north_star on {200 ... 1600} frames: the headline batch is the ragged
+    # reading of that (U[0.6T, T]); here the FIXED-length reading - every utterance exactly T frames, T / 8 labels -
+    # and the ragged batches at the other frame counts, all through the same Solver method
+    spec = CONFIGS["cfg2"]
+    c, B = dict(spec["model"]), spec["batch"]
+    sv = make_solver(c, B, spec["frames"], os.path.join(tmp, "sweep"))
+    for name, T, fixed in (("cfg2_fixed_T", spec["frames"], True), ("cfg2_T200", 200, False), ("cfg2_T400", 400, False),
+                           ("cfg2_T1600", 1600, False)):
+        if main_config == "cfg2" and main_frames == T and not fixed:
+            continue
+        note("workload %s" % name)
+        if fixed:
+            rs = np.random.RandomState(1234)
+            lens = [T] * B
+            xs = rs.normal(0, 1, size=(B, T, c["input_dim"])).astype(np.float32)
+            ys = [rs.randint(3, c["output_dim"], size=(T // 8,)).astype(np.int64) for _ in range(B)]
+        else:
+            xs, lens, ys = synth.ragged_batch(B, T, c["input_dim"], c["output_dim"], 1234)
+        xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+        ms, loss, paths = run(lambda: sv.sup_train_one_iteration(xs_d, lens, ys_d, 1.0), sv.flush)
+        res[name] = dict(call="Solver.sup_train_one_iteration",
+                         workload="cfg-2's model, batch %d, 80x%d, %s (mean %.0f frames, %.0f labels per utterance)"
+                                  % (B, T, "every utterance exactly T frames" if fixed else "ragged 0.6T..T",
+                                     float(np.mean(lens)), float(np.mean([len(y) for y in ys]))),
+                         ms_per_step=ms, value=B / ms * 1e3, unit="utterances/sec", loss=float(loss), sequence_op_paths=paths)
+        del xs_d, ys_d
+    del sv
+    torch.cuda.empty_cache()
     # cfg-4's iteration at cfg-2's shape: 32 labeled + 32 unlabeled utterances of T = 800, judge 2 x 640 (config.yaml).
     # Random weights + random labels drift to an all-<EOS> hypothesis within a few steps (mask sum 0, the reference's 0 / 0):
     # a negligible learning rate and an <EOS> bias keep the timed iterations in the regime a trained model is in.

@@ -138,14 +138,13 @@ extern "C" int asr_rows_unpack_bwd_f32(int B, int T, int C, const float* dout, c
                                        const int32_t* rowext, int ext_max, const float* mask, uint64_t seed, float p,
                                        float* drows, float* dfill, const float* relu_of, asr_stream_t stream) {
   if (!dout || !lens || !rowbase || !rowext || !drows || B <= 0 || T <= 0 || C <= 0 || ext_max <= 0 || p < 0.f || p >= 1.f) return ASR_E_ARG;
-  if (C % 4) return ASR_E_SHAPE;
+  if (C % 4 || (dfill && C / 4 > 512)) return ASR_E_SHAPE;          // (checked before anything is launched: no half-done result)
   if (!asr_aligned16(dout) || !asr_aligned16(drows) || (mask && !asr_aligned16(mask)) || (relu_of && !asr_aligned16(relu_of)))
     return ASR_E_ALIGN;
   hipLaunchKernelGGL(rows_unpack_bwd_kernel, dim3((ext_max + 3) / 4, B), dim3(threads_for(C / 4)), 0, (hipStream_t)stream, T, C / 4,
                      (const float4*)dout, lens, rowbase, rowext, (float4*)drows);
   if (dfill) {
     const int C4 = C / 4;
-    if (C4 > 512) return ASR_E_SHAPE;
     int FL = 512 / C4;                                     // frame lanes: as many as 512 threads hold, at most 8
     if (FL > 8) FL = 8;
     hipLaunchKernelGGL(rows_fill_grad_kernel, dim3(B), dim3(FL * C4), (size_t)FL * C4 * sizeof(float4), (hipStream_t)stream, T, C4,

@@ -14,9 +14,10 @@ zero padding, `ilens` a host list, `ys` a list of int64 tensors) and changes how
     global constants the exact-parity rules need (B_global, T_max, olength, the judge's normaliser) from the
     lengths of the whole batch, which every rank sees (the samplers are seeded identically): a `parallel.LocalShard`.
 
-The optional Gaussian input noise (solver.py:370-373) is drawn here, for the GLOBAL batch from a numpy stream of its own
-(seeded from the process's numpy stream when the feed is built, so data-parallel ranks agree), and added on the host
-before the upload.
+The optional Gaussian input noise (solver.py:370-373) is drawn here and added on the host before the upload: one numpy
+generator per GLOBAL row of a batch, seeded from (the feed's seed - taken from the process's numpy stream when the feed is
+built, so data-parallel ranks agree -, the batch's index, the row).  A rank draws only the rows it uploads, and the union of
+the rank-local batches is the one-process batch.
 """
 import queue
 import threading
@@ -100,7 +101,7 @@ class DeviceFeed(object):
 
       kind        "labeled" (features + labels), "speech" (features only), "text" (labels only)
       rank/world  data-parallel position: world > 1 yields this rank's strided rows as a parallel.LocalShard
-      noise_std   > 0: add N(0, noise_std) noise to the features (drawn for the global batch, see the module docstring)
+      noise_std   > 0: add N(0, noise_std) noise to the features (a generator per global row, see the module docstring)
       thread      collate + upload in a background thread (default) or inline in next()
     """
 
@@ -113,9 +114,9 @@ class DeviceFeed(object):
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.depth = max(1, int(depth))
         self.noise_std = float(noise_std)
-        # the noise stream: seeded from the process's numpy stream HERE (the consumer's thread), so that identically
-        # seeded data-parallel ranks draw identical noise whatever the interleaving of the threads
-        self.noise_rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1)) if self.noise_std > 0 else None
+        # the noise seed: taken from the process's numpy stream HERE (the consumer's thread), so that identically seeded
+        # data-parallel ranks draw identical noise whatever the interleaving of the threads
+        self.noise_seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.noise_std > 0 else None
         self.thread = bool(thread)
         self._slots = None                               # borrowed for the length of one iteration
         self._side = torch.cuda.Stream(device=self.device) if self.cuda else None
@@ -148,10 +149,12 @@ class DeviceFeed(object):
                 n = lens_all[i]
                 xs_n[r, :n] = items[i][0]
                 xs_n[r, n:] = 0.0
-            if self.noise_rng is not None:
-                noise = self.noise_rng.normal(0.0, self.noise_std, (len(items), t_max, dim)).astype(np.float32)
-                if rows:
-                    xs_h.add_(torch.from_numpy(noise[self.rank::self.world] if sharded else noise))
+            if self.noise_seed is not None:
+                # one generator per GLOBAL row, seeded from (feed, batch, row): a rank draws its own rows only - the work
+                # per rank does not grow with the world size - and every rank would draw the same values for a given row
+                for r, i in enumerate(rows):
+                    rs = np.random.RandomState([self.noise_seed, self._n - 1, i])
+                    xs_n[r] += rs.normal(0.0, self.noise_std, (t_max, dim)).astype(np.float32)
             info.update(t_max=t_max, olength=None)
         if self.kind != "speech":
             tok_all = [items[i][1] for i in range(len(items))]

@@ -744,7 +744,8 @@ def disable_persistent(device=None, permanent=False):
     if permanent:
         st["wanted"] = (False, False, False)
     USE_PERSIST = USE_PERSIST_DEC = USE_PERSIST_DEC_BWD = False
-    st["aborts"] += 1
+    if not permanent:                 # (ranks sharing a card leave by decision, not after an abort: nothing to count, and a
+        st["aborts"] += 1             #  later abort's probation starts at the base length)
     if permanent or PERSIST_RETRY_STEPS <= 0 or not any(st["wanted"]):
         st["retry_at"] = None
     else:

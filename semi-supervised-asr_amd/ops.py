@@ -71,7 +71,18 @@ class _Arena(object):
     ONE fill zeroes at the start of the step (Solver._step opens the scope: `with ops.step_arena(device)`), instead of a
     zero pass or a memset in front of each (39 fills per cfg-2 step, 0.2 ms).  A slice is valid until the next scope opens;
     outside a scope, and for what does not fit yet (the buffer grows to the step's need at the next scope), take() returns
-    None and the caller falls back to its own zero fill."""
+    None and the caller falls back to its own zero fill.
+
+    LIFETIME.  A slice is raw storage of the arena (set_ on the untyped storage: autograd cannot see that slices of
+    different steps overlap), so everything a step produced inside its scope - the outputs of ops.linear (the logits and
+    log-probs of E2E.forward among them), the weight gradients in .grad - is valid UNTIL THE NEXT SCOPE OPENS and is zeroed
+    then.  Solver._step keeps to that: its closures hand back scalars only, which are copied to the step's host record
+    inside the scope.  Code that wants to keep a tensor of a step (logging logits, comparing gradients across steps)
+    clones it before the next step, or runs the model outside a scope (tests, validation: take() returns None there).
+
+    INVARIANT.  Everything at and behind the cursor is zero: begin() zeroes what the previous scope used, nothing else was
+    ever written.  A scope opened inside another one (Solver._recover, from the end of the step that found the abort) relies
+    on it; ASR_ARENA_DEBUG=1 checks it at every begin() (a device sync: debugging only)."""
 
     def __init__(self):
         self.buf, self.cursor, self.want, self.active = None, 0, 0, False
@@ -83,6 +94,8 @@ class _Arena(object):
             self.buf = torch.zeros(int(self.want * 1.25) + 4096, device=device, dtype=torch.float32) if self.want > 0 else None
         elif self.cursor > 0:
             self.buf[:self.cursor].zero_()               # what the previous step used: ONE fill
+        if _ARENA_DEBUG and self.buf is not None:
+            assert float(self.buf.abs().max()) == 0.0, "step arena: a value survived behind the cursor"
         self.cursor, self.want, self.active = 0, 0, True
 
     def end(self):
@@ -112,6 +125,7 @@ class _Arena(object):
         return out
 
 
+_ARENA_DEBUG = os.environ.get("ASR_ARENA_DEBUG", "0") == "1"
 _ARENA = _Arena()
 _LINEAR_ARENA = os.environ.get("ASR_LINEAR_ARENA", "1") != "0"      # measurement: the outputs of ops.linear from the arena
 
@@ -226,7 +240,8 @@ def _lstm_workspace(rows, nbatch, H, ndir, dev, with_bwd):
     call's actual shape out of them."""
     f32 = dict(device=dev, dtype=torch.float32)
     # (zeros, and one row more than asked for: the packed-row dW_hh product reads ONE row behind the matrix on each side -
-    # against a zero padding row of the other operand - and that row must hold finite numbers, stale or not)
+    # against a zero padding row of the other operand - and that row must hold finite numbers: _LstmLayer.backward zeroes it
+    # when a longer batch has used the workspace before)
     alloc = torch.zeros if with_bwd else torch.empty
     ws = dict(gates_buf=alloc(rows + 1, ndir, 4 * H, **f32), y_buf=alloc(rows + 1, ndir * H, **f32),
               c_buf=torch.empty(rows, ndir * H, **f32))
@@ -313,6 +328,7 @@ class _LstmLayer(torch.autograd.Function):
         else:
             lease, ws = None, _lstm_workspace(T * B, nbatch, H, ndir, dev, False)
         _lstm_views(ws, T, B, H, ndir)
+        ws["rows_written"] = max(ws.get("rows_written", 0), T * B)      # rows of gates_buf / y_buf that may hold stale values
         ws["lens"] = lens                      # int32 device tensor, kept for the backward (no copy)
         hb.gemm(x2, w_ih, trans_b=True, bias=bias, out=ws["gates"].view(T * B, ndir * 4 * H))
         hb.lstm_seq_fwd(ws["gates"], w_hh, ws["lens"], ws["y"], ws["c"], use_graphs=pooled, rows=rows)
@@ -359,6 +375,11 @@ class _LstmLayer(torch.autograd.Function):
             # is (row R of dG, the last row of y) resp. (the last row of dG, row R of y): the last row of the matrix is a
             # padding row - zero in both - and row R exists in the workspace and holds finite numbers (_lstm_workspace)
             kk = T * B if ctx.rows is not None else (T - 1) * B
+            if ctx.rows is not None and ws.get("rows_written", 0) > T * B:
+                # the workspace is shared by capacity: a LONGER batch left its own values in row R - finite ones normally,
+                # but NaN when that batch's launch aborted (the kernels poison their outputs), and 0 * NaN is NaN
+                ws["gates_buf"][T * B].zero_()
+                ws["y_buf"][T * B].zero_()
             hb.gemm_batched(dG, y, ws["dw_hh"], True, False, 4 * H, H, kk, ldg, ldy, H, ndir,
                             4 * H - B * ldg, B * ldy + H, 4 * H * H, accumulate=True, a_off=B * ldg, b_off=0)
         # the gradients stay gate-interleaved (_LstmPack.backward converts every layer's in one launch); what lives in the

@@ -453,8 +453,9 @@ class FlatBuffers(object):
         """Move the gradients autograd produced into the flat buffer and re-attach .grad to its views.
         sumsq (a zeroed 1-element device tensor, one-process steps): the sum of squares of ALL gradients is added to it on the
         way (asr_gather_sumsq_f32: the gather and the norm of clip_grad_norm_ in one pass); returns True if it was - False
-        (the caller takes the norm over the flat buffer) when a gradient is missing, already in place, not contiguous, or
-        the buffers are not on a GPU."""
+        (the caller takes the norm over the flat buffer) when a gradient is already in place or not contiguous, when there is
+        nothing to gather, or when the buffers are not on a GPU.  A MISSING gradient does not prevent the fused norm: its slice
+        of the flat buffer is zeroed first and adds nothing to the sum."""
         dst, src, offs, missing, in_place = [], [], [], False, False
         for i, p in enumerate(self.params):
             v = self._view(i)

@@ -499,9 +499,11 @@ class Solver(object):
 
     def _recover(self):
         """The oldest outstanding step found the abort latch set: neither its update nor that of any step enqueued behind it
-        was applied (the latch is sticky and the Adam kernel checks it on the device).  Leave the persistent kernels for
-        good, take the optimisers' step counts back and run those steps again, in order, from the numpy stream the first
-        of them started with."""
+        was applied (the latch is sticky and the Adam kernel checks it on the device).  Leave the persistent kernels (until
+        the probation of hip_backend.persistent_step_tick ends), take the optimisers' step counts back and run those steps
+        again, in order, each from the numpy stream it started with and in an arena scope of its own (this may run at the end
+        of the step that found the abort, inside ITS scope: that step is fully enqueued by then and hands back scalars only,
+        so its slices may be zeroed - ops._Arena, LIFETIME)."""
         torch.cuda.synchronize()
         redo, self._pending = self._pending, []
         dev = redo[0]["opt"].buf.flat_g.device
@@ -516,15 +518,16 @@ class Solver(object):
             # this file - the input noise has a stream of its own, feed.DeviceFeed - but a caller may make some) are not
             # part of a step and must not shift the teacher-forcing draws of the repeats
             np.random.set_state(rec["rng"])
-            loss, scalars = rec["make_local"]()
-            rec["opt"].zero_grad()
-            loss.backward()
-            both = torch.stack([v.detach().reshape(()).float() for v in scalars[:rec["n"]]] +
-                               [hb.persist_abort_flag(dev)[0].float()]).tolist()
-            if both[-1] != 0.0:
-                raise RuntimeError("the abort latch is set (code %d) after a step on the per-step kernels"
-                                   % hb.persist_abort_code(dev))
-            rec["opt"].step()
+            with ops.step_arena(dev):
+                loss, scalars = rec["make_local"]()
+                rec["opt"].zero_grad()
+                loss.backward()
+                both = torch.stack([v.detach().reshape(()).float() for v in scalars[:rec["n"]]] +
+                                   [hb.persist_abort_flag(dev)[0].float()]).tolist()
+                if both[-1] != 0.0:
+                    raise RuntimeError("the abort latch is set (code %d) after a step on the per-step kernels"
+                                       % hb.persist_abort_code(dev))
+                rec["opt"].step()
             rec["values"] = both[:rec["n"]]
             rec["make_local"] = rec["opt"] = None
         np.random.set_state(resume)                      # a step draws the same number of values whatever its outputs were

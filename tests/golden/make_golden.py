@@ -396,6 +396,222 @@ def gen_tiny_opt():
     print("tiny_opt: %d arrays, %d state entries" % (len(out), len(sd["state"])))
 
 
+def _tensor_norms(module):
+    return {n: float(np.sqrt((npy(v).astype(np.float64) ** 2).sum())) for n, v in module.state_dict().items()}
+
+
+def _solver_run(over, stages):
+    """Drive the reference's own Solver (solver.py:13-565; main.py cannot be used, F10) over synth.SOLVER_RUN and record what
+    its loops produce.  The methods are wrapped from outside to note their return values; nothing of them is restated."""
+    import contextlib
+    import io
+    import tempfile
+    import time
+    import yaml
+    import solver as ref_solver
+    run = synth.SOLVER_RUN
+    with open("/root/reference/config.yaml") as f:
+        base = yaml.safe_load(f)
+    rec = dict(sup=[], judge=[], ssl_steps=[], ssl_summaries=[])
+    with tempfile.TemporaryDirectory() as root:
+        synth.write_solver_run_corpus(root)
+        cfg = synth.solver_run_config(base, root, **over)
+        cwd = os.getcwd()
+        os.chdir(root)                                   # Solver.test writes {test_set}.txt into the working directory
+        try:
+            torch.manual_seed(0)
+            np.random.seed(run["numpy_seed"])            # the reference seeds nothing (F7): the caller does
+            with contextlib.redirect_stdout(io.StringIO()):
+                s = ref_solver.Solver(cfg)
+            mcfg, jcfg = synth.solver_run_model_cfg(cfg)
+            load_sd(s.model, synth.e2e_weights(mcfg, run["model_wseed"]))
+            load_sd(s.judge, synth.lm_weights(jcfg, run["judge_wseed"]))
+            rec.update(proportion=float(s.proportion), labeldist=[float(v) for v in s.labeldist],
+                       unlab_labeldist=[float(v) for v in s.unlab_labeldist], steps_per_epoch=len(s.train_lab_loader),
+                       judge_steps_per_epoch=len(s.train_unlab_y_loader), dev_batches=len(s.dev_loader))
+            t0 = time.time()
+            cur = {}
+            real = dict(epoch=s.sup_train_one_epoch, val=s.validation, lmval=s.lm_validation,
+                        jit=s.judge_train_one_iteration, git=s.gen_train_one_iteration)
+
+            def epoch(e, tf_rate):
+                cur.update(epoch=int(e), tf_rate=float(tf_rate))
+                cur["train_loss"] = float(real["epoch"](e, tf_rate))
+                return cur["train_loss"]
+
+            def val():
+                out = real["val"]()
+                item = dict(cur, val_loss=float(out[0]), cer=float(out[1]), hyps=list(out[2]), refs=list(out[3]))
+                (rec["ssl_summaries"] if cur.get("stage") == "ssl" else rec["sup"]).append(item)
+                sys.stderr.write("  %s val_loss %.4f CER %.4f (%.0f s)\n" % (cur.get("stage", "sup"), out[0], out[1], time.time() - t0))
+                return out
+
+            def lmval():
+                out = real["lmval"]()
+                rec["judge"].append(dict(val_loss=float(out[0]), losses=cur.pop("jlosses", []), probs=cur.pop("jprobs", [])))
+                return out
+
+            def jit(ys):
+                meta = real["jit"](ys)
+                cur.setdefault("jlosses", []).append(float(meta["loss"]))
+                cur.setdefault("jprobs", []).append(float(meta["avg_prob"]))
+                return meta
+
+            def git(*a):
+                meta = real["git"](*a)
+                rec["ssl_steps"].append({k: float(v) for k, v in meta.items()})
+                return meta
+
+            s.sup_train_one_epoch, s.validation, s.lm_validation = epoch, val, lmval
+            s.judge_train_one_iteration, s.gen_train_one_iteration = jit, git
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(sys.stderr):
+                import warnings
+                warnings.simplefilter("ignore")
+                _, best_cer = s.sup_pretrain()
+                rec["sup_best_cer"] = float(best_cer)
+                rec["sup_final_norms"] = _tensor_norms(s.model)
+                if "judge" in stages:
+                    s.judge_pretrain()
+                    rec["judge_final_norms"] = _tensor_norms(s.judge)
+                if "ssl" in stages:
+                    cur.clear()
+                    cur["stage"] = "ssl"
+                    s.ssl_train()
+                    rec["ssl_final_norms"] = _tensor_norms(s.model)
+                if "test" in stages:
+                    rec["test_cer"] = float(s.test(state_dict=s.model.state_dict()))
+                    with open(cfg["test_set"] + ".txt") as f:
+                        rec["test_hyps"] = f.read().splitlines()
+        finally:
+            os.chdir(cwd)
+    for item in rec["sup"] + rec["ssl_summaries"]:
+        item.pop("stage", None)
+    rec["seconds"] = round(time.time() - t0, 1)
+    return rec
+
+
+def _spread(primary, others, key):
+    """Per entry of `key` (the epochs / summaries): what the reference's OWN runs at other thread counts made of it."""
+    out = []
+    for i, item in enumerate(primary[key]):
+        alt = [o[key][i] for o in others]
+        out.append(dict(cer=[a["cer"] for a in alt], val_loss=[a["val_loss"] for a in alt],
+                        train_loss=[a.get("train_loss") for a in alt],
+                        same_hyps=[sum(h1 == h2 for h1, h2 in zip(item["hyps"], a["hyps"])) for a in alt]))
+    return out
+
+
+def gen_solver_run():
+    """The reference's training LOOPS, held by the reference: Solver.sup_pretrain (tf-rate schedule, per-epoch validation ->
+    CER, best-CER checkpointing: solver.py:395-458, 360-393, 212-242), judge_pretrain across its learning-rate milestone
+    (303-358), ssl_train with two summary periods (497-565, 460-495) and test (244-286), on the learnable corpus of
+    synth.SOLVER_RUN.  Stored per epoch / summary: train loss, dev loss, CER, every hypothesis and reference sentence; per
+    judge epoch the step losses and the validation loss; per semi-supervised iteration the three losses; tensor norms of
+    the weights each stage ends with.
+
+    A training run is a chaotic system and the reference is its own witness: the SAME run at 4, 2 and 1 host threads (other
+    summation orders inside torch's CPU kernels, nothing else) leaves the primary's trajectory after about 100 steps.  The
+    fixture therefore carries, per epoch, what those runs produced (`spread`): where they agree a port must agree too,
+    where they differ the reference's own spread is the resolution at which any implementation can be compared.
+
+    `ssl_early`: ssl_train behind ONE supervised epoch (the runs still agree there), 30 iterations with summaries every 10 - the
+    semi-supervised loop inside the window in which the reference agrees with itself.  (Straight from the synthetic weights
+    the reference's own loop divides by zero: every hypothesis token is <EOS>, sum(mask) = 0, solver.py:477-478.)
+    The last run repeats the supervised stage with dropout 0.3."""
+    EARLY = dict(epochs=1, ssl_iterations=30, summary_steps=10)
+    threads = [int(t) for t in os.environ.get("GOLDEN_SPREAD_THREADS", "4,2,1").split(",") if t]
+    primary_threads = torch.get_num_threads()
+    rec = _solver_run({}, ("judge", "ssl", "test"))
+    cold = _solver_run(EARLY, ("ssl",))
+    others, cold_others = [], []
+    for t in threads:
+        torch.set_num_threads(t)
+        others.append(_solver_run({}, ("judge", "ssl")))
+        cold_others.append(_solver_run(EARLY, ("ssl",)))
+    torch.set_num_threads(primary_threads)
+    rec["threads"] = dict(primary=primary_threads, spread=threads)
+    rec["spread"] = dict(sup=_spread(rec, others, "sup"), ssl_summaries=_spread(rec, others, "ssl_summaries"),
+                         judge_val_loss=[[o["judge"][i]["val_loss"] for o in others] for i in range(len(rec["judge"]))],
+                         judge_train_loss=[[float(np.mean(o["judge"][i]["losses"])) for o in others] for i in range(len(rec["judge"]))],
+                         sup_best_cer=[o["sup_best_cer"] for o in others],
+                         sup_final_norms=[o["sup_final_norms"] for o in others],
+                         judge_final_norms=[o["judge_final_norms"] for o in others],
+                         ssl_final_norms=[o["ssl_final_norms"] for o in others])
+    rec["ssl_early"] = dict(sup=cold["sup"], ssl_steps=cold["ssl_steps"], ssl_summaries=cold["ssl_summaries"], ssl_final_norms=cold["ssl_final_norms"],
+                           spread=dict(ssl_summaries=_spread(cold, cold_others, "ssl_summaries"),
+                                       ssl_final_norms=[o["ssl_final_norms"] for o in cold_others],
+                                       ssl_steps=[[o["ssl_steps"][i]["loss"] for o in cold_others]
+                                                  for i in range(len(cold["ssl_steps"]))]))
+    with open(os.path.join(HERE, "solver_run.json"), "w") as f:
+        json.dump(rec, f, indent=0)
+    print("solver_run: %d epochs, CER %s, best %.4f, ssl CER %s, test CER %.4f (%.0f s)"
+          % (len(rec["sup"]), " ".join("%.3f" % e["cer"] for e in rec["sup"]), rec["sup_best_cer"],
+             " ".join("%.4f" % e["cer"] for e in rec["ssl_summaries"]), rec["test_cer"], rec["seconds"]))
+    for i, (e, sp) in enumerate(zip(rec["sup"], rec["spread"]["sup"])):
+        print("  epoch %2d CER %.4f | other thread counts %s | same hypotheses %s of %d"
+              % (i, e["cer"], " ".join("%.4f" % c for c in sp["cer"]), sp["same_hyps"], len(e["hyps"])))
+    for i, (e, sp) in enumerate(zip(cold["ssl_summaries"], rec["ssl_early"]["spread"]["ssl_summaries"])):
+        print("  early ssl summary %d CER %.4f | %s | same hypotheses %s" % (i, e["cer"], " ".join("%.4f" % c for c in sp["cer"]),
+                                                                          sp["same_hyps"]))
+    drop = _solver_run(synth.SOLVER_RUN_DROPOUT, ())
+    keep = dict(sup=[{k: e[k] for k in ("epoch", "tf_rate", "train_loss", "val_loss", "cer")} for e in drop["sup"]],
+                sup_best_cer=drop["sup_best_cer"])
+    with open(os.path.join(HERE, "solver_run_dropout.json"), "w") as f:
+        json.dump(keep, f, indent=0)
+    print("solver_run_dropout: CER %s" % " ".join("%.3f" % e["cer"] for e in drop["sup"]))
+
+
+def gen_solver_loops():
+    """The CONTROL FLOW of the reference's loops with the compute scripted (a stub per step / validation that returns given
+    numbers): which teacher-forcing rate each epoch gets (solver.py:414-418), when the best model is saved and under which
+    names (446-456: strict <, from 200), the judge's learning rate per epoch (MultiStepLR stepped at the epoch's start,
+    308-315) and its saves (347-357: from 100), the semi-supervised loop's learning rate, summary steps and saves
+    (519-563: from 2).  Deterministic, so the product's loops are held to it exactly (tests/test_solver_loops_cpu.py)."""
+    import contextlib
+    import io
+    import tempfile
+    import warnings
+    import yaml
+    import solver as ref_solver
+    script = synth.SOLVER_LOOPS
+    with open("/root/reference/config.yaml") as f:
+        base = yaml.safe_load(f)
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        synth.write_solver_run_corpus(root, sizes=script["corpus"])
+        cfg = synth.solver_run_config(base, root, **script["config"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            warnings.simplefilter("ignore")
+            s = ref_solver.Solver(cfg)
+            log = []
+            s.save_model = lambda path: log.append(["save_model", os.path.relpath(path, root)])
+            s.save_judge = lambda path: log.append(["save_judge", os.path.relpath(path, root)])
+            vals = iter(script["sup_cers"])
+            s.sup_train_one_epoch = lambda e, tf: (log.append(["epoch", int(e), float(tf)]), 1.0)[1]
+            s.validation = lambda: (log.append(["validation"]), (0.5, next(vals), ["a"], ["a"]))[1]
+            _, best = s.sup_pretrain()
+            out["sup"] = dict(log=list(log), best_cer=float(best))
+            del log[:]
+            jvals = iter(script["judge_val_losses"])
+            s.judge_train_one_iteration = lambda ys: (log.append(["step", float(s.dis_opt.param_groups[0]["lr"])]),
+                                                      dict(loss=1.0, avg_prob=0.1))[1]
+            s.lm_validation = lambda: (log.append(["lm_validation"]), (next(jvals), ["a"]))[1]
+            s.judge_pretrain()
+            out["judge"] = dict(log=list(log), steps_per_epoch=len(s.train_unlab_y_loader))
+            del log[:]
+            svals = iter(script["ssl_cers"])
+            s.validation = lambda: (log.append(["validation"]), (0.5, next(svals), ["a"], ["a"]))[1]
+            s.ssl_train_one_iteration = lambda iteration: (log.append(["iteration", int(iteration),
+                                                                        float(s.gen_opt.param_groups[0]["lr"])]),
+                                                           dict(sup_loss=1.0, unsup_loss=0.5, loss=1.5))[1]
+            s.ssl_train()
+            out["ssl"] = dict(log=list(log))
+    with open(os.path.join(HERE, "solver_loops.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("solver_loops: sup %d events, judge %d, ssl %d" % (len(out["sup"]["log"]), len(out["judge"]["log"]),
+                                                              len(out["ssl"]["log"])))
+
+
 def gen_text():
     """utils.py:192-235 helpers on a toy vocabulary."""
     vocab = {"<PAD>": 0, "<BOS>": 1, "<EOS>": 2, "a": 3, "b": 4, "c": 5, "<space>": 6, "<NOISE>": 7,
@@ -418,6 +634,7 @@ if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "4")))
     jobs = dict(tiny_e2e=gen_tiny_e2e, tiny_lm=gen_tiny_lm, tiny_ssl=gen_tiny_ssl, cfg1=gen_cfg1, text=gen_text,
                 tiny_opt=gen_tiny_opt, cfg2=lambda: gen_big("cfg2", synth.CFG2_SHAPE),
-                cfg5=lambda: gen_big("cfg5", synth.CFG5_SHAPE), big_ssl=gen_big_ssl)
+                cfg5=lambda: gen_big("cfg5", synth.CFG5_SHAPE), big_ssl=gen_big_ssl,
+                solver_run=gen_solver_run, solver_loops=gen_solver_loops)
     for name in (sys.argv[1:] or list(jobs)):          # no arguments: everything (cfg2 / cfg5 take minutes)
         jobs[name]()

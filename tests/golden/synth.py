@@ -143,3 +143,107 @@ def ragged_batch(n_utt, t_max, input_dim, V, seed):
         ys.append(rs.randint(3, V, size=(max(2, int(0.125 * l)),)).astype(np.int64))
     ys[0] = rs.randint(3, V, size=(int(0.125 * t_max),)).astype(np.int64)
     return xs, lens, ys
+
+
+# ---- a corpus a model can learn (make_golden.py gen_solver_run; tests regenerate the identical pickles from the seeds)
+WSJ_SYMBOLS = (["<PAD>", "<BOS>", "<EOS>"] + [chr(ord("A") + i) for i in range(26)] + ["'", ".", "-", "<space>", "<NOISE>"])
+NON_LANG_SYMS = ["<NOISE>", "<PAD>", "<BOS>", "<EOS>"]
+
+
+def wsj_vocab():
+    """The character inventory of the reference's WSJ recipe (preprocess.py:25-36,73 -> V = 34), ids in its order."""
+    return {s: i for i, s in enumerate(WSJ_SYMBOLS)}
+
+
+def learnable_corpus(n, seed, input_dim=80, words=(2, 4), word_len=(1, 4), hold=(6, 10), noise=0.3, proto_seed=4242,
+                     p_noise_sym=0.05):
+    """{utt: {'feature': f32[T, D], 'token_ids': list}} (dataset.py:46-80's format) in which every token id owns a fixed
+    prototype vector (N(0,1), drawn once from `proto_seed`: shared by train / dev / eval) that its frames repeat for
+    `hold` frames + N(0, noise) - a monotonic, learnable alignment task.  Transcripts are words of letters joined by
+    <space>, now and then a <NOISE> symbol (which CER scoring strips, preprocess.py:81)."""
+    vocab = wsj_vocab()
+    proto = np.random.RandomState(proto_seed).normal(0, 1, size=(len(vocab), input_dim)).astype(np.float32)
+    rs = np.random.RandomState(seed)
+    letters = list(range(3, 3 + 26 + 3))
+    out = {}
+    for i in range(n):
+        toks = []
+        for w in range(int(rs.randint(words[0], words[1] + 1))):
+            if w:
+                toks.append(vocab["<space>"])
+            if rs.uniform() < p_noise_sym:
+                toks += [vocab["<NOISE>"], vocab["<space>"]]
+            toks += [int(letters[j]) for j in rs.randint(0, len(letters), size=int(rs.randint(word_len[0], word_len[1] + 1)))]
+        frames = []
+        for t in toks:
+            d = int(rs.randint(hold[0], hold[1] + 1))
+            frames.append(proto[t][None, :] + rs.normal(0, noise, size=(d, input_dim)).astype(np.float32))
+        out["utt%05d" % i] = dict(feature=np.concatenate(frames, 0).astype(np.float32), token_ids=[int(t) for t in toks])
+    return out
+
+
+# The run both Solvers make over that corpus (make_golden.py gen_solver_run drives the reference's; tests/test_solver_run_gpu.py
+# the product's): cfg-1's model (BASELINE configs[0]: 1 x 128 BiLSTM encoder, 320-unit decoder), no dropout (the two sides
+# have different dropout generators), no shuffling (the reference never seeds its sampler), a teacher-forcing rate that
+# decays, so that the scheduled-sampling draws (model.py:328) and the rule for them (solver.py:414-418) are part of what
+# is pinned; then judge pre-training across its learning-rate milestone and semi-supervised iterations with an auxiliary
+# weight large enough to move the model.
+SOLVER_RUN = dict(
+    corpus=dict(train=(400, 101), dev=(224, 102), eval=(16, 103)),           # (utterances, seed)
+    numpy_seed=7, model_wseed=311, judge_wseed=312,
+    config=dict(labeled_set="train", unlabeled_speech_set="train", unlabeled_text_set="train", dev_set="dev", test_set="eval",
+                min_feature_length=4, max_dec_timesteps=30, batch_size=8, shuffle=False, input_dim=80, enc_hidden_dim=128,
+                enc_n_layers=1, subsample=[2], dec_hidden_dim=320, att_dim=320, att_odim=320, embedding_dim=128,
+                dropout_rate=0.0, dis_dropout_rate=0.0, dis_hidden_dim=128, dis_embedding_dim=64, dis_layers=2,
+                epochs=12, learning_rate=0.002, init_tf_rate=1.0, tf_rate_lowerbound=0.8, tf_decay_epochs=8,
+                judge_epochs=3, dis_change_learning_rate_epoch=2, d_learning_rate=0.002, lr_gamma=0.2,
+                ssl_iterations=40, summary_steps=20, g_learning_rate=0.0005, unsup_weight=0.2, smooth_embedding=True,
+                softmax_scaling=3, add_gaussian=False))
+# the same supervised run with the reference's default dropout: the two sides draw different masks, so this one is held to a band
+SOLVER_RUN_DROPOUT = dict(dropout_rate=0.3, epochs=12)
+
+
+def write_solver_run_corpus(root, sizes=None):
+    """Pickles + vocabulary files of SOLVER_RUN under `root`, in the reference's on-disk format."""
+    import os
+    import pickle
+    for name, (n, seed) in (sizes or SOLVER_RUN["corpus"]).items():
+        with open(os.path.join(root, name + ".pkl"), "wb") as f:
+            pickle.dump(learnable_corpus(n, seed), f)
+    with open(os.path.join(root, "vocab_dict.pkl"), "wb") as f:
+        pickle.dump(wsj_vocab(), f)
+    with open(os.path.join(root, "non_lang_syms.pkl"), "wb") as f:
+        pickle.dump(list(NON_LANG_SYMS), f)
+
+
+def solver_run_config(base, root, **over):
+    """`base` (a config.yaml's 62 keys) with SOLVER_RUN's values and the paths under `root`."""
+    import os
+    cfg = dict(base)
+    cfg.update(logdir=os.path.join(root, "log"), model_dir=root, model_name="m", load_model_path=os.path.join(root, "m"),
+               load_judge_path=os.path.join(root, "m"), dataset_root_dir=root, vocab_path=os.path.join(root, "vocab_dict.pkl"),
+               non_lang_syms_path=os.path.join(root, "non_lang_syms.pkl"))
+    cfg.update(SOLVER_RUN["config"])
+    cfg.update(over)
+    return cfg
+
+
+def solver_run_model_cfg(cfg):
+    """The constructor arguments e2e_weights / lm_weights need, from a Solver config."""
+    V = len(WSJ_SYMBOLS)
+    model = {k: cfg[k] for k in ("input_dim", "enc_hidden_dim", "enc_n_layers", "subsample", "dec_hidden_dim", "att_dim",
+                                 "conv_channels", "conv_kernel_size", "att_odim", "embedding_dim")}
+    model["output_dim"] = V
+    judge = dict(output_dim=V, embedding_dim=cfg["dis_embedding_dim"], hidden_dim=cfg["dis_hidden_dim"], n_layers=cfg["dis_layers"])
+    return model, judge
+
+
+# scripted control flow (make_golden.py gen_solver_loops): the CERs / validation losses the stubbed validations return, ties and
+# values above the loops' initial bests included
+SOLVER_LOOPS = dict(
+    corpus=dict(train=(20, 201), dev=(6, 202), eval=(2, 203)),
+    config=dict(batch_size=8, epochs=7, init_tf_rate=1.0, tf_rate_lowerbound=0.6, tf_decay_epochs=4, judge_epochs=5,
+                dis_change_learning_rate_epoch=3, d_learning_rate=0.002, lr_gamma=0.2, ssl_iterations=7, summary_steps=2,
+                g_learning_rate=0.0003, learning_rate=0.002),
+    sup_cers=[250.0, 0.9, 0.5, 0.5, 0.7, 0.3, 0.31], judge_val_losses=[150.0, 90.0, 95.0, 80.0, 80.0],
+    ssl_cers=[2.5, 1.9, 1.9, 1.2])

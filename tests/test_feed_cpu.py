@@ -89,8 +89,8 @@ def test_rank_local_batch_is_the_shard_of_the_global_collate(world):
 
 
 def test_noise_is_drawn_for_the_global_batch():
-    """Input noise (solver.py:370-373): identically seeded ranks add the rows of ONE global draw, so the union of the
-    rank-local batches is the one-process batch; without noise_std nothing is drawn from the numpy stream."""
+    """Input noise (solver.py:370-373): a generator per global row, so identically seeded ranks draw only their own rows and
+    the union of the rank-local batches is the one-process batch; without noise_std nothing is drawn from the numpy stream."""
     def batches(rank, world):
         np.random.seed(7)
         return [b.xs for b in DeviceFeed(_loaders()[1], "cpu", rank=rank, world=world, noise_std=0.3, thread=True)]

@@ -888,6 +888,28 @@ def test_lstm_layer_packed_rows_persistent_kernels(ndir, B, T, H, sub, lens, ari
         _packed_lstm_case(ndir, B, T, H, sub, lens, persistent=True)
 
 
+@pytest.mark.parametrize("persistent,H", [(False, 16), (True, 512)])
+def test_packed_rows_after_a_longer_batch_left_nan_in_the_shared_workspace(persistent, H):
+    """The pooled LSTM workspace is shared by row CAPACITY, and the packed-row dW_hh product reads one row behind the matrix
+    (against a zero padding row of the other operand).  A longer batch whose launch aborted leaves NaN there - the kernels
+    poison their outputs on purpose - and 0 * NaN is NaN: _LstmLayer.backward zeroes that row when a longer batch has used
+    the workspace.  Here: a long batch, its workspace filled with NaN behind its back, then a shorter batch of the same
+    capacity class, checked against the oracle."""
+    _gpu()
+    import ops
+    B = 8 if persistent else 3
+    _packed_lstm_case(2, B, 9, H, 2, [9] * B, persistent=persistent)
+    pooled = [ws for key, lst in ops._POOL.free.items() if key[0] == "lstm" and key[4] == H for ws in lst]
+    assert pooled, "the long batch's workspace went back to the pool"
+    for ws in pooled:
+        assert ws["rows_written"] > 0
+        ws["gates_buf"].fill_(float("nan"))
+        ws["y_buf"].fill_(float("nan"))
+        ws["c_buf"].fill_(float("nan"))
+    _packed_lstm_case(2, B, 5, H, 2, [5] * (B - 1) + [2], persistent=persistent)
+    assert any(ws["rows_written"] > 0 for ws in pooled)
+
+
 def test_lstm_judge_width_packed_rows():
     """H = 640 (the judge LM's width) on packed rows: forward on the bf16 kernels, backward on its own exchanged-partials kernel."""
     _packed_lstm_case(1, 32, 11, 640, 1, None, persistent=True)
@@ -2055,4 +2077,31 @@ def test_greedy_decoding_with_a_large_vocabulary():
     net.zero_grad()
     (-lp.mean()).backward()
     for n, gr in _grads(net).items():
+        _close(gr, rg[n], atol=1e-6, what="grad " + n)
+
+
+def test_embedding_gradient_with_a_table_larger_than_lds():
+    """asr_embedding_grad_f32 folds its rows into an LDS table [V][E] and declines tables over 64 KB (ASR_E_SHAPE on the C side;
+    hip_backend.embedding_grad returns False before calling it): ops._DecoderSeq then takes index_add_.  V * E = 300 * 64
+    floats = 76.8 KB - teacher-forced gradients against the oracle, the embedding's among them."""
+    dev = _gpu()
+    cfg = dict(synth.TINY, output_dim=300, embedding_dim=64)
+    assert cfg["output_dim"] * cfg["embedding_dim"] * 4 > 65536
+    ld = synth.labeldist(300, 12)
+    w = synth.e2e_weights(cfg, 19)
+    xs, ilens, ys = synth.batch(8, 300, synth.TINY_ILENS, synth.TINY_YLENS, 13)
+    net = _product(cfg, w, ld, dev)
+    np.random.seed(3)
+    _, lp, _, _ = net(torch.from_numpy(xs).to(dev), ilens, [torch.from_numpy(y).to(dev) for y in ys])
+    sd = O.make_leaf_state(w)
+    np.random.seed(3)
+    _, rlp, _, _ = O.e2e_forward(sd, dict(cfg, labeldist=ld), torch.from_numpy(xs), ilens, [torch.from_numpy(y) for y in ys])
+    _close(lp, rlp, what="lp")
+    names = O.unique_param_names(sd)
+    rg = dict(zip(names, torch.autograd.grad(-rlp.mean(), [sd[n] for n in names])))
+    net.zero_grad()
+    (-lp.mean()).backward()
+    got = _grads(net)
+    assert float(got["decoder.embedding.weight"].abs().max()) > 0
+    for n, gr in got.items():
         _close(gr, rg[n], atol=1e-6, what="grad " + n)
