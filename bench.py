@@ -616,7 +616,7 @@ def main():
              % (rank, dist.get_world_size(), torch.cuda.current_device(), torch.cuda.get_device_name(dev), dist.get_backend(),
                 "one all-reduce of the flat buffer after the backward pass",
                 "host reads a step's record one step late (parallel.DpPipeline)" if int(solver.config.get("pipeline_steps", 1)) > 0
-                else "host read between all-reduce and update (parallel.dp_step)"))
+                else "the same path, every record read at once (pipeline_steps: 0)"))
     # Rehearsal of the product's abort handling (Solver._recover in one process, parallel.DpPipeline's coordinated
     # repeat under data parallelism): ASR_BENCH_INJECT_ABORT=warmup|timed sets the sticky latch from the host once, as an
     # aborting persistent kernel would (on the last rank only).

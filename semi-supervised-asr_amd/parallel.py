@@ -199,48 +199,48 @@ def judge_local_loss(judge_fwd, masked_sum, ys, rank, world_size):
 
 
 def dp_step(make_loss, opt, n_aux, latch, leave_fast_path):
-    """One data-parallel optimiser step with a coordinated fallback (Solver._dp_step; no kernel code in here, so the gloo
-    tests run it on CPU).  make_loss() -> (local loss or None for an empty shard, [scalars]); opt: zero_grad() / buf
-    (FlatBuffers) / reduce() / apply().  latch() -> this rank's abort latch (0 = clean) as a float or 0-d tensor; it goes
-    into the last aux slot of the step's ONE all-reduce, so every rank reads the same sum between reduce() and apply().
-    If the sum is not zero nothing is applied and EVERY rank restores the numpy stream it had before the step (the
-    teacher-forcing draws), calls leave_fast_path(n_ranks_aborted) - which must also clear the latch - and repeats the
-    step; the collectives stay matched because the decision is identical on all ranks.  A second failure raises.
-    Returns the first n_aux scalars summed over the ranks."""
+    """One data-parallel optimiser step, resolved at once: DpPipeline.step + resolve - the same code path as the pipelined
+    default, with the host read right behind the step (config `pipeline_steps: 0`, and what the tests of the coordinated
+    fallback call).  Returns the first n_aux scalars summed over the ranks; raises if the repeat after an abort fails too."""
+    pipe = DpPipeline(1, latch, leave_fast_path)
+    rec = pipe.step(make_loss, opt, n_aux)
+    pipe.resolve(rec)
+    return rec["values"]
+
+
+def _repeat_step(make_loss, opt, n_aux, latch):
+    """A step that DpPipeline._recover runs again off the fast path: the host reads the reduced latch BETWEEN the all-reduce
+    and the update (the decision is identical on every rank, so the collectives stay matched) and raises if it is still set -
+    nothing was applied then."""
     flag_slot = opt.buf.NAUX - 1
-    assert n_aux <= flag_slot
-    rng = np.random.get_state()
-    for attempt in (0, 1):
-        loss, scalars = make_loss()
-        opt.zero_grad()
-        if loss is not None:
-            backward(loss)
-        aux = [v if v is not None else 0.0 for v in scalars[:n_aux]] + [0.0] * (flag_slot - n_aux)
-        aux.append(latch())
-        opt.buf.set_aux(aux)
-        opt.reduce()
-        values = opt.buf.aux.tolist()                   # the step's one host sync, between the all-reduce and the update
-        if values[flag_slot] == 0.0:
-            opt.apply()
-            return values[:n_aux]
-        if attempt == 1:
-            raise RuntimeError("the abort latch is still set on %d rank(s) after a data-parallel step was repeated off the "
-                               "persistent kernels; nothing was applied" % int(values[flag_slot]))
-        np.random.set_state(rng)
-        leave_fast_path(int(values[flag_slot]))
+    loss, scalars = make_loss()
+    opt.zero_grad()
+    if loss is not None:
+        backward(loss)
+    aux = [v if v is not None else 0.0 for v in scalars[:n_aux]] + [0.0] * (flag_slot - n_aux)
+    aux.append(latch())
+    opt.buf.set_aux(aux)
+    opt.reduce()
+    values = opt.buf.aux.tolist()
+    if values[flag_slot] != 0.0:
+        raise RuntimeError("the abort latch is still set on %d rank(s) after a data-parallel step was repeated off the "
+                           "persistent kernels; nothing was applied" % int(values[flag_slot]))
+    opt.apply()
+    return values[:n_aux]
 
 
 class DpPipeline(object):
-    """Data-parallel optimiser steps with NO host wait inside the step (Solver._step under data parallelism; no kernel
-    code in here, so the gloo tests run it on CPU).  dp_step reads the reduced abort latch on the host between the
-    all-reduce and the update - a GPU that idles for the length of a host round trip plus the launch of the update, every
-    step.  Here the update is enqueued behind the all-reduce at once, PREDICATED ON THE DEVICE on the reduced latch (the
+    """THE data-parallel optimiser step (Solver._step under data parallelism; no kernel code in here, so the gloo tests run it
+    on CPU), with NO host wait inside the step: reading the reduced abort latch on the host between the all-reduce and the
+    update would idle the GPU for a host round trip plus the launch of the update, every step.
+    make_loss() -> (local loss or None for an empty shard, [scalars]); opt: zero_grad() / buf (FlatBuffers) / reduce() /
+    apply(skip_if) / unapply().  The update is enqueued behind the all-reduce at once, PREDICATED ON THE DEVICE on the reduced latch (the
     last aux slot of the flat buffer: opt.apply(skip_if=...); the sum is the same word on every rank, so all ranks skip or
     none does), the reduced aux slots travel to the host asynchronously (stage), and the host looks at step i while step
     i + 1 .. i + depth run.  A rank's latch is sticky until leave_fast_path() clears it, so every step enqueued behind an
     aborted one carries a non-zero sum too and was skipped as well; the first record found set makes EVERY rank (the
     values are identical) take the step counts back, restore the numpy stream that step started with, leave the fast
-    path and run the skipped steps again through dp_step, in order.  Every rank has to resolve records at the same points
+    path and run the skipped steps again (_repeat_step: host read before the update), in order.  Every rank has to resolve records at the same points
     of its program (the Solver's loops do: they run the same code on all ranks) - the replay is a sequence of collectives.
       latch()              -> this rank's abort latch (0 = clean), float or 0-d tensor
       leave_fast_path(n)   -> switch to the fallback path AND clear the latch (n = ranks that reported an abort)
@@ -297,12 +297,9 @@ class DpPipeline(object):
         resume = np.random.get_state()
         self.leave(n_ranks)
 
-        def again(n):
-            raise RuntimeError("the abort latch is set on %d rank(s) after a data-parallel step off the fast path; nothing "
-                               "was applied" % n)
         for r in redo:
             np.random.set_state(r["rng"])                # every step again from the stream state it started with
-            r["values"] = dp_step(r["make_loss"], r["opt"], r["n"], self.latch, again)
+            r["values"] = _repeat_step(r["make_loss"], r["opt"], r["n"], self.latch)
             r["make_loss"] = r["opt"] = None
         np.random.set_state(resume)                      # draws per step do not depend on the poisoned values
 

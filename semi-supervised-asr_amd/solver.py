@@ -194,9 +194,8 @@ class Solver(object):
         # `dp_overlap` (not a reference key): issue the gradient all-reduce in buckets from inside the backward pass
         # (parallel.FlatBuffers.enable_overlap).  Off by default HERE: an RCCL kernel that is resident while a persistent
         # kernel is being placed could - if the two do not fit a CU together and a rank is late - hold that kernel's
-        # workgroups back until its bounded spins expire, and a data-parallel step cannot repair an abort locally
-        # (_dp_step raises).  bench.py turns it on and falls back by itself; turn it on here once a multi-GPU run has
-        # shown the latch stays clear.
+        # workgroups back until its bounded spins expire (every rank then repeats the step off the persistent kernels).
+        # bench.py measures it as a labelled sub-object; turn it on here once a multi-GPU run has shown the latch stays clear.
         overlap = bool(cfg.get("dp_overlap", False))
         # `persist_retry_steps` (not a reference key): train steps on the per-step kernels after an abort of the persistent
         # ones before they are tried again (hip_backend.PERSIST_RETRY_STEPS: 200, doubling per abort; 0: never)
@@ -317,28 +316,6 @@ class Solver(object):
         return cer
 
     # ------------------------------------------------------------------ judge (LM) pre-training
-    def _dp_step(self, make_loss, opt, n_aux):
-        """One data-parallel step: zero_grad -> backward of this rank's local loss -> ONE all-reduce of the flat buffer
-        (gradients + the per-rank partial scalars + this rank's abort latch in its aux slots) -> clip -> Adam.
-        make_loss() -> (local loss or None for an empty shard, [scalars]); returns the scalars summed over ranks = the
-        single-process values.
-        An aborted persistent kernel (NaN-poisoned outputs on ONE rank) cannot be repaired by that rank alone - its
-        repeat would be one collective the others do not take part in.  The abort latch therefore rides in the last aux
-        slot of the SAME all-reduce: every rank reads the same sum between reduce() and apply() (the step's one host
-        sync), and when it is not zero EVERY rank restores the numpy stream it had before the step (teacher-forcing
-        draws), switches to the per-step kernels and repeats the step - nothing of the poisoned attempt was applied, and
-        the collectives stay matched because the decision is identical everywhere.  A second failure raises."""
-        dev = opt.buf.flat_g.device
-
-        def latch():
-            return hb.persist_abort_flag(dev)[0].float() if dev.type == "cuda" else 0.0
-
-        def leave_persistent(n_ranks):
-            print("rank %d: persistent kernels aborted on %d rank(s) (this rank: %s, code %d): every rank repeats the step "
-                  "on the per-step kernels" % (self.rank, n_ranks, hb.persist_aborted(dev), hb.persist_abort_code(dev)))
-            hb.disable_persistent(dev)                  # also clears this rank's latch
-        return parallel.dp_step(make_loss, opt, n_aux, latch, leave_persistent)
-
     # Number of train steps whose host read may be outstanding when the next one is enqueued.  1 (default): the host looks
     # at step i's loss and abort latch while step i + 1 runs - no GPU idle time between steps.  0: the reference's order,
     # loss.item() inside every step (solver.py:379).  Config key `pipeline_steps` (not a reference key).
@@ -361,8 +338,8 @@ class Solver(object):
         non-finite loss without the latch is the model's own and is applied, as in the reference.
 
         Data parallel: the same, with the latch SUMMED OVER THE RANKS in the step's one all-reduce (last aux slot of the flat
-        buffer) as the device-side predicate - every rank skips or none does - and the coordinated repeat of _dp_step one
-        step late (parallel.DpPipeline).  Every rank resolves its StepScalars at the same points of the program (the loops
+        buffer) as the device-side predicate - every rank skips or none does - and the coordinated repeat one step late
+        (parallel.DpPipeline).  Every rank resolves its StepScalars at the same points of the program (the loops
         below run the same code on all ranks): a recovery is a sequence of collectives."""
         dev0 = opt.buf.flat_g.device
         if hb.persistent_step_tick() and self.rank == 0:     # the end of a probation after an abort (hb.PERSIST_RETRY_STEPS)
@@ -373,13 +350,12 @@ class Solver(object):
     def _step_inner(self, make_local, opt, n_scalars):
         depth = min(int(self.config.get("pipeline_steps", self.PIPELINE_STEPS)), self.PINNED_ROWS - 2)   # one landing row each
         if self.world > 1 or parallel.FORCE_DP:
-            if depth <= 0 or opt.buf.flat_g.device.type != "cuda":
-                out = self._dp_step(make_local, opt, n_scalars)        # the host reads between all-reduce and update
-            else:
-                rec = self._dp_pipeline(depth).step(make_local, opt, n_scalars)
-                out = [StepScalar(rec, i) for i in range(n_scalars)]
+            pipe = self._dp_pipeline(depth, opt.buf.flat_g.device)
+            rec = pipe.step(make_local, opt, n_scalars)
+            if depth <= 0:
+                pipe.resolve(rec)                        # `pipeline_steps: 0`: the same path, read at once
             self._report_paths()
-            return out
+            return [StepScalar(rec, i) for i in range(n_scalars)]
         rec = dict(resolve=self._resolve_through, opt=opt, make_local=make_local, n=n_scalars, rng=np.random.get_state(),
                    values=None, event=None, slot=None)
         loss, scalars = make_local()
@@ -425,10 +401,14 @@ class Solver(object):
             busy |= set((r["host"].data_ptr() - self._pinned.data_ptr()) // row for r in self._dp_pipe.pending)
         return next(i for i in range(self._pinned.shape[0]) if i not in busy)
 
-    def _dp_pipeline(self, depth):
-        """The data-parallel step without a host wait (parallel.DpPipeline): the reduced abort latch predicates the update on
-        the device, the reduced scalars land in pinned host memory behind an event; on an abort every rank leaves the
-        persistent kernels and repeats what was skipped (the decision of _dp_step, one step late)."""
+    def _dp_pipeline(self, depth, dev):
+        """The data-parallel step (parallel.DpPipeline, the only one): the abort latch rides in the last aux slot of the step's
+        ONE all-reduce, its sum predicates the update on the device - every rank skips or none does -, the reduced scalars
+        land in pinned host memory behind an event; when a record shows the latch set EVERY rank leaves the persistent
+        kernels (a rank that alone repeats a batch would be one collective the others do not take part in) and repeats what
+        was skipped, from the numpy streams those steps started with."""
+        if self._dp_pipe is None and dev.type != "cuda":           # (CPU tensors: tests of the host logic on gloo)
+            self._dp_pipe = parallel.DpPipeline(max(1, depth), lambda: 0.0, lambda n: None)
         if self._dp_pipe is None:
             def stage(aux):
                 host = self._pinned[self._free_slot(), :aux.numel()]

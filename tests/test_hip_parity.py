@@ -899,15 +899,19 @@ def test_packed_rows_after_a_longer_batch_left_nan_in_the_shared_workspace(persi
     import ops
     B = 8 if persistent else 3
     _packed_lstm_case(2, B, 9, H, 2, [9] * B, persistent=persistent)
-    pooled = [ws for key, lst in ops._POOL.free.items() if key[0] == "lstm" and key[4] == H for ws in lst]
+    keys = [key for key in ops._POOL.free if key[0] == "lstm" and key[3] == B and key[4] == H]
+    pooled = [ws for key in keys for ws in ops._POOL.free[key]]
     assert pooled, "the long batch's workspace went back to the pool"
-    for ws in pooled:
-        assert ws["rows_written"] > 0
-        ws["gates_buf"].fill_(float("nan"))
-        ws["y_buf"].fill_(float("nan"))
-        ws["c_buf"].fill_(float("nan"))
-    _packed_lstm_case(2, B, 5, H, 2, [5] * (B - 1) + [2], persistent=persistent)
-    assert any(ws["rows_written"] > 0 for ws in pooled)
+    try:
+        for ws in pooled:
+            assert ws["rows_written"] > 0
+            ws["gates_buf"][:ws["rows_written"] + 1].fill_(float("nan"))     # what a poisoned launch of that batch could have left
+            ws["y_buf"][:ws["rows_written"] + 1].fill_(float("nan"))
+            ws["c_buf"][:ws["rows_written"]].fill_(float("nan"))
+        _packed_lstm_case(2, B, 5, H, 2, [5] * (B - 1) + [2], persistent=persistent)
+    finally:
+        for key in keys:                 # (other tests lease by the same keys: they get fresh workspaces)
+            del ops._POOL.free[key]
 
 
 def test_lstm_judge_width_packed_rows():
