@@ -400,7 +400,20 @@ def _tensor_norms(module):
     return {n: float(np.sqrt((npy(v).astype(np.float64) ** 2).sum())) for n, v in module.state_dict().items()}
 
 
-def _solver_run(over, stages):
+def _ulp_perturbed(arrays, seed):
+    """Every weight moved by ONE unit in its last place, up or down (seeded): the smallest perturbation fp32 weights can have."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for k in sorted(arrays):
+        v = np.asarray(arrays[k], dtype=np.float32)
+        out[k] = np.where(rs.randint(0, 2, size=v.shape) == 1, np.nextafter(v, np.float32(np.inf)), np.nextafter(v, np.float32(-np.inf))).astype(np.float32)
+    for k in list(out):                                  # (the attention module's weights are stored twice, F9: one object)
+        if k.startswith("decoder.attention."):
+            out[k] = out[k[len("decoder."):]]
+    return out
+
+
+def _solver_run(over, stages, ulp_seed=None):
     """Drive the reference's own Solver (solver.py:13-565; main.py cannot be used, F10) over synth.SOLVER_RUN and record what
     its loops produce.  The methods are wrapped from outside to note their return values; nothing of them is restated."""
     import contextlib
@@ -424,8 +437,11 @@ def _solver_run(over, stages):
             with contextlib.redirect_stdout(io.StringIO()):
                 s = ref_solver.Solver(cfg)
             mcfg, jcfg = synth.solver_run_model_cfg(cfg)
-            load_sd(s.model, synth.e2e_weights(mcfg, run["model_wseed"]))
-            load_sd(s.judge, synth.lm_weights(jcfg, run["judge_wseed"]))
+            mw, jw = synth.e2e_weights(mcfg, run["model_wseed"]), synth.lm_weights(jcfg, run["judge_wseed"])
+            if ulp_seed is not None:
+                mw, jw = _ulp_perturbed(mw, ulp_seed), _ulp_perturbed(jw, ulp_seed + 1)
+            load_sd(s.model, mw)
+            load_sd(s.judge, jw)
             rec.update(proportion=float(s.proportion), labeldist=[float(v) for v in s.labeldist],
                        unlab_labeldist=[float(v) for v in s.unlab_labeldist], steps_per_epoch=len(s.train_lab_loader),
                        judge_steps_per_epoch=len(s.train_unlab_y_loader), dev_batches=len(s.dev_loader))
@@ -510,9 +526,11 @@ def gen_solver_run():
     the weights each stage ends with.
 
     A training run is a chaotic system and the reference is its own witness: the SAME run at 4, 2 and 1 host threads (other
-    summation orders inside torch's CPU kernels, nothing else) leaves the primary's trajectory after about 100 steps.  The
-    fixture therefore carries, per epoch, what those runs produced (`spread`): where they agree a port must agree too,
-    where they differ the reference's own spread is the resolution at which any implementation can be compared.
+    summation orders inside some of torch's CPU kernels, nothing else) leaves the primary's trajectory after about 100 steps;
+    and the same run with every initial weight moved by ONE unit in its last place - what any implementation with another
+    rounding in every product amounts to from the first step on - leaves it sooner.  The fixture therefore carries, per
+    epoch, what those runs produced (`spread`, in the order of threads.spread_order): where they agree a port must agree
+    too, where they differ the reference's own spread is the resolution at which any implementation can be compared.
 
     `ssl_early`: ssl_train behind ONE supervised epoch (the runs still agree there), 30 iterations with summaries every 10 - the
     semi-supervised loop inside the window in which the reference agrees with itself.  (Straight from the synthetic weights
@@ -529,7 +547,12 @@ def gen_solver_run():
         others.append(_solver_run({}, ("judge", "ssl")))
         cold_others.append(_solver_run(EARLY, ("ssl",)))
     torch.set_num_threads(primary_threads)
-    rec["threads"] = dict(primary=primary_threads, spread=threads)
+    ulps = [int(u) for u in os.environ.get("GOLDEN_SPREAD_ULP_SEEDS", "901,902,903").split(",") if u]
+    for u in ulps:                                       # the primary's thread count, every initial weight one ulp off
+        others.append(_solver_run({}, ("judge", "ssl"), ulp_seed=u))
+        cold_others.append(_solver_run(EARLY, ("ssl",), ulp_seed=u))
+    rec["threads"] = dict(primary=primary_threads, spread=threads, ulp_seeds=ulps,
+                          spread_order=["%d threads" % t for t in threads] + ["weights one ulp off (seed %d)" % u for u in ulps])
     rec["spread"] = dict(sup=_spread(rec, others, "sup"), ssl_summaries=_spread(rec, others, "ssl_summaries"),
                          judge_val_loss=[[o["judge"][i]["val_loss"] for o in others] for i in range(len(rec["judge"]))],
                          judge_train_loss=[[float(np.mean(o["judge"][i]["losses"])) for o in others] for i in range(len(rec["judge"]))],

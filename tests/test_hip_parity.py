@@ -2109,3 +2109,70 @@ def test_embedding_gradient_with_a_table_larger_than_lds():
     assert float(got["decoder.embedding.weight"].abs().max()) > 0
     for n, gr in got.items():
         _close(gr, rg[n], atol=1e-6, what="grad " + n)
+
+
+class _ExactAllocation(object):
+    """`numel` floats from hipMalloc itself (ctypes on libamdhip64: not torch's caching allocator, which rounds a request up
+    and parks it inside a larger segment), exposed to torch through __cuda_array_interface__: the tensor's last element is
+    the allocation's last."""
+
+    _hip = None
+
+    def __init__(self, shape):
+        import ctypes
+        if _ExactAllocation._hip is None:
+            _ExactAllocation._hip = ctypes.CDLL("libamdhip64.so")
+        self.shape = tuple(int(v) for v in shape)
+        n = 1
+        for v in self.shape:
+            n *= v
+        self.ptr = ctypes.c_void_p()
+        rc = self._hip.hipMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(4 * n))
+        assert rc == 0 and self.ptr.value, "hipMalloc(%d) -> %d" % (4 * n, rc)
+        self.__cuda_array_interface__ = dict(shape=self.shape, typestr="<f4", data=(int(self.ptr.value), False), version=2, strides=None)
+
+    def tensor(self, values=None):
+        t = torch.as_tensor(self, device="cuda")
+        assert t.data_ptr() == self.ptr.value
+        if values is not None:
+            t.copy_(values)
+        return t
+
+    def free(self):
+        if self.ptr.value:
+            torch.cuda.synchronize()
+            self._hip.hipFree(self.ptr)
+            self.ptr.value = None
+
+
+@pytest.mark.parametrize("case", ["bfk_m_tail", "bfs_k_tail_tn", "bfs_k_tail_nt", "bfs_m_tail"])
+def test_gemm_operands_flush_against_the_end_of_an_allocation(case):
+    """gemm_bfk_kernel's M tiles and the masked K tail of gemm_bfs_kernel used to carry their tile offset in the
+    buffer instruction's SGPR offset, which the hardware's range check does not see - a fetch behind the operand.  Operands
+    from exact-size hipMalloc allocations (the operand's last byte is the allocation's last), M % 128 != 0 or K % 32 != 0:
+    the products against float64, with nothing behind the operands that a stray fetch could lean on.  (The static half of
+    this guard - no buffer load of these kernels has an SGPR offset - is tests/test_isa_guard_cpu.py.)"""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(11)
+    if case == "bfk_m_tail":                 # layer-0 input projection: [M, 80] x [8H, 80]^T, M % 128 = 37
+        M, N, K, ta, tb, mode = 10021, 4096, 80, False, True, "bf16x6"
+    elif case == "bfs_k_tail_tn":            # weight gradient over packed rows: dG^T x, K = rows, K % 32 = 4
+        M, N, K, ta, tb, mode = 4096, 512, 10916, True, False, "bf16x6"
+    elif case == "bfs_k_tail_nt":            # k-contiguous operands with a masked tail
+        M, N, K, ta, tb, mode = 1000, 1024, 2084, False, True, "bf16x6+sp"
+    else:                                    # M % 256 = 148: edge tile rows clamped
+        M, N, K, ta, tb, mode = 10900, 512, 2048, False, True, "bf16x6"
+    a_shape = (K, M) if ta else (M, K)
+    b_shape = (N, K) if tb else (K, N)
+    A, B = torch.randn(*a_shape, generator=g), torch.randn(*b_shape, generator=g)
+    allocs = [_ExactAllocation(a_shape), _ExactAllocation(b_shape), _ExactAllocation((M, N))]
+    try:
+        At, Bt, Ct = allocs[0].tensor(A), allocs[1].tensor(B), allocs[2].tensor(torch.zeros(M, N))
+        with hb.arith(mode):
+            hb.gemm(At, Bt, trans_a=ta, trans_b=tb, out=Ct)
+        ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+        _close(Ct, ref.float(), rtol=1e-5, atol=1e-4 * float(K) ** 0.5, what=case)
+    finally:
+        for a in allocs:
+            a.free()

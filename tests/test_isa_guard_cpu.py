@@ -53,3 +53,16 @@ def test_the_guard_sees_a_planted_regression(tables):
         fake = json.loads(json.dumps(want))
         fake["lstm_persist.hip"][k][field] = got["lstm_persist.hip"][k][field] + delta
         assert any(k in f for f in guard.compare(got, fake)), field
+
+
+def test_kernels_that_rely_on_the_buffer_range_check_load_with_a_zero_sgpr_offset():
+    """ADVICE r4 (the static half; the dynamic half is test_gemm_operands_flush_against_the_end_of_an_allocation): the range
+    check of a buffer instruction sees the VGPR offset, not the SGPR offset.  gemm_bfk_kernel and the KT instantiations of
+    gemm_bfs_kernel fetch behind their operand by design - every buffer load of theirs carries its whole offset in the VGPR."""
+    import isa_guard
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    found = isa_guard.range_checked_loads()
+    assert any(k.startswith("gemm_bfk_kernel") for k in found) and any(k.startswith("gemm_bfs_kernel") for k in found), sorted(found)
+    offending = {k: v[:3] for k, v in found.items() if v}
+    assert not offending, offending

@@ -136,6 +136,37 @@ def compare(table, want, instr_tol=0.02):
     return bad
 
 
+def range_checked_loads(kernel_filter=("gemm_bfk_kernel", "gemm_bfs_kernel")):
+    """ADVICE r4, statically: the hardware's buffer range check covers the VGPR offset (+ the immediate), not the SGPR offset.
+    gemm_bfk_kernel (its M tiles) and the masked-K-tail instantiations of gemm_bfs_kernel (KT = true) reach behind their
+    operand by design and rely on that check, so every buffer load of theirs must carry a ZERO SGPR offset.
+    -> {kernel: [offending instructions]} over csrc/gemm.hip."""
+    path = compile_asm("gemm.hip")
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):\s*(?:;.*)?$", txt, re.M):
+        name = m.group(1)
+        short = short_name(name)
+        if not short.startswith(kernel_filter):
+            continue
+        if short.startswith("gemm_bfs_kernel") and not short.endswith(",true>"):
+            continue                                   # KT = false: every K tile lies inside the operand
+        desc = txt.find(".amdhsa_kernel " + name + "\n", m.end())
+        if desc < 0:
+            continue
+        bad = []
+        for l in txt[m.end():desc].splitlines():
+            l = l.split(";")[0].strip()
+            if l.startswith("buffer_load"):
+                # buffer_load_dwordx4 vdst, voffset, srsrc[4], soffset [offen] [offset:imm]
+                ops = [o.strip() for o in l.split(None, 1)[1].split(",")]
+                soff = ops[3].split()[0]
+                if soff not in ("0", "off", "null"):
+                    bad.append(l)
+        out[short] = bad
+    return out
+
+
 if __name__ == "__main__":
     t = measure()
     if "--update" in sys.argv:
