@@ -24,7 +24,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "semi-supervised-asr_amd", "csrc")
 TABLE = os.path.join(ROOT, "tests", "golden", "isa_table.json")
-SOURCES = ("lstm_persist.hip", "dec_persist.hip")
+SOURCES = ("lstm_persist.hip", "dec_persist.hip", "gemm.hip")
 TIGHT = 8                                        # instructions
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only"]     # the flags of build() + -S
 
