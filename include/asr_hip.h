@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 4
+#define ASR_ABI_VERSION 5
 
 #define ASR_E_ARG    (-1)  /* null pointer / non-positive size */
 #define ASR_E_SHAPE  (-2)  /* size not supported by the kernel (see each function) */
@@ -124,6 +124,21 @@ int asr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
 int asr_gemm_drop_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                       const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu, int split_k,
                       int arith, uint64_t seed, float p, asr_stream_t stream);
+
+/* C[b] += op(A[b]) op(B[b]) on the XCDs of `xcd_mask` only (bit x = XCC id x), by workgroups built to run BESIDE the
+ * persistent XCD-local kernels below: a batch of <= 8 utterances keeps the LSTM / decoder recurrences on four of the eight
+ * XCDs (group g of a persistent launch = XCC id g; groups without rows leave at once), and the weight-gradient products
+ * (the autograd mm's of torch.nn.LSTM / Linear behind model.py:67-68,93-94,262-263 - off the backward's critical path) run
+ * on the other four, issued on a side stream under the recurrence of the layer below.  64 x 64 tiles, <= 128 VGPRs and 30 KB
+ * of LDS (a workgroup fits next to a persistent one on a CU, so no persistent launch waits for room), one (tile, K slice)
+ * per workgroup drawn from the ticket counter `queue` (ONE zeroed 32-bit word of the caller's, consumed by the call).  The
+ * K slices are ADDED to C with atomics: C holds zeros for a plain product.  Arguments as asr_gemm_f32 (strides in elements,
+ * negative batch strides allowed); arith: ASR_ARITH_BF16X6 / _BF16X3 (ASR_E_SHAPE for ASR_ARITH_F32: the caller runs
+ * asr_gemm_f32 instead).  The result does not depend on where the hardware places workgroups (a second, unmasked launch
+ * draws whatever tickets the masked one left). */
+int asr_gemm_side_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                      const float* B, int64_t ldb, float* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC,
+                      int arith, unsigned xcd_mask, unsigned* queue, asr_stream_t stream);
 
 /* Skinny GEMM for the sequential chains (M = batch rows, tens not thousands):
  *   C[M,N] (ldc) (+)= A[M,K] (lda) * Bt[N,K]^T (ldb)  (+ bias[N]) (* mask[M,N] from col mask_from)

@@ -102,6 +102,10 @@ struct GemmArgs {
   int relu, accumulate, split_k;
   int64_t sA, sB, sC;
   int tiles_m, tiles_n;
+  // gemm_bf3_kernel<..., 64, QUEUE = true> (asr_gemm_side_f32): the ticket counter the workgroups draw their (tile, K slice)
+  // from, and the XCDs they may run on (bit x = XCC id x; a workgroup that lands elsewhere leaves at once)
+  unsigned* queue;
+  unsigned xcd_mask;
 };
 
 
@@ -422,8 +426,18 @@ __device__ __forceinline__ void tile_store_bf3(unsigned short* img, const float4
 // products too small to fill the chip with 128 x 128 tiles - the decoder-side projections, their gradients, the output
 // layer: [3 200, 512] outputs are 100 large tiles, each a serial walk of 16-64 K tiles alone on its CU; as 400 small tiles
 // every CU holds one or two workgroups whose K tiles cost a quarter (tools/gemm_shapes.py).
-template <bool AKC, bool BKC, int NT, int TS = 128>
-__global__ __launch_bounds__(256, TS == 64 ? ASR_GEMM_SMALL_OCC : 1) void gemm_bf3_kernel(GemmArgs g) {
+//
+// QUEUE (TS = 64 only; asr_gemm_side_f32): the instantiation that runs BESIDE the persistent XCD-local kernels of a small
+// batch (8 utterances keep the LSTM / decoder chains on four of the eight XCDs).  Three things make it a good
+// neighbour: it FITS next to a persistent workgroup on a CU (<= 128 VGPRs by its launch bounds - the LSTM backward leaves 144
+// per SIMD -, 30 KB of LDS beside their 82), so a persistent launch never waits for one of its workgroups to find room; a
+// workgroup that lands on an XCD outside g.xcd_mask leaves at once, so the chain's L2 sees none of its operand traffic; and
+// a workgroup computes ONE (tile, K slice) - drawn from the ticket counter g.queue, because which workgroups survive the mask
+// is not known at launch - and ends, so the critical-path kernels of the main stream find CUs at tile granularity.  One K tile
+// in flight instead of three (registers); the partial products meet in atomics (C starts from zero or accumulates).
+template <bool AKC, bool BKC, int NT, int TS = 128, bool QUEUE = false>
+__global__ __launch_bounds__(256, QUEUE ? 4 : (TS == 64 ? ASR_GEMM_SMALL_OCC : 1)) void gemm_bf3_kernel(GemmArgs g) {
+  static_assert(!QUEUE || TS == 64, "the queue instantiation is the 64 x 64 tile");
   // NT images (split terms, most significant first) per operand: 40 KB for two terms, 60 KB for three (TS = 128)
   constexpr int BM = TS, BN = TS, NP = TS / 32, NB = TS / 64;      // tile, float4 pieces per thread and operand, blocks per wave and side
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * NT * BM * BS];
@@ -432,12 +446,22 @@ __global__ __launch_bounds__(256, TS == 64 ? ASR_GEMM_SMALL_OCC : 1) void gemm_b
 
   const int ntile = g.tiles_m * g.tiles_n;
   int tid = blockIdx.x;
-  {
+  int z = blockIdx.y;
+  if constexpr (QUEUE) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;      // XCC_ID
+    if (!((g.xcd_mask >> xcc) & 1u)) return;
+    __shared__ unsigned ticket;
+    if (threadIdx.x == 0) ticket = atomicAdd(g.queue, 1u);
+    __syncthreads();
+    const unsigned tk = ticket;
+    if (tk >= (unsigned)ntile * gridDim.y) return;       // gridDim.y = batch * split_k; the x extent is oversubscribed
+    tid = (int)(tk % (unsigned)ntile);
+    z = (int)(tk / (unsigned)ntile);
+  } else {
     const int q = ntile >> 3, rmd = ntile & 7, xcd = tid & 7, idx = tid >> 3;
     tid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + idx;
   }
   const int tm = tid / g.tiles_n, tn = tid % g.tiles_n;
-  const int z = blockIdx.y;
   const int bz = z / g.split_k, kz = z % g.split_k;
 
   MatView A = g.A, B = g.B;
@@ -547,7 +571,7 @@ __global__ __launch_bounds__(256, TS == 64 ? ASR_GEMM_SMALL_OCC : 1) void gemm_b
     // K tiles are in flight in registers (12 float4 per thread).  The steady state runs in groups of PD tiles with
     // unconditional fetches - a conditional one makes hipcc wait for ALL outstanding loads (vmcnt(0)) at the next store -
     // and the last < 2 PD tiles take the conditional form.
-    constexpr int PD = 3;
+    constexpr int PD = QUEUE ? 1 : 3;
     float4 qa[PD][NP], qb[PD][NP];
     auto fetch_set = [&](int64_t kt2, float4 (&xa)[NP], float4 (&xb)[NP]) __attribute__((always_inline)) {
       const int64_t k0 = kt2 * BK;
@@ -644,7 +668,7 @@ __global__ __launch_bounds__(256, TS == 64 ? ASR_GEMM_SMALL_OCC : 1) void gemm_b
   // epilogue (as gemm_f32_kernel: the C/D lane map of the 32x32 MFMAs does not depend on the input type)
   if (m0 + BM <= g.M && n0 + BN <= g.N) {
     const unsigned ldc = (unsigned)g.ldc;
-    const bool split = g.split_k > 1, accum = g.accumulate != 0, relu = g.relu != 0;
+    const bool split = QUEUE || g.split_k > 1, accum = g.accumulate != 0, relu = g.relu != 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int64_t n = n0 + wn * (TS / 2) + j * 32 + l31;
@@ -690,7 +714,7 @@ __global__ __launch_bounds__(256, TS == 64 ? ASR_GEMM_SMALL_OCC : 1) void gemm_b
         if (m >= g.M) continue;
         float v = acc[i][j][e];
         float* dst = C + m * g.ldc + n;
-        if (g.split_k > 1) {
+        if (QUEUE || g.split_k > 1) {
           atomicAdd(dst, v);
         } else {
           v += bv;
@@ -2136,6 +2160,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
   g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.accumulate = accumulate;
   g.sA = sA; g.sB = sB; g.sC = sC;
+  g.queue = nullptr; g.xcd_mask = 0xffu;
   const bool epi = bias || relu;
   // Wide-tile LDS-DMA kernels (gemm_bf3w_kernel / gemm_bf6w_kernel) for conforming shapes: any M, N (edge tiles clamp their
   // DMA rows / columns and guard the stores); K % 32 == 0; row-contiguous operands need a multiple of 4 rows; per-lane
@@ -2302,6 +2327,67 @@ extern "C" int asr_gemm_drop_f32(int transA, int transB, int64_t M, int64_t N, i
   const DropEpi d = {(unsigned long long)seed, asr_drop_thresh(p), 1.0f / (1.0f - p)};
   return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, 0, 1, 0, 0, 0, split_k, arith, d,
                    (hipStream_t)stream);
+}
+
+// C += op(A) op(B) on the XCDs of `xcd_mask` only, by workgroups that fit beside a persistent XCD-local kernel: the
+// weight-gradient products of a small batch, issued on a side stream while the recurrence of the layer below runs on the
+// other XCDs (gemm_bf3_kernel<..., 64, QUEUE>).  The partial products of all K slices are ADDED to C with atomics:
+// C holds zeros (a plain product) or what the product accumulates onto.  `queue`: one zeroed 32-bit word of the caller's
+// (the ticket counter; consumed).  Two launches: the masked one, oversubscribed by 8 / popcount(mask) (a workgroup that
+// lands on an excluded XCD leaves at once and draws no ticket), and an unmasked sweep behind it that draws whatever tickets
+// are left - none, when workgroups are dealt round robin over the XCDs; the result does not depend on that.
+extern "C" int asr_gemm_side_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                 const float* B, int64_t ldb, float* C, int64_t ldc, int batch, int64_t sA, int64_t sB,
+                                 int64_t sC, int arith, unsigned xcd_mask, unsigned* queue, asr_stream_t stream_) {
+  if (!A || !B || !C || !queue || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !(xcd_mask & 0xffu)) return ASR_E_ARG;
+  const int ar = arith & ASR_ARITH_MASK;
+  if (ar != ASR_ARITH_BF16X6 && ar != ASR_ARITH_BF16X3) return ASR_E_SHAPE;      // (the fp32-input MFMA kernel has no such form)
+  hipStream_t stream = (hipStream_t)stream_;
+  GemmArgs g;
+  const bool akc = !transA, bkc = transB != 0;
+  g.A.p = A; g.A.ld = lda;
+  if (akc) { g.A.R = M; g.A.Cn = K; } else { g.A.R = K; g.A.Cn = M; }
+  g.A.vec = (lda % 4 == 0) && asr_aligned16(A) && (sA % 4 == 0);
+  g.B.p = B; g.B.ld = ldb;
+  if (bkc) { g.B.R = N; g.B.Cn = K; } else { g.B.R = K; g.B.Cn = N; }
+  g.B.vec = (ldb % 4 == 0) && asr_aligned16(B) && (sB % 4 == 0);
+  g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.bias = nullptr; g.relu = 0; g.accumulate = 1;
+  g.sA = sA; g.sB = sB; g.sC = sC;
+  g.tiles_m = (int)((M + 63) / 64);
+  g.tiles_n = (int)((N + 63) / 64);
+  g.queue = queue; g.xcd_mask = xcd_mask & 0xffu;
+  const int nx = __builtin_popcount(g.xcd_mask);
+  // K slices: about four tickets per CU of the allowed XCDs (a workgroup is 1 of up to 4 on its CU), at least 8 K tiles each
+  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch, ktiles = (K + BK - 1) / BK;
+  int64_t sk = (4 * 32 * nx + tiles - 1) / tiles;
+  if (sk > ktiles / 8) sk = ktiles / 8;
+  if (sk < 1) sk = 1;
+  if (sk > 64) sk = 64;
+  g.split_k = (int)sk;
+  const int64_t tickets = (int64_t)g.tiles_m * g.tiles_n * batch * sk;
+  if (tickets > 0x3fffffff) return ASR_E_SHAPE;
+  const unsigned gy = (unsigned)(batch * sk);
+  const int64_t per_y = (int64_t)g.tiles_m * g.tiles_n;                 // tickets per unit of grid.y
+  const unsigned gx = (unsigned)((per_y * 8 + nx - 1) / nx + 8);      // x extent oversubscribed: 1 in 8 / nx workgroups survives
+  auto launch = [&](dim3 grid) {
+    const dim3 block(256);
+#define SIDE_LAUNCH(nt_)                                                                                                     \
+    do {                                                                                                                     \
+      if (akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, true, nt_, 64, true>), grid, block, 0, stream, g);           \
+      else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf3_kernel<true, false, nt_, 64, true>), grid, block, 0, stream, g);    \
+      else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf3_kernel<false, true, nt_, 64, true>), grid, block, 0, stream, g);    \
+      else hipLaunchKernelGGL((gemm_bf3_kernel<false, false, nt_, 64, true>), grid, block, 0, stream, g);                    \
+    } while (0)
+    if (ar == ASR_ARITH_BF16X6) SIDE_LAUNCH(3); else SIDE_LAUNCH(2);
+#undef SIDE_LAUNCH
+  };
+  launch(dim3(gx, gy, 1));
+  // the sweep: every XCD, one workgroup per ticket that could be left at most - all of them leave at once in the expected case
+  g.xcd_mask = 0xffu;
+  launch(dim3((unsigned)per_y, gy, 1));
+  ASR_CHECK_LAUNCH();
+  return 0;
 }
 
 int asr_skinny_launch(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* Bt, int64_t ldb,

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libasr_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "asr_abi_version", "asr_persist_scratch_bytes", "asr_gemm_f32", "asr_gemm_skinny_f32", "asr_colsum_f32",
@@ -20,7 +20,7 @@ EXPORTS = (
     "asr_dropout_mask_f32",
     "asr_dec_step_fwd", "asr_att_step_fwd", "asr_dec_seq_fwd", "asr_dec_seq_fwd_persist", "asr_dec_seq_fwd_persist_fault", "asr_dec_seq_fwd_persist_free", "asr_dec_step_bwd", "asr_dec_seq_bwd", "asr_dec_seq_bwd_persist", "asr_dec_seq_bwd_persist_free",
     "asr_lstm_pack_f32", "asr_lstm_unpack_f32", "asr_lstm_unpack2_f32", "asr_dec_prepare_f32", "asr_cell_pack_f32", "asr_cell_unpack_f32",
-    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32", "asr_embedding_grad_f32",
+    "asr_lstm_pack_multi_f32", "asr_lstm_unpack_multi_f32", "asr_dec_pack_f32", "asr_colsum_parts_f32", "asr_gemm_drop_f32", "asr_gemm_side_f32", "asr_embedding_grad_f32",
     "asr_label_logprob_fwd", "asr_label_logprob_bwd", "asr_dec_feedback_fwd", "asr_dec_feedback_bwd",
     "asr_adam_clip_f32", "asr_sumsq_f32", "asr_gather_sumsq_f32", "asr_graphs_create", "asr_graphs_destroy", "asr_graphs_stats",
 )
@@ -143,6 +143,8 @@ def load():
     lib.asr_embedding_grad_f32.argtypes = [c_i64, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]
     lib.asr_gemm_drop_f32.argtypes = [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_i, c_i,
                                       ctypes.c_uint64, c_f, c_p]
+    lib.asr_gemm_side_f32.argtypes = [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i, c_i64, c_i64, c_i64,
+                                      c_i, ctypes.c_uint, c_p, c_p]
     if lib.asr_abi_version() != ABI_VERSION:
         raise RuntimeError("libasr_hip.so ABI %d != expected %d" % (lib.asr_abi_version(), ABI_VERSION))
     _lib = lib
@@ -274,6 +276,36 @@ def gemm_batched(A, B, out, trans_a, trans_b, M, N, K, lda, ldb, ldc, batch, sA,
                               None, 0, int(accumulate), batch, sA, sB, sC, 0 if split_k is None else int(split_k),
                               ARITH[0] if arith is None else _arith_code(arith), stream()), "asr_gemm_f32(batched)")
     return out
+
+
+def gemm_side(A, B, out, queue, xcd_mask, trans_a=False, trans_b=False, arith=None):
+    """out[M,N] += op(A) op(B) on the XCDs of `xcd_mask` only, by workgroups that fit beside a persistent kernel
+    (asr_gemm_side_f32); `queue`: a zeroed int32 / float32 word (tensor), consumed.  False when the arithmetic has no such
+    kernel (the fp32-input MFMA): the caller runs gemm() instead."""
+    code = ARITH[0] if arith is None else _arith_code(arith)
+    if (code & 0xff) == ARITH_F32:
+        return False
+    A, lda = _rowmajor(_dev(A, "A"))
+    B, ldb = _rowmajor(_dev(B, "B"))
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    K2, N = (B.shape[1], B.shape[0]) if trans_b else B.shape
+    assert K == K2 and out.shape == (M, N)
+    out, ldc = _rowmajor(out)
+    check(load().asr_gemm_side_f32(int(trans_a), int(trans_b), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc, 1, 0, 0, 0,
+                                   code, int(xcd_mask) & 0xff, c_p(queue.data_ptr()), stream()), "asr_gemm_side_f32")
+    return True
+
+
+def gemm_side_batched(A, B, out, queue, xcd_mask, trans_a, trans_b, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, arith=None,
+                      a_off=0, b_off=0):
+    """The raw batched form of gemm_side (as gemm_batched)."""
+    code = ARITH[0] if arith is None else _arith_code(arith)
+    if (code & 0xff) == ARITH_F32:
+        return False
+    check(load().asr_gemm_side_f32(int(trans_a), int(trans_b), M, N, K, _off(A, a_off), lda, _off(B, b_off), ldb, ptr(out), ldc,
+                                   batch, sA, sB, sC, code, int(xcd_mask) & 0xff, c_p(queue.data_ptr()), stream()),
+          "asr_gemm_side_f32(batched)")
+    return True
 
 
 def gemm_skinny(A, Bt, bias=None, out=None, accumulate=False):

@@ -2176,3 +2176,43 @@ def test_gemm_operands_flush_against_the_end_of_an_allocation(case):
     finally:
         for a in allocs:
             a.free()
+
+
+@pytest.mark.parametrize("arith,rtol", [("bf16x6", 1e-5), ("bf16x3", 3e-5)])
+@pytest.mark.parametrize("mask", [0xff, 0xf0, 0x01, 0xaa])
+def test_gemm_side_on_a_subset_of_the_xcds(mask, arith, rtol):
+    """asr_gemm_side_f32: the 64 x 64 queue instantiation that runs beside the persistent kernels of a small batch, restricted
+    to the XCDs of `mask` - every (tile, K slice) is computed exactly once wherever the hardware places the workgroups (one
+    XCD, four, all eight), the K slices and an initial C add up, edges in M, N and a K tail are guarded; transposed operands;
+    the batched row-shifted form of dW_hh.  Against float64."""
+    dev = _gpu()
+    import hip_backend as hb
+    g = torch.Generator().manual_seed(mask)
+    tol = dict(rtol=rtol)
+    for (ta, tb, M, N, K) in ((True, False, 1024, 512, 5248), (True, False, 100, 70, 333), (False, True, 200, 130, 96),
+                              (False, False, 64, 64, 2048), (True, True, 130, 64, 40)):
+        A = torch.randn(*((K, M) if ta else (M, K)), generator=g)
+        B = torch.randn(*((N, K) if tb else (K, N)), generator=g)
+        C0 = torch.randn(M, N, generator=g)
+        out = C0.clone().to(dev)
+        queue = torch.zeros(1, dtype=torch.int32, device=dev)
+        with hb.arith(arith):
+            assert hb.gemm_side(A.to(dev), B.to(dev), out, queue, mask, trans_a=ta, trans_b=tb)
+        ref = C0.double() + (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+        _close(out, ref.float(), atol=1e-4 * float(K) ** 0.5, what="%s%s %dx%dx%d mask %#x" % ("T" if ta else "N", "T" if tb else "N", M, N, K, mask), **tol)
+        assert int(queue.item()) > 0
+    # dW_hh of a bidirectional layer over packed rows: batch over the directions, K = R rows, operands shifted by one row
+    H, R = 64, 520
+    dG = torch.randn(R + 1, 2, 4 * H, generator=g)
+    y = torch.randn(R + 1, 2 * H, generator=g)
+    dG[R], y[R] = 0.0, 0.0
+    out = torch.zeros(2, 4 * H, H, device=dev)
+    queue = torch.zeros(1, dtype=torch.int32, device=dev)
+    ldg, ldy = 2 * 4 * H, 2 * H
+    with hb.arith(arith):
+        assert hb.gemm_side_batched(dG.to(dev), y.to(dev), out, queue, mask, True, False, 4 * H, H, R, ldg, ldy, H, 2,
+                                    4 * H - ldg, ldy + H, 4 * H * H, a_off=ldg, b_off=0)
+    ref = torch.stack([dG[1:, 0].double().t() @ y[:R, :H].double(), dG[:R, 1].double().t() @ y[1:, H:].double()])
+    _close(out, ref.float(), atol=1e-4 * float(R) ** 0.5, what="batched dW_hh mask %#x" % mask, **tol)
+    with hb.arith("f32"):
+        assert hb.gemm_side(A.to(dev), B.to(dev), torch.zeros(M, N, device=dev), queue.zero_(), mask, trans_a=ta, trans_b=tb) is False
