@@ -786,6 +786,17 @@ def disable_persistent(device=None, permanent=False):
         persist_clear_abort(device)
 
 
+def idle_xcd_mask(nbatch):
+    """The XCDs NO persistent kernel of a step uses when a rank's batch has `nbatch` utterances (bit x = XCC id x), 0 when
+    there are fewer than four.  Group g of a persistent launch is XCC id g; the LSTM kernels use ndir * ceil(nb / 4) groups
+    for nb <= 16 rows (4-row groups, csrc/lstm_persist.hip: rows_per_group), the decoder kernels ceil(nb / 2) or ceil(nb / 4)
+    (csrc/dec_persist.hip: DecGeo): eight utterances or fewer stay on XCDs 0-3.  Not with the per-step kernels (they use the
+    whole chip) or with a forced row geometry (ASR_LSTM_ROWS: measurements)."""
+    if not (USE_PERSIST and USE_PERSIST_DEC and USE_PERSIST_DEC_BWD) or os.environ.get("ASR_LSTM_ROWS"):
+        return 0
+    return 0xF0 if 0 < int(nbatch) <= 8 else 0
+
+
 def persistent_step_tick():
     """Called once per train step (Solver._step).  True when this call ended a probation: the sequence operators of the
     step that follows run on the persistent kernels again (an abort there is found and repeated like any other)."""

@@ -152,6 +152,64 @@ def zeros_acc(shape, device):
     return t if t is not None else torch.zeros(*shape, device=device, dtype=torch.float32)
 
 
+# -------------------------------------------------------------------------------------- weight gradients beside the chains
+class _SideStream(object):
+    """A batch of <= 8 utterances keeps every persistent kernel of the step (LSTM, decoder, judge) on four of the eight XCDs
+    (hb.idle_xcd_mask).  The weight-gradient products of the backward pass are off its critical path - dG -> dX -> the
+    recurrence of the layer below is - so they go to a SIDE stream, onto the idle XCDs, by workgroups that fit beside a
+    persistent one (hb.gemm_side / asr_gemm_side_f32), and run under the recurrence of the layer below.
+      begin(mask, dev)   inside a backward function, once the operands are final on the current stream: -> the side stream
+                         (ordered behind everything enqueued so far), or None when the products stay on the main stream.
+                         The first begin() of a backward pass registers the join with the autograd engine: when the pass
+                         ends, the stream the backward ran on waits for the side stream - code that reads .grad afterwards
+                         (the optimiser, a test) finds every gradient complete without knowing about any of this.
+      join_now()         the same wait at once (a node that consumes side results inside the pass: _LstmPack.backward).
+    Outputs are zeroed on the main stream BEFORE begin() (the side products add into them with atomics).  A tensor the side
+    stream reads that is not a pooled workspace or an arena slice is handed to record_stream().  Off: ASR_SIDE_GEMM=0, the
+    fp32-input MFMA arithmetic (no such kernel), gradients exchanged from inside the backward pass (dp_overlap: its hooks
+    read a gradient as soon as autograd has it)."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("ASR_SIDE_GEMM", "1") != "0"
+        self.streams, self.active, self.mask_hint = {}, None, 0
+        self.uses = {}                     # weight data_ptr -> forward passes since the last join (see _Linear)
+        self.launches = 0
+
+    def mask_for(self, nbatch):
+        return hb.idle_xcd_mask(nbatch) if self.enabled else 0
+
+    def usable(self, mask):
+        return bool(mask) and self.enabled and (hb.current_arith() & 0xff) != hb.ARITH_F32
+
+    def begin(self, mask, dev):
+        if not self.usable(mask):
+            return None
+        main = torch.cuda.current_stream(dev)
+        st = self.streams.get(dev.index)
+        if st is None:
+            st = self.streams[dev.index] = torch.cuda.Stream(device=dev)
+        if self.active is None:
+            self.active = (main, st)
+            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        st.wait_event(ev)
+        self.launches += 1
+        return st
+
+    def join_now(self):
+        if self.active is not None:
+            self.active[0].wait_stream(self.active[1])
+
+    def join(self):
+        self.join_now()
+        self.active = None
+        self.uses.clear()
+
+
+_SIDE = _SideStream()
+
+
 def _gemm_acc(A, B, trans_a=False, trans_b=False, shape=None):
     """A product into a fresh output that no epilogue follows (the weight gradients): inside a step's arena the output is a
     pre-zeroed slice and the library accumulates into it - no zero pass in front of a split-K product."""
@@ -194,6 +252,10 @@ class _Linear(torch.autograd.Function):
         y = hb.gemm(x2, weight, trans_b=True, bias=bias, relu=relu, drop=drop if seeded else None, out=out,
                     out_zeroed=out is not None)
         ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.side_mask = 0
+        if _SIDE.mask_hint and x2.shape[0] >= 512 and ctx.needs_input_grad[1]:      # (grad mode is off inside forward: ask the node)
+            ctx.side_mask = _SIDE.mask_hint
+            _SIDE.uses[weight.data_ptr()] = _SIDE.uses.get(weight.data_ptr(), 0) + 1
         ctx.relu = relu
         ctx.drop = (drop.seed, drop.p) if seeded else None
         ctx.has_bias = bias is not None
@@ -216,7 +278,21 @@ class _Linear(torch.autograd.Function):
         elif ctx.relu:
             dy2 = dy2 * (y > 0).to(dy2.dtype)
         dx = hb.gemm(dy2, weight).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
-        dw = _gemm_acc(dy2, x2, trans_a=True, shape=(dy2.shape[1], x2.shape[1]))
+        # the weight gradient beside the recurrence of the layer below (a small batch; _SideStream) - unless this weight has
+        # a second gradient on its way (the two model passes of the semi-supervised step: autograd would ADD the two on the
+        # main stream while the side stream still writes them) or nothing follows this node in the pass
+        side = None
+        if ctx.side_mask and ctx.needs_input_grad[0] and _SIDE.uses.get(weight.data_ptr(), 0) == 1 and _SIDE.usable(ctx.side_mask):
+            dw = zeros_acc((dy2.shape[1], x2.shape[1]), dy2.device)
+            queue = zeros_acc((1,), dy2.device)
+            side = _SIDE.begin(ctx.side_mask, dy2.device)
+        if side is not None:
+            with torch.cuda.stream(side):
+                hb.gemm_side(dy2, x2, dw, queue, ctx.side_mask, trans_a=True)
+            for t in (dy2, x2, queue):     # (temporaries of this function: the allocator must not hand their memory to the main
+                t.record_stream(side)      #  stream's next allocation - a fresh, ZEROED ticket counter - while the side stream runs)
+        else:
+            dw = _gemm_acc(dy2, x2, trans_a=True, shape=(dy2.shape[1], x2.shape[1]))
         db = _colsum_acc(dy2) if ctx.has_bias else None
         return dx, dw, db, None, None
 
@@ -282,6 +358,7 @@ class _LstmPack(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        _SIDE.join_now()                   # the layers' dW_ih / dW_hh may still be on their way on the side stream
         n = len(ctx.dims)
         per_layer = [grads[3 * j:3 * j + 3] for j in range(n)]
         for j, g in enumerate(per_layer):
@@ -329,6 +406,7 @@ class _LstmLayer(torch.autograd.Function):
             lease, ws = None, _lstm_workspace(T * B, nbatch, H, ndir, dev, False)
         _lstm_views(ws, T, B, H, ndir)
         ws["rows_written"] = max(ws.get("rows_written", 0), T * B)      # rows of gates_buf / y_buf that may hold stale values
+        ctx.side_mask = _SIDE.mask_hint = _SIDE.mask_for(nbatch) if pooled else 0
         ws["lens"] = lens                      # int32 device tensor, kept for the backward (no copy)
         hb.gemm(x2, w_ih, trans_b=True, bias=bias, out=ws["gates"].view(T * B, ndir * 4 * H))
         hb.lstm_seq_fwd(ws["gates"], w_hh, ws["lens"], ws["y"], ws["c"], use_graphs=pooled, rows=rows)
@@ -362,8 +440,34 @@ class _LstmLayer(torch.autograd.Function):
                                              ws["c"], ws["dcarry"], y=y, dw_hh=ws["dw_hh"], db=ws["db"],
                                              w_hh=w_hh, rows=ctx.rows)                    # gates <- dG in place
         dG = gates.view(T * B, ndir * 4 * H)
+        # a small batch: this layer's weight gradients go beside the recurrence of the layer BELOW (_SideStream) - not those of
+        # the bottom layer (no input gradient: nothing follows it in the pass, and the main stream's kernels have the whole chip)
+        side, side_dw_hh = None, False
+        if ctx.side_mask and ctx.needs_input_grad[0] and _SIDE.usable(ctx.side_mask):
+            dw_ih = zeros_acc((ndir * 4 * H, I), dev)
+            queue = zeros_acc((2,), dev)
+            # (without a step arena the accumulators live in the leased workspace and are copied out below, on the main
+            # stream: the side product then needs a tensor of its own)
+            dw_hh_side = ws["dw_hh"] if zb is not None else torch.zeros_like(ws["dw_hh"])
+            if ctx.rows is not None and not fused_dw and T > 1 and ws.get("rows_written", 0) > T * B:
+                ws["gates_buf"][T * B].zero_()             # (row R of a workspace a longer batch has used: see below)
+                ws["y_buf"][T * B].zero_()
+            side = _SIDE.begin(ctx.side_mask, dev)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
-        dw_ih = _gemm_acc(dG, x2, trans_a=True, shape=(ndir * 4 * H, I))      # [ndir*4H, I]
+        if side is not None:
+            with torch.cuda.stream(side):
+                hb.gemm_side(dG, x2, dw_ih, queue[0:1], ctx.side_mask, trans_a=True)
+                if not fused_dw and T > 1:
+                    ldg, ldy = ndir * 4 * H, ndir * H
+                    kk = T * B if ctx.rows is not None else (T - 1) * B
+                    hb.gemm_side_batched(dG, y, dw_hh_side, queue[1:2], ctx.side_mask, True, False, 4 * H, H, kk, ldg, ldy, H,
+                                         ndir, 4 * H - B * ldg, B * ldy + H, 4 * H * H, a_off=B * ldg, b_off=0)
+                    side_dw_hh = True
+            x2.record_stream(side)
+            queue.record_stream(side)                      # (see _Linear.backward)
+            fused_dw = True                                # (done: skip the main-stream product below)
+        else:
+            dw_ih = _gemm_acc(dG, x2, trans_a=True, shape=(ndir * 4 * H, I))      # [ndir*4H, I]
         db = ws["db"] if fused_db else _colsum_acc(dG)     # the persistent kernels sum the bias gradient themselves
         if not fused_dw and T > 1:
             # dW_hh[d] = sum_t dG_t[d]^T h_prev(t), h_prev = y[t-1] (d = 0) or y[t+1] (reverse direction): ONE batched GEMM
@@ -385,6 +489,8 @@ class _LstmLayer(torch.autograd.Function):
         # the gradients stay gate-interleaved (_LstmPack.backward converts every layer's in one launch); what lives in the
         # leased workspace is copied out of it, slices of the step's arena outlive the lease
         dw_hh, db = (ws["dw_hh"], db) if zb is not None else (ws["dw_hh"].clone(), db.clone() if fused_db else db)
+        if side_dw_hh:
+            dw_hh = dw_hh_side
         lease.release()
         return dx, None, None, None, None, dw_ih, dw_hh, db
 

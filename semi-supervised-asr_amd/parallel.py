@@ -23,6 +23,8 @@ spare floats at the end of that buffer (`FlatBuffers.aux`).
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -375,6 +377,8 @@ class FlatBuffers(object):
         if self.overlap or not (dist.is_available() and dist.is_initialized()) or (world() <= 1 and not force):
             return
         self.overlap, self._group = True, group
+        import ops
+        ops._SIDE.enabled = False          # the hooks below read a gradient the moment autograd has it: no products in flight
         for i, p in enumerate(self.params):
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, i=i: self._on_grad(i)))
 
@@ -389,6 +393,8 @@ class FlatBuffers(object):
             h.remove()
         self._hooks, self.overlap = [], False
         self._reset_overlap_state()
+        import ops
+        ops._SIDE.enabled = os.environ.get("ASR_SIDE_GEMM", "1") != "0"
 
     def _on_grad(self, i):
         b = self.bucket_of[i]

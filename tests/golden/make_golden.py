@@ -413,7 +413,19 @@ def _ulp_perturbed(arrays, seed):
     return out
 
 
-def _solver_run(over, stages, ulp_seed=None):
+def _rel_perturbed(arrays, rel, seed):
+    """Every weight times (1 + rel * N(0, 1)) (seeded): what an implementation whose every product rounds differently - another
+    summation order, another split of the operands - amounts to after its first step."""
+    rs = np.random.RandomState(seed)
+    out = {k: (np.asarray(arrays[k], dtype=np.float32) * (1.0 + rel * rs.normal(0, 1, size=np.shape(arrays[k])))).astype(np.float32)
+           for k in sorted(arrays)}
+    for k in list(out):
+        if k.startswith("decoder.attention."):
+            out[k] = out[k[len("decoder."):]]
+    return out
+
+
+def _solver_run(over, stages, ulp_seed=None, rel=None):
     """Drive the reference's own Solver (solver.py:13-565; main.py cannot be used, F10) over synth.SOLVER_RUN and record what
     its loops produce.  The methods are wrapped from outside to note their return values; nothing of them is restated."""
     import contextlib
@@ -440,6 +452,8 @@ def _solver_run(over, stages, ulp_seed=None):
             mw, jw = synth.e2e_weights(mcfg, run["model_wseed"]), synth.lm_weights(jcfg, run["judge_wseed"])
             if ulp_seed is not None:
                 mw, jw = _ulp_perturbed(mw, ulp_seed), _ulp_perturbed(jw, ulp_seed + 1)
+            if rel is not None:
+                mw, jw = _rel_perturbed(mw, rel[0], rel[1]), _rel_perturbed(jw, rel[0], rel[1] + 1)
             load_sd(s.model, mw)
             load_sd(s.judge, jw)
             rec.update(proportion=float(s.proportion), labeldist=[float(v) for v in s.labeldist],
@@ -584,6 +598,46 @@ def gen_solver_run():
     print("solver_run_dropout: CER %s" % " ".join("%.3f" % e["cer"] for e in drop["sup"]))
 
 
+def gen_solver_run_extend():
+    """Append runs of the reference with its initial weights perturbed by 1e-6 RELATIVE (GOLDEN_SPREAD_REL = "1e-6:911,912") to
+    the spread of an existing solver_run.json: the size of the differences a from-scratch implementation has in every
+    operation (the parity gate of the hot path is 1e-3; its kernels are held to ~1e-6).  How well the reference agrees with
+    itself under THAT perturbation is how well any implementation can be asked to agree with it."""
+    path = os.path.join(HERE, "solver_run.json")
+    with open(path) as f:
+        rec = json.load(f)
+    spec = os.environ.get("GOLDEN_SPREAD_REL", "1e-6:911,912")
+    rel, seeds = float(spec.split(":")[0]), [int(v) for v in spec.split(":")[1].split(",")]
+    EARLY = dict(epochs=1, ssl_iterations=30, summary_steps=10)
+    early = rec["ssl_early"]
+    for sd in seeds:
+        o = _solver_run({}, ("judge", "ssl"), rel=(rel, sd))
+        c = _solver_run(EARLY, ("ssl",), rel=(rel, sd))
+        for key, primary, other, sp in (("sup", rec, o, rec["spread"]), ("ssl_summaries", rec, o, rec["spread"]),
+                                        ("ssl_summaries", early, c, early["spread"])):
+            add = _spread(primary, [other], key)
+            for dst, a in zip(sp[key], add):
+                for fld in ("cer", "val_loss", "train_loss", "same_hyps"):
+                    dst[fld] += a[fld]
+        for i in range(len(rec["judge"])):
+            rec["spread"]["judge_val_loss"][i].append(o["judge"][i]["val_loss"])
+            rec["spread"]["judge_train_loss"][i].append(float(np.mean(o["judge"][i]["losses"])))
+        rec["spread"]["sup_best_cer"].append(o["sup_best_cer"])
+        for k in ("sup_final_norms", "judge_final_norms", "ssl_final_norms"):
+            rec["spread"][k].append(o[k])
+        early["spread"]["ssl_final_norms"].append(c["ssl_final_norms"])
+        for i in range(len(early["ssl_steps"])):
+            early["spread"]["ssl_steps"][i].append(c["ssl_steps"][i]["loss"])
+        rec["threads"]["spread_order"].append("weights x (1 + %g N(0,1)) (seed %d)" % (rel, sd))
+        rec["threads"].setdefault("rel_runs", []).append(len(rec["threads"]["spread_order"]) - 1)
+    with open(path, "w") as f:
+        json.dump(rec, f, indent=0)
+    for i, (e, sp) in enumerate(zip(rec["sup"], rec["spread"]["sup"])):
+        print("  epoch %2d CER %.4f | %s | same hypotheses %s" % (i, e["cer"], " ".join("%.4f" % c for c in sp["cer"]), sp["same_hyps"]))
+    for i, (e, sp) in enumerate(zip(early["ssl_summaries"], early["spread"]["ssl_summaries"])):
+        print("  early ssl summary %d CER %.4f | %s | same hypotheses %s" % (i, e["cer"], " ".join("%.4f" % c for c in sp["cer"]), sp["same_hyps"]))
+
+
 def gen_solver_loops():
     """The CONTROL FLOW of the reference's loops with the compute scripted (a stub per step / validation that returns given
     numbers): which teacher-forcing rate each epoch gets (solver.py:414-418), when the best model is saved and under which
@@ -658,6 +712,7 @@ if __name__ == "__main__":
     jobs = dict(tiny_e2e=gen_tiny_e2e, tiny_lm=gen_tiny_lm, tiny_ssl=gen_tiny_ssl, cfg1=gen_cfg1, text=gen_text,
                 tiny_opt=gen_tiny_opt, cfg2=lambda: gen_big("cfg2", synth.CFG2_SHAPE),
                 cfg5=lambda: gen_big("cfg5", synth.CFG5_SHAPE), big_ssl=gen_big_ssl,
-                solver_run=gen_solver_run, solver_loops=gen_solver_loops)
-    for name in (sys.argv[1:] or list(jobs)):          # no arguments: everything (cfg2 / cfg5 take minutes)
+                solver_run=gen_solver_run, solver_loops=gen_solver_loops,
+                solver_run_extend=gen_solver_run_extend)
+    for name in (sys.argv[1:] or [j for j in jobs if j != "solver_run_extend"]):          # no arguments: everything (cfg2 / cfg5 take minutes)
         jobs[name]()

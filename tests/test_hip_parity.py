@@ -2216,3 +2216,51 @@ def test_gemm_side_on_a_subset_of_the_xcds(mask, arith, rtol):
     _close(out, ref.float(), atol=1e-4 * float(R) ** 0.5, what="batched dW_hh mask %#x" % mask, **tol)
     with hb.arith("f32"):
         assert hb.gemm_side(A.to(dev), B.to(dev), torch.zeros(M, N, device=dev), queue.zero_(), mask, trans_a=ta, trans_b=tb) is False
+
+
+def test_weight_gradients_beside_the_chains_equal_the_main_stream_ones():
+    """A batch of <= 8 utterances: the encoder's weight-gradient products run on a side stream, on the XCDs the persistent
+    kernels leave idle (ops._SideStream, asr_gemm_side_f32), joined when the backward pass ends.  The 3 x 512 model (persistent
+    kernels on) at B = 8: every gradient equals the one of the same pass with the side stream switched off (the K slices meet
+    in atomics on both paths: equal to rounding, not to the bit), the side stream was used, and reading .grad right behind
+    backward() needs no synchronisation of the caller's.  Twice the same model in ONE graph (the semi-supervised step's two
+    passes): a weight with two gradients on their way keeps its products on the main stream."""
+    dev = _gpu()
+    import ops
+    import hip_backend as hb
+    cfg = dict(synth.CFG2)
+    ld = synth.labeldist(cfg["output_dim"], 5)
+    w = synth.e2e_weights(cfg, 99)
+    net = _product(cfg, w, ld, dev)
+    xs, ilens, ys = synth.ragged_batch(8, 320, cfg["input_dim"], cfg["output_dim"], 77)
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+    assert hb.idle_xcd_mask(8) == 0xF0 and hb.idle_xcd_mask(9) == 0 and hb.idle_xcd_mask(0) == 0
+
+    def grads(side, passes=1):
+        ops._SIDE.enabled = side
+        before = ops._SIDE.launches
+        net.zero_grad()
+        np.random.seed(4)
+        loss = 0.0
+        for _ in range(passes):
+            _, lp, _, _ = net(xs_d, ilens, ys_d)
+            loss = loss - lp.mean()
+        with hb.require_persistent():
+            loss.backward()
+        out = {n: g_.clone() for n, g_ in _grads(net).items()}          # (no synchronize: the join is the engine's)
+        return out, ops._SIDE.launches - before
+
+    try:
+        on, used = grads(True)
+        off, unused = grads(False)
+        assert used >= 3 and unused == 0, (used, unused)      # layers 1, 2 (dW_ih + dW_hh each), the layer-0 projection
+        for n in off:
+            _close(on[n], off[n], rtol=2e-5, atol=1e-7, what="side vs main: " + n)
+        two, used2 = grads(True, passes=2)
+        ref2, _ = grads(False, passes=2)
+        assert 0 < used2, used2
+        for n in ref2:
+            _close(two[n], ref2[n], rtol=2e-5, atol=1e-7, what="two passes, side vs main: " + n)
+    finally:
+        ops._SIDE.enabled = True
+    assert not hb.persist_aborted(dev)
