@@ -158,14 +158,13 @@ class _SideStream(object):
     (hb.idle_xcd_mask).  The weight-gradient products of the backward pass are off its critical path - dG -> dX -> the
     recurrence of the layer below is - so they go to a SIDE stream, onto the idle XCDs, by workgroups that fit beside a
     persistent one (hb.gemm_side / asr_gemm_side_f32), and run under the recurrence of the layer below.
-      begin(mask, dev)   inside a backward function, once the operands are final on the current stream: -> the side stream
-                         (ordered behind everything enqueued so far), or None when the products stay on the main stream.
-                         The first begin() of a backward pass registers the join with the autograd engine: when the pass
-                         ends, the stream the backward ran on waits for the side stream - code that reads .grad afterwards
-                         (the optimiser, a test) finds every gradient complete without knowing about any of this.
-      join_now()         the same wait at once (a node that consumes side results inside the pass: _LstmPack.backward).
-    Outputs are zeroed on the main stream BEFORE begin() (the side products add into them with atomics).  A tensor the side
-    stream reads that is not a pooled workspace or an arena slice is handed to record_stream().  Off: ASR_SIDE_GEMM=0, the
+      defer(dev, launch, keep)   inside a backward function: queue products for the side stream (see there).  The first one
+                         of a backward pass registers the join with the autograd engine: when the pass ends, the stream the
+                         backward ran on waits for the side stream - code that reads .grad afterwards (the optimiser, a
+                         test) finds every gradient complete without knowing about any of this.
+      flush()            in front of a recurrence: start what is queued, beside it.
+      join_now()         flush + the wait at once (a node that consumes side results inside the pass: _LstmPack.backward).
+    Outputs are zeroed on the main stream BEFORE defer() (the side products add into them with atomics).  Off: ASR_SIDE_GEMM=0, the
     fp32-input MFMA arithmetic (no such kernel), gradients exchanged from inside the backward pass (dp_overlap: its hooks
     read a gradient as soon as autograd has it)."""
 
@@ -173,6 +172,7 @@ class _SideStream(object):
         self.enabled = os.environ.get("ASR_SIDE_GEMM", "1") != "0"
         self.streams, self.active, self.mask_hint = {}, None, 0
         self.uses = {}                     # weight data_ptr -> forward passes since the last join (see _Linear)
+        self.deferred = []                 # (launch closure, temporaries) waiting for the next recurrence
         self.launches = 0
 
     def mask_for(self, nbatch):
@@ -181,9 +181,15 @@ class _SideStream(object):
     def usable(self, mask):
         return bool(mask) and self.enabled and (hb.current_arith() & 0xff) != hb.ARITH_F32
 
-    def begin(self, mask, dev):
-        if not self.usable(mask):
-            return None
+    def defer(self, dev, launch, keep):
+        """Inside a backward function, once the operands are final on the current stream: queue `launch` (a closure that
+        enqueues the products on whatever stream is current) for the side stream.  It is NOT started here - right behind a
+        recurrence the main stream runs the critical dX products, and side workgroups on half the chip's CUs would starve
+        them (measured: a [5 248, 2 048] x [2 048, 512] dX product 394 us instead of 106) - but when the NEXT recurrence is
+        about to be enqueued (flush(), called by _LstmLayer.backward in front of its chain kernel), or when the pass ends.
+        `keep`: the tensors the products read or write that are temporaries of the caller (kept alive until the launch, then
+        handed to record_stream: the allocator must not give their memory to the main stream's next allocation - a fresh,
+        ZEROED ticket counter, say - while the side stream still runs)."""
         main = torch.cuda.current_stream(dev)
         st = self.streams.get(dev.index)
         if st is None:
@@ -191,14 +197,27 @@ class _SideStream(object):
         if self.active is None:
             self.active = (main, st)
             torch.autograd.Variable._execution_engine.queue_callback(self.join)
+        self.deferred.append((launch, keep))
+        self.launches += 1
+
+    def flush(self):
+        """Start what has been deferred: the side stream waits for everything enqueued on the main stream so far."""
+        if self.active is None or not self.deferred:
+            return
+        main, st = self.active
         ev = torch.cuda.Event()
         ev.record(main)
         st.wait_event(ev)
-        self.launches += 1
-        return st
+        with torch.cuda.stream(st):
+            for launch, keep in self.deferred:
+                launch()
+                for t in keep:
+                    t.record_stream(st)
+        del self.deferred[:]
 
     def join_now(self):
         if self.active is not None:
+            self.flush()
             self.active[0].wait_stream(self.active[1])
 
     def join(self):
@@ -208,6 +227,10 @@ class _SideStream(object):
 
 
 _SIDE = _SideStream()
+
+
+def _side_product(a, b, out, queue, mask):
+    return lambda: hb.gemm_side(a, b, out, queue, mask, trans_a=True)
 
 
 def _gemm_acc(A, B, trans_a=False, trans_b=False, shape=None):
@@ -281,16 +304,13 @@ class _Linear(torch.autograd.Function):
         # the weight gradient beside the recurrence of the layer below (a small batch; _SideStream) - unless this weight has
         # a second gradient on its way (the two model passes of the semi-supervised step: autograd would ADD the two on the
         # main stream while the side stream still writes them) or nothing follows this node in the pass
-        side = None
         if ctx.side_mask and ctx.needs_input_grad[0] and _SIDE.uses.get(weight.data_ptr(), 0) == 1 and _SIDE.usable(ctx.side_mask):
             dw = zeros_acc((dy2.shape[1], x2.shape[1]), dy2.device)
             queue = zeros_acc((1,), dy2.device)
-            side = _SIDE.begin(ctx.side_mask, dy2.device)
-        if side is not None:
-            with torch.cuda.stream(side):
-                hb.gemm_side(dy2, x2, dw, queue, ctx.side_mask, trans_a=True)
-            for t in (dy2, x2, queue):     # (temporaries of this function: the allocator must not hand their memory to the main
-                t.record_stream(side)      #  stream's next allocation - a fresh, ZEROED ticket counter - while the side stream runs)
+            # (the closure writes through an ALIAS of dw - a tensor object of its own over the same memory: AccumulateGrad
+            # takes a gradient over as .grad only while nobody else holds the tensor object, and CLONES it otherwise - at once,
+            # on the main stream, i.e. the zeros)
+            _SIDE.defer(dy2.device, _side_product(dy2, x2, dw.detach(), queue, ctx.side_mask), (dy2, x2, queue))
         else:
             dw = _gemm_acc(dy2, x2, trans_a=True, shape=(dy2.shape[1], x2.shape[1]))
         db = _colsum_acc(dy2) if ctx.has_bias else None
@@ -435,6 +455,7 @@ class _LstmLayer(torch.autograd.Function):
             ws = dict(ws, dcarry=zb[:nb_].view_as(ws["dcarry"]), dw_hh=zb[nb_:nb_ + n2].view_as(ws["dw_hh"]),
                       db=zb[nb_ + n2:].view_as(ws["db"]))
         gates, y = ws["gates"], ws["y"]
+        _SIDE.flush()                          # weight-gradient products of the layers above: beside THIS layer's recurrence
         # the transposed recurrent weights are only formed if the kernel that reads the forward layout does not apply
         fused_dw, fused_db = hb.lstm_seq_bwd(gates, lambda: ws["w_hhT"].copy_(w_hh.transpose(1, 2)), ws["lens"], dyc,
                                              ws["c"], ws["dcarry"], y=y, dw_hh=ws["dw_hh"], db=ws["db"],
@@ -442,8 +463,9 @@ class _LstmLayer(torch.autograd.Function):
         dG = gates.view(T * B, ndir * 4 * H)
         # a small batch: this layer's weight gradients go beside the recurrence of the layer BELOW (_SideStream) - not those of
         # the bottom layer (no input gradient: nothing follows it in the pass, and the main stream's kernels have the whole chip)
-        side, side_dw_hh = None, False
+        side, side_dw_hh = False, False
         if ctx.side_mask and ctx.needs_input_grad[0] and _SIDE.usable(ctx.side_mask):
+            side = True
             dw_ih = zeros_acc((ndir * 4 * H, I), dev)
             queue = zeros_acc((2,), dev)
             # (without a step arena the accumulators live in the leased workspace and are copied out below, on the main
@@ -452,19 +474,20 @@ class _LstmLayer(torch.autograd.Function):
             if ctx.rows is not None and not fused_dw and T > 1 and ws.get("rows_written", 0) > T * B:
                 ws["gates_buf"][T * B].zero_()             # (row R of a workspace a longer batch has used: see below)
                 ws["y_buf"][T * B].zero_()
-            side = _SIDE.begin(ctx.side_mask, dev)
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
-        if side is not None:
-            with torch.cuda.stream(side):
-                hb.gemm_side(dG, x2, dw_ih, queue[0:1], ctx.side_mask, trans_a=True)
-                if not fused_dw and T > 1:
+        if side:
+            mask, with_hh = ctx.side_mask, (not fused_dw and T > 1)
+            kk = T * B if ctx.rows is not None else (T - 1) * B
+
+            def launch():
+                # (dG and y live in the layer's pooled workspace: no forward pass leases it again before the pass has ended)
+                hb.gemm_side(dG, x2, dw_ih, queue[0:1], mask, trans_a=True)
+                if with_hh:
                     ldg, ldy = ndir * 4 * H, ndir * H
-                    kk = T * B if ctx.rows is not None else (T - 1) * B
-                    hb.gemm_side_batched(dG, y, dw_hh_side, queue[1:2], ctx.side_mask, True, False, 4 * H, H, kk, ldg, ldy, H,
-                                         ndir, 4 * H - B * ldg, B * ldy + H, 4 * H * H, a_off=B * ldg, b_off=0)
-                    side_dw_hh = True
-            x2.record_stream(side)
-            queue.record_stream(side)                      # (see _Linear.backward)
+                    hb.gemm_side_batched(dG, y, dw_hh_side, queue[1:2], mask, True, False, 4 * H, H, kk, ldg, ldy, H, ndir,
+                                         4 * H - B * ldg, B * ldy + H, 4 * H * H, a_off=B * ldg, b_off=0)
+            _SIDE.defer(dev, launch, (x2, queue))
+            side_dw_hh = with_hh
             fused_dw = True                                # (done: skip the main-stream product below)
         else:
             dw_ih = _gemm_acc(dG, x2, trans_a=True, shape=(ndir * 4 * H, I))      # [ndir*4H, I]
