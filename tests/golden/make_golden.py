@@ -425,7 +425,7 @@ def _rel_perturbed(arrays, rel, seed):
     return out
 
 
-def _solver_run(over, stages, ulp_seed=None, rel=None):
+def _solver_run(over, stages, ulp_seed=None, rel=None, grad_noise=None):
     """Drive the reference's own Solver (solver.py:13-565; main.py cannot be used, F10) over synth.SOLVER_RUN and record what
     its loops produce.  The methods are wrapped from outside to note their return values; nothing of them is restated."""
     import contextlib
@@ -461,6 +461,20 @@ def _solver_run(over, stages, ulp_seed=None, rel=None):
                        judge_steps_per_epoch=len(s.train_unlab_y_loader), dev_batches=len(s.dev_loader))
             t0 = time.time()
             cur = {}
+            real_clip = torch.nn.utils.clip_grad_norm_
+            if grad_noise is not None:
+                # every gradient element of every step off by grad_noise[0] x (the largest element of its tensor) x N(0, 1):
+                # what an implementation with its own rounding in every operation looks like to the optimiser (the kernels
+                # of the hot path are held to ~1e-6 of a tensor's scale; the parity gate is 1e-3)
+                gen = torch.Generator().manual_seed(grad_noise[1])
+
+                def noisy_clip(params, max_norm, *a, **k):
+                    params = list(params)
+                    for q in params:
+                        if q.grad is not None:
+                            q.grad.add_(torch.randn(q.grad.shape, generator=gen) * (grad_noise[0] * float(q.grad.abs().max())))
+                    return real_clip(params, max_norm, *a, **k)
+                torch.nn.utils.clip_grad_norm_ = noisy_clip
             real = dict(epoch=s.sup_train_one_epoch, val=s.validation, lmval=s.lm_validation,
                         jit=s.judge_train_one_iteration, git=s.gen_train_one_iteration)
 
@@ -514,6 +528,8 @@ def _solver_run(over, stages, ulp_seed=None, rel=None):
                         rec["test_hyps"] = f.read().splitlines()
         finally:
             os.chdir(cwd)
+            if grad_noise is not None:
+                torch.nn.utils.clip_grad_norm_ = real_clip
     for item in rec["sup"] + rec["ssl_summaries"]:
         item.pop("stage", None)
     rec["seconds"] = round(time.time() - t0, 1)
@@ -607,12 +623,16 @@ def gen_solver_run_extend():
     with open(path) as f:
         rec = json.load(f)
     spec = os.environ.get("GOLDEN_SPREAD_REL", "1e-6:911,912")
+    kind = "weights"
+    if spec.startswith("grad:"):
+        kind, spec = "grad", spec[5:]
     rel, seeds = float(spec.split(":")[0]), [int(v) for v in spec.split(":")[1].split(",")]
     EARLY = dict(epochs=1, ssl_iterations=30, summary_steps=10)
     early = rec["ssl_early"]
     for sd in seeds:
-        o = _solver_run({}, ("judge", "ssl"), rel=(rel, sd))
-        c = _solver_run(EARLY, ("ssl",), rel=(rel, sd))
+        kw = dict(rel=(rel, sd)) if kind == "weights" else dict(grad_noise=(rel, sd))
+        o = _solver_run({}, ("judge", "ssl"), **kw)
+        c = _solver_run(EARLY, ("ssl",), **kw)
         for key, primary, other, sp in (("sup", rec, o, rec["spread"]), ("ssl_summaries", rec, o, rec["spread"]),
                                         ("ssl_summaries", early, c, early["spread"])):
             add = _spread(primary, [other], key)
@@ -628,8 +648,9 @@ def gen_solver_run_extend():
         early["spread"]["ssl_final_norms"].append(c["ssl_final_norms"])
         for i in range(len(early["ssl_steps"])):
             early["spread"]["ssl_steps"][i].append(c["ssl_steps"][i]["loss"])
-        rec["threads"]["spread_order"].append("weights x (1 + %g N(0,1)) (seed %d)" % (rel, sd))
-        rec["threads"].setdefault("rel_runs", []).append(len(rec["threads"]["spread_order"]) - 1)
+        rec["threads"]["spread_order"].append(("weights x (1 + %g N(0,1)) (seed %d)" if kind == "weights" else
+                                               "every gradient + %g max|g| N(0,1), every step (seed %d)") % (rel, sd))
+        rec["threads"].setdefault("rel_runs" if kind == "weights" else "grad_noise_runs", []).append(len(rec["threads"]["spread_order"]) - 1)
     with open(path, "w") as f:
         json.dump(rec, f, indent=0)
     for i, (e, sp) in enumerate(zip(rec["sup"], rec["spread"]["sup"])):
