@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int tile = wave + 8 * it;
-        if (FPT * tile < TpP) {
+        if (FPT * tile < TpP && !(ASR_DP_ABL & 256)) {              // bit 256 (measurement): no score backward
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // pair 4 q4 + i of the tile: row ri (a compile-time constant: 4 q4 is a multiple of RG), frame t
@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       for (int w2 = 0; w2 < 8; ++w2) v += dDp[(w2 * 4 + row) * 16 + al];
       const int b = r0 + row;
       if (al < AU) {
-        if (row < RG && b < nb) a.dD[((int64_t)s * B + b) * AA + AU * slice + al] = v;
+        if (row < RG && b < nb && !(ASR_DP_ABL & 2048)) a.dD[((int64_t)s * B + b) * AA + AU * slice + al] = v;
         word_store(xg + BX_D + (slot * 4 + row) * 512 + AU * slice + al, v, bit);
       }
     }
@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
         // round 1).  js = j + 4 >= 0 is the loop variable; taps with j + jj < 0 are masked.
         const float* ap = dfh + cc * DFS + 16 * aq + 4 * li + 2 * K + 4;
         const float* bp = Fs + cc * FSS + li - 4;
-        const int jend = taps + 3 + 4;
+        const int jend = (ASR_DP_ABL & 128) ? 1 : taps + 3 + 4;      // bit 128 (measurement): one trip of each Toeplitz product
         for (int j = wave; j < jend; j += 32) {      // 4 taps per trip: 8 LDS reads in flight, then 4 MFMAs
           float av[4], bv[4];
 #pragma unroll
@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
         const float* bq = dfh + cc * DFS + K - li;
         const float* a0 = wph + 16 * aq + 4 * li;
         const bool two = 16 * (aq + PPR) < taps;
-        const int uend = Tp + 3;
+        const int uend = (ASR_DP_ABL & 128) ? 1 : Tp + 3;
         for (int u = wave; u < uend; u += 32) {
           float bv[4], a0v[4], a1v[4];
 #pragma unroll
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};   // even / odd k partials
       const float* dr = dDs + ((lane_ & 3) % RG) * DS + wave * AKW + (lane_ >> 4) * AQ;      // rows >= RG alias (results unused)
 #pragma unroll
-      for (int q = 0; q < AQ; q += 2) {
+      for (int q = 0; q < ((ASR_DP_ABL & 1024) ? 2 : AQ); q += 2) {      // bit 1024 (measurement): one pair of the dz product
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[q], dr[q], acc, 0, 0, 0);
         if (q + 1 < AQ) accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wd[q + 1], dr[q + 1], accb, 0, 0, 0);
       }
@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       dcarry = dc * ga.y;
       if (aborted || abort_seen != 0u) da.x = __builtin_nanf("");
       const int un = DU * slice + ul, b = r0 + row;
-      if (row < RG && b < nb) *reinterpret_cast<float4*>(a.dgates + ((int64_t)s * B + b) * GK + un * 4) = da;
+      if (row < RG && b < nb && !(ASR_DP_ABL & 2048)) *reinterpret_cast<float4*>(a.dgates + ((int64_t)s * B + b) * GK + un * 4) = da;   // bit 2048: no global stores
       float* dst = xg + BX_G + (slot * 4 + row) * 2048 + un * 4;
       word_store(dst, da.x, bit); word_store(dst + 1, da.y, bit);
       word_store(dst + 2, da.z, bit); word_store(dst + 3, da.w, bit);
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(DecPersistBwdArg
       DP_MARK(8);
       const float* gr = dgs + ((lane_ & 3) % RG) * GS + wave * GKW + ((lane_ >> 2) & 1) * GKS;   // rows >= RG alias
 #pragma unroll
-      for (int q4 = 0; q4 < GKS / 4; ++q4) {
+      for (int q4 = 0; q4 < ((ASR_DP_ABL & 512) ? 1 : GKS / 4); ++q4) {      // bit 512 (measurement): one quad of the dX product
         const float4 b = *reinterpret_cast<const float4*>(gr + 4 * q4);
         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4], b.x, acc, 0, 0, 0);
         accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wx[4 * q4 + 1], b.y, accb, 0, 0, 0);
