@@ -794,7 +794,12 @@ def idle_xcd_mask(nbatch):
     whole chip) or with a forced row geometry (ASR_LSTM_ROWS: measurements)."""
     if not (USE_PERSIST and USE_PERSIST_DEC and USE_PERSIST_DEC_BWD) or os.environ.get("ASR_LSTM_ROWS"):
         return 0
+    if _SIDE_FORCE_MASK is not None:           # measurement: ASR_SIDE_FORCE_MASK=0xff puts the products beside the chains of ANY batch
+        return _SIDE_FORCE_MASK if int(nbatch) > 0 else 0
     return 0xF0 if 0 < int(nbatch) <= 8 else 0
+
+
+_SIDE_FORCE_MASK = int(os.environ["ASR_SIDE_FORCE_MASK"], 0) & 0xff if os.environ.get("ASR_SIDE_FORCE_MASK") else None
 
 
 def persistent_step_tick():
