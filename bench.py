@@ -188,11 +188,11 @@ def _time_events(fn, reps):
 
 def mfma_busy_table():
     """MFMA-pipe busy fractions per kernel family from the committed counter pass (tools/pmc_mfma.py ->
-    profiles/r05_pmc_mfma.json (r04 / r03 when absent): SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES-derived kernel cycles), keyed for the rows
+    profiles/r06_pmc_mfma.json (r05 ... r03 when absent): SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CYCLES-derived kernel cycles), keyed for the rows
     of this bench; {} when the file is absent or was collected under another arithmetic."""
     import hip_backend as hb
     try:
-        for name in ("r05_pmc_mfma.json", "r04_pmc_mfma.json", "r03_pmc_mfma.json"):
+        for name in ("r06_pmc_mfma.json", "r05_pmc_mfma.json", "r04_pmc_mfma.json", "r03_pmc_mfma.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:
@@ -426,7 +426,7 @@ def kernel_roofline(dev, c, B, t_frames, olength, lens_batch=None):
     # HBM-side traffic of that kernel from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
     # tools/pmc_probe.py, FETCH doubled as the gfx950 guide prescribes); measured at H=512, 8-row groups
     if H == 512 and B >= 32:
-        for name in ("r05_pmc_lstm_persist.json", "r04_pmc_lstm_persist.json", "r03_pmc_lstm_persist.json", "r02_pmc_lstm_persist.json", "r01_pmc_lstm_persist.json"):
+        for name in ("r06_pmc_lstm_persist.json", "r05_pmc_lstm_persist.json", "r04_pmc_lstm_persist.json", "r03_pmc_lstm_persist.json", "r02_pmc_lstm_persist.json", "r01_pmc_lstm_persist.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)["lstm_persist_bwd_kernel<512>"]
@@ -871,6 +871,14 @@ def other_workloads(dev, tmp, main_config, main_frames):
                          ms_per_step=ms, value=B / ms * 1e3, unit="utterances/sec", loss=float(loss), sequence_op_paths=paths)
         del sv, xs_d, ys_d
         torch.cuda.empty_cache()
+        if name == "cfg5":
+            # its dominant kernel against its roof, as for the headline (B = 8: the chains run on four of the eight XCDs, and
+            # the weight-gradient products of the layers above run beside them on the other four - ops._SideStream)
+            import ops
+            res[name]["roofline"] = kernel_roofline(dev, c, B, T, max(int(y.shape[0]) for y in ys) + 1, lens)
+            res[name]["weight_gradients_beside_the_chains"] = dict(
+                enabled=bool(ops._SIDE.enabled and hb.idle_xcd_mask(B)), idle_xcd_mask=hb.idle_xcd_mask(B),
+                products_on_the_side_stream_so_far=ops._SIDE.launches)
     # BASELINE.json quotes cfg-2 on "80x800" batches and north_star on {200 ... 1600} frames: the headline batch is the ragged
     # reading of that (U[0.6T, T]); here the FIXED-length reading - every utterance exactly T frames, T / 8 labels -
     # and the ragged batches at the other frame counts, all through the same Solver method

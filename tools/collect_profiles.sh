@@ -30,4 +30,5 @@ with open('profiles/%s_pmc_mfma_bf16x6_counters.csv' % R, 'w') as f:
     for (k, c), (n, v) in sorted(agg.items()):
         f.write('"%s",%s,%d,%.0f\n' % (k, c, n, v))
 PY
+for f in cfg5_side_ab cfg5_timeline solver_run gpu_only_time; do [ -f $O/$f.txt ] && cp $O/$f.txt profiles/${R}_$f.txt; done
 ls -la profiles | grep $R

@@ -23,8 +23,14 @@ f, fk = rows(fcsv, 'FETCH_SIZE'); w, wk = rows(wcsv, 'WRITE_SIZE')
 # (bf16x6, the default: dW_hh is a GEMM after the kernel, so the backward does not read the h rows: PMC_FUSED_DW=0)
 fused = os.environ.get('PMC_FUSED_DW', '0') == '1'
 alg = {'fwd': B * ndir * (2 * 4 * H + 2 * H) * 4, 'bwd': B * ndir * (2 * 4 * H + 2 * H + (H if fused else 0)) * 4}
-res = {'shape': 'T=%d B=%d H=%d ndir=%d (cfg-2 encoder layer 0); separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
-                'passes of tools/pmc_probe.py, FETCH_SIZE doubled as the gfx950 guide prescribes' % (T, B, H, ndir)}
+# packed rows (tools/pmc_probe.py's default since round 6: the instantiation the step runs): the algorithmic bytes are those of
+# the batch's VALID (utterance, frame) pairs, not B x T - PMC_VALID_PAIRS, printed by the probe
+pairs = int(os.environ.get('PMC_VALID_PAIRS', '0'))
+if pairs:
+    alg = {k: v / float(B) * pairs / T for k, v in alg.items()}          # per "time step" of the launch's T = max length
+res = {'shape': 'T=%d B=%d H=%d ndir=%d (cfg-2 encoder layer 0%s); separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                'passes of tools/pmc_probe.py, FETCH_SIZE doubled as the gfx950 guide prescribes'
+                % (T, B, H, ndir, '; PACKED rows with the bench batch\'s lengths, %d valid (utterance, frame) pairs' % pairs if pairs else '')}
 for kind, key in (('bwd', 'lstm_persist_bwd_kernel<512>'), ('fwd', 'lstm_persist_fwd_kernel<512>')):
     hbm = (2.0 * f[kind][1] + w[kind][1]) * 1024.0
     res[key] = {'kernel': f[kind][0], 'FETCH_SIZE_KB': f[kind][1], 'WRITE_SIZE_KB': w[kind][1], 'hbm_side_bytes_per_launch': hbm,
