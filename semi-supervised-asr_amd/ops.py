@@ -173,6 +173,7 @@ class _SideStream(object):
         self.streams, self.active, self.mask_hint = {}, None, 0
         self.uses = {}                     # weight data_ptr -> forward passes since the last join (see _Linear)
         self.deferred = []                 # (launch closure, temporaries) waiting for the next recurrence
+        self.task = -1                     # the autograd graph task (backward pass) `active` belongs to
         self.launches = 0
 
     def mask_for(self, nbatch):
@@ -194,8 +195,16 @@ class _SideStream(object):
         st = self.streams.get(dev.index)
         if st is None:
             st = self.streams[dev.index] = torch.cuda.Stream(device=dev)
+        task = torch._C._current_graph_task_id()
+        if self.active is not None and task != self.task:
+            # a pass that never ended (an exception inside backward): its join never ran - what it left is dropped, the
+            # side stream is drained, and this pass registers its own join
+            self.active[0].wait_stream(self.active[1])
+            del self.deferred[:]
+            self.active = None
+            self.uses.clear()
         if self.active is None:
-            self.active = (main, st)
+            self.active, self.task = (main, st), task
             torch.autograd.Variable._execution_engine.queue_callback(self.join)
         self.deferred.append((launch, keep))
         self.launches += 1
@@ -204,6 +213,8 @@ class _SideStream(object):
         """Start what has been deferred: the side stream waits for everything enqueued on the main stream so far."""
         if self.active is None or not self.deferred:
             return
+        if self.task != torch._C._current_graph_task_id() and torch._C._current_graph_task_id() != -1:
+            return                         # (leftovers of a pass that never ended: defer() of THIS pass will drop them)
         main, st = self.active
         ev = torch.cuda.Event()
         ev.record(main)

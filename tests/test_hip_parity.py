@@ -2264,3 +2264,45 @@ def test_weight_gradients_beside_the_chains_equal_the_main_stream_ones():
     finally:
         ops._SIDE.enabled = True
     assert not hb.persist_aborted(dev)
+
+
+def test_side_stream_survives_a_backward_pass_that_raised():
+    """ops._SideStream registers its join with the autograd engine per backward PASS.  A pass that raises half way (here: in
+    the backward of encoder layer 1, with the products of layer 2 queued) never runs that join; the next pass must drop what
+    it left, register its own join and deliver complete gradients."""
+    dev = _gpu()
+    import ops
+    cfg = dict(synth.CFG2)
+    ld = synth.labeldist(cfg["output_dim"], 5)
+    net = _product(cfg, synth.e2e_weights(cfg, 99), ld, dev)
+    xs, ilens, ys = synth.ragged_batch(8, 320, cfg["input_dim"], cfg["output_dim"], 78)
+    xs_d, ys_d = torch.from_numpy(xs).to(dev), [torch.from_numpy(y).to(dev) for y in ys]
+
+    def run():
+        net.zero_grad()
+        np.random.seed(4)
+        _, lp, _, _ = net(xs_d, ilens, ys_d)
+        (-lp.mean()).backward()
+        return {n: g_.clone() for n, g_ in _grads(net).items()}
+
+    real = ops._LstmLayer.backward
+    state = {"calls": 0}
+
+    def exploding(ctx, dy):
+        state["calls"] += 1
+        if state["calls"] == 2:                      # the second LSTM layer of the pass (layer 1): products of layer 2 are queued
+            raise RuntimeError("boom")
+        return real(ctx, dy)
+
+    want = run()
+    ops._LstmLayer.backward = staticmethod(exploding)
+    try:
+        with pytest.raises(RuntimeError, match="boom"):
+            run()
+    finally:
+        ops._LstmLayer.backward = staticmethod(real)
+    assert ops._SIDE.active is not None and ops._SIDE.deferred, "the failed pass left its state behind (what this test is about)"
+    got = run()
+    assert ops._SIDE.active is None and not ops._SIDE.deferred
+    for n in want:
+        _close(got[n], want[n], rtol=2e-5, atol=1e-7, what="after a failed pass: " + n)
