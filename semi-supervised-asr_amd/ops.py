@@ -241,7 +241,8 @@ _SIDE = _SideStream()
 
 
 def _side_product(a, b, out, queue, mask):
-    return lambda: hb.gemm_side(a, b, out, queue, mask, trans_a=True)
+    code = hb.current_arith()              # (the arithmetic of the node that queued it, not of whoever flushes)
+    return lambda: hb.gemm_side(a, b, out, queue, mask, trans_a=True, arith=code)
 
 
 def _gemm_acc(A, B, trans_a=False, trans_b=False, shape=None):
@@ -487,16 +488,16 @@ class _LstmLayer(torch.autograd.Function):
                 ws["y_buf"][T * B].zero_()
         dx = hb.gemm(dG, w_ih).view(T, B, I) if ctx.needs_input_grad[0] else None
         if side:
-            mask, with_hh = ctx.side_mask, (not fused_dw and T > 1)
+            mask, with_hh, code = ctx.side_mask, (not fused_dw and T > 1), hb.current_arith()
             kk = T * B if ctx.rows is not None else (T - 1) * B
 
             def launch():
                 # (dG and y live in the layer's pooled workspace: no forward pass leases it again before the pass has ended)
-                hb.gemm_side(dG, x2, dw_ih, queue[0:1], mask, trans_a=True)
+                hb.gemm_side(dG, x2, dw_ih, queue[0:1], mask, trans_a=True, arith=code)
                 if with_hh:
                     ldg, ldy = ndir * 4 * H, ndir * H
                     hb.gemm_side_batched(dG, y, dw_hh_side, queue[1:2], mask, True, False, 4 * H, H, kk, ldg, ldy, H, ndir,
-                                         4 * H - B * ldg, B * ldy + H, 4 * H * H, a_off=B * ldg, b_off=0)
+                                         4 * H - B * ldg, B * ldy + H, 4 * H * H, arith=code, a_off=B * ldg, b_off=0)
             _SIDE.defer(dev, launch, (x2, queue))
             side_dw_hh = with_hh
             fused_dw = True                                # (done: skip the main-stream product below)
