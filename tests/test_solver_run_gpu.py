@@ -16,7 +16,9 @@ WHAT CAN BE ASKED.  A training run amplifies rounding differences, and the refer
 The product lands where the last two runs land (204 / 96 - 100 / 9 - 13), i.e. it is the reference plus rounding noise a
 thousand times inside the parity gate, and that is the resolution at which a trajectory can be compared at all.  The bars:
   * HYPOTHESES, every epoch / summary: at least as many identical to the primary's as the WORSE of the reference's two
-    gradient-noise runs keeps, less 10 % of the dev set (the product's own runs differ among themselves: atomics);
+    gradient-noise runs keeps, less 10 % of the dev set or - where the reference itself has drifted further - half of what
+    that run has lost (the product's own runs differ among themselves: atomics): 180 of 224 after the first epoch, nothing
+    in the epochs where the attention forms and the reference keeps a quarter of its own hypotheses, 148 at the end;
   * CER / dev loss, every epoch / summary: inside the range all eleven runs of the reference span, widened by twice that
     range's width and by 0.3 abs (0.003) at least - where the reference agrees with itself (first epoch: 1.1230 ... 1.1239) that IS
     the 0.3 abs of north_star; where it does not, nothing tighter means anything;
@@ -133,7 +135,8 @@ def _check_trajectory(got, want, spread, what, report, noise_runs=None):
         vals = [w["val_loss"]] + sp["val_loss"]
         floor = None
         if noise_runs and sp["same_hyps"]:
-            floor = max(0, min(sp["same_hyps"][j] for j in noise_runs) - int(0.10 * n))
+            worst = min(sp["same_hyps"][j] for j in noise_runs)
+            floor = max(0, worst - max(int(0.10 * n), (n - worst) // 2))       # (the allowance grows with the reference's own drift)
         report.append("%s %2d: CER %.4f (reference %.4f; its own runs %.4f ... %.4f) dev loss %.4f (%.4f) same hypotheses %d / %d"
                       " (the reference's runs %s%s)" % (what, i, g["cer"], w["cer"], min(cers), max(cers), g["val_loss"],
                                                        w["val_loss"], same, n, sp["same_hyps"],
