@@ -19,8 +19,9 @@ thousand times inside the parity gate, and that is the resolution at which a tra
     gradient-noise runs keeps, less 10 % of the dev set or - where the reference itself has drifted further - half of what
     that run has lost (the product's own runs differ among themselves: atomics): 180 of 224 after the first epoch, nothing
     in the epochs where the attention forms and the reference keeps a quarter of its own hypotheses, 148 at the end;
-  * CER / dev loss, every epoch / summary: inside the range all eleven runs of the reference span, widened by twice that
-    range's width and by 0.3 abs (0.003) at least - where the reference agrees with itself (first epoch: 1.1230 ... 1.1239) that IS
+  * CER / dev loss, every epoch / summary: inside the range all eleven runs of the reference span - where the reference has
+    lost more than 10 % of its own hypotheses, the range over that epoch AND its neighbours: one run of a chaotic system
+    can be an epoch ahead of another - widened by that range's width and by 0.3 abs (0.003) at least - where the reference agrees with itself (first epoch: 1.1230 ... 1.1239) that IS
     the 0.3 abs of north_star; where it does not, nothing tighter means anything;
   * final state: CER below 0.15 after starting above 1, weight norms inside the reference's own spread;
   * RULES - which epoch is saved as best, the per-epoch copies, the judge's schedule: exact, from the product's own numbers
@@ -125,35 +126,44 @@ def _rel(a, b):
 
 def _check_trajectory(got, want, spread, what, report, noise_runs=None):
     """`got` / `want`: lists of per-epoch (or per-summary) records; `spread`: the reference's own other runs per entry;
-    noise_runs: indices (into the spread lists) of the runs with per-step gradient noise - the floor for identical hypotheses."""
+    noise_runs: indices (into the spread lists) of the runs with per-step gradient noise - the floor for identical hypotheses.
+    The band of entry i is the range the reference's runs span there - and, where the reference no longer reproduces its own
+    hypotheses (fewer than 90 % in some run), also at the entries before and behind it: a run of a chaotic system can be one
+    epoch ahead of another or behind it - widened by that range's width (0.3 abs of CER, 0.2 % of a loss at least)."""
     assert len(got) == len(want)
+    n_e = len(want)
+
+    def values(key, i):
+        return [want[i][key]] + [v for v in spread[i].get(key, []) if v is not None]
+
     for i, (g, w, sp) in enumerate(zip(got, want, spread)):
         n = len(w["hyps"])
         assert g["refs"] == w["refs"], "%s %d: the reference sentences (dev order, CER strings)" % (what, i)
         same = sum(a == b for a, b in zip(g["hyps"], w["hyps"]))
-        cers = [w["cer"]] + sp["cer"]
-        vals = [w["val_loss"]] + sp["val_loss"]
+        chaotic = bool(sp["same_hyps"]) and min(sp["same_hyps"]) < 0.9 * n
+        near = [j for j in ((i - 1, i, i + 1) if chaotic else (i,)) if 0 <= j < n_e]
+        cers = [v for j in near for v in values("cer", j)]
+        vals = [v for j in near for v in values("val_loss", j)]
         floor = None
         if noise_runs and sp["same_hyps"]:
             worst = min(sp["same_hyps"][j] for j in noise_runs)
             floor = max(0, worst - max(int(0.10 * n), (n - worst) // 2))       # (the allowance grows with the reference's own drift)
-        report.append("%s %2d: CER %.4f (reference %.4f; its own runs %.4f ... %.4f) dev loss %.4f (%.4f) same hypotheses %d / %d"
-                      " (the reference's runs %s%s)" % (what, i, g["cer"], w["cer"], min(cers), max(cers), g["val_loss"],
-                                                       w["val_loss"], same, n, sp["same_hyps"],
-                                                       "" if floor is None else "; asked: >= %d" % floor))
+        report.append("%s %2d: CER %.4f (reference %.4f; band of its own runs %.4f ... %.4f%s) dev loss %.4f (%.4f) same hypotheses "
+                      "%d / %d (the reference's runs %s%s)" % (what, i, g["cer"], w["cer"], min(cers), max(cers),
+                                                             " incl. the neighbouring entries" if chaotic else "", g["val_loss"],
+                                                             w["val_loss"], same, n, sp["same_hyps"],
+                                                             "" if floor is None else "; asked: >= %d" % floor))
         if "tf_rate" in w:
             assert abs(g["tf_rate"] - w["tf_rate"]) < 1e-12 and g["epoch"] == w["epoch"]
         if floor is not None:
             assert same >= floor, report[-1]
-        # (eleven runs sample the reference's spread, they do not bound it - and the product's own runs differ among themselves
-        # as much, its partial sums meet in atomics: twice the observed width on either side)
-        tol = max(CER_ABS, 2.0 * (max(cers) - min(cers)))
+        tol = max(CER_ABS, max(cers) - min(cers))
         assert min(cers) - tol <= g["cer"] <= max(cers) + tol, report[-1]
-        vtol = max(2e-3 * abs(w["val_loss"]), 2.0 * (max(vals) - min(vals)))
+        vtol = max(2e-3 * abs(w["val_loss"]), max(vals) - min(vals))
         assert min(vals) - vtol <= g["val_loss"] <= max(vals) + vtol, report[-1]
         if w.get("train_loss") is not None and sp.get("train_loss"):
-            trs = [w["train_loss"]] + [v for v in sp["train_loss"] if v is not None]
-            ttol = max(1e-3 * abs(w["train_loss"]), 2.0 * (max(trs) - min(trs)))
+            trs = [v for j in near for v in values("train_loss", j)]
+            ttol = max(1e-3 * abs(w["train_loss"]), max(trs) - min(trs))
             assert min(trs) - ttol <= g["train_loss"] <= max(trs) + ttol, report[-1]
 
 
